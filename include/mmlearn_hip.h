@@ -1,0 +1,198 @@
+/*
+ * mmlearn_hip.h -- C ABI of libmmlearn_hip.so (gfx950 / MI355X).
+ *
+ * The reference (VectorInstitute/mmlearn) is pure Python over ATen ops; it has no
+ * FFI for this path, so every entry point below replaces a *sequence of ATen ops*
+ * of the reference, cited per function (paths relative to the reference root).
+ * The reference-side binding is the ctypes stub shown in INTEGRATION.md
+ * (mmlearn_amd/_lib.py is that stub in this repo).
+ *
+ * Conventions
+ *  - every pointer is caller-owned DEVICE memory (row-major, contiguous unless a
+ *    leading dimension is given, 16-byte aligned); the library never allocates,
+ *    frees or synchronises; all work is enqueued on `stream` (a hipStream_t
+ *    passed as void*, NULL = default stream);
+ *  - return value: 0 on success, negative on error; mmk_last_error() returns a
+ *    thread-local message (the Python layer raises RuntimeError/ValueError);
+ *  - re-entrant; the only global state is the optional profiling recorder.
+ */
+#ifndef MMLEARN_HIP_H
+#define MMLEARN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMK_ABI_VERSION 1
+
+/* element types of user tensors */
+enum { MMK_F32 = 0, MMK_BF16 = 1, MMK_F16 = 2 };
+/* arithmetic modes of the similarity GEMMs */
+enum { MMK_COMPUTE_BF16 = 1, MMK_COMPUTE_F32 = 0 };
+
+int mmk_abi_version(void);
+const char* mmk_last_error(void);
+/* device check: returns 0 when a gfx950 device is current, <0 (and an error text) otherwise */
+int mmk_device_check(void);
+
+/* ------------------------------------------------------------------ profiling
+ * HIP-event recorder around every kernel launch (events are recorded on the
+ * launch stream).  Used by bench.py for the roofline object.  Kernel ids: MMK_K_*.
+ */
+enum {
+  MMK_K_MATCH = 0, MMK_K_PACK, MMK_K_TRANSPOSE, MMK_K_SIM_STATS, MMK_K_LSE_REDUCE, MMK_K_LOSS_COMBINE,
+  MMK_K_SIM_GRAD, MMK_K_GRAD_GEMM, MMK_K_GRAD_FINALIZE, MMK_K_L2NORM, MMK_K_IJEPA_LOSS_FWD,
+  MMK_K_IJEPA_LOSS_BWD, MMK_K_GATHER_ROWS, MMK_K_SCATTER_ROWS, MMK_K_PRED_ASSEMBLE, MMK_K_PRED_ASSEMBLE_BWD,
+  MMK_K_EMA, MMK_K_MASK_INDEX, MMK_K_COUNT
+};
+int mmk_profile_enable(int on);          /* on=1 start recording (clears), on=0 stop */
+/* resolve recorded events (synchronises on them); fills count[k] and total_ms[k] for k < MMK_K_COUNT */
+int mmk_profile_read(int32_t* count, double* total_ms);
+const char* mmk_kernel_name(int kernel_id);
+
+/* ------------------------------------------------------------------ matching
+ * Replaces find_matching_indices (mmlearn/datasets/core/example.py:101-166):
+ * all (i, j) with ids_a[i] == ids_b[j] (both int64 columns), in row-major
+ * (torch.where) order; duplicates give several pairs.
+ *   row_count : int32[n_a + n_b + 2] workspace (per-row match counts of a and of b, then exclusive offsets)
+ *   status    : int32[4]  -> {total matches R, 1 if the pairing is the identity
+ *               (R == n_a == n_b and idx_a[p] == idx_b[p] == p), 1 if idx_a has
+ *               repeated entries, 1 if idx_b has repeated entries}
+ *   idx_a/idx_b : int32[capacity]; pairs beyond `capacity` are dropped (status[0]
+ *               still holds the true total, so the caller can detect overflow).
+ */
+int mmk_match_ids(const int64_t* ids_a, int n_a, const int64_t* ids_b, int n_b, int32_t* row_count,
+                  int32_t* idx_a, int32_t* idx_b, int capacity, int32_t* status, void* stream);
+
+/* ------------------------------------------------------------------ packing
+ * Gather + (optional) L2 normalise + cast of embedding rows into the GEMM operand
+ * layout.  Replaces F.normalize (mmlearn/modules/losses/contrastive.py:89-90) and
+ * the advanced-index gathers emb[indices] (:290-291, :318-319).
+ *   src  : [n_src, d] of src_dtype; idx: int32[r] or NULL (identity)
+ *   dst  : [r_pad, k_pad] of compute type (bf16 or f32), rows >= r and columns >= d zero
+ *   dstT : [k_pad, ldt] transpose of dst (NULL to skip), ldt >= r_pad, zero padded
+ * k_pad is a multiple of 64 (bf16) / 32 (f32); r_pad a multiple of 128.
+ */
+int mmk_pack_rows(const void* src, int src_dtype, int n_src, int d, const int32_t* idx, int r, int normalize,
+                  void* dst, void* dstT, int r_pad, int k_pad, int ldt, int compute, void* stream);
+
+/* ------------------------------------------------------------------ CLIP loss
+ * One "direction" = CE over the rows of  s * X @ Y^T  with label(i) = label_off + i.
+ * A LossPairSpec with local rows gives two directions (a->b, b->a), the reference's
+ * logits_per_feature_a / logits_per_feature_b (contrastive.py:327-340).
+ */
+typedef struct {
+  const void* x;      /* packed owned rows   [>= r rows, k_pad]            */
+  const void* y;      /* packed all columns  [>= c rows, k_pad]            */
+  const void* yT;     /* transpose of y      [k_pad, ldt] (backward only)  */
+  int32_t r;          /* owned rows                                         */
+  int32_t c;          /* columns                                            */
+  int32_t label_off;  /* positive column of row i is label_off + i         */
+  int32_t ldt;        /* leading dimension of yT                            */
+  float* part;        /* fwd workspace: float2[r * n_col_tiles] (max,sum)   */
+  float* diag;        /* fwd out: float[r] positive logit                    */
+  float* lse;         /* fwd out: float[r] row log-sum-exp                   */
+  float* loss_sum;    /* fwd out: float[1] sum_i (lse_i - diag_i)            */
+  /* backward */
+  const float* lse_col; /* float[c]: LSE of the opposite direction for every column */
+  void* g;            /* bwd workspace: [r_pad, ldg] compute type            */
+  int32_t ldg;        /* >= round_up(c, 128)                                 */
+  float c_row, c_col, c_diag;     /* G = c_row*P_row + c_col*P_col - c_diag*[j == label] */
+  float s_row, s_col, s_diag;     /* same triple for the d/dscale reduction               */
+  float kappa;        /* w / (2 * rows in the mean) (times W for gather_with_grad), applied to dX */
+  float ds_kappa;     /* same factor for the d/dscale reduction */
+  float* slab;        /* bwd workspace: float[n_split, r_pad, k_pad]          */
+  float* ds_part;     /* bwd workspace: float[n_grad_blocks]                  */
+  /* finalize: scatter dX back to the user gradient */
+  void* dx;           /* [n_src, d] user-dtype gradient buffer (pre-zeroed by caller) */
+  const int32_t* dx_rows; /* int32[r] destination row per owned row, or NULL (identity) */
+  int32_t dx_dtype;
+  int32_t dx_accumulate; /* 1: destination rows may repeat -> atomic adds into f32 dx */
+  const void* src;    /* original rows [n_src, d] (only when normalize=1, for the L2-norm backward) */
+  int32_t src_dtype;
+  int32_t normalize;
+} mmk_clip_dir;
+
+/* tile configuration query: n_col_tiles for `part`, blocks for `ds_part`, split-K factor for `slab` */
+int mmk_clip_plan(int r, int c, int k_pad, int compute, int32_t* n_col_tiles, int32_t* n_grad_blocks,
+                  int32_t* n_split);
+
+/* forward: similarity tiles + online row log-sum-exp + positive logit (K5-K6 of SURVEY 2.3:
+ * _safe_matmul, logit_scale*, F.cross_entropy of contrastive.py:134-144,327-340), all
+ * directions in one launch; scale is a device float (the reference's 0-dim logit_scale). */
+int mmk_clip_forward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale,
+                     void* stream);
+/* loss = sum_d weight[d] * loss_sum[d]  (contrastive.py:134-144,160); weight = w / (2 * rows in the mean) */
+int mmk_clip_loss_combine(const float* const* loss_sums, const float* weights, int n, float* loss_out, void* stream);
+/* backward: recompute tiles -> G, dX = G @ Y (split-K), scale/normalise/scatter; dscale accumulated into
+ * dscale_out (float[1], pre-zeroed by the caller); upstream is the device scalar dL/dloss. */
+int mmk_clip_backward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale,
+                      const float* upstream, float* dscale_out, void* stream);
+
+/* ------------------------------------------------------------------ row ops
+ * F.normalize(x, p=2, dim=-1, eps=1e-12) forward / backward
+ * (mmlearn/tasks/contrastive_pretraining.py:428-429; modules/layers/normalization.py:34). */
+int mmk_l2norm_fwd(const void* x, void* y, float* inv_norm, int rows, int d, int dtype, void* stream);
+int mmk_l2norm_bwd(const void* x, const void* dy, const float* inv_norm, void* dx, int rows, int d, int dtype,
+                   void* stream);
+
+/* ------------------------------------------------------------------ I-JEPA
+ * mask -> sorted keep indices (replaces the boolean-mask nonzero of apply_masks,
+ * mmlearn/datasets/processors/masking.py:264-283).  mask: int32[b, n] of 0/1; idx: int32[b, keep];
+ * bad: int32[1] set to 1 if any row's popcount != keep. */
+int mmk_mask_to_index(const int32_t* mask, int b, int n, int keep, int32_t* idx, int32_t* bad, void* stream);
+
+/* out[m*b + bi, p, :] = x[bi, idx[m, bi_or_0, p], :]   (apply_masks, masking.py:241-287)
+ * idx: int32[n_masks, idx_b, keep] with idx_b == b (per-sample) or 1 (batch-shared). */
+int mmk_gather_rows(const void* x, void* out, const int32_t* idx, int b, int n, int d, int n_masks, int idx_b,
+                    int keep, int dtype, void* stream);
+/* backward of gather: dx[bi, idx[...], :] += dout[...] ; dx pre-zeroed by the caller */
+int mmk_scatter_rows(const void* dout, void* dx, const int32_t* idx, int b, int n, int d, int n_masks, int idx_b,
+                     int keep, int dtype, void* stream);
+
+/* fused target path + regression loss (tasks/ijepa.py:232-238,250-261):
+ *   t = layer_norm(h[bi, idx[m,.,p], :])  (no affine, eps) ; loss = mean(rho(z - t))
+ * kind 0: smooth-L1 (beta=1, the reference default), kind 1: MSE.
+ * z: [n_masks*b, keep, d]; h: [b, n, d]; target_out (optional) receives t in z's dtype;
+ * part: float[n_blocks] workspace; loss: float[1]. */
+int mmk_ijepa_loss_fwd(const void* z, const void* h, const int32_t* idx, int b, int n, int d, int n_masks, int idx_b,
+                       int keep, int dtype, int kind, float eps, void* target_out, float* part, int n_blocks,
+                       float* loss, void* stream);
+int mmk_ijepa_loss_blocks(int rows);
+/* dz = upstream * rho'(z - t) / numel, t recomputed from h */
+int mmk_ijepa_loss_bwd(const void* z, const void* h, const int32_t* idx, int b, int n, int d, int n_masks, int idx_b,
+                       int keep, int dtype, int kind, float eps, const float* upstream, void* dz, void* stream);
+
+/* predictor sequence assembly (mmlearn/modules/encoders/vision.py:545-560):
+ *   seq[m*b*ne + r, :n_ctxt]  = x[r] + pos[enc_idx[e(r), bi(r), :]]
+ *   seq[m*b*ne + r, n_ctxt:]  = mask_token + pos[pred_idx[m, bi, :]]
+ * x: [ne*b, n_ctxt, d]; pos: [n, d]; mask_token: [d]; seq: [np*ne*b, n_ctxt + n_pred, d]. */
+int mmk_pred_assemble(const void* x, const void* pos, const void* mask_token, const int32_t* enc_idx,
+                      const int32_t* pred_idx, int b, int n, int d, int n_enc, int n_pred_masks, int enc_idx_b,
+                      int pred_idx_b, int n_ctxt, int n_pred, int dtype, void* seq, void* stream);
+/* dx[r] = sum_m dseq[m*b*ne + r, :n_ctxt];  dtok_part[blk, :] partial sums of dseq[:, n_ctxt:, :] (float) */
+int mmk_pred_assemble_bwd(const void* dseq, int b, int d, int n_enc, int n_pred_masks, int n_ctxt, int n_pred,
+                          int dtype, void* dx, float* dtok_part, int n_tok_blocks, void* dtok, void* stream);
+int mmk_pred_tok_blocks(int rows);
+
+/* multi-tensor EMA / copy (mmlearn/modules/ema.py:132-158).  table: device array of n_tensors
+ * records {teacher ptr, student ptr, numel, teacher dtype, student dtype}; mode 0: teacher = student
+ * (the reference's observable behaviour), mode 1: teacher = decay*teacher + (1-decay)*student
+ * computed in f32. */
+typedef struct {
+  void* teacher;
+  const void* student;
+  int64_t numel;
+  int32_t teacher_dtype;
+  int32_t student_dtype;
+} mmk_ema_entry;
+int mmk_ema_update(const mmk_ema_entry* table, int n_tensors, int64_t max_numel, float decay, int mode,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMLEARN_HIP_H */

@@ -1,0 +1,12 @@
+"""mmlearn_amd -- MI355X-native contrastive / I-JEPA hot path for VectorInstitute/mmlearn.
+
+Only the hot path lives here: the ContrastiveLoss boundary, the
+ContrastivePretraining / IJEPA task surface around it and the HIP kernels (``csrc/``) behind a
+C ABI (``include/mmlearn_hip.h``).  Importing the package does not load the HIP library;
+the first op does, and fails loudly if it is missing.
+"""
+
+from .losses import ContrastiveLoss, LossPairSpec, find_matching_indices  # noqa: F401
+from .modalities import Modalities  # noqa: F401
+
+__version__ = "0.1.0"

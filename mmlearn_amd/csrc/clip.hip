@@ -1,0 +1,786 @@
+// CLIP-style InfoNCE over a similarity matrix, for gfx950 (MI355X).
+//
+// Replaces the ATen sequence of mmlearn/modules/losses/contrastive.py:134-144,327-340
+// (_safe_matmul -> logit_scale * -> F.cross_entropy x2 and their autograd) with:
+//
+//   forward : sim_stats   T[j][i] = Y[j].X[i] on MFMA, fused online row-LSE over j per owned row i
+//             lse_reduce  merges the per-column-tile (max,sum) partials, sums (lse_i - S_i,label)
+//   backward: sim_grad    recomputes the tile, writes G = c_row*P_row + c_col*P_col - c_diag*delta
+//             grad_gemm   dX = G @ Y   (split-K, f32 slabs)
+//             finalize    sums slabs, scales, (L2-norm backward), scatters to the user gradient
+//
+// One GEMM main loop serves all three MFMA kernels:  T[m][n] = sum_k P[m][k] * Q[n][k]
+// (both operands K-contiguous).  P rows land on the accumulator REGISTERS, Q rows on the
+// LANES (MFMA A = P, B = Q^T), so the reduction over m that the row-LSE needs is lane-local.
+//
+// Data layout: operands are [rows][k_pad] with k_pad a multiple of one 128-byte LDS row
+// (64 bf16 / 32 f32).  LDS tiles are [rows][128 B], 16-byte chunks XOR-swizzled with
+// (row>>1)&7 so that the 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots.
+#include <algorithm>
+
+#include "common.h"
+
+namespace mmk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---------------------------------------------------------------- MMA atoms
+// One "macro k-step" consumes 32 bytes of K per operand row: lane (r = lane&31, h = lane>>5)
+// reads the 16-byte chunk (2*kk + h) of row r.  bf16: one v_mfma_f32_32x32x16_bf16 (k = 8h+j).
+// f32: four v_mfma_f32_32x32x2_f32 (MFMA t pairs k = 4h+t of both halves) -- exact f32.
+template <typename T>
+struct Atom;
+template <>
+struct Atom<bf16_t> {
+  static constexpr int BK = 64;
+  typedef bf16x8 Frag;
+  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Atom<float> {
+  static constexpr int BK = 32;
+  typedef f32x4 Frag;
+  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
+  }
+};
+
+enum { EPI_STATS = 0, EPI_GRAD = 1, EPI_PLAIN = 2 };
+constexpr int MAX_PROBS = 8;
+
+struct Prob {
+  const char* P;  // rows -> accumulator registers (MFMA A)
+  const char* Q;  // rows -> lanes                 (MFMA B)
+  int M, N;       // valid rows of P / Q
+  int K;          // elements, multiple of Atom::BK
+  int ldp, ldq;   // elements
+  int tiles_m, tiles_n;
+  // EPI_STATS
+  float2* part;   // [N][part_ld]
+  int part_ld;
+  float* diag;    // [N]
+  int label_off;
+  // EPI_GRAD
+  const float* lse_row;  // [N]
+  const float* lse_col;  // [M]
+  char* G;               // [>= tiles_n*BN][ldg]
+  int ldg;
+  float c_row, c_col, c_diag, s_row, s_col, s_diag;
+  float* ds_part;        // [tiles_m * tiles_n]
+  // EPI_PLAIN (split-K)
+  float* slab;           // [n_split][slab_rows][slab_ld]
+  int slab_ld;
+  long slab_split_stride;
+  int k_per_split;
+};
+struct ProbBatch {
+  Prob p[MAX_PROBS];
+  int n_split;
+};
+
+// ------------------------------------------------------------------ main loop
+template <typename T, int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const ProbBatch batch, const float* __restrict__ scale_ptr) {
+  typedef Atom<T> A;
+  typedef typename A::Frag Frag;
+  constexpr int MT = BM / 64, NT = BN / 64;          // 32x32 MFMA tiles per wave per dim (2x2 waves)
+  constexpr int ROWS = BM + BN;
+  constexpr int CPT = ROWS * 8 / 256;                // 16-byte chunks per thread per stage
+  constexpr int STAGE_BYTES = ROWS * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+  const int zsplit = (EPI == EPI_PLAIN) ? (blockIdx.z % batch.n_split) : 0;
+  const int zprob = (EPI == EPI_PLAIN) ? (blockIdx.z / batch.n_split) : blockIdx.z;
+  const Prob& p = batch.p[zprob];
+  const int tile = blockIdx.x;
+  if (tile >= p.tiles_m * p.tiles_n) return;
+  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  int k_begin = 0, k_end = p.K;
+  if (EPI == EPI_PLAIN) {
+    k_begin = zsplit * p.k_per_split;
+    k_end = min(p.K, k_begin + p.k_per_split);
+  }
+  const int nk = (k_end - k_begin) / A::BK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1, r = lane & 31, h = lane >> 5;
+
+  // ---- global -> register staging assignment (chunk c = tid + 256*u; 8 chunks per row)
+  const char* gsrc[CPT];
+  int lds_off[CPT];
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+    const int c = tid + 256 * u;
+    const int row = c >> 3, ch = c & 7;
+    const char* base;
+    if (row < BM) {
+      const int g = min(m0 + row, p.M - 1);
+      base = p.P + ((size_t)g * p.ldp + k_begin) * sizeof(T);
+    } else {
+      const int g = min(n0 + (row - BM), p.N - 1);
+      base = p.Q + ((size_t)g * p.ldq + k_begin) * sizeof(T);
+    }
+    gsrc[u] = base + ch * 16;
+    lds_off[u] = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+  }
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  uint4 stage[CPT];
+  if (nk > 0) {
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) stage[u] = *reinterpret_cast<const uint4*>(gsrc[u]);
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) *reinterpret_cast<uint4*>(smem + lds_off[u]) = stage[u];
+  }
+  __syncthreads();
+
+  // fragment read offsets (row-dependent swizzle is constant over k)
+  int p_off[MT], q_off[NT], p_sw[MT], q_sw[NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    const int row = wm * (BM / 2) + a * 32 + r;
+    p_off[a] = row * 128;
+    p_sw[a] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    const int row = BM + wn * (BN / 2) + b * 32 + r;
+    q_off[b] = row * 128;
+    q_sw[b] = (row >> 1) & 7;
+  }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* cur = smem + (kt & 1) * STAGE_BYTES;
+    const bool more = kt + 1 < nk;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < CPT; ++u)
+        stage[u] = *reinterpret_cast<const uint4*>(gsrc[u] + (size_t)(kt + 1) * 128);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      Frag fa[MT], fb[NT];
+      const int ch = 2 * kk + h;
+#pragma unroll
+      for (int a = 0; a < MT; ++a) fa[a] = *reinterpret_cast<const Frag*>(cur + p_off[a] + ((ch ^ p_sw[a]) << 4));
+#pragma unroll
+      for (int b = 0; b < NT; ++b) fb[b] = *reinterpret_cast<const Frag*>(cur + q_off[b] + ((ch ^ q_sw[b]) << 4));
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) A::mma(fa[a], fb[b], acc[a][b]);
+    }
+    if (more) {
+      char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) *reinterpret_cast<uint4*>(nxt + lds_off[u]) = stage[u];
+    }
+    __syncthreads();
+  }
+
+  // -------------------------------------------------------------- epilogues
+  // element (a, b, e): m = m0 + wm*BM/2 + a*32 + (e&3) + 8*(e>>2) + 4*h ; n = n0 + wn*BN/2 + b*32 + r
+  if (EPI == EPI_STATS) {
+    const float s = *scale_ptr;
+    float2* red = reinterpret_cast<float2*>(smem);  // [2][BN]
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int nl = wn * (BN / 2) + b * 32 + r;
+      const int i = n0 + nl;
+      const int lab = p.label_off + i;
+      float vmax = -INFINITY;
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int j = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const float v = (j < p.M) ? s * acc[a][b][e] : -INFINITY;
+          acc[a][b][e] = v;
+          vmax = fmaxf(vmax, v);
+          if (j == lab && i < p.N && j < p.M) p.diag[i] = v;
+        }
+      vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+      float sum = 0.f;
+      if (vmax > -INFINITY) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sum += __expf(acc[a][b][e] - vmax);
+      }
+      sum += __shfl_xor(sum, 32);
+      if (h == 0) red[wm * BN + nl] = make_float2(vmax, sum);
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const float2 x = red[tid], y = red[BN + tid];
+      const float mx = fmaxf(x.x, y.x);
+      float l = 0.f;
+      if (x.x > -INFINITY) l += x.y * __expf(x.x - mx);
+      if (y.x > -INFINITY) l += y.y * __expf(y.x - mx);
+      const int i = n0 + tid;
+      if (i < p.N) p.part[(size_t)i * p.part_ld + tm] = make_float2(mx, l);
+    }
+  } else if (EPI == EPI_GRAD) {
+    const float s = *scale_ptr;
+    const bool use_col = (p.c_col != 0.f) || (p.s_col != 0.f);
+    float ds_acc = 0.f;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int i = n0 + wn * (BN / 2) + b * 32 + r;
+      const bool iv = i < p.N;
+      const float lr = iv ? p.lse_row[i] : 0.f;
+      const int lab = p.label_off + i;
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int jb = m0 + wm * (BM / 2) + a * 32 + 8 * q + 4 * h;
+          float g4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = jb + e;
+            const float t = acc[a][b][4 * q + e];
+            const float v = s * t;
+            const bool valid = iv && (j < p.M);
+            const float pr = __expf(v - lr);
+            const float pc = (use_col && valid) ? __expf(v - p.lse_col[j]) : 0.f;
+            const float d = (j == lab) ? 1.f : 0.f;
+            float g = p.c_row * pr + p.c_col * pc - p.c_diag * d;
+            float gs = p.s_row * pr + p.s_col * pc - p.s_diag * d;
+            if (!valid) {
+              g = 0.f;
+              gs = 0.f;
+            }
+            ds_acc += gs * t;
+            g4[e] = g;
+          }
+          T* dst = reinterpret_cast<T*>(p.G) + (size_t)i * p.ldg + jb;
+          Vec4<T>::store(dst, make_float4(g4[0], g4[1], g4[2], g4[3]));
+        }
+    }
+    ds_acc = wave_sum(ds_acc);
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane == 0) red[wave] = ds_acc;
+    __syncthreads();
+    if (tid == 0) p.ds_part[tile] = red[0] + red[1] + red[2] + red[3];
+  } else {  // EPI_PLAIN: slab[split][n][m] = acc
+    float* slab = p.slab + (size_t)zsplit * p.slab_split_stride;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int i = n0 + wn * (BN / 2) + b * 32 + r;
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int mb = m0 + wm * (BM / 2) + a * 32 + 8 * q + 4 * h;
+          if (i < p.N && mb < p.M) {
+            float4 v = make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+            *reinterpret_cast<float4*>(slab + (size_t)i * p.slab_ld + mb) = v;
+          }
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ LSE reduce
+// one block per direction: lse[i] = logsumexp over the column-tile partials; loss_sum = sum_i (lse_i - diag_i)
+struct ReduceProb {
+  const float2* part;
+  int part_ld, tiles_m, N;
+  const float* diag;
+  float* lse;
+  float* loss_sum;
+};
+struct ReduceBatch {
+  ReduceProb p[MAX_PROBS];
+};
+__global__ __launch_bounds__(1024) void lse_reduce_kernel(const ReduceBatch batch) {
+  const ReduceProb& p = batch.p[blockIdx.x];
+  float local = 0.f;
+  for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
+    const float2* row = p.part + (size_t)i * p.part_ld;
+    float mx = -INFINITY;
+    for (int t = 0; t < p.tiles_m; ++t) mx = fmaxf(mx, row[t].x);
+    float l = 0.f;
+    for (int t = 0; t < p.tiles_m; ++t) {
+      const float2 v = row[t];
+      if (v.x > -INFINITY) l += v.y * __expf(v.x - mx);
+    }
+    const float lse = mx + logf(l);
+    p.lse[i] = lse;
+    local += lse - p.diag[i];
+  }
+  __shared__ float red[16];
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    *p.loss_sum = t;
+  }
+}
+
+struct CombineArgs {
+  const float* sums[2 * MAX_PROBS];
+  float w[2 * MAX_PROBS];
+  int n;
+};
+__global__ void loss_combine_kernel(const CombineArgs a, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < a.n; ++k) t += a.w[k] * *a.sums[k];
+    *out = t;
+  }
+}
+
+// ------------------------------------------------------------------ pack / transpose
+// one wave per destination row: gather, optional L2 normalise (eps 1e-12, F.normalize), cast, zero pad
+template <typename S, typename T>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const S* __restrict__ src, int d, const int32_t* __restrict__ idx,
+                                                        int r, int normalize, T* __restrict__ dst, int r_pad, int k_pad) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= r_pad) return;
+  T* out = dst + (size_t)row * k_pad;
+  if (row >= r) {
+    for (int c = lane * 4; c < k_pad; c += 256) Vec4<T>::store(out + c, make_float4(0.f, 0.f, 0.f, 0.f));
+    return;
+  }
+  const S* in = src + (size_t)(idx ? idx[row] : row) * d;
+  const bool vec = (d & 3) == 0;
+  float inv = 1.f;
+  if (normalize) {
+    float ss = 0.f;
+    if (vec) {
+      for (int c = lane * 4; c < d; c += 256) {
+        const float4 v = Vec4<S>::load(in + c);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+    } else {
+      for (int c = lane; c < d; c += 64) {
+        const float v = to_f32(in[c]);
+        ss += v * v;
+      }
+    }
+    ss = wave_sum(ss);
+    inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+  }
+  for (int c = lane * 4; c < k_pad; c += 256) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec) {
+      if (c < d) v = Vec4<S>::load(in + c);
+    } else {
+      if (c + 0 < d) v.x = to_f32(in[c + 0]);
+      if (c + 1 < d) v.y = to_f32(in[c + 1]);
+      if (c + 2 < d) v.z = to_f32(in[c + 2]);
+      if (c + 3 < d) v.w = to_f32(in[c + 3]);
+    }
+    v.x *= inv;
+    v.y *= inv;
+    v.z *= inv;
+    v.w *= inv;
+    Vec4<T>::store(out + c, v);
+  }
+}
+
+// dstT[k][p] = dst[p][k]; 64x64 tiles through LDS (+1 padding), both dims multiples of 64
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int rows, int cols,
+                                                        int ld_out) {
+  __shared__ T tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int y = ty; y < 64; y += 4) tile[y][tx] = in[(size_t)(r0 + y) * cols + c0 + tx];
+  __syncthreads();
+  for (int y = ty; y < 64; y += 4) out[(size_t)(c0 + y) * ld_out + r0 + tx] = tile[tx][y];
+}
+
+// ------------------------------------------------------------------ finalize
+// one wave per owned row: dy = coef * sum_splits slab ; optional F.normalize backward ; scatter to user grad
+struct FinProb {
+  const float* slab;
+  long split_stride;
+  int slab_ld;
+  int r;
+  float kappa;
+  void* dx;
+  const int32_t* dx_rows;
+  int accumulate;
+  const void* src;  // original rows (normalize backward)
+  int normalize;
+};
+struct FinBatch {
+  FinProb p[MAX_PROBS];
+  int n_split;
+  int d;
+};
+template <typename U>
+__global__ __launch_bounds__(256) void grad_finalize_kernel(const FinBatch batch, const float* __restrict__ scale_ptr,
+                                                            const float* __restrict__ upstream) {
+  extern __shared__ __attribute__((aligned(16))) float rowbuf[];  // [4][slab_ld]
+  const FinProb& p = batch.p[blockIdx.y];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= p.r) return;
+  const int d = batch.d;
+  const float coef = p.kappa * (*scale_ptr) * (*upstream);
+  float* buf = rowbuf + (size_t)wave * p.slab_ld;
+  const int dst_row = p.dx_rows ? p.dx_rows[i] : i;
+  const U* x = reinterpret_cast<const U*>(p.src) + (size_t)dst_row * d;
+  float dot = 0.f, ss = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    float v = 0.f;
+    for (int s = 0; s < batch.n_split; ++s) v += p.slab[(size_t)s * p.split_stride + (size_t)i * p.slab_ld + c];
+    v *= coef;
+    buf[c] = v;
+    if (p.normalize) {
+      const float xv = to_f32(x[c]);
+      dot += v * xv;
+      ss += xv * xv;
+    }
+  }
+  float inv = 1.f, proj = 0.f;
+  if (p.normalize) {
+    dot = wave_sum(dot);
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    inv = 1.f / fmaxf(nrm, 1e-12f);
+    // y = x*inv ; dx = (dy - y (y.dy)) * inv   (norm clamped at eps => constant, no projection)
+    proj = (nrm > 1e-12f) ? dot * inv * inv : 0.f;
+  }
+  for (int c = lane; c < d; c += 64) {
+    float v = buf[c];
+    if (p.normalize) v = (v - to_f32(x[c]) * proj) * inv;
+    if (p.accumulate) {
+      atomicAdd(reinterpret_cast<float*>(p.dx) + (size_t)dst_row * d + c, v);
+    } else {
+      reinterpret_cast<U*>(p.dx)[(size_t)dst_row * d + c] = from_f32<U>(v);
+    }
+  }
+}
+
+struct DsBatch {
+  const float* part[MAX_PROBS];
+  int n[MAX_PROBS];
+  float kappa[MAX_PROBS];
+  int n_probs;
+};
+__global__ __launch_bounds__(256) void ds_reduce_kernel(const DsBatch b, const float* __restrict__ upstream, float* out) {
+  float local = 0.f;
+  for (int k = 0; k < b.n_probs; ++k) {
+    float t = 0.f;
+    for (int i = threadIdx.x; i < b.n[k]; i += 256) t += b.part[k][i];
+    local += b.kappa[k] * t;
+  }
+  __shared__ float red[4];
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) *out += (*upstream) * (red[0] + red[1] + red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------ host side
+struct Plan {
+  int bt;        // square tile edge for the similarity kernels: 128 or 64
+  int bt_g;      // tile edge for the gradient GEMM
+  int n_split;   // split-K factor of the gradient GEMM
+};
+static Plan make_plan(int r_max, int c_max, int k_pad, int n_dirs, int compute) {
+  Plan pl;
+  const long tiles128 = (long)cdiv(r_max, 128) * cdiv(c_max, 128) * n_dirs;
+  pl.bt = tiles128 >= 256 ? 128 : 64;
+  const int bk = compute == MMK_COMPUTE_BF16 ? 64 : 32;
+  const int c_pad = round_up(c_max, 128);
+  const long gt128 = (long)cdiv(k_pad, 128) * cdiv(r_max, 128) * n_dirs;
+  pl.bt_g = gt128 >= 128 ? 128 : 64;
+  const long gt = (long)cdiv(k_pad, pl.bt_g) * cdiv(r_max, pl.bt_g) * n_dirs;
+  int split = (int)((768 + gt - 1) / gt);
+  const int max_split = c_pad / (2 * bk) > 0 ? c_pad / (2 * bk) : 1;  // >= 2 k-steps per split
+  if (split > max_split) split = max_split;
+  if (split > 16) split = 16;
+  if (split < 1) split = 1;
+  pl.n_split = split;
+  return pl;
+}
+
+template <typename T, int EPI>
+static int launch_gemm(const ProbBatch& b, int n_probs, int bt, int max_tiles, const float* scale, hipStream_t st) {
+  dim3 grid(max_tiles, 1, n_probs * (EPI == EPI_PLAIN ? b.n_split : 1));
+  if (bt == 128)
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 128, 128, EPI>), grid, dim3(256), 0, st, b, scale);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<T, 64, 64, EPI>), grid, dim3(256), 0, st, b, scale);
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, const float* scale, hipStream_t st) {
+  int r_max = 0, c_max = 0;
+  for (int k = 0; k < n_dirs; ++k) {
+    r_max = std::max(r_max, dirs[k].r);
+    c_max = std::max(c_max, dirs[k].c);
+  }
+  const Plan pl = make_plan(r_max, c_max, k_pad, n_dirs, sizeof(T) == 2 ? MMK_COMPUTE_BF16 : MMK_COMPUTE_F32);
+  ProbBatch b;
+  ReduceBatch rb;
+  int max_tiles = 0;
+  for (int k = 0; k < n_dirs; ++k) {
+    const mmk_clip_dir& d = dirs[k];
+    Prob& p = b.p[k];
+    p = Prob{};
+    p.P = static_cast<const char*>(d.y);
+    p.Q = static_cast<const char*>(d.x);
+    p.M = d.c;
+    p.N = d.r;
+    p.K = k_pad;
+    p.ldp = p.ldq = k_pad;
+    p.tiles_m = cdiv(d.c, pl.bt);
+    p.tiles_n = cdiv(d.r, pl.bt);
+    p.part = reinterpret_cast<float2*>(d.part);
+    p.part_ld = cdiv(d.c, 64);
+    p.diag = d.diag;
+    p.label_off = d.label_off;
+    max_tiles = std::max(max_tiles, p.tiles_m * p.tiles_n);
+    rb.p[k] = ReduceProb{p.part, p.part_ld, p.tiles_m, d.r, d.diag, d.lse, d.loss_sum};
+  }
+  b.n_split = 1;
+  {
+    ProfScope ps(MMK_K_SIM_STATS, st);
+    int rc = launch_gemm<T, EPI_STATS>(b, n_dirs, pl.bt, max_tiles, scale, st);
+    if (rc) return rc;
+  }
+  {
+    ProfScope ps(MMK_K_LSE_REDUCE, st);
+    hipLaunchKernelGGL(lse_reduce_kernel, dim3(n_dirs), dim3(1024), 0, st, rb);
+    MMK_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+template <typename T, typename U>
+static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d_user, const float* scale,
+                              const float* upstream, float* dscale_out, hipStream_t st) {
+  int r_max = 0, c_max = 0;
+  for (int k = 0; k < n_dirs; ++k) {
+    r_max = std::max(r_max, dirs[k].r);
+    c_max = std::max(c_max, dirs[k].c);
+  }
+  const Plan pl = make_plan(r_max, c_max, k_pad, n_dirs, sizeof(T) == 2 ? MMK_COMPUTE_BF16 : MMK_COMPUTE_F32);
+  const int bk = Atom<T>::BK;
+  ProbBatch gb, xb;
+  FinBatch fb;
+  DsBatch db;
+  int max_tiles_g = 0, max_tiles_x = 0, max_r = 0;
+  const int c_pad_max = round_up(c_max, 128);
+  const int k_per_split = round_up(cdiv(c_pad_max, pl.n_split), bk);
+  for (int k = 0; k < n_dirs; ++k) {
+    const mmk_clip_dir& d = dirs[k];
+    const int r_pad = round_up(d.r, 128), c_pad = round_up(d.c, 128);
+    MMK_REQUIRE(d.ldg >= c_pad && d.ldt >= c_pad, "ldg/ldt must be >= round_up(c, 128)");
+    // recompute + G
+    Prob& p = gb.p[k];
+    p = Prob{};
+    p.P = static_cast<const char*>(d.y);
+    p.Q = static_cast<const char*>(d.x);
+    p.M = d.c;
+    p.N = d.r;
+    p.K = k_pad;
+    p.ldp = p.ldq = k_pad;
+    p.tiles_m = c_pad / pl.bt;   // cover the zero padding of G up to ldg
+    p.tiles_n = cdiv(d.r, pl.bt);
+    p.label_off = d.label_off;
+    p.lse_row = d.lse;
+    p.lse_col = d.lse_col;
+    p.G = static_cast<char*>(d.g);
+    p.ldg = d.ldg;
+    p.c_row = d.c_row; p.c_col = d.c_col; p.c_diag = d.c_diag;
+    p.s_row = d.s_row; p.s_col = d.s_col; p.s_diag = d.s_diag;
+    p.ds_part = d.ds_part;
+    MMK_REQUIRE(d.lse_col != nullptr || (d.c_col == 0.f && d.s_col == 0.f), "lse_col required when c_col/s_col != 0");
+    max_tiles_g = std::max(max_tiles_g, p.tiles_m * p.tiles_n);
+    db.part[k] = d.ds_part;
+    db.n[k] = p.tiles_m * p.tiles_n;
+    db.kappa[k] = d.ds_kappa;
+    // dX^T[dcol][i] = sum_j yT[dcol][j] * G[i][j]
+    Prob& x = xb.p[k];
+    x = Prob{};
+    x.P = static_cast<const char*>(d.yT);
+    x.Q = static_cast<const char*>(d.g);
+    x.M = k_pad;
+    x.N = d.r;
+    x.K = c_pad;
+    x.ldp = d.ldt;
+    x.ldq = d.ldg;
+    x.tiles_m = cdiv(k_pad, pl.bt_g);
+    x.tiles_n = cdiv(d.r, pl.bt_g);
+    x.slab = d.slab;
+    x.slab_ld = k_pad;
+    x.slab_split_stride = (long)r_pad * k_pad;
+    x.k_per_split = k_per_split;
+    max_tiles_x = std::max(max_tiles_x, x.tiles_m * x.tiles_n);
+    fb.p[k] = FinProb{d.slab, x.slab_split_stride, k_pad, d.r, d.kappa, d.dx, d.dx_rows, d.dx_accumulate, d.src, d.normalize};
+    max_r = std::max(max_r, d.r);
+  }
+  gb.n_split = 1;
+  xb.n_split = pl.n_split;
+  fb.n_split = pl.n_split;
+  fb.d = d_user;
+  db.n_probs = n_dirs;
+  {
+    ProfScope ps(MMK_K_SIM_GRAD, st);
+    int rc = launch_gemm<T, EPI_GRAD>(gb, n_dirs, pl.bt, max_tiles_g, scale, st);
+    if (rc) return rc;
+  }
+  {
+    ProfScope ps(MMK_K_GRAD_GEMM, st);
+    int rc = launch_gemm<T, EPI_PLAIN>(xb, n_dirs, pl.bt_g, max_tiles_x, scale, st);
+    if (rc) return rc;
+  }
+  {
+    ProfScope ps(MMK_K_GRAD_FINALIZE, st);
+    hipLaunchKernelGGL((grad_finalize_kernel<U>), dim3(cdiv(max_r, 4), n_dirs), dim3(256), 4 * k_pad * sizeof(float), st, fb,
+                       scale, upstream);
+    MMK_LAUNCH_CHECK();
+    if (dscale_out) {
+      hipLaunchKernelGGL(ds_reduce_kernel, dim3(1), dim3(256), 0, st, db, upstream, dscale_out);
+      MMK_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}
+
+}  // namespace mmk
+
+using namespace mmk;
+
+extern "C" {
+
+int mmk_clip_plan(int r, int c, int k_pad, int compute, int32_t* n_col_tiles, int32_t* n_grad_blocks, int32_t* n_split) {
+  MMK_REQUIRE(r > 0 && c > 0 && k_pad > 0, "empty problem");
+  // sized for the worst case over tile choices / batch sizes so that callers need not know them
+  if (n_col_tiles) *n_col_tiles = cdiv(c, 64);
+  if (n_grad_blocks) *n_grad_blocks = (round_up(c, 128) / 64) * cdiv(r, 64);
+  int split = 1;
+  for (int nd = 1; nd <= MAX_PROBS; ++nd) split = std::max(split, make_plan(r, c, k_pad, nd, compute).n_split);
+  if (n_split) *n_split = split;
+  return 0;
+}
+
+int mmk_pack_rows(const void* src, int src_dtype, int n_src, int d, const int32_t* idx, int r, int normalize, void* dst,
+                  void* dstT, int r_pad, int k_pad, int ldt, int compute, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int bk = compute == MMK_COMPUTE_BF16 ? 64 : 32;
+  MMK_REQUIRE(src && dst, "null pointer");
+  MMK_REQUIRE(d > 0 && r >= 0 && n_src >= 0, "bad shape");
+  MMK_REQUIRE(r_pad % 128 == 0 && r_pad >= r && r_pad > 0, "r_pad must be a positive multiple of 128 and >= r");
+  MMK_REQUIRE(k_pad % bk == 0 && k_pad >= d && k_pad % 64 == 0, "k_pad must be a multiple of 64 and >= d");
+  MMK_REQUIRE(dstT == nullptr || ldt == r_pad, "ldt must equal r_pad");
+  {
+    ProfScope ps(MMK_K_PACK, st);
+    int rc = MMK_DISPATCH_DTYPE(src_dtype, S, [&]() -> int {
+      if (compute == MMK_COMPUTE_BF16)
+        hipLaunchKernelGGL((pack_rows_kernel<S, bf16_t>), dim3(r_pad / 4), dim3(256), 0, st, static_cast<const S*>(src), d,
+                           idx, r, normalize, static_cast<bf16_t*>(dst), r_pad, k_pad);
+      else
+        hipLaunchKernelGGL((pack_rows_kernel<S, float>), dim3(r_pad / 4), dim3(256), 0, st, static_cast<const S*>(src), d,
+                           idx, r, normalize, static_cast<float*>(dst), r_pad, k_pad);
+      return 0;
+    });
+    if (rc) return rc;
+    MMK_LAUNCH_CHECK();
+  }
+  if (dstT) {
+    ProfScope ps(MMK_K_TRANSPOSE, st);
+    dim3 grid(k_pad / 64, r_pad / 64);
+    if (compute == MMK_COMPUTE_BF16)
+      hipLaunchKernelGGL((transpose_kernel<bf16_t>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(dst),
+                         static_cast<bf16_t*>(dstT), r_pad, k_pad, ldt);
+    else
+      hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, st, static_cast<const float*>(dst),
+                         static_cast<float*>(dstT), r_pad, k_pad, ldt);
+    MMK_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+static int check_dirs(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int compute) {
+  MMK_REQUIRE(dirs && n_dirs > 0 && n_dirs <= MAX_PROBS, "1..8 directions per call");
+  const int bk = compute == MMK_COMPUTE_BF16 ? 64 : 32;
+  MMK_REQUIRE(k_pad > 0 && k_pad % 64 == 0 && k_pad % bk == 0, "k_pad must be a positive multiple of 64");
+  for (int k = 0; k < n_dirs; ++k) {
+    const mmk_clip_dir& d = dirs[k];
+    MMK_REQUIRE(d.x && d.y, "null operand");
+    MMK_REQUIRE(d.r > 0 && d.c > 0, "empty direction");
+    MMK_REQUIRE(d.label_off >= 0 && d.label_off + d.r <= d.c, "labels out of range");
+  }
+  return 0;
+}
+
+int mmk_clip_forward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale, void* stream) {
+  (void)d;
+  int rc = check_dirs(dirs, n_dirs, k_pad, compute);
+  if (rc) return rc;
+  MMK_REQUIRE(scale, "null scale");
+  for (int k = 0; k < n_dirs; ++k)
+    MMK_REQUIRE(dirs[k].part && dirs[k].diag && dirs[k].lse && dirs[k].loss_sum, "null forward buffer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (compute == MMK_COMPUTE_BF16) return clip_forward_impl<bf16_t>(dirs, n_dirs, k_pad, scale, st);
+  return clip_forward_impl<float>(dirs, n_dirs, k_pad, scale, st);
+}
+
+int mmk_clip_loss_combine(const float* const* loss_sums, const float* weights, int n, float* loss_out, void* stream) {
+  MMK_REQUIRE(loss_sums && weights && loss_out && n > 0 && n <= 2 * MAX_PROBS, "bad arguments");
+  CombineArgs a;
+  a.n = n;
+  for (int k = 0; k < n; ++k) {
+    a.sums[k] = loss_sums[k];
+    a.w[k] = weights[k];
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope ps(MMK_K_LOSS_COMBINE, st);
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, st, a, loss_out);
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+int mmk_clip_backward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale,
+                      const float* upstream, float* dscale_out, void* stream) {
+  int rc = check_dirs(dirs, n_dirs, k_pad, compute);
+  if (rc) return rc;
+  MMK_REQUIRE(scale && upstream, "null scale/upstream");
+  MMK_REQUIRE(d > 0 && d <= k_pad, "bad d");
+  const int dt = dirs[0].dx_dtype;
+  for (int k = 0; k < n_dirs; ++k) {
+    const mmk_clip_dir& q = dirs[k];
+    MMK_REQUIRE(q.yT && q.lse && q.g && q.slab && q.ds_part && q.dx, "null backward buffer");
+    MMK_REQUIRE(q.dx_dtype == dt, "all directions of one call must share dx_dtype");
+    MMK_REQUIRE(!q.dx_accumulate || q.dx_dtype == MMK_F32, "accumulating scatter needs an f32 gradient buffer");
+    MMK_REQUIRE(!q.normalize || (q.src && q.src_dtype == q.dx_dtype), "normalize backward needs src of dx dtype");
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return MMK_DISPATCH_DTYPE(dt, U, [&]() -> int {
+    if (compute == MMK_COMPUTE_BF16)
+      return clip_backward_impl<bf16_t, U>(dirs, n_dirs, k_pad, d, scale, upstream, dscale_out, st);
+    return clip_backward_impl<float, U>(dirs, n_dirs, k_pad, d, scale, upstream, dscale_out, st);
+  });
+}
+
+}  // extern "C"

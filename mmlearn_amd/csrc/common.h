@@ -1,0 +1,148 @@
+// Shared helpers for libmmlearn_hip.so (gfx950 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+
+#include "../../include/mmlearn_hip.h"
+
+namespace mmk {
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+void set_error(const std::string& msg);
+
+#define MMK_REQUIRE(cond, msg)                                     \
+  do {                                                             \
+    if (!(cond)) {                                                 \
+      ::mmk::set_error(std::string(__func__) + ": " + (msg));      \
+      return -1;                                                   \
+    }                                                              \
+  } while (0)
+
+#define MMK_HIP(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      ::mmk::set_error(std::string(__func__) + ": " #expr ": " + hipGetErrorString(_e)); \
+      return -2;                                                                        \
+    }                                                                                   \
+  } while (0)
+
+// HIP-event recorder around a launch (active only when mmk_profile_enable(1)).
+struct ProfScope {
+  int id;
+  hipStream_t stream;
+  void* slot;
+  ProfScope(int kernel_id, hipStream_t s);
+  ~ProfScope();
+};
+
+#define MMK_LAUNCH_CHECK()                                                                 \
+  do {                                                                                     \
+    hipError_t _e = hipGetLastError();                                                     \
+    if (_e != hipSuccess) {                                                                \
+      ::mmk::set_error(std::string(__func__) + ": launch failed: " + hipGetErrorString(_e)); \
+      return -3;                                                                           \
+    }                                                                                      \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// ------------------------------------------------------------------ device side
+template <typename T>
+__device__ __forceinline__ float to_f32(T v) {
+  return (float)v;
+}
+template <typename T>
+__device__ __forceinline__ T from_f32(float v) {
+  return (T)v;  // bf16: v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// load / store 4 consecutive elements of type T as floats (pointer 4-element aligned)
+template <typename T>
+struct Vec4;
+template <>
+struct Vec4<float> {
+  static __device__ __forceinline__ float4 load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void store(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+};
+template <>
+struct Vec4<bf16_t> {
+  static __device__ __forceinline__ float4 load(const bf16_t* p) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    float4 r;
+    r.x = __uint_as_float(u.x << 16);
+    r.y = __uint_as_float(u.x & 0xffff0000u);
+    r.z = __uint_as_float(u.y << 16);
+    r.w = __uint_as_float(u.y & 0xffff0000u);
+    return r;
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, float4 v) {
+    typedef bf16_t bf4 __attribute__((ext_vector_type(4)));
+    bf4 o;
+    o[0] = (bf16_t)v.x;
+    o[1] = (bf16_t)v.y;
+    o[2] = (bf16_t)v.z;
+    o[3] = (bf16_t)v.w;
+    *reinterpret_cast<bf4*>(p) = o;
+  }
+};
+template <>
+struct Vec4<f16_t> {
+  static __device__ __forceinline__ float4 load(const f16_t* p) {
+    typedef f16_t h4 __attribute__((ext_vector_type(4)));
+    h4 u = *reinterpret_cast<const h4*>(p);
+    return make_float4((float)u[0], (float)u[1], (float)u[2], (float)u[3]);
+  }
+  static __device__ __forceinline__ void store(f16_t* p, float4 v) {
+    typedef f16_t h4 __attribute__((ext_vector_type(4)));
+    h4 o;
+    o[0] = (f16_t)v.x;
+    o[1] = (f16_t)v.y;
+    o[2] = (f16_t)v.z;
+    o[3] = (f16_t)v.w;
+    *reinterpret_cast<h4*>(p) = o;
+  }
+};
+
+static inline size_t dtype_size(int dt) { return dt == MMK_F32 ? 4 : 2; }
+
+// dispatch a generic lambda on a user dtype tag
+#define MMK_DISPATCH_DTYPE(dt, TYPE, ...)             \
+  [&]() -> int {                                      \
+    switch (dt) {                                     \
+      case MMK_F32: {                                 \
+        typedef float TYPE;                           \
+        return __VA_ARGS__();                         \
+      }                                               \
+      case MMK_BF16: {                                \
+        typedef ::mmk::bf16_t TYPE;                   \
+        return __VA_ARGS__();                         \
+      }                                               \
+      case MMK_F16: {                                 \
+        typedef ::mmk::f16_t TYPE;                    \
+        return __VA_ARGS__();                         \
+      }                                               \
+      default:                                        \
+        ::mmk::set_error("unsupported dtype tag");    \
+        return -1;                                    \
+    }                                                 \
+  }()
+
+}  // namespace mmk

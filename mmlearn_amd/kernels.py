@@ -1,0 +1,327 @@
+"""Tensor-level wrappers over the C ABI (``include/mmlearn_hip.h``).
+
+Each function takes/returns torch tensors that live on the MI355X and enqueues HIP
+kernels on the current stream.  torch is used for device memory and streams only; no
+ATen math runs here.  There is deliberately no CPU path: CPU tensors raise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import COMPUTE_BF16, COMPUTE_F32, ClipDir, check, dtype_tag, ptr, require_gpu, stream
+
+MAX_DIRS_PER_CALL = 8
+
+
+def round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+def compute_torch_dtype(compute: int) -> torch.dtype:
+    return torch.bfloat16 if compute == COMPUTE_BF16 else torch.float32
+
+
+# ------------------------------------------------------------------ matching
+@dataclass
+class Match:
+    """Result of the device matcher (find_matching_indices, example.py:101-166)."""
+
+    n: int                      # number of matched pairs R
+    identity: bool              # R == n_a == n_b and pair p is (p, p)
+    idx_a: Optional[torch.Tensor]  # int32[R] (None when identity)
+    idx_b: Optional[torch.Tensor]
+    repeats_a: bool = False     # some row of a is in more than one pair
+    repeats_b: bool = False
+
+
+def match_ids(ids_a: torch.Tensor, ids_b: torch.Tensor) -> Match:
+    """All (i, j) with ids_a[i] == ids_b[j] in row-major order; one 16-byte D2H read of the status."""
+    require_gpu(ids_a, "example_ids")
+    require_gpu(ids_b, "example_ids")
+    ids_a = ids_a.contiguous()
+    ids_b = ids_b.contiguous()
+    n_a, n_b = ids_a.shape[0], ids_b.shape[0]
+    dev = ids_a.device
+    if n_a == 0 or n_b == 0:
+        return Match(0, False, torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev))
+    cap = max(n_a, n_b)
+    counts = torch.empty(n_a + n_b + 2, dtype=torch.int32, device=dev)
+    idx_a = torch.empty(cap, dtype=torch.int32, device=dev)
+    idx_b = torch.empty(cap, dtype=torch.int32, device=dev)
+    status = torch.empty(4, dtype=torch.int32, device=dev)
+    check(_lib.lib().mmk_match_ids(ptr(ids_a), n_a, ptr(ids_b), n_b, ptr(counts), ptr(idx_a), ptr(idx_b), cap, ptr(status), stream()))
+    total, ident, rep_a, rep_b = status.tolist()  # the one host sync of the loss path
+    if total > cap:  # heavy duplication: re-run the fill pass with the exact capacity
+        idx_a = torch.empty(total, dtype=torch.int32, device=dev)
+        idx_b = torch.empty(total, dtype=torch.int32, device=dev)
+        check(_lib.lib().mmk_match_ids(ptr(ids_a), n_a, ptr(ids_b), n_b, ptr(counts), ptr(idx_a), ptr(idx_b), total, ptr(status), stream()))
+    if ident:
+        return Match(total, True, None, None)
+    return Match(total, False, idx_a[:total], idx_b[:total], bool(rep_a), bool(rep_b))
+
+
+# ------------------------------------------------------------------ packing
+def pack_rows(src: torch.Tensor, idx: Optional[torch.Tensor], r: int, normalize: bool, compute: int, want_transpose: bool):
+    """Gather rows ``src[idx]`` (identity when idx is None), optionally L2-normalise, cast to the
+    compute type and zero-pad to [r_pad, k_pad]; optionally also emit the transpose [k_pad, r_pad]."""
+    require_gpu(src, "embedding")
+    src = src.contiguous()
+    n_src, d = src.shape
+    r_pad, k_pad = round_up(max(r, 1), 128), round_up(d, 64)
+    cdt = compute_torch_dtype(compute)
+    dst = torch.empty((r_pad, k_pad), dtype=cdt, device=src.device)
+    dst_t = torch.empty((k_pad, r_pad), dtype=cdt, device=src.device) if want_transpose else None
+    if idx is not None:
+        assert idx.dtype == torch.int32 and idx.numel() >= r
+    check(_lib.lib().mmk_pack_rows(ptr(src), dtype_tag(src.dtype), n_src, d, ptr(idx), r, int(normalize), ptr(dst), ptr(dst_t),
+                                   r_pad, k_pad, r_pad, compute, stream()))
+    return dst, dst_t
+
+
+# ------------------------------------------------------------------ CLIP loss
+@dataclass
+class Direction:
+    """One CE direction: rows of ``s * X @ Y^T`` with label(i) = label_off + i (mmk_clip_dir)."""
+
+    x: torch.Tensor                 # packed owned rows  [>= r, k_pad]
+    y: torch.Tensor                 # packed columns     [>= c, k_pad]
+    y_t: Optional[torch.Tensor]     # [k_pad, ldt]
+    r: int
+    c: int
+    label_off: int = 0
+    kappa: float = 1.0              # w / (2 * rows in the mean) [x W for gather_with_grad]
+    ds_kappa: float = 1.0           # factor of the d/dscale reduction
+    # gradient recipe: G = c_row*P_row + c_col*P_col - c_diag*delta ; same triple for dscale
+    c_row: float = 1.0
+    c_col: float = 1.0
+    c_diag: float = 2.0
+    s_row: float = 1.0
+    s_col: float = 1.0
+    s_diag: float = 2.0
+    # forward outputs
+    lse: Optional[torch.Tensor] = None
+    diag: Optional[torch.Tensor] = None
+    loss_sum: Optional[torch.Tensor] = None
+    # backward inputs
+    lse_col: Optional[torch.Tensor] = None
+    dx: Optional[torch.Tensor] = None        # [n_src, d] gradient buffer
+    dx_rows: Optional[torch.Tensor] = None   # int32[r]
+    dx_accumulate: bool = False
+    src: Optional[torch.Tensor] = None       # original rows when normalize=True
+    normalize: bool = False
+    _keep: list = field(default_factory=list)
+
+
+def _plan(r: int, c: int, k_pad: int, compute: int):
+    a, b, s = C.c_int32(), C.c_int32(), C.c_int32()
+    check(_lib.lib().mmk_clip_plan(r, c, k_pad, compute, C.addressof(a), C.addressof(b), C.addressof(s)))
+    return a.value, b.value, s.value
+
+
+def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.Tensor) -> None:
+    """Fills dir.lse / dir.diag / dir.loss_sum for every direction (two launches for all of them)."""
+    assert scale.dtype == torch.float32 and scale.is_cuda
+    dev = scale.device
+    for i0 in range(0, len(dirs), MAX_DIRS_PER_CALL):
+        chunk = dirs[i0:i0 + MAX_DIRS_PER_CALL]
+        arr = (ClipDir * len(chunk))()
+        k_pad = chunk[0].x.shape[1]
+        for k, dr in enumerate(chunk):
+            assert dr.x.shape[1] == k_pad and dr.y.shape[1] == k_pad
+            n_col_tiles, _, _ = _plan(dr.r, dr.c, k_pad, compute)
+            part = torch.empty((dr.r, n_col_tiles, 2), dtype=torch.float32, device=dev)
+            dr.lse = torch.empty(dr.r, dtype=torch.float32, device=dev)
+            dr.diag = torch.empty(dr.r, dtype=torch.float32, device=dev)
+            dr.loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
+            dr._keep.append(part)
+            e = arr[k]
+            e.x, e.y, e.r, e.c, e.label_off = ptr(dr.x), ptr(dr.y), dr.r, dr.c, dr.label_off
+            e.part, e.diag, e.lse, e.loss_sum = ptr(part), ptr(dr.diag), ptr(dr.lse), ptr(dr.loss_sum)
+        check(_lib.lib().mmk_clip_forward(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), stream()))
+
+
+def loss_combine(loss_sums: Sequence[torch.Tensor], weights: Sequence[float]) -> torch.Tensor:
+    """loss = sum_k weights[k] * loss_sums[k]  (one tiny launch; contrastive.py:134-144,160)."""
+    n = len(loss_sums)
+    out = torch.empty((), dtype=torch.float32, device=loss_sums[0].device)
+    if n > 2 * MAX_DIRS_PER_CALL:
+        raise ValueError("too many loss terms for one combine call")
+    ptrs = (C.c_void_p * n)(*[ptr(t) for t in loss_sums])
+    ws = (C.c_float * n)(*[float(w) for w in weights])
+    check(_lib.lib().mmk_clip_loss_combine(C.cast(ptrs, C.c_void_p), C.cast(ws, C.c_void_p), n, ptr(out), stream()))
+    return out
+
+
+def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.Tensor, upstream: torch.Tensor,
+                  dscale: Optional[torch.Tensor]) -> None:
+    """dX for every direction (scattered into dir.dx) and dscale += d loss / d scale."""
+    dev = scale.device
+    assert upstream.dtype == torch.float32 and upstream.is_cuda
+    cdt = compute_torch_dtype(compute)
+    for i0 in range(0, len(dirs), MAX_DIRS_PER_CALL):
+        chunk = dirs[i0:i0 + MAX_DIRS_PER_CALL]
+        arr = (ClipDir * len(chunk))()
+        k_pad = chunk[0].x.shape[1]
+        r_max, c_max = max(x.r for x in chunk), max(x.c for x in chunk)
+        _, _, n_split = _plan(r_max, c_max, k_pad, compute)
+        keep = []
+        for k, dr in enumerate(chunk):
+            r_pad, c_pad = round_up(dr.r, 128), round_up(dr.c, 128)
+            _, n_grad_blocks, _ = _plan(dr.r, dr.c, k_pad, compute)
+            g = torch.empty((r_pad, c_pad), dtype=cdt, device=dev)
+            slab = torch.empty((n_split, r_pad, k_pad), dtype=torch.float32, device=dev)
+            ds_part = torch.empty(n_grad_blocks, dtype=torch.float32, device=dev)
+            keep += [g, slab, ds_part]
+            e = arr[k]
+            e.x, e.y, e.yT, e.r, e.c, e.label_off = ptr(dr.x), ptr(dr.y), ptr(dr.y_t), dr.r, dr.c, dr.label_off
+            e.ldt = dr.y_t.shape[1]
+            e.lse, e.lse_col, e.g, e.ldg = ptr(dr.lse), ptr(dr.lse_col), ptr(g), c_pad
+            e.c_row, e.c_col, e.c_diag = dr.c_row, dr.c_col, dr.c_diag
+            e.s_row, e.s_col, e.s_diag = dr.s_row, dr.s_col, dr.s_diag
+            e.kappa, e.ds_kappa, e.slab, e.ds_part = dr.kappa, dr.ds_kappa, ptr(slab), ptr(ds_part)
+            e.dx, e.dx_rows, e.dx_dtype = ptr(dr.dx), ptr(dr.dx_rows), dtype_tag(dr.dx.dtype)
+            e.dx_accumulate = int(dr.dx_accumulate)
+            e.src, e.normalize = ptr(dr.src), int(dr.normalize)
+            e.src_dtype = dtype_tag(dr.src.dtype) if dr.src is not None else 0
+        check(_lib.lib().mmk_clip_backward(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), ptr(upstream),
+                                           ptr(dscale), stream()))
+        del keep  # the caching allocator keeps the blocks alive until the stream has consumed them
+
+
+# ------------------------------------------------------------------ row ops
+def l2norm_fwd(x: torch.Tensor):
+    require_gpu(x)
+    x2 = x.contiguous().view(-1, x.shape[-1])
+    y = torch.empty_like(x2)
+    inv = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+    check(_lib.lib().mmk_l2norm_fwd(ptr(x2), ptr(y), ptr(inv), x2.shape[0], x2.shape[1], dtype_tag(x.dtype), stream()))
+    return y.view(x.shape), inv
+
+
+def l2norm_bwd(x: torch.Tensor, dy: torch.Tensor, inv: torch.Tensor) -> torch.Tensor:
+    x2 = x.contiguous().view(-1, x.shape[-1])
+    dy2 = dy.contiguous().view(-1, x.shape[-1])
+    dx = torch.empty_like(x2)
+    check(_lib.lib().mmk_l2norm_bwd(ptr(x2), ptr(dy2), ptr(inv), ptr(dx), x2.shape[0], x2.shape[1], dtype_tag(x.dtype), stream()))
+    return dx.view(x.shape)
+
+
+# ------------------------------------------------------------------ I-JEPA ops
+def mask_to_index(mask: torch.Tensor, keep: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """mask int32[b, n] of 0/1 -> sorted keep indices int32[b, keep]; second value is a device flag
+    (int32[1]) that is 1 when some row's popcount != keep."""
+    require_gpu(mask, "mask")
+    mask = mask.to(torch.int32).contiguous()
+    b, n = mask.shape
+    idx = torch.zeros((b, keep), dtype=torch.int32, device=mask.device)
+    bad = torch.zeros(1, dtype=torch.int32, device=mask.device)
+    check(_lib.lib().mmk_mask_to_index(ptr(mask), b, n, keep, ptr(idx), ptr(bad), stream()))
+    return idx, bad
+
+
+def gather_rows(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """x [b, n, d], idx int32 [n_masks, b or 1, keep] -> [n_masks*b, keep, d]."""
+    require_gpu(x)
+    x = x.contiguous()
+    b, n, d = x.shape
+    n_masks, idx_b, keep = idx.shape
+    out = torch.empty((n_masks * b, keep, d), dtype=x.dtype, device=x.device)
+    check(_lib.lib().mmk_gather_rows(ptr(x), ptr(out), ptr(idx), b, n, d, n_masks, idx_b, keep, dtype_tag(x.dtype), stream()))
+    return out
+
+
+def scatter_rows(dout: torch.Tensor, idx: torch.Tensor, b: int, n: int) -> torch.Tensor:
+    dout = dout.contiguous()
+    d = dout.shape[-1]
+    n_masks, idx_b, keep = idx.shape
+    dx = torch.empty((b, n, d), dtype=dout.dtype, device=dout.device)
+    check(_lib.lib().mmk_scatter_rows(ptr(dout), ptr(dx), ptr(idx), b, n, d, n_masks, idx_b, keep, dtype_tag(dout.dtype), stream()))
+    return dx
+
+
+def ijepa_loss_fwd(z: torch.Tensor, h: torch.Tensor, idx: torch.Tensor, kind: int, eps: float, want_target: bool):
+    require_gpu(z)
+    z, h = z.contiguous(), h.contiguous()
+    b, n, d = h.shape
+    n_masks, idx_b, keep = idx.shape
+    rows = n_masks * b * keep
+    assert z.shape == (n_masks * b, keep, d), (z.shape, (n_masks * b, keep, d))
+    n_blocks = _lib.lib().mmk_ijepa_loss_blocks(rows)
+    part = torch.empty(n_blocks, dtype=torch.float32, device=z.device)
+    loss = torch.empty((), dtype=torch.float32, device=z.device)
+    target = torch.empty((n_masks * b, keep, d), dtype=h.dtype, device=z.device) if want_target else None
+    dt = dtype_tag(z.dtype) | (dtype_tag(h.dtype) << 4)
+    check(_lib.lib().mmk_ijepa_loss_fwd(ptr(z), ptr(h), ptr(idx), b, n, d, n_masks, idx_b, keep, dt, kind, float(eps), ptr(target),
+                                        ptr(part), n_blocks, ptr(loss), stream()))
+    return loss, target
+
+
+def ijepa_loss_bwd(z: torch.Tensor, h: torch.Tensor, idx: torch.Tensor, kind: int, eps: float, upstream: torch.Tensor) -> torch.Tensor:
+    z, h = z.contiguous(), h.contiguous()
+    b, n, d = h.shape
+    n_masks, idx_b, keep = idx.shape
+    dz = torch.empty_like(z)
+    dt = dtype_tag(z.dtype) | (dtype_tag(h.dtype) << 4)
+    check(_lib.lib().mmk_ijepa_loss_bwd(ptr(z), ptr(h), ptr(idx), b, n, d, n_masks, idx_b, keep, dt, kind, float(eps), ptr(upstream),
+                                        ptr(dz), stream()))
+    return dz
+
+
+def pred_assemble(x: torch.Tensor, pos: torch.Tensor, tok: torch.Tensor, enc_idx: torch.Tensor, pred_idx: torch.Tensor,
+                  b: int, out_dtype: torch.dtype) -> torch.Tensor:
+    """x [ne*b, n_ctxt, d]; pos f32 [n, d]; tok f32 [d] -> seq [np*ne*b, n_ctxt + n_pred, d]."""
+    require_gpu(x)
+    x = x.contiguous()
+    n_enc, enc_b, n_ctxt = enc_idx.shape
+    n_pm, pred_b, n_pred = pred_idx.shape
+    n, d = pos.shape
+    assert x.shape == (n_enc * b, n_ctxt, d)
+    seq = torch.empty((n_pm * n_enc * b, n_ctxt + n_pred, d), dtype=out_dtype, device=x.device)
+    dt = dtype_tag(x.dtype) | (dtype_tag(out_dtype) << 4)
+    check(_lib.lib().mmk_pred_assemble(ptr(x), ptr(pos), ptr(tok), ptr(enc_idx), ptr(pred_idx), b, n, d, n_enc, n_pm, enc_b, pred_b,
+                                       n_ctxt, n_pred, dt, ptr(seq), stream()))
+    return seq
+
+
+def pred_assemble_bwd(dseq: torch.Tensor, b: int, n_enc: int, n_pm: int, n_ctxt: int, n_pred: int, x_dtype: torch.dtype,
+                      want_dx: bool, want_dtok: bool):
+    dseq = dseq.contiguous()
+    d = dseq.shape[-1]
+    dev = dseq.device
+    dx = torch.empty((n_enc * b, n_ctxt, d), dtype=x_dtype, device=dev) if want_dx else None
+    dtok = part = None
+    n_blocks = 0
+    if want_dtok:
+        n_blocks = _lib.lib().mmk_pred_tok_blocks(n_pm * n_enc * b * n_pred)
+        part = torch.empty((n_blocks, d), dtype=torch.float32, device=dev)
+        dtok = torch.empty(d, dtype=torch.float32, device=dev)
+    dt = dtype_tag(x_dtype) | (dtype_tag(dseq.dtype) << 4)
+    check(_lib.lib().mmk_pred_assemble_bwd(ptr(dseq), b, d, n_enc, n_pm, n_ctxt, n_pred, dt, ptr(dx), ptr(part), n_blocks, ptr(dtok),
+                                           stream()))
+    return dx, dtok
+
+
+def ema_table(teacher: Sequence[torch.Tensor], student: Sequence[torch.Tensor]):
+    """Device-resident pointer table for ``ema_update`` (build once, reuse every step)."""
+    n = len(teacher)
+    arr = (_lib.EmaEntry * n)()
+    max_numel = 1
+    for k, (t, s) in enumerate(zip(teacher, student)):
+        require_gpu(t)
+        assert t.is_contiguous() and s.is_contiguous() and t.numel() == s.numel()
+        arr[k].teacher, arr[k].student, arr[k].numel = t.data_ptr(), s.data_ptr(), t.numel()
+        arr[k].teacher_dtype, arr[k].student_dtype = dtype_tag(t.dtype), dtype_tag(s.dtype)
+        max_numel = max(max_numel, t.numel())
+    raw = bytes(arr)
+    host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    return host.to(teacher[0].device), n, max_numel
+
+
+def ema_update(table: torch.Tensor, n: int, max_numel: int, decay: float, true_ema: bool) -> None:
+    check(_lib.lib().mmk_ema_update(ptr(table), n, max_numel, float(decay), int(true_ema), stream()))

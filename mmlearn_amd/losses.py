@@ -1,0 +1,549 @@
+"""Drop-in ``ContrastiveLoss`` for mmlearn, computed by hand-written HIP kernels on MI355X.
+
+Boundary (mmlearn/modules/losses/contrastive.py:40-47,59-65; docs/user_guide.md:149-165):
+
+    loss = ContrastiveLoss(l2_normalize, local_loss, gather_with_grad, modality_alignment, cache_labels)
+    loss(embeddings, example_ids, logit_scale, modality_loss_pairs) -> 0-dim tensor
+
+with ``embeddings`` keyed by ``Modality.embedding`` ("rgb_embedding"), ``example_ids`` keyed by
+modality name with int64 ``[B, 2]`` values, ``logit_scale`` a 0-dim tensor and
+``modality_loss_pairs`` a list of ``LossPairSpec(modalities, weight)``.
+
+What runs where
+---------------
+* device matcher (``find_matching_indices``), gather+normalise+cast packing, the similarity tiles
+  with fused row log-sum-exp, the gradient tiles and the ``G @ Y`` products are HIP kernels
+  (``mmlearn_amd/csrc``), reached through ``mmlearn_amd.kernels``;
+* across ranks the [N, N] matrix is sharded by rows: two all-gathers
+  (embeddings, ids) replace the reference's >= 12 collectives, then every rank computes only its
+  own row blocks and one all-reduce of the per-row LSEs (+ loss partial sums) makes the full
+  gradient local.  The four ``(local_loss, gather_with_grad)`` cells reproduce the reference's
+  per-rank loss values and gradient scalings.
+
+There is no eager/CPU fallback: CPU tensors raise ``RuntimeError``.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Any, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import kernels as K
+from ._lib import COMPUTE_BF16, COMPUTE_F32
+from .modalities import Modalities
+from .registry import store
+
+_ACCUM_DTYPE = torch.float32
+
+
+@dataclass
+class LossPairSpec:
+    """Specification for a pair of modalities to compute the contrastive loss
+    (mmlearn/tasks/contrastive_pretraining.py:44-52)."""
+
+    modalities: tuple[str, str]
+    weight: float = 1.0
+
+
+def find_matching_indices(first_example_ids: torch.Tensor, second_example_ids: torch.Tensor):
+    """Device version of mmlearn.datasets.core.find_matching_indices (example.py:101-166): the
+    indices of matching examples of the first and second tensor, in ``torch.where`` order."""
+    if not isinstance(first_example_ids, torch.Tensor) or not isinstance(second_example_ids, torch.Tensor):
+        raise TypeError(f"Expected inputs to be tensors, but got {type(first_example_ids)} and {type(second_example_ids)}.")
+    for name, t in (("first_example_ids", first_example_ids), ("second_example_ids", second_example_ids)):
+        if not (t.ndim == 2 and t.shape[1] == 2):
+            raise ValueError(f"Expected argument `{name}` to be a tensor of shape (N, 2), but got shape {t.shape}.")
+    m = K.match_ids(first_example_ids.to(torch.int64), second_example_ids.to(torch.int64))
+    if m.identity:
+        ar = torch.arange(m.n, device=first_example_ids.device)
+        return ar, ar.clone()
+    return m.idx_a.to(torch.int64), m.idx_b.to(torch.int64)
+
+
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class _View:
+    """One modality as seen by the loss: rows of every rank (compact, rank order)."""
+
+    name: str
+    local: Optional[torch.Tensor]        # this rank's [B_r, D] embedding (None if the rank lacks the modality)
+    src: torch.Tensor                    # matrix holding all ranks' rows
+    ids: torch.Tensor                    # int64 [N_m, 2]
+    rows: Optional[torch.Tensor]         # int32 [N_m]: compact index -> row of src (None = identity)
+    counts: list[int]                    # rows per rank
+
+    def my_range(self, rank: int) -> tuple[int, int]:
+        lo = sum(self.counts[:rank])
+        return lo, lo + self.counts[rank]
+
+
+@dataclass
+class _Pair:
+    spec: Any
+    dirs: list = field(default_factory=list)       # K.Direction, at most [a->b, b->a]
+    roles: list = field(default_factory=list)      # "a" / "b" per direction
+    r_global: int = 0
+    kappa_loss: float = 0.0                        # factor of (sum_a + sum_b) in the loss value
+    own: dict = field(default_factory=dict)        # role -> (p0, p1) contiguous or int64 index tensor
+    exch_off: int = 0                              # offset of this pair's block in the exchange buffer
+    col_perm: dict = field(default_factory=dict)   # role -> int64 tensor (column permutation) or None
+    lse_adj: dict = field(default_factory=dict)    # role -> tensor subtracted from lse_col (local+gwg, uneven)
+    loss_terms: list = field(default_factory=list)
+
+
+def _compose(rows: Optional[torch.Tensor], idx: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if rows is None:
+        return idx
+    if idx is None:
+        return rows
+    return rows[idx.long()].contiguous()
+
+
+def _slice_rows(t: torch.Tensor, p0: int) -> torch.Tensor:
+    return t[p0:] if p0 else t
+
+
+class _Run:
+    """One evaluation of the loss: forward state kept for the backward pass."""
+
+    def __init__(self, owner: "ContrastiveLoss", embeddings, example_ids, logit_scale, pairs):
+        self.o = owner
+        self.embeddings = embeddings
+        self.example_ids = example_ids
+        self.logit_scale = logit_scale
+        self.pair_specs = pairs
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.pairs: list[_Pair] = []
+        self.inputs: list[torch.Tensor] = []
+        self.input_names: list[str] = []
+
+    # ------------------------------------------------------------------ set-up
+    def compute_mode(self) -> int:
+        dts = {t.dtype for t in self.embeddings.values()}
+        if len(dts) > 1:
+            raise ValueError(f"all embeddings must share one dtype, got {sorted(map(str, dts))}")
+        dt = dts.pop()
+        if self.o.compute_dtype is not None:
+            return COMPUTE_BF16 if self.o.compute_dtype == torch.bfloat16 else COMPUTE_F32
+        if dt == torch.bfloat16:
+            return COMPUTE_BF16
+        if dt == torch.float32 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            return COMPUTE_BF16  # the reference's matmul runs in bf16 under Lightning's bf16-mixed
+        return COMPUTE_F32  # fp32, and fp16 (torchmetrics _safe_matmul up-casts fp16 to fp32)
+
+    def build_views(self) -> dict[str, _View]:
+        emb = {k: v for k, v in self.embeddings.items()}
+        key_to_name = {}
+        for key in emb:
+            name = key[: -len("_embedding")] if key.endswith("_embedding") else key
+            if Modalities.has_modality(name):
+                name = Modalities.get_modality(name).name
+            key_to_name[key] = name
+        local = {key_to_name[k]: v for k, v in emb.items()}
+        for name, t in local.items():
+            if t.ndim != 2:
+                raise ValueError(f"embedding of modality {name!r} must be [B, D], got {tuple(t.shape)}")
+            if name not in self.example_ids:
+                raise KeyError(f"example_ids has no entry for modality {name!r}")
+        if self.world == 1:
+            return {n: _View(n, t, t.detach().contiguous(), self.example_ids[n].to(torch.int64), None, [t.shape[0]])
+                    for n, t in local.items()}
+        return self._gather_views(local)
+
+    def _gather_views(self, local: dict[str, torch.Tensor]) -> dict[str, _View]:
+        """Two all-gathers (embedding rows, id rows) instead of the reference's barrier + object gather +
+        per-key shape gather + per-key data gather (contrastive.py:431-578)."""
+        names_all = [m.name for m in Modalities.list_modalities()]
+        for n in local:
+            if n not in names_all:
+                raise ValueError(f"modality {n!r} is not registered")
+        any_t = next(iter(local.values()))
+        dev, dt, d = any_t.device, any_t.dtype, any_t.shape[1]
+        W, rank = self.world, self.rank
+        if self.o.static_shapes:
+            counts = {n: [t.shape[0]] * W for n, t in local.items()}
+        else:
+            header = torch.tensor([local[n].shape[0] if n in local else -1 for n in names_all] + [d], dtype=torch.int64, device=dev)
+            gathered = torch.empty((W, header.numel()), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(gathered, header)
+            table = gathered.tolist()
+            if any(row[-1] != d for row in table):
+                raise ValueError("embedding dimension differs across ranks")
+            counts = {n: [max(table[r][i], 0) for r in range(W)] for i, n in enumerate(names_all)
+                      if any(table[r][i] >= 0 for r in range(W))}
+        names = sorted(counts)  # the reference iterates the sorted key union (contrastive.py:466)
+        bmax = {n: max(counts[n]) for n in names}
+        roff, tot = {}, 0
+        for n in names:
+            roff[n] = tot
+            tot += bmax[n]
+        send_e = torch.zeros((tot, d), dtype=dt, device=dev)
+        send_i = torch.zeros((tot, 2), dtype=torch.int64, device=dev)
+        for n, t in local.items():
+            send_e[roff[n]: roff[n] + t.shape[0]].copy_(t.detach())
+            send_i[roff[n]: roff[n] + t.shape[0]].copy_(self.example_ids[n])
+        all_e = torch.empty((W * tot, d), dtype=dt, device=dev)
+        all_i = torch.empty((W * tot, 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(all_e, send_e)
+        dist.all_gather_into_tensor(all_i, send_i)
+        views = {}
+        for n in names:
+            rows_np = np.concatenate([np.arange(counts[n][r], dtype=np.int32) + (r * tot + roff[n]) for r in range(W)]) \
+                if sum(counts[n]) else np.zeros(0, np.int32)
+            rows = torch.from_numpy(rows_np).to(dev)
+            ids = all_i[rows.long()] if rows.numel() else all_i[:0]
+            views[n] = _View(n, local.get(n), all_e, ids.contiguous(), rows, counts[n])
+        return views
+
+    # ------------------------------------------------------------------ forward
+    def forward(self) -> Optional[torch.Tensor]:
+        o = self.o
+        scale = self.logit_scale
+        K.require_gpu(scale, "logit_scale")
+        self.compute = self.compute_mode()
+        # needs_grad is decided by the caller (autograd.Function.forward runs with grad mode off)
+        self.scale32 = scale.detach().to(torch.float32).reshape(1).contiguous()
+        views = self.build_views()
+        self.views = views
+        W, rank = self.world, self.rank
+        local_mode = o.local_loss and W > 1
+        self.local_mode = local_mode
+        self.d = next(iter(self.embeddings.values())).shape[1]
+        dev = scale.device
+
+        # ---- matching + operand packing per pair
+        local_counts_needed = []
+        for spec in self.pair_specs:
+            ma, mb = (Modalities.get_modality(m).name if Modalities.has_modality(m) else m for m in spec.modalities)
+            if ma not in views or mb not in views:
+                continue  # contrastive.py:266-274 / :303-307
+            va, vb = views[ma], views[mb]
+            mg = K.match_ids(va.ids, vb.ids)
+            if mg.n == 0:
+                continue  # :283-287 / :314-316
+            p = _Pair(spec=spec, r_global=mg.n)
+            p.ma, p.mb, p.mg = ma, mb, mg
+            p.a_g, p.a_gt = K.pack_rows(va.src, _compose(va.rows, mg.idx_a), mg.n, o.l2_normalize, self.compute, self.needs_grad)
+            p.b_g, p.b_gt = K.pack_rows(vb.src, _compose(vb.rows, mg.idx_b), mg.n, o.l2_normalize, self.compute, self.needs_grad)
+            if local_mode:
+                has_local = va.local is not None and vb.local is not None
+                p.ml = K.match_ids(self.example_ids[ma].to(torch.int64), self.example_ids[mb].to(torch.int64)) if has_local \
+                    else K.Match(0, False, None, None)
+                local_counts_needed.append(p)
+            self.pairs.append(p)
+
+        if local_mode and self.pairs:
+            # per-rank row counts of every pair (the reference all-gathers them per pair, contrastive.py:196-206)
+            mine = torch.tensor([p.ml.n for p in self.pairs], dtype=torch.int64, device=dev)
+            allc = torch.empty((W, len(self.pairs)), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(allc, mine)
+            table = allc.tolist()
+            for k, p in enumerate(self.pairs):
+                p.local_sizes = [table[r][k] for r in range(W)]
+
+        dirs_all = []
+        for p in self.pairs:
+            self._build_dirs(p)
+            dirs_all += p.dirs
+        if dirs_all:
+            K.clip_forward(dirs_all, self.d, self.compute, self.scale32)
+
+        if not self.pairs:
+            return None
+        return self._finish_forward(dev)
+
+    def _own_rows(self, view: _View, idx: Optional[torch.Tensor], n: int):
+        """Rows p of the matched list whose `view` row belongs to this rank -> (contiguous?, p0, p1 | index array)."""
+        lo, hi = view.my_range(self.rank)
+        if self.world == 1:
+            return True, 0, n, None
+        if idx is None:  # identity pairing: p == compact index
+            p0, p1 = min(lo, n), min(hi, n)
+            return True, p0, p1, None
+        host = idx.cpu().numpy()
+        sel = np.nonzero((host >= lo) & (host < hi))[0]
+        if sel.size == 0:
+            return True, 0, 0, None
+        if sel[-1] - sel[0] + 1 == sel.size:
+            return True, int(sel[0]), int(sel[-1]) + 1, None
+        return False, 0, 0, sel
+
+    def _build_dirs(self, p: _Pair) -> None:
+        o, W, rank = self.o, self.world, self.rank
+        va, vb = self.views[p.ma], self.views[p.mb]
+        mg, R = p.mg, p.r_global
+        w = float(p.spec.weight)
+        dev = p.a_g.device
+        if not self.local_mode:
+            kg = w / (2.0 * R)
+            p.kappa_loss = kg
+            for role, view, idx, xg, yg, ygt in (("a", va, mg.idx_a, p.a_g, p.b_g, p.b_gt), ("b", vb, mg.idx_b, p.b_g, p.a_g, p.a_gt)):
+                contiguous, p0, p1, sel = self._own_rows(view, idx, R)
+                lo, _ = view.my_range(rank)
+                if contiguous:
+                    r = p1 - p0
+                    p.own[role] = (p0, p1)
+                    if r == 0:
+                        continue
+                    x, y, yt, label_off = _slice_rows(xg, p0), yg, ygt, p0
+                    p.col_perm[role] = None
+                    dx_rows = None if idx is None else ((idx[p0:p1] - lo).to(torch.int32) if W > 1 else idx[p0:p1])
+                else:  # owned rows scattered over the matched list: put their partners first in the column order
+                    r = sel.size
+                    rest = np.setdiff1d(np.arange(R), sel, assume_unique=True)
+                    perm = torch.from_numpy(np.concatenate([sel, rest])).to(dev)
+                    sel_t = torch.from_numpy(sel).to(dev)
+                    p.own[role] = sel_t
+                    p.col_perm[role] = perm
+                    other_view, other_idx = (vb, mg.idx_b) if role == "a" else (va, mg.idx_a)
+                    x, _ = K.pack_rows(view.src, _compose(view.rows, idx[sel_t].contiguous()), r, o.l2_normalize, self.compute, False)
+                    y, yt = K.pack_rows(other_view.src, _compose(other_view.rows, other_idx[perm].contiguous()), R, o.l2_normalize,
+                                        self.compute, self.needs_grad)
+                    label_off = 0
+                    dx_rows = (idx[sel_t] - lo).to(torch.int32).contiguous()
+                dr = K.Direction(x=x, y=y, y_t=yt, r=r, c=R, label_off=label_off,
+                                 kappa=kg * (W if (o.gather_with_grad and W > 1) else 1.0), ds_kappa=kg)
+                if role == "b":
+                    dr.s_row = dr.s_col = dr.s_diag = 0.0  # the b->a tiles are the transposed a->b tiles
+                dr.dx_rows = dx_rows
+                p.dirs.append(dr)
+                p.roles.append(role)
+        else:
+            ml = p.ml
+            sizes = p.local_sizes
+            offs = [0]
+            for s in sizes:
+                offs.append(offs[-1] + s)
+            p.offs = offs
+            Rl = ml.n
+            p.kappa_loss = w / (2.0 * Rl) if Rl else 0.0
+            if Rl == 0:
+                return
+            kl = w / (2.0 * Rl)
+            reuse = ml.identity and mg.identity and va.my_range(rank)[0] == offs[rank] == vb.my_range(rank)[0] and offs[rank] + Rl <= R
+            for role, view, lidx, xg, yg, ygt in (("a", va, ml.idx_a, p.a_g, p.b_g, p.b_gt), ("b", vb, ml.idx_b, p.b_g, p.a_g, p.a_gt)):
+                if reuse:
+                    x = _slice_rows(xg, offs[rank])
+                else:
+                    x, _ = K.pack_rows(view.local, lidx, Rl, o.l2_normalize, self.compute, False)
+                dr = K.Direction(x=x, y=yg, y_t=ygt, r=Rl, c=R, label_off=offs[rank], kappa=kl, ds_kappa=kl)
+                dr.s_row, dr.s_col, dr.s_diag = 1.0, 0.0, 1.0
+                if o.gather_with_grad:
+                    dr.c_row, dr.c_col, dr.c_diag = 1.0, 1.0, 2.0
+                    if any(s != Rl for s in sizes if s):  # uneven means: fold kappa_r'/kappa_r into the column LSEs
+                        ratio = torch.cat([torch.full((s,), math.log(Rl / s) if s else 0.0, dtype=torch.float32) for s in sizes]).to(dev)
+                        p.lse_adj[role] = ratio
+                else:
+                    dr.c_row, dr.c_col, dr.c_diag = 1.0, 0.0, 1.0
+                dr.dx_rows = lidx
+                p.own[role] = (offs[rank], offs[rank] + Rl)
+                p.col_perm[role] = None
+                p.dirs.append(dr)
+                p.roles.append(role)
+
+    def _finish_forward(self, dev) -> torch.Tensor:
+        o, W = self.o, self.world
+        exchange_lse = W > 1 and self.needs_grad and (not self.local_mode or o.gather_with_grad)
+        exchange_sum = W > 1 and not self.local_mode
+        terms, weights = [], []
+        if exchange_lse or exchange_sum:
+            size = 0
+            for p in self.pairs:
+                p.exch_off = size
+                size += 2 * p.r_global + 2
+            buf = torch.zeros(size, dtype=torch.float32, device=dev)
+            for p in self.pairs:
+                R = p.r_global
+                for dr, role in zip(p.dirs, p.roles):
+                    base = p.exch_off + (0 if role == "a" else R)
+                    own = p.own[role]
+                    if isinstance(own, tuple):
+                        buf[base + own[0]: base + own[1]].copy_(dr.lse)
+                    else:
+                        buf[base: base + R].index_copy_(0, own, dr.lse)
+                    buf[p.exch_off + 2 * R + (0 if role == "a" else 1)].copy_(dr.loss_sum[0])
+            dist.all_reduce(buf)
+            self.exch = buf
+            for p in self.pairs:
+                R = p.r_global
+                p.lse_global = {"a": buf[p.exch_off: p.exch_off + R], "b": buf[p.exch_off + R: p.exch_off + 2 * R]}
+                if exchange_sum:
+                    terms += [buf[p.exch_off + 2 * R: p.exch_off + 2 * R + 1], buf[p.exch_off + 2 * R + 1: p.exch_off + 2 * R + 2]]
+                    weights += [p.kappa_loss, p.kappa_loss]
+        if not exchange_sum:
+            for p in self.pairs:
+                for dr in p.dirs:
+                    terms.append(dr.loss_sum)
+                    weights.append(p.kappa_loss)
+        if W == 1:
+            for p in self.pairs:
+                by_role = dict(zip(p.roles, p.dirs))
+                p.lse_global = {r: d.lse for r, d in by_role.items()}
+        if not terms:  # this rank owns no rows (e.g. it lacks a modality): graph-attached zero
+            return torch.zeros((), dtype=torch.float32, device=dev)
+        out = None
+        for i0 in range(0, len(terms), 2 * K.MAX_DIRS_PER_CALL):
+            part = K.loss_combine(terms[i0:i0 + 2 * K.MAX_DIRS_PER_CALL], weights[i0:i0 + 2 * K.MAX_DIRS_PER_CALL])
+            out = part if out is None else out + part
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, grad_out: torch.Tensor):
+        o, W = self.o, self.world
+        dev = self.scale32.device
+        upstream = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+        key_of = {}
+        for key in self.embeddings:
+            name = key[: -len("_embedding")] if key.endswith("_embedding") else key
+            name = Modalities.get_modality(name).name if Modalities.has_modality(name) else name
+            key_of[name] = key
+        # how many directions write each modality's gradient
+        writers: dict[str, int] = {}
+        for p in self.pairs:
+            for role in p.roles:
+                n = p.ma if role == "a" else p.mb
+                writers[n] = writers.get(n, 0) + 1
+        grads: dict[str, torch.Tensor] = {}
+        accumulate: dict[str, bool] = {}
+        for p in self.pairs:
+            for role in p.roles:
+                n = p.ma if role == "a" else p.mb
+                m = p.ml if self.local_mode else p.mg
+                rep = (m.repeats_a if role == "a" else m.repeats_b) if not m.identity else False
+                accumulate[n] = accumulate.get(n, False) or rep or writers[n] > 1
+        for n, acc in accumulate.items():
+            t = self.embeddings[key_of[n]]
+            grads[n] = torch.zeros(t.shape, dtype=_ACCUM_DTYPE if acc else t.dtype, device=dev)
+        dirs_all = []
+        for p in self.pairs:
+            for dr, role in zip(p.dirs, p.roles):
+                n = p.ma if role == "a" else p.mb
+                other = "b" if role == "a" else "a"
+                if dr.c_col != 0.0 or dr.s_col != 0.0:
+                    lc = p.lse_global[other]
+                    if role in p.lse_adj:
+                        lc = lc - p.lse_adj[role]
+                    if p.col_perm.get(role) is not None:
+                        lc = lc[p.col_perm[role]]
+                    dr.lse_col = lc.contiguous()
+                dr.dx = grads[n]
+                dr.dx_accumulate = accumulate[n]
+                if o.l2_normalize:
+                    dr.normalize = True
+                    dr.src = self.embeddings[key_of[n]].detach().contiguous()
+                dirs_all.append(dr)
+        dscale = torch.zeros(1, dtype=torch.float32, device=dev)
+        if dirs_all:
+            if o.l2_normalize and any(d.dx_accumulate for d in dirs_all):
+                # the normalise-backward of an accumulating scatter needs the summed upstream gradient first:
+                # run un-normalised, then apply the projection once per row.
+                for d_ in dirs_all:
+                    d_.normalize = False
+                K.clip_backward(dirs_all, self.d, self.compute, self.scale32, upstream, dscale)
+                for n in grads:
+                    src = self.embeddings[key_of[n]].detach()
+                    g = grads[n]
+                    y, inv = K.l2norm_fwd(src.float())
+                    # rows were packed normalised, so G@Y is d/dy; map to d/dx
+                    grads[n] = K.l2norm_bwd(src.float(), g.float(), inv)
+            else:
+                K.clip_backward(dirs_all, self.d, self.compute, self.scale32, upstream, dscale)
+        if W > 1 and not self.local_mode:
+            dist.all_reduce(dscale)  # every rank returns the full d loss / d scale (reference: identical graphs)
+        out = []
+        for key, t in self.embeddings.items():
+            name = next(n for n, k in key_of.items() if k == key)
+            g = grads.get(name)
+            if g is None:
+                out.append(torch.zeros_like(t) if t.requires_grad else None)
+            else:
+                out.append(g if g.dtype == t.dtype else g.to(t.dtype))
+        ds = dscale.reshape(self.logit_scale.shape).to(self.logit_scale.dtype) if self.logit_scale.requires_grad else None
+        return ds, out
+
+
+class _ContrastiveFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, run: _Run, logit_scale: torch.Tensor, *embs: torch.Tensor):
+        loss = run.forward()
+        ctx.run = run
+        if loss is None:  # no pair matched; the caller returns the reference's graph-less constant
+            return torch.zeros((), device=logit_scale.device)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ds, gs = ctx.run.backward(grad_out)
+        return (None, ds, *gs)
+
+
+@store(group="modules/losses", name="ContrastiveLossHIP")
+class ContrastiveLoss(nn.Module):
+    """Contrastive (CLIP-style InfoNCE) loss on MI355X; same constructor and call signature as
+    ``mmlearn.modules.losses.ContrastiveLoss`` (contrastive.py:19-57).
+
+    Parameters
+    ----------
+    l2_normalize, local_loss, gather_with_grad, modality_alignment, cache_labels
+        As in the reference.  ``cache_labels`` is accepted and ignored (labels are never
+        materialised: label(i) = offset + i inside the kernels).  ``modality_alignment=True`` is not
+        implemented yet and raises.
+    compute_dtype : torch.dtype, optional
+        Force the arithmetic of the similarity products (``torch.bfloat16`` -> bf16 MFMA,
+        ``torch.float32`` -> exact-f32 MFMA).  Default: bf16 for bf16 inputs or under bf16 autocast,
+        f32 otherwise.
+    static_shapes : bool
+        Multi-rank only: promise that every rank holds the same modalities with the same batch
+        size, which removes the per-step header exchange (one collective + host sync).
+    """
+
+    def __init__(self, l2_normalize: bool = False, local_loss: bool = False, gather_with_grad: bool = False,
+                 modality_alignment: bool = False, cache_labels: bool = False, compute_dtype: Optional[torch.dtype] = None,
+                 static_shapes: bool = False):
+        super().__init__()
+        if modality_alignment:
+            raise NotImplementedError(
+                "modality_alignment=True (contrastive.py:344-413) is not implemented in mmlearn_amd yet; "
+                "it is off by default in the reference.")
+        if compute_dtype not in (None, torch.bfloat16, torch.float32):
+            raise ValueError("compute_dtype must be None, torch.bfloat16 or torch.float32")
+        self.l2_normalize = l2_normalize
+        self.local_loss = local_loss
+        self.gather_with_grad = gather_with_grad
+        self.modality_alignment = modality_alignment
+        self.cache_labels = cache_labels
+        self.compute_dtype = compute_dtype
+        self.static_shapes = static_shapes
+
+    def forward(self, embeddings: dict[str, torch.Tensor], example_ids: dict[str, torch.Tensor], logit_scale: torch.Tensor,
+                modality_loss_pairs: Sequence[Any]) -> torch.Tensor:
+        if not embeddings:
+            raise ValueError("embeddings is empty")
+        for t in embeddings.values():
+            K.require_gpu(t, "embedding")
+        if not isinstance(logit_scale, torch.Tensor):
+            raise TypeError("logit_scale must be a 0-dim tensor")
+        run = _Run(self, embeddings, example_ids, logit_scale, list(modality_loss_pairs))
+        first = next(iter(embeddings.values()))
+        run.needs_grad = torch.is_grad_enabled() and (logit_scale.requires_grad or any(t.requires_grad for t in embeddings.values()))
+        if not run.needs_grad:
+            with torch.no_grad():
+                loss = run.forward()
+        else:
+            loss = _ContrastiveFn.apply(run, logit_scale, *embeddings.values())
+            if not run.pairs:
+                loss = None
+        if loss is None or not run.pairs:
+            # no loss to compute (e.g. no paired data in batch): constant zero, contrastive.py:151-158
+            return torch.tensor(0.0, device=logit_scale.device, dtype=first.dtype)
+        # CE runs in f32 under autocast; without it the reference's loss has the embeddings' dtype
+        if first.dtype != torch.float32 and not torch.is_autocast_enabled():
+            loss = loss.to(first.dtype)
+        return loss

@@ -1,0 +1,90 @@
+"""CPU-side checks of the boundary: the C-ABI library loads here (no GPU) and exports every symbol
+that include/mmlearn_hip.h declares; the product refuses CPU tensors."""
+
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from mmlearn_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mmlearn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mmk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(built):
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    out = subprocess.run(["nm", "-D", "--defined-only", built.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (mmk_[a-z0-9_]+)", out))
+    missing = [s for s in declared if s not in exported]
+    assert not missing, missing
+    # the ctypes stub binds exactly the declared set
+    assert sorted(built.EXPORTED_SYMBOLS) == declared
+
+
+def test_library_loads_without_gpu(built):
+    lib = built.lib()
+    assert lib.mmk_abi_version() == 1
+    assert lib.mmk_kernel_name(3) == b"sim_stats"
+    for k, name in enumerate(built.KERNEL_NAMES):
+        assert lib.mmk_kernel_name(k).decode() == name
+
+
+def test_struct_layout_matches_header(built):
+    # sizeof(mmk_clip_dir) as laid out by the C compiler vs the ctypes mirror
+    src = '#include <stdio.h>\n#include "mmlearn_hip.h"\nint main(){printf("%zu %zu", sizeof(mmk_clip_dir), sizeof(mmk_ema_entry));return 0;}'
+    exe = "/tmp/_mmk_sizeof"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src, text=True, check=True)
+    a, b = map(int, subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split())
+    import ctypes
+
+    assert ctypes.sizeof(built.ClipDir) == a
+    assert ctypes.sizeof(built.EmaEntry) == b
+
+
+def test_no_cpu_fallback():
+    from mmlearn_amd import ContrastiveLoss, LossPairSpec, find_matching_indices
+
+    a = torch.randn(4, 8)
+    ids = torch.zeros(4, 2, dtype=torch.long)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ContrastiveLoss()({"rgb_embedding": a, "text_embedding": a}, {"rgb": ids, "text": ids}, torch.tensor(1.0), [LossPairSpec(("rgb", "text"))])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        find_matching_indices(ids, ids)
+    with pytest.raises(TypeError):
+        find_matching_indices([(0, 0)], ids)
+    with pytest.raises(ValueError):
+        find_matching_indices(torch.zeros(3), ids)
+
+
+def test_product_does_not_import_oracle():
+    import ast
+
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "mmlearn_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                tree = ast.parse(open(os.path.join(dirpath, f)).read())
+                for node in ast.walk(tree):
+                    names = []
+                    if isinstance(node, ast.Import):
+                        names = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom) and node.module:
+                        names = [node.module]
+                    bad += [(f, n) for n in names if n.split(".")[0] == "oracle"]
+    assert not bad, bad

@@ -1,0 +1,202 @@
+"""GPU parity tests of the contrastive path: HIP kernels (through the C ABI) vs the golden vectors
+produced by the reference and vs the numpy oracle on seeded inputs.
+
+Tolerances (BASELINE.json north_star): 1e-3 for f32 arithmetic, 1e-2 for bf16, on the loss and its
+gradients.  Gradients are compared relative to the largest reference gradient entry.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden, parse_flags, parse_pairs
+from oracle import clip_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"float32": 1e-3, "float16": 1e-3, "bfloat16": 1e-2}
+TDT = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16}
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _run_hip(embs, ids, scale, pairs, dtype="float32", **flags):
+    from mmlearn_amd import ContrastiveLoss, LossPairSpec
+
+    dev = _dev()
+    e = {f"{k}_embedding": torch.tensor(np.asarray(v), device=dev).to(TDT[dtype]).requires_grad_(True) for k, v in embs.items()}
+    i = {k: torch.tensor(np.asarray(v), device=dev, dtype=torch.int64) for k, v in ids.items()}
+    s = torch.tensor(float(scale), device=dev, requires_grad=True)
+    loss = ContrastiveLoss(**flags)(e, i, s, [LossPairSpec(modalities=p[0], weight=p[1]) for p in pairs])
+    out = {"loss": float(loss.detach().float().cpu()), "requires_grad": loss.requires_grad, "dtype": loss.dtype}
+    if loss.requires_grad:
+        loss.float().backward()
+        out["grads"] = {k[: -len("_embedding")]: (v.grad.float().cpu().numpy() if v.grad is not None else np.zeros(v.shape, np.float32))
+                        for k, v in e.items()}
+        out["dscale"] = float(s.grad.cpu()) if s.grad is not None else 0.0
+    return out
+
+
+def _check(res, ref_loss, ref_grads, ref_ds, tol, tag=""):
+    assert abs(res["loss"] - ref_loss) <= tol * max(1.0, abs(ref_loss)), (tag, res["loss"], ref_loss)
+    for m, g in ref_grads.items():
+        err = np.abs(res["grads"][m] - g).max()
+        assert err <= tol * max(np.abs(g).max(), 1e-6), (tag, m, err, np.abs(g).max())
+    assert abs(res["dscale"] - ref_ds) <= tol * max(1.0, abs(ref_ds)), (tag, res["dscale"], ref_ds)
+
+
+CLIP = Golden("g1_g2_clip")
+
+
+@pytest.mark.parametrize("name", CLIP.names())
+def test_golden_clip(name):
+    c = CLIP[name]
+    dtype = str(c["dtype"])
+    mods = sorted(k[3:] for k in c if k.startswith("in_"))
+    embs = {m: c[f"in_{m}"] for m in mods}
+    ids = {m: c[f"ids_{m}"] for m in mods}
+    flags = parse_flags(c["flags"])
+    res = _run_hip(embs, ids, float(c["scale"]), parse_pairs(c["pairs"]), dtype=dtype, **flags)
+    assert res["requires_grad"] == bool(c["out_loss_requires_grad"])
+    assert res["dtype"] == TDT[dtype]
+    if not res["requires_grad"]:
+        assert res["loss"] == 0.0
+        return
+    # the reference ran in `dtype`; compare against the f64 oracle on the same inputs (tighter) and
+    # against the reference's own output
+    orc = co.contrastive_loss(embs, ids, float(c["scale"]), parse_pairs(c["pairs"]), l2norm=flags.get("l2_normalize", False))
+    _check(res, orc["loss"], orc["grads"], orc["dscale"], TOL[dtype], name + ":oracle")
+    ref_tol = TOL[dtype] if dtype == "float32" else 3e-2
+    _check(res, float(c["out_loss"]), {m: c[f"out_grad_{m}"] for m in mods}, float(c["out_grad_scale"]), ref_tol, name + ":golden")
+
+
+@pytest.mark.parametrize("n,d,dtype", [(1024, 512, "bfloat16"), (1024, 512, "float32"), (333, 200, "float32"), (777, 136, "bfloat16"),
+                                       (2048, 512, "bfloat16")])
+def test_seeded_vs_oracle(n, d, dtype):
+    g = np.random.default_rng(n + d)
+    a = g.standard_normal((n, d)).astype(np.float32)
+    b = g.standard_normal((n, d)).astype(np.float32)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    b = 0.6 * b + 0.4 * a  # correlated positives
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    if dtype == "bfloat16":  # oracle sees the rounded inputs
+        a = torch.tensor(a).bfloat16().float().numpy()
+        b = torch.tensor(b).bfloat16().float().numpy()
+    ids = np.stack([np.zeros(n, np.int64), np.arange(n)], 1)
+    pairs = [(("rgb", "text"), 1.0)]
+    res = _run_hip({"rgb": a, "text": b}, {"rgb": ids, "text": ids}, 1 / 0.07, pairs, dtype=dtype)
+    orc = co.contrastive_loss({"rgb": a, "text": b}, {"rgb": ids, "text": ids}, 1 / 0.07, pairs)
+    _check(res, orc["loss"], orc["grads"], orc["dscale"], TOL[dtype], f"{n}x{d}:{dtype}")
+
+
+def test_three_modalities_shared_rows_and_weights():
+    g = np.random.default_rng(5)
+    embs = {m: (lambda x: x / np.linalg.norm(x, axis=1, keepdims=True))(g.standard_normal((n, 96)).astype(np.float32))
+            for m, n in (("rgb", 300), ("text", 300), ("audio", 180))}
+    ids = {"rgb": np.stack([np.zeros(300, np.int64), np.arange(300)], 1),
+           "text": np.stack([np.zeros(300, np.int64), g.permutation(300)], 1),
+           "audio": np.stack([np.zeros(180, np.int64), g.choice(400, 180, replace=False)], 1)}
+    pairs = [(("rgb", "text"), 1.0), (("rgb", "audio"), 0.5), (("text", "audio"), 0.25)]
+    res = _run_hip(embs, ids, 20.0, pairs)
+    orc = co.contrastive_loss(embs, ids, 20.0, pairs)
+    _check(res, orc["loss"], orc["grads"], orc["dscale"], 1e-3, "n3")
+
+
+def test_full_size_properties():
+    """BASELINE config-3-equivalent size (N = 8192, D = 512, bf16): properties that need no oracle run.
+
+    * perfectly aligned one-hot-like embeddings -> loss ~ log-sum bound known in closed form
+    * permuting the batch leaves the loss unchanged
+    * gradient rows sum: sum_i dL/dA_i . A_i + sum_j dL/dB_j . B_j = 2 * s * dL/ds (Euler, S is bilinear)
+    """
+    from mmlearn_amd import ContrastiveLoss, LossPairSpec
+
+    dev = _dev()
+    n, d, s0 = 8192, 512, 1 / 0.07
+    torch.manual_seed(0)
+    a = torch.nn.functional.normalize(torch.randn(n, d, device=dev), dim=-1).bfloat16()
+    b = torch.nn.functional.normalize(torch.randn(n, d, device=dev), dim=-1).bfloat16()
+    ids = torch.stack([torch.zeros(n, dtype=torch.long, device=dev), torch.arange(n, device=dev)], 1)
+    pairs = [LossPairSpec(("rgb", "text"))]
+    fn = ContrastiveLoss()
+
+    def run(a_, b_, ia, ib):
+        a_ = a_.clone().requires_grad_(True)
+        b_ = b_.clone().requires_grad_(True)
+        s = torch.tensor(s0, device=dev, requires_grad=True)
+        loss = fn({"rgb_embedding": a_, "text_embedding": b_}, {"rgb": ia, "text": ib}, s, pairs)
+        loss.float().backward()
+        return loss.float().item(), a_.grad.float(), b_.grad.float(), s.grad.item()
+
+    l0, ga, gb, gs = run(a, b, ids, ids)
+    perm = torch.randperm(n, device=dev)
+    l1, ga1, _, gs1 = run(a[perm], b[perm], ids[perm], ids[perm])
+    assert abs(l0 - l1) <= 1e-2 * abs(l0)
+    assert abs(gs - gs1) <= 1e-2 * max(1.0, abs(gs))
+    assert (ga[perm] - ga1).abs().max() <= 1e-2 * ga.abs().max()
+    euler = ((ga * a.float()).sum() + (gb * b.float()).sum()).item()
+    assert abs(euler - 2 * s0 * gs) <= 2e-2 * max(1.0, abs(2 * s0 * gs)), (euler, 2 * s0 * gs)
+    # random embeddings at this N: loss close to log(N) + small correction, never below 0
+    assert 0.0 < l0 < np.log(n) + 5.0
+    # a == b (identical modalities) -> symmetric problem, the two gradients coincide
+    l2, ga2, gb2, _ = run(a, a, ids, ids)
+    assert (ga2 - gb2).abs().max() <= 1e-2 * ga2.abs().max()
+    assert l2 < l0
+
+
+def test_no_grad_and_eval_paths():
+    from mmlearn_amd import ContrastiveLoss, LossPairSpec
+
+    dev = _dev()
+    a = torch.nn.functional.normalize(torch.randn(64, 32, device=dev), dim=-1)
+    ids = torch.stack([torch.zeros(64, dtype=torch.long, device=dev), torch.arange(64, device=dev)], 1)
+    s = torch.tensor(10.0, device=dev)
+    with torch.no_grad():
+        l = ContrastiveLoss()({"rgb_embedding": a, "text_embedding": a}, {"rgb": ids, "text": ids}, s, [LossPairSpec(("rgb", "text"))])
+    assert not l.requires_grad and torch.isfinite(l)
+    orc = co.contrastive_loss({"rgb": a.cpu().numpy(), "text": a.cpu().numpy()}, {"rgb": ids.cpu().numpy(), "text": ids.cpu().numpy()}, 10.0,
+                              [(("rgb", "text"), 1.0)])
+    assert abs(l.item() - orc["loss"]) < 1e-3
+
+
+def test_cpu_tensors_raise():
+    from mmlearn_amd import ContrastiveLoss, LossPairSpec
+
+    a = torch.randn(4, 8)
+    ids = torch.zeros(4, 2, dtype=torch.long)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ContrastiveLoss()({"rgb_embedding": a, "text_embedding": a}, {"rgb": ids, "text": ids}, torch.tensor(1.0), [LossPairSpec(("rgb", "text"))])
+
+
+MATCH = Golden("g4_match")
+
+
+@pytest.mark.parametrize("name", MATCH.names())
+def test_golden_match(name):
+    from mmlearn_amd import find_matching_indices
+
+    c = MATCH[name]
+    dev = _dev()
+    ia, ib = find_matching_indices(torch.tensor(c["a"].reshape(-1, 2), device=dev), torch.tensor(c["b"].reshape(-1, 2), device=dev))
+    np.testing.assert_array_equal(ia.cpu().numpy(), c["ia"])
+    np.testing.assert_array_equal(ib.cpu().numpy(), c["ib"])
+
+
+def test_match_large_and_errors():
+    from mmlearn_amd import find_matching_indices
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    a = torch.stack([torch.randint(0, 2, (5000,), generator=g), torch.randint(0, 3000, (5000,), generator=g)], 1)
+    b = torch.stack([torch.randint(0, 2, (4097,), generator=g), torch.randint(0, 3000, (4097,), generator=g)], 1)
+    ia, ib = find_matching_indices(a.to(dev), b.to(dev))
+    ra, rb = co.find_matching_indices(a.numpy(), b.numpy())
+    np.testing.assert_array_equal(ia.cpu().numpy(), ra)
+    np.testing.assert_array_equal(ib.cpu().numpy(), rb)
+    with pytest.raises(TypeError):
+        find_matching_indices([(0, 0)], b.to(dev))
+    with pytest.raises(ValueError):
+        find_matching_indices(torch.zeros(3, device=dev), b.to(dev))

@@ -1,0 +1,257 @@
+"""Headline benchmark: image-text pairs/s of one contrastive-pretraining step.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1] per GPU; configs[2] at N = 8): CLIP ViT-B/16 image encoder
+(HF ``CLIPVisionModelWithProjection`` from config, projection 512) + BERT-base text encoder (HF
+``BertModel`` from config + Linear(768, 512)), random-init weights, synthetic batches
+(``rand(B,3,224,224)`` pixels, ``randint(0, 30522, (B,77))`` tokens, fully paired ids), bf16 autocast,
+per-GPU batch 1024, AdamW.  One step = encoders forward -> HIP L2-normalise -> HIP contrastive loss
+(global-batch negatives via the packed all-gather when N > 1) -> backward -> optimizer step.
+
+The JSON line carries, besides the driver contract:
+  roofline     -- the dominant MFMA kernel of the loss path, timed with HIP events on its launch stream
+                  inside the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s);
+  cpu_baseline -- the same step (same model, torch eager ops, oracle/eager_torch loss = the reference's op
+                  sequence) on the host cores for a bounded sample (rank 0, N = 1 only).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from functools import partial
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+class VisionEncoder(nn.Module):
+    """HF CLIP ViT-B/16 with projection; mmlearn encoder contract: forward(dict) -> (embedding,)"""
+
+    def __init__(self, small: bool = False):
+        super().__init__()
+        from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+
+        cfg = CLIPVisionConfig(patch_size=16, image_size=224, projection_dim=512, hidden_size=768, intermediate_size=3072,
+                               num_hidden_layers=12, num_attention_heads=12)
+        if small:
+            cfg = CLIPVisionConfig(patch_size=32, image_size=224, projection_dim=512, hidden_size=128, intermediate_size=256,
+                                   num_hidden_layers=2, num_attention_heads=2)
+        self.model = CLIPVisionModelWithProjection(cfg)
+
+    def forward(self, inputs):
+        return (self.model(pixel_values=inputs["rgb"]).image_embeds,)
+
+
+class TextEncoder(nn.Module):
+    """HF BERT-base (no pooler) + CLS token + Linear(768, 512)."""
+
+    def __init__(self, small: bool = False):
+        super().__init__()
+        from transformers import BertConfig, BertModel
+
+        cfg = BertConfig()
+        if small:
+            cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256)
+        self.model = BertModel(cfg, add_pooling_layer=False)
+        self.proj = nn.Linear(cfg.hidden_size, 512, bias=False)
+
+    def forward(self, inputs):
+        h = self.model(input_ids=inputs["text"]).last_hidden_state[:, 0]
+        return (self.proj(h),)
+
+
+class _Step(nn.Module):
+    """DDP wraps forward(); route it to training_step like Lightning's strategy wrapper does."""
+
+    def __init__(self, task):
+        super().__init__()
+        self.task = task
+
+    def forward(self, batch):
+        return self.task.training_step(batch, 0)
+
+
+def synthetic_batch(b: int, rank: int, device):
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    ids = torch.stack([torch.zeros(b, dtype=torch.long), torch.arange(rank * b, (rank + 1) * b)], 1)
+    return {
+        "rgb": torch.rand(b, 3, 224, 224, generator=g).to(device),
+        "text": torch.randint(0, 30522, (b, 77), generator=g).to(device),
+        "example_ids": {"rgb": ids.to(device), "text": ids.to(device)},
+    }
+
+
+def build_task(loss, small: bool):
+    from mmlearn_amd.tasks.contrastive_pretraining import ContrastivePretraining
+
+    torch.manual_seed(0)
+    return ContrastivePretraining(
+        encoders={"rgb": VisionEncoder(small), "text": TextEncoder(small)},
+        loss=loss,
+        optimizer=partial(torch.optim.AdamW, lr=1e-4, weight_decay=0.1),
+        compute_validation_loss=False,
+        compute_test_loss=False,
+    )
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """The reference's step on the host cores: same encoders (f32), eager torch ops, the reference's loss op
+    sequence (oracle/eager_torch.py).  Bounded sample: batches of 16 pairs until the budget is spent."""
+    from oracle.eager_torch import EagerContrastiveLoss
+
+    import mmlearn_amd.tasks.contrastive_pretraining as cp
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    b = 16
+    saved = cp.l2_normalize
+    cp.l2_normalize = lambda x: torch.nn.functional.normalize(x, p=2, dim=-1)  # the reference's K1 on CPU (baseline leg only)
+    try:
+        task = build_task(EagerContrastiveLoss(), small=False)
+        opt = task.configure_optimizers()
+        batch = synthetic_batch(b, 0, torch.device("cpu"))
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = task.training_step(batch, 0)
+            loss.backward()
+            opt.step()
+
+        step()  # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while n < 1 or (time.perf_counter() - t0) < seconds_budget and n < 50:
+            step()
+            n += 1
+        dt = time.perf_counter() - t0
+    finally:
+        cp.l2_normalize = saved
+    return {"value": round(b * n / dt, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of {b} pairs (ViT-B/16 + BERT-base, f32, torch eager on host cores, reference loss op sequence)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch (BASELINE: 1024)")
+    ap.add_argument("--small", action="store_true", help="tiny encoders (debug only; invalid as a result)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mmlearn_amd import ContrastiveLoss, _lib
+
+    _lib.check(_lib.lib().mmk_device_check())
+    task = build_task(ContrastiveLoss(static_shapes=True), args.small).to(dev)
+    opt = task.configure_optimizers()
+    stepper = _Step(task)
+    if world > 1:
+        stepper = nn.parallel.DistributedDataParallel(stepper, device_ids=[local_rank], gradient_as_bucket_view=True)
+    batch = synthetic_batch(args.batch, rank, dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = stepper(batch)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+    final_loss = float(loss.detach().float().item())
+    if rank == 0:
+        print(f"[bench] peak HBM allocated {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", file=sys.stderr)
+
+    if rank == 0:
+        n_rows, n_cols, d = args.batch, args.batch * world, 512
+        # algorithmic FLOPs per launch (DESIGN.md "Kernels"): every launch covers both directions of the pair
+        algo = {"sim_stats": 2 * 2.0 * n_rows * n_cols * d,   # S_r and T_r row blocks (8RCD/4 per GEMM, two of them)
+                "grad_gemm": 2 * 2.0 * n_rows * n_cols * d,   # dA_r = G_r B_all, dB_r = H_r A_all
+                "sim_grad": 0.0}                               # tile recompute: implementation cost, not counted
+        if world == 1:
+            algo["sim_stats"] = 2.0 * n_rows * n_cols * d      # one [N,N,D] product is algorithmically enough
+        mfma = {k: v for k, v in prof.items() if k in algo}
+        dom = max(mfma, key=lambda k: mfma[k][1]) if mfma else None
+        roofline = None
+        if dom is not None:
+            # report the dominant kernel with counted work; the recompute kernel has no algorithmic FLOPs of its own
+            rep = dom if algo[dom] > 0 else max((k for k in mfma if algo[k] > 0), key=lambda k: mfma[k][1])
+            cnt, ms = mfma[rep]
+            avg_s = ms / cnt * 1e-3
+            achieved = algo[rep] / avg_s / 1e12
+            roofline = {"bound": "mfma", "kernel": rep, "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                        "launches": cnt, "dominant_by_time": dom,
+                        "loss_path_kernel_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in prof.items()}}
+        out = {
+            "metric": "image-text pairs/s (whole node), ViT-B/16+BERT-base contrastive step",
+            "value": round(args.batch * world * args.steps / dt, 2),
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: CLIP ViT-B/16 + BERT-base, D=512 projection, bf16 autocast, "
+                                   f"per-GPU batch {args.batch}, {'local' if world == 1 else 'global-batch (all-gather)'} negatives"
+                                   + (" [DEBUG small encoders]" if args.small else ""),
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": "mmlearn_amd.ContrastiveLoss (HIP)",
+                       "final_loss": round(final_loss, 4)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

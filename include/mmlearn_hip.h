@@ -57,14 +57,15 @@ const char* mmk_kernel_name(int kernel_id);
  * Replaces find_matching_indices (mmlearn/datasets/core/example.py:101-166):
  * all (i, j) with ids_a[i] == ids_b[j] (both int64 columns), in row-major
  * (torch.where) order; duplicates give several pairs.
- *   row_count : int32[n_a + n_b + 2] workspace (per-row match counts of a and of b, then exclusive offsets)
+ *   workspace : int32[mmk_match_workspace_ints(n_a, n_b)]
  *   status    : int32[4]  -> {total matches R, 1 if the pairing is the identity
  *               (R == n_a == n_b and idx_a[p] == idx_b[p] == p), 1 if idx_a has
  *               repeated entries, 1 if idx_b has repeated entries}
  *   idx_a/idx_b : int32[capacity]; pairs beyond `capacity` are dropped (status[0]
  *               still holds the true total, so the caller can detect overflow).
  */
-int mmk_match_ids(const int64_t* ids_a, int n_a, const int64_t* ids_b, int n_b, int32_t* row_count,
+int mmk_match_workspace_ints(int n_a, int n_b);
+int mmk_match_ids(const int64_t* ids_a, int n_a, const int64_t* ids_b, int n_b, int32_t* workspace,
                   int32_t* idx_a, int32_t* idx_b, int capacity, int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------ packing
@@ -92,10 +93,10 @@ typedef struct {
   int32_t c;          /* columns                                            */
   int32_t label_off;  /* positive column of row i is label_off + i         */
   int32_t ldt;        /* leading dimension of yT                            */
-  float* part;        /* fwd workspace: float2[r * n_col_tiles] (max,sum)   */
+  float* part;        /* fwd workspace: float2[n_col_tiles * r] (max,sum)   */
   float* diag;        /* fwd out: float[r] positive logit                    */
   float* lse;         /* fwd out: float[r] row log-sum-exp                   */
-  float* loss_sum;    /* fwd out: float[1] sum_i (lse_i - diag_i)            */
+  float* loss_part;   /* fwd out: float[ceil(r/256)] block sums of (lse_i - diag_i) */
   /* backward */
   const float* lse_col; /* float[c]: LSE of the opposite direction for every column */
   void* g;            /* bwd workspace: [r_pad, ldg] compute type            */
@@ -125,8 +126,10 @@ int mmk_clip_plan(int r, int c, int k_pad, int compute, int32_t* n_col_tiles, in
  * directions in one launch; scale is a device float (the reference's 0-dim logit_scale). */
 int mmk_clip_forward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale,
                      void* stream);
-/* loss = sum_d weight[d] * loss_sum[d]  (contrastive.py:134-144,160); weight = w / (2 * rows in the mean) */
-int mmk_clip_loss_combine(const float* const* loss_sums, const float* weights, int n, float* loss_out, void* stream);
+/* separate=0: out[0] = sum_k weights[k] * sum(ptrs[k][0..counts[k]))  -- the loss value
+ * (contrastive.py:134-144,160; weight = w / (2 * rows in the mean));  separate=1: out[k] = weights[k] * sum(ptrs[k]) */
+int mmk_reduce_sums(const float* const* ptrs, const int32_t* counts, const float* weights, int n, int separate, float* out,
+                    void* stream);
 /* backward: recompute tiles -> G, dX = G @ Y (split-K), scale/normalise/scatter; dscale accumulated into
  * dscale_out (float[1], pre-zeroed by the caller); upstream is the device scalar dL/dloss. */
 int mmk_clip_backward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale,

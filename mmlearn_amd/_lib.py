@@ -36,7 +36,7 @@ class ClipDir(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("y", C.c_void_p), ("yT", C.c_void_p),
         ("r", C.c_int32), ("c", C.c_int32), ("label_off", C.c_int32), ("ldt", C.c_int32),
-        ("part", C.c_void_p), ("diag", C.c_void_p), ("lse", C.c_void_p), ("loss_sum", C.c_void_p),
+        ("part", C.c_void_p), ("diag", C.c_void_p), ("lse", C.c_void_p), ("loss_part", C.c_void_p),
         ("lse_col", C.c_void_p), ("g", C.c_void_p), ("ldg", C.c_int32),
         ("c_row", C.c_float), ("c_col", C.c_float), ("c_diag", C.c_float),
         ("s_row", C.c_float), ("s_col", C.c_float), ("s_diag", C.c_float),
@@ -65,7 +65,8 @@ _SIGNATURES = {
     "mmk_pack_rows": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "mmk_clip_plan": [_i, _i, _i, _i, _vp, _vp, _vp],
     "mmk_clip_forward": [_vp, _i, _i, _i, _i, _vp, _vp],
-    "mmk_clip_loss_combine": [_vp, _vp, _i, _vp, _vp],
+    "mmk_reduce_sums": [_vp, _vp, _vp, _i, _i, _vp, _vp],
+    "mmk_match_workspace_ints": [_i, _i],
     "mmk_clip_backward": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "mmk_l2norm_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mmk_l2norm_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],

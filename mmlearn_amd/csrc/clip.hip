@@ -63,7 +63,7 @@ struct Prob {
   int ldp, ldq;   // elements
   int tiles_m, tiles_n;
   // EPI_STATS
-  float2* part;   // [N][part_ld]
+  float2* part;   // [tiles_m][part_ld = N]  (column-tile major: coalesced for the reduce)
   int part_ld;
   float* diag;    // [N]
   int label_off;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const ProbBatch batch, con
       if (x.x > -INFINITY) l += x.y * __expf(x.x - mx);
       if (y.x > -INFINITY) l += y.y * __expf(y.x - mx);
       const int i = n0 + tid;
-      if (i < p.N) p.part[(size_t)i * p.part_ld + tm] = make_float2(mx, l);
+      if (i < p.N) p.part[(size_t)tm * p.part_ld + i] = make_float2(mx, l);
     }
   } else if (EPI == EPI_GRAD) {
     const float s = *scale_ptr;
@@ -299,55 +299,63 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const ProbBatch batch, con
 }
 
 // ------------------------------------------------------------------ LSE reduce
-// one block per direction: lse[i] = logsumexp over the column-tile partials; loss_sum = sum_i (lse_i - diag_i)
+// one thread per owned row: lse[i] = logsumexp over the column-tile partials (coalesced: partials are
+// tile-major); block partial sums of (lse_i - diag_i) go to loss_part[dir][block].
 struct ReduceProb {
   const float2* part;
   int part_ld, tiles_m, N;
   const float* diag;
   float* lse;
-  float* loss_sum;
+  float* loss_part;
 };
 struct ReduceBatch {
   ReduceProb p[MAX_PROBS];
 };
-__global__ __launch_bounds__(1024) void lse_reduce_kernel(const ReduceBatch batch) {
-  const ReduceProb& p = batch.p[blockIdx.x];
+__global__ __launch_bounds__(256) void lse_reduce_kernel(const ReduceBatch batch) {
+  const ReduceProb& p = batch.p[blockIdx.y];
+  if (blockIdx.x * 256 >= p.N) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
   float local = 0.f;
-  for (int i = threadIdx.x; i < p.N; i += blockDim.x) {
-    const float2* row = p.part + (size_t)i * p.part_ld;
+  if (i < p.N) {
     float mx = -INFINITY;
-    for (int t = 0; t < p.tiles_m; ++t) mx = fmaxf(mx, row[t].x);
+    for (int t = 0; t < p.tiles_m; ++t) mx = fmaxf(mx, p.part[(size_t)t * p.part_ld + i].x);
     float l = 0.f;
     for (int t = 0; t < p.tiles_m; ++t) {
-      const float2 v = row[t];
+      const float2 v = p.part[(size_t)t * p.part_ld + i];
       if (v.x > -INFINITY) l += v.y * __expf(v.x - mx);
     }
     const float lse = mx + logf(l);
     p.lse[i] = lse;
-    local += lse - p.diag[i];
+    local = lse - p.diag[i];
   }
-  __shared__ float red[16];
+  __shared__ float red[4];
   local = wave_sum(local);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
-    *p.loss_sum = t;
-  }
+  if (threadIdx.x == 0) p.loss_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// out[k] = w[k] * sum(ptr[k][0..cnt[k]))   (separate)   or   out[0] = sum_k of that   (combined)
 struct CombineArgs {
-  const float* sums[2 * MAX_PROBS];
+  const float* ptr[2 * MAX_PROBS];
+  int cnt[2 * MAX_PROBS];
   float w[2 * MAX_PROBS];
   int n;
+  int separate;
 };
-__global__ void loss_combine_kernel(const CombineArgs a, float* out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+__global__ __launch_bounds__(64) void reduce_sums_kernel(const CombineArgs a, float* out) {
+  float total = 0.f;
+  for (int k = 0; k < a.n; ++k) {
     float t = 0.f;
-    for (int k = 0; k < a.n; ++k) t += a.w[k] * *a.sums[k];
-    *out = t;
+    for (int i = threadIdx.x; i < a.cnt[k]; i += 64) t += a.ptr[k][i];
+    t = wave_sum(t) * a.w[k];
+    if (a.separate) {
+      if (threadIdx.x == 0) out[k] = t;
+    } else {
+      total += t;
+    }
   }
+  if (!a.separate && threadIdx.x == 0) out[0] = total;
 }
 
 // ------------------------------------------------------------------ pack / transpose
@@ -555,11 +563,11 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
     p.tiles_m = cdiv(d.c, pl.bt);
     p.tiles_n = cdiv(d.r, pl.bt);
     p.part = reinterpret_cast<float2*>(d.part);
-    p.part_ld = cdiv(d.c, 64);
+    p.part_ld = d.r;
     p.diag = d.diag;
     p.label_off = d.label_off;
     max_tiles = std::max(max_tiles, p.tiles_m * p.tiles_n);
-    rb.p[k] = ReduceProb{p.part, p.part_ld, p.tiles_m, d.r, d.diag, d.lse, d.loss_sum};
+    rb.p[k] = ReduceProb{p.part, p.part_ld, p.tiles_m, d.r, d.diag, d.lse, d.loss_part};
   }
   b.n_split = 1;
   {
@@ -569,7 +577,7 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
   }
   {
     ProfScope ps(MMK_K_LSE_REDUCE, st);
-    hipLaunchKernelGGL(lse_reduce_kernel, dim3(n_dirs), dim3(1024), 0, st, rb);
+    hipLaunchKernelGGL(lse_reduce_kernel, dim3(cdiv(r_max, 256), n_dirs), dim3(256), 0, st, rb);
     MMK_LAUNCH_CHECK();
   }
   return 0;
@@ -740,23 +748,26 @@ int mmk_clip_forward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int
   if (rc) return rc;
   MMK_REQUIRE(scale, "null scale");
   for (int k = 0; k < n_dirs; ++k)
-    MMK_REQUIRE(dirs[k].part && dirs[k].diag && dirs[k].lse && dirs[k].loss_sum, "null forward buffer");
+    MMK_REQUIRE(dirs[k].part && dirs[k].diag && dirs[k].lse && dirs[k].loss_part, "null forward buffer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (compute == MMK_COMPUTE_BF16) return clip_forward_impl<bf16_t>(dirs, n_dirs, k_pad, scale, st);
   return clip_forward_impl<float>(dirs, n_dirs, k_pad, scale, st);
 }
 
-int mmk_clip_loss_combine(const float* const* loss_sums, const float* weights, int n, float* loss_out, void* stream) {
-  MMK_REQUIRE(loss_sums && weights && loss_out && n > 0 && n <= 2 * MAX_PROBS, "bad arguments");
+int mmk_reduce_sums(const float* const* ptrs, const int32_t* counts, const float* weights, int n, int separate, float* out,
+                    void* stream) {
+  MMK_REQUIRE(ptrs && counts && weights && out && n > 0 && n <= 2 * MAX_PROBS, "bad arguments");
   CombineArgs a;
   a.n = n;
+  a.separate = separate;
   for (int k = 0; k < n; ++k) {
-    a.sums[k] = loss_sums[k];
+    a.ptr[k] = ptrs[k];
+    a.cnt[k] = counts[k];
     a.w[k] = weights[k];
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(MMK_K_LOSS_COMBINE, st);
-  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, st, a, loss_out);
+  hipLaunchKernelGGL(reduce_sums_kernel, dim3(1), dim3(64), 0, st, a, out);
   MMK_LAUNCH_CHECK();
   return 0;
 }

@@ -2,75 +2,87 @@
 //
 // Replaces find_matching_indices (mmlearn/datasets/core/example.py:160-166): the reference
 // broadcasts [N,1,2]==[1,M,2] into an N*M*2 bool tensor, reduces, and calls torch.where
-// (nonzero + host sync).  Here: count pass -> single-block exclusive scan -> fill pass, the
-// (dataset_index, example_index) rows of b streamed through LDS and broadcast to all lanes.
-// Output order is row-major (i ascending, then j ascending), exactly torch.where's.
+// (nonzero + host sync).  Here the N x M compare is a 2-D grid (256 rows of a  x  256-row chunk
+// of b held in LDS and broadcast to all lanes): count pass -> single-block exclusive scan over the
+// (row, chunk) counts -> fill pass.  Output order is row-major (i ascending, then j ascending),
+// exactly torch.where's, and independent of scheduling (integer atomics only feed flags).
+#include <algorithm>
+
 #include "common.h"
 
 namespace mmk {
 
-constexpr int MATCH_CHUNK = 1024;  // id pairs of b per LDS refill (16 KiB)
+constexpr int MATCH_CHUNK = 256;  // id pairs of b per block (4 KiB of LDS): a 256 x 256 compare tile per block
 
-// MODE 0: counts[i] = #{j : a[i] == b[j]}.   MODE 1: write pairs at offs[i]...
+// MODE 0: cnt[i*n_chunks + chunk] = #{j in chunk : a[i] == b[j]}, cnt_b[j] += 1 per match.
+// MODE 1: write the pairs of (i, chunk) at offs[i*n_chunks + chunk]; maintain the status flags.
 template <int MODE>
 __global__ __launch_bounds__(256) void match_kernel(const longlong2* __restrict__ a, int n_a, const longlong2* __restrict__ b,
-                                                    int n_b, int32_t* __restrict__ counts, const int32_t* __restrict__ offs,
-                                                    int32_t* __restrict__ idx_a, int32_t* __restrict__ idx_b, int capacity,
-                                                    int32_t* __restrict__ status) {
+                                                    int n_b, int n_chunks, int32_t* __restrict__ cnt,
+                                                    int32_t* __restrict__ cnt_b, int32_t* __restrict__ idx_a,
+                                                    int32_t* __restrict__ idx_b, int capacity, int32_t* __restrict__ status) {
   __shared__ longlong2 sb[MATCH_CHUNK];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool live = i < n_a;
-  longlong2 mine = make_longlong2(0, 0);
-  if (live) mine = a[i];
-  int cnt = 0;
-  int pos = (MODE == 1 && live) ? offs[i] : 0;
-  bool not_identity = false;
-  for (int j0 = 0; j0 < n_b; j0 += MATCH_CHUNK) {
-    const int len = min(MATCH_CHUNK, n_b - j0);
-    __syncthreads();
-    for (int t = threadIdx.x; t < len; t += 256) sb[t] = b[j0 + t];
-    __syncthreads();
-    if (live) {
-      for (int t = 0; t < len; ++t) {
-        const longlong2 o = sb[t];
-        if (o.x == mine.x && o.y == mine.y) {
-          if (MODE == 0) {
-            ++cnt;
-          } else {
-            if (pos < capacity) {
-              idx_a[pos] = i;
-              idx_b[pos] = j0 + t;
-            }
-            if (pos != i || j0 + t != i) not_identity = true;
-            ++pos;
-          }
-        }
+  const int chunk = blockIdx.y;
+  const int j0 = chunk * MATCH_CHUNK;
+  const int len = min(MATCH_CHUNK, n_b - j0);
+  for (int t = threadIdx.x; t < len; t += 256) sb[t] = b[j0 + t];
+  __syncthreads();
+  if (i >= n_a) return;
+  const longlong2 mine = a[i];
+  if (MODE == 0) {
+    int c = 0;
+#pragma unroll 8
+    for (int t = 0; t < len; ++t) {
+      const longlong2 o = sb[t];
+      if (o.x == mine.x && o.y == mine.y) {
+        ++c;
+        atomicAdd(&cnt_b[j0 + t], 1);
       }
     }
-  }
-  if (MODE == 0) {
-    if (live) counts[i] = cnt;
+    cnt[(size_t)i * n_chunks + chunk] = c;
   } else {
-    if (not_identity) status[1] = 0;
+    // row_off[i] = pairs before row i; the chunks of a row are laid out in chunk order behind it
+    const int32_t* row_off = cnt + (size_t)n_a * n_chunks;
+    int pos = row_off[i];
+    for (int c = 0; c < chunk; ++c) pos += cnt[(size_t)i * n_chunks + c];
+    if (chunk == 0 && row_off[i + 1] - pos > 1) status[2] = 1;  // row i is in several pairs
+    if (cnt[(size_t)i * n_chunks + chunk] == 0) return;
+    bool off_diag = false, col_rep = false;
+#pragma unroll 8
+    for (int t = 0; t < len; ++t) {
+      const longlong2 o = sb[t];
+      if (o.x == mine.x && o.y == mine.y) {
+        const int j = j0 + t;
+        if (pos < capacity) {
+          idx_a[pos] = i;
+          idx_b[pos] = j;
+        }
+        if (pos != i || j != i) off_diag = true;
+        if (cnt_b[j] > 1) col_rep = true;
+        ++pos;
+      }
+    }
+    if (off_diag) status[1] = 0;
+    if (col_rep) status[3] = 1;
   }
 }
 
-// exclusive scan of counts[0..n) in place, counts[n] = total; flags any count > 1 into *dup
-__global__ __launch_bounds__(1024) void scan_kernel(int32_t* __restrict__ counts, int n, int32_t* dup) {
+// row_off[0..n] = exclusive scan of the per-row totals (sum over chunks); status = {total, identity candidate, 0, 0}
+__global__ __launch_bounds__(1024) void match_scan_kernel(const int32_t* __restrict__ cnt, int n_chunks,
+                                                          int32_t* __restrict__ v, int n, int n_a, int n_b,
+                                                          int32_t* __restrict__ status) {
   __shared__ int wsum[16];
   __shared__ int carry;
-  __shared__ int any_dup;
-  if (threadIdx.x == 0) {
-    carry = 0;
-    any_dup = 0;
-  }
+  if (threadIdx.x == 0) carry = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int base = 0; base < n; base += 1024) {
     const int i = base + threadIdx.x;
-    const int v = i < n ? counts[i] : 0;
-    if (v > 1) any_dup = 1;
-    int x = v;
+    int x0 = 0;
+    if (i < n)
+      for (int c = 0; c < n_chunks; ++c) x0 += cnt[(size_t)i * n_chunks + c];
+    int x = x0;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int y = __shfl_up(x, o);
@@ -81,57 +93,47 @@ __global__ __launch_bounds__(1024) void scan_kernel(int32_t* __restrict__ counts
     int woff = 0;
     for (int w = 0; w < wave; ++w) woff += wsum[w];
     const int c = carry;
-    if (i < n) counts[i] = c + woff + x - v;
+    if (i < n) v[i] = c + woff + x - x0;
     __syncthreads();
     if (threadIdx.x == 1023) carry = c + woff + x;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    counts[n] = carry;
-    *dup = any_dup;
+    const int total = carry;
+    v[n] = total;
+    status[0] = total;
+    status[1] = (total == n_a && n_a == n_b) ? 1 : 0;  // cleared by the fill pass on any off-diagonal pair
+    status[2] = 0;
+    status[3] = 0;
   }
-}
-
-__global__ void match_status_kernel(const int32_t* offs_a, int n_a, int n_b, int32_t* status) {
-  const int total = offs_a[n_a];
-  status[0] = total;
-  status[1] = (total == n_a && n_a == n_b) ? 1 : 0;  // cleared by the fill pass on any off-diagonal pair
 }
 
 }  // namespace mmk
 
 using namespace mmk;
 
-extern "C" int mmk_match_ids(const int64_t* ids_a, int n_a, const int64_t* ids_b, int n_b, int32_t* row_count,
+extern "C" int mmk_match_workspace_ints(int n_a, int n_b) {
+  return n_a * cdiv(std::max(n_b, 1), MATCH_CHUNK) + (n_a + 1) + n_b + 1;
+}
+
+extern "C" int mmk_match_ids(const int64_t* ids_a, int n_a, const int64_t* ids_b, int n_b, int32_t* workspace,
                              int32_t* idx_a, int32_t* idx_b, int capacity, int32_t* status, void* stream) {
-  MMK_REQUIRE(n_a >= 0 && n_b >= 0 && capacity >= 0, "negative size");
-  MMK_REQUIRE(row_count && status, "null workspace");
+  MMK_REQUIRE(n_a > 0 && n_b > 0 && capacity >= 0, "empty or negative size");
+  MMK_REQUIRE(ids_a && ids_b && workspace && status, "null pointer");
   MMK_REQUIRE(capacity == 0 || (idx_a && idx_b), "null index buffers");
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(MMK_K_MATCH, st);
   const longlong2* a = reinterpret_cast<const longlong2*>(ids_a);
   const longlong2* b = reinterpret_cast<const longlong2*>(ids_b);
-  int32_t* cnt_a = row_count;            // [n_a + 1]
-  int32_t* cnt_b = row_count + n_a + 1;  // [n_b + 1]
-  if (n_a > 0) {
-    hipLaunchKernelGGL((match_kernel<0>), dim3(cdiv(n_a, 256)), dim3(256), 0, st, a, n_a, b, n_b, cnt_a, nullptr, nullptr,
-                       nullptr, 0, status);
-    MMK_LAUNCH_CHECK();
-  }
-  if (n_b > 0) {  // column multiplicities (only for the "idx_b repeats" flag)
-    hipLaunchKernelGGL((match_kernel<0>), dim3(cdiv(n_b, 256)), dim3(256), 0, st, b, n_b, a, n_a, cnt_b, nullptr, nullptr,
-                       nullptr, 0, status);
-    MMK_LAUNCH_CHECK();
-  }
-  // a row of a that matches k > 1 rows of b repeats in idx_a; likewise for b
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, cnt_a, n_a, status + 2);
-  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, cnt_b, n_b, status + 3);
-  hipLaunchKernelGGL(match_status_kernel, dim3(1), dim3(1), 0, st, cnt_a, n_a, n_b, status);
+  const int n_chunks = cdiv(n_b, MATCH_CHUNK);
+  int32_t* cnt = workspace;                                     // [n_a * n_chunks] then row_off [n_a + 1]
+  int32_t* row_off = workspace + (size_t)n_a * n_chunks;
+  int32_t* cnt_b = row_off + n_a + 1;                             // [n_b]
+  MMK_HIP(hipMemsetAsync(cnt_b, 0, sizeof(int32_t) * n_b, st));
+  dim3 grid(cdiv(n_a, 256), n_chunks);
+  hipLaunchKernelGGL((match_kernel<0>), grid, dim3(256), 0, st, a, n_a, b, n_b, n_chunks, cnt, cnt_b, nullptr, nullptr, 0, status);
+  hipLaunchKernelGGL(match_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, n_chunks, row_off, n_a, n_a, n_b, status);
+  hipLaunchKernelGGL((match_kernel<1>), grid, dim3(256), 0, st, a, n_a, b, n_b, n_chunks, cnt, cnt_b, idx_a, idx_b, capacity, status);
   MMK_LAUNCH_CHECK();
-  if (n_a > 0 && n_b > 0) {
-    hipLaunchKernelGGL((match_kernel<1>), dim3(cdiv(n_a, 256)), dim3(256), 0, st, a, n_a, b, n_b, nullptr, cnt_a, idx_a, idx_b,
-                       capacity, status);
-    MMK_LAUNCH_CHECK();
-  }
   return 0;
 }

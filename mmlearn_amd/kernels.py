@@ -51,7 +51,7 @@ def match_ids(ids_a: torch.Tensor, ids_b: torch.Tensor) -> Match:
     if n_a == 0 or n_b == 0:
         return Match(0, False, torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev))
     cap = max(n_a, n_b)
-    counts = torch.empty(n_a + n_b + 2, dtype=torch.int32, device=dev)
+    counts = torch.empty(_lib.lib().mmk_match_workspace_ints(n_a, n_b), dtype=torch.int32, device=dev)
     idx_a = torch.empty(cap, dtype=torch.int32, device=dev)
     idx_b = torch.empty(cap, dtype=torch.int32, device=dev)
     status = torch.empty(4, dtype=torch.int32, device=dev)
@@ -107,7 +107,7 @@ class Direction:
     # forward outputs
     lse: Optional[torch.Tensor] = None
     diag: Optional[torch.Tensor] = None
-    loss_sum: Optional[torch.Tensor] = None
+    loss_part: Optional[torch.Tensor] = None   # block partial sums of (lse_i - diag_i)
     # backward inputs
     lse_col: Optional[torch.Tensor] = None
     dx: Optional[torch.Tensor] = None        # [n_src, d] gradient buffer
@@ -125,7 +125,7 @@ def _plan(r: int, c: int, k_pad: int, compute: int):
 
 
 def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.Tensor) -> None:
-    """Fills dir.lse / dir.diag / dir.loss_sum for every direction (two launches for all of them)."""
+    """Fills dir.lse / dir.diag / dir.loss_part for every direction (two launches for all of them)."""
     assert scale.dtype == torch.float32 and scale.is_cuda
     dev = scale.device
     for i0 in range(0, len(dirs), MAX_DIRS_PER_CALL):
@@ -135,26 +135,32 @@ def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.T
         for k, dr in enumerate(chunk):
             assert dr.x.shape[1] == k_pad and dr.y.shape[1] == k_pad
             n_col_tiles, _, _ = _plan(dr.r, dr.c, k_pad, compute)
-            part = torch.empty((dr.r, n_col_tiles, 2), dtype=torch.float32, device=dev)
+            part = torch.empty((n_col_tiles, dr.r, 2), dtype=torch.float32, device=dev)
             dr.lse = torch.empty(dr.r, dtype=torch.float32, device=dev)
             dr.diag = torch.empty(dr.r, dtype=torch.float32, device=dev)
-            dr.loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
+            dr.loss_part = torch.empty((dr.r + 255) // 256, dtype=torch.float32, device=dev)
             dr._keep.append(part)
             e = arr[k]
             e.x, e.y, e.r, e.c, e.label_off = ptr(dr.x), ptr(dr.y), dr.r, dr.c, dr.label_off
-            e.part, e.diag, e.lse, e.loss_sum = ptr(part), ptr(dr.diag), ptr(dr.lse), ptr(dr.loss_sum)
+            e.part, e.diag, e.lse, e.loss_part = ptr(part), ptr(dr.diag), ptr(dr.lse), ptr(dr.loss_part)
         check(_lib.lib().mmk_clip_forward(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), stream()))
 
 
-def loss_combine(loss_sums: Sequence[torch.Tensor], weights: Sequence[float]) -> torch.Tensor:
-    """loss = sum_k weights[k] * loss_sums[k]  (one tiny launch; contrastive.py:134-144,160)."""
-    n = len(loss_sums)
-    out = torch.empty((), dtype=torch.float32, device=loss_sums[0].device)
+def reduce_sums(parts: Sequence[torch.Tensor], weights: Sequence[float], separate: bool = False,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """separate=False: 0-dim ``sum_k weights[k] * parts[k].sum()`` (the loss value, contrastive.py:134-144,160);
+    separate=True: ``out[k] = weights[k] * parts[k].sum()``.  One tiny launch."""
+    n = len(parts)
     if n > 2 * MAX_DIRS_PER_CALL:
-        raise ValueError("too many loss terms for one combine call")
-    ptrs = (C.c_void_p * n)(*[ptr(t) for t in loss_sums])
+        raise ValueError("too many terms for one reduce_sums call")
+    dev = parts[0].device
+    if out is None:
+        out = torch.empty(n if separate else (), dtype=torch.float32, device=dev)
+    ptrs = (C.c_void_p * n)(*[ptr(t) for t in parts])
+    cnts = (C.c_int32 * n)(*[t.numel() for t in parts])
     ws = (C.c_float * n)(*[float(w) for w in weights])
-    check(_lib.lib().mmk_clip_loss_combine(C.cast(ptrs, C.c_void_p), C.cast(ws, C.c_void_p), n, ptr(out), stream()))
+    check(_lib.lib().mmk_reduce_sums(C.cast(ptrs, C.c_void_p), C.cast(cnts, C.c_void_p), C.cast(ws, C.c_void_p), n, int(separate),
+                                     ptr(out), stream()))
     return out
 
 

@@ -368,7 +368,8 @@ class _Run:
                         buf[base + own[0]: base + own[1]].copy_(dr.lse)
                     else:
                         buf[base: base + R].index_copy_(0, own, dr.lse)
-                    buf[p.exch_off + 2 * R + (0 if role == "a" else 1)].copy_(dr.loss_sum[0])
+                    k = p.exch_off + 2 * R + (0 if role == "a" else 1)
+                    K.reduce_sums([dr.loss_part], [1.0], separate=True, out=buf[k:k + 1])
             dist.all_reduce(buf)
             self.exch = buf
             for p in self.pairs:
@@ -380,7 +381,7 @@ class _Run:
         if not exchange_sum:
             for p in self.pairs:
                 for dr in p.dirs:
-                    terms.append(dr.loss_sum)
+                    terms.append(dr.loss_part)
                     weights.append(p.kappa_loss)
         if W == 1:
             for p in self.pairs:
@@ -390,7 +391,7 @@ class _Run:
             return torch.zeros((), dtype=torch.float32, device=dev)
         out = None
         for i0 in range(0, len(terms), 2 * K.MAX_DIRS_PER_CALL):
-            part = K.loss_combine(terms[i0:i0 + 2 * K.MAX_DIRS_PER_CALL], weights[i0:i0 + 2 * K.MAX_DIRS_PER_CALL])
+            part = K.reduce_sums(terms[i0:i0 + 2 * K.MAX_DIRS_PER_CALL], weights[i0:i0 + 2 * K.MAX_DIRS_PER_CALL])
             out = part if out is None else out + part
         return out
 

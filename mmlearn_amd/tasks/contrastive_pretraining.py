@@ -1,0 +1,297 @@
+"""``ContrastivePretraining`` task with the reference's constructor, attributes and hooks
+(mmlearn/tasks/contrastive_pretraining.py:87-701), driving the HIP loss path.
+
+Differences from the reference, all inside the hot path:
+
+* ``encode(..., normalize=True)`` normalises with the HIP ``l2_normalize`` op;
+* the default ``loss`` is this package's :class:`~mmlearn_amd.losses.ContrastiveLoss`
+  (any module with the documented ``forward(embeddings, example_ids, logit_scale,
+  modality_loss_pairs)`` signature is accepted, as in the reference).
+"""
+
+from __future__ import annotations
+
+import itertools
+import math
+from dataclasses import dataclass
+from functools import partial
+from typing import Any, Literal, Mapping, Optional, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..losses import ContrastiveLoss, LossPairSpec
+from ..modalities import Modalities
+from ..ops import l2_normalize
+from ..registry import store
+from .base import EvaluationHooks, TrainingTask
+
+__all__ = ["ModuleKeySpec", "LossPairSpec", "AuxiliaryTaskSpec", "EvaluationSpec", "ContrastivePretraining"]
+
+
+@dataclass
+class ModuleKeySpec:
+    """Which encoder / head / postprocessor key serves a modality (reference :30-41)."""
+
+    encoder_key: Optional[str] = None
+    head_key: Optional[str] = None
+    postprocessor_key: Optional[str] = None
+
+
+@dataclass
+class AuxiliaryTaskSpec:
+    """An auxiliary task trained on one modality's encoder (reference :55-70): ``task`` is a
+    ``functools.partial`` that receives the initialised encoder."""
+
+    modality: str
+    task: Any
+    loss_weight: float = 1.0
+
+
+@dataclass
+class EvaluationSpec:
+    """An evaluation task (``EvaluationHooks``) and when it runs (reference :73-85)."""
+
+    task: Any
+    run_on_validation: bool = True
+    run_on_test: bool = True
+
+
+def _unsupported(modality: str) -> ValueError:
+    return ValueError(
+        f"Found unsupported modality `{modality}` in the input. Supported modalities are {Modalities.list_modalities()}."
+        "HINT: New modalities can be added with `Modalities.register_modality` method.")
+
+
+def _as_module(entry: Union[nn.Module, Mapping[str, nn.Module]]) -> nn.Module:
+    # a dict of modules becomes a Sequential over the SAME instances (shared parameters), reference :297-307
+    return entry if isinstance(entry, nn.Module) else nn.Sequential(*entry.values())
+
+
+@store(group="task", name="ContrastivePretrainingHIP")
+class ContrastivePretraining(TrainingTask):
+    """N-modality contrastive pretraining (see the reference docstring for the parameter semantics)."""
+
+    def __init__(  # noqa: PLR0912
+        self,
+        encoders: dict[str, nn.Module],
+        heads: Optional[dict[str, Union[nn.Module, dict[str, nn.Module]]]] = None,
+        postprocessors: Optional[dict[str, Union[nn.Module, dict[str, nn.Module]]]] = None,
+        modality_module_mapping: Optional[dict[str, ModuleKeySpec]] = None,
+        optimizer: Optional[partial] = None,
+        lr_scheduler: Optional[Union[dict[str, Any], partial]] = None,
+        init_logit_scale: float = 1 / 0.07,
+        max_logit_scale: float = 100,
+        learnable_logit_scale: bool = True,
+        loss: Optional[nn.Module] = None,
+        modality_loss_pairs: Optional[list[LossPairSpec]] = None,
+        auxiliary_tasks: Optional[dict[str, AuxiliaryTaskSpec]] = None,
+        log_auxiliary_tasks_loss: bool = False,
+        compute_validation_loss: bool = True,
+        compute_test_loss: bool = True,
+        evaluation_tasks: Optional[dict[str, EvaluationSpec]] = None,
+    ) -> None:
+        super().__init__(optimizer=optimizer, lr_scheduler=lr_scheduler, loss_fn=loss,
+                         compute_validation_loss=compute_validation_loss, compute_test_loss=compute_test_loss)
+        self.save_hyperparameters(ignore=["encoders", "heads", "postprocessors", "modality_module_mapping", "loss",
+                                          "auxiliary_tasks", "evaluation_tasks", "modality_loss_pairs"])
+
+        if modality_module_mapping is None:  # all module dicts are keyed by modality
+            modality_module_mapping = {k: ModuleKeySpec(encoder_key=k, head_key=k, postprocessor_key=k) for k in encoders}
+
+        enc_of: dict[str, Optional[str]] = {}
+        head_of: dict[str, Optional[str]] = {}
+        post_of: dict[str, Optional[str]] = {}
+        for modality_key, spec in modality_module_mapping.items():
+            if not Modalities.has_modality(modality_key):
+                raise _unsupported(modality_key)
+            enc_of[modality_key], head_of[modality_key], post_of[modality_key] = spec.encoder_key, spec.head_key, spec.postprocessor_key
+
+        # every provided module must end up mapped to a modality
+        for table, modules in ((enc_of, encoders), (head_of, heads), (post_of, postprocessors)):
+            for key in modules or {}:
+                if key not in table.values():
+                    if not Modalities.has_modality(key):
+                        raise _unsupported(key)
+                    table[key] = key
+
+        self._available_modalities = [Modalities.get_modality(k) for k in enc_of]
+        assert len(self._available_modalities) >= 2, "Expected at least two modalities to be available. "
+
+        def name(k: str) -> str:
+            return Modalities.get_modality(k).name
+
+        #: encoders keyed by modality name
+        self.encoders = nn.ModuleDict({name(k): encoders[ek] for k, ek in enc_of.items() if ek is not None})
+        #: projection heads keyed by modality name (or None)
+        self.heads = None if heads is None else nn.ModuleDict(
+            {name(k): _as_module(heads[hk]) for k, hk in head_of.items() if hk is not None and hk in heads})
+        #: postprocessors keyed by modality name (or None)
+        self.postprocessors = None if postprocessors is None else nn.ModuleDict(
+            {name(k): _as_module(postprocessors[pk]) for k, pk in post_of.items() if pk is not None and pk in postprocessors})
+
+        # logit scale: log-space scalar, Parameter when learnable (reference :327-337)
+        log_logit_scale = torch.ones([]) * np.log(init_logit_scale)
+        self.max_logit_scale = max_logit_scale
+        self.learnable_logit_scale = learnable_logit_scale
+        if learnable_logit_scale:
+            self.log_logit_scale = nn.Parameter(log_logit_scale, requires_grad=True)
+        else:
+            self.register_buffer("log_logit_scale", log_logit_scale)
+
+        if modality_loss_pairs is None:
+            modality_loss_pairs = [LossPairSpec(modalities=(m1.name, m2.name))
+                                   for m1, m2 in itertools.combinations(self._available_modalities, 2)]
+        for pair in modality_loss_pairs:
+            if not all(Modalities.get_modality(m) in self._available_modalities for m in pair.modalities):
+                raise ValueError(f"Found unspecified modality in the loss pair specification {pair.modalities}. "
+                                 f"Available modalities are {self._available_modalities}.")
+        #: pairs of modalities (and weights) the contrastive loss is computed between
+        self.modality_loss_pairs = modality_loss_pairs
+
+        self.aux_task_specs = auxiliary_tasks or {}
+        self.auxiliary_tasks = nn.ModuleDict()
+        for task_name, spec in self.aux_task_specs.items():
+            if not Modalities.has_modality(spec.modality):
+                raise ValueError(f"Found unsupported modality `{spec.modality}` in the auxiliary tasks. "
+                                 f"Available modalities are {self._available_modalities}.")
+            if not isinstance(spec.task, partial):
+                raise TypeError(f"Expected auxiliary task to be a partial function, but got {type(spec.task)}.")
+            self.auxiliary_tasks[task_name] = spec.task(self.encoders[name(spec.modality)])
+        self.log_auxiliary_tasks_loss = log_auxiliary_tasks_loss
+
+        for spec in (evaluation_tasks or {}).values():
+            if not isinstance(spec.task, EvaluationHooks) and not _is_eval_hooks(spec.task):
+                raise TypeError(f"Expected {spec.task} to be an instance of `EvaluationHooks` but got {type(spec.task)}.")
+        self.evaluation_tasks = evaluation_tasks
+
+    # ------------------------------------------------------------------ model
+    def configure_model(self) -> None:
+        for task in self.auxiliary_tasks.values():
+            task.configure_model()
+
+    def encode(self, inputs: dict[str, Any], modality: Any, normalize: bool = False) -> torch.Tensor:
+        """encoder -> postprocessor -> head -> (optional) L2 normalisation (reference :400-431)."""
+        output = self.encoders[modality.name](inputs)[0]
+        if self.postprocessors and modality.name in self.postprocessors:
+            output = self.postprocessors[modality.name](output)
+        if self.heads and modality.name in self.heads:
+            output = self.heads[modality.name](output)
+        if normalize:
+            output = l2_normalize(output)
+        return output
+
+    def forward(self, inputs: dict[str, Any]) -> dict[str, torch.Tensor]:
+        outputs = {m.embedding: self.encode(inputs, m, normalize=True) for m in self._available_modalities if m.name in inputs}
+        dims = {o.size(-1) for o in outputs.values()}
+        if len(dims) > 1:
+            raise ValueError("Expected all model outputs to have the same dimension.")
+        return outputs
+
+    # ------------------------------------------------------------------ train
+    def on_train_epoch_start(self) -> None:
+        self.encoders.train()
+        if self.heads:
+            self.heads.train()
+        if self.postprocessors:
+            self.postprocessors.train()
+
+    def training_step(self, batch: dict[str, Any], batch_idx: int) -> torch.Tensor:
+        outputs = self(batch)
+        with torch.no_grad():  # in place, after the encoders ran, before the loss reads exp() (reference :488-489)
+            self.log_logit_scale.clamp_(0, math.log(self.max_logit_scale))
+        loss = self._compute_loss(batch, batch_idx, outputs)
+        if loss is None:
+            raise ValueError("The loss function must be provided for training.")
+        self.log("train/loss", loss, prog_bar=True, sync_dist=True)
+        self.log("train/logit_scale", self.log_logit_scale.exp(), prog_bar=True, on_step=True, on_epoch=False)
+        return loss
+
+    def on_before_zero_grad(self, optimizer: torch.optim.Optimizer) -> None:
+        for task in self.auxiliary_tasks.values():
+            task.on_before_zero_grad(optimizer)
+
+    # ------------------------------------------------------------------ eval
+    def on_validation_epoch_start(self) -> None:
+        self._on_eval_epoch_start("val")
+
+    def validation_step(self, batch: dict[str, Any], batch_idx: int) -> Optional[torch.Tensor]:
+        return self._shared_eval_step(batch, batch_idx, "val")
+
+    def on_validation_epoch_end(self) -> None:
+        self._on_eval_epoch_end("val")
+
+    def on_test_epoch_start(self) -> None:
+        self._on_eval_epoch_start("test")
+
+    def test_step(self, batch: dict[str, Any], batch_idx: int) -> Optional[torch.Tensor]:
+        return self._shared_eval_step(batch, batch_idx, "test")
+
+    def on_test_epoch_end(self) -> None:
+        self._on_eval_epoch_end("test")
+
+    def on_load_checkpoint(self, checkpoint: dict[str, Any]) -> None:
+        for task in self.auxiliary_tasks.values():
+            task.on_load_checkpoint(checkpoint)
+
+    def on_save_checkpoint(self, checkpoint: dict[str, Any]) -> None:
+        for task in self.auxiliary_tasks.values():
+            task.on_save_checkpoint(checkpoint)
+
+    # ------------------------------------------------------------------ internals
+    def _compute_loss(self, batch: dict[str, Any], batch_idx: int, outputs: dict[str, torch.Tensor]) -> Optional[torch.Tensor]:
+        if self.loss_fn is None:
+            return None
+        contrastive_loss = self.loss_fn(outputs, batch["example_ids"], self.log_logit_scale.exp(), self.modality_loss_pairs)
+
+        aux_losses: list[torch.Tensor] = []
+        for task_name, spec in self.aux_task_specs.items():
+            out = self.auxiliary_tasks[task_name].training_step(batch, batch_idx)
+            if isinstance(out, torch.Tensor):
+                aux = out
+            elif isinstance(out, Mapping):
+                aux = out["loss"]
+            else:
+                raise ValueError(f"Expected auxiliary task output to be a tensor or a mapping containing a 'loss' key, but got {type(out)}.")
+            aux *= spec.loss_weight  # in place, like the reference (Q12)
+            aux_losses.append(aux)
+            if self.log_auxiliary_tasks_loss:
+                self.log(f"train/{task_name}_loss", aux, sync_dist=True)
+        if not aux_losses:
+            return contrastive_loss
+        return torch.stack(aux_losses).sum() + contrastive_loss
+
+    def _eval_specs(self, eval_type: Literal["val", "test"]):
+        for spec in (self.evaluation_tasks or {}).values():
+            if (eval_type == "val" and spec.run_on_validation) or (eval_type == "test" and spec.run_on_test):
+                yield spec
+
+    def _on_eval_epoch_start(self, eval_type: Literal["val", "test"]) -> None:
+        self.encoders.eval()
+        if self.heads:
+            self.heads.eval()
+        if self.postprocessors:
+            self.postprocessors.eval()
+        for spec in self._eval_specs(eval_type):
+            spec.task.on_evaluation_epoch_start(self)
+
+    def _shared_eval_step(self, batch: dict[str, Any], batch_idx: int, eval_type: Literal["val", "test"]) -> Optional[torch.Tensor]:
+        loss: Optional[torch.Tensor] = None
+        if (eval_type == "val" and self.compute_validation_loss) or (eval_type == "test" and self.compute_test_loss):
+            outputs = self(batch)
+            loss = self._compute_loss(batch, batch_idx, outputs)
+            if loss is not None and not self.trainer.sanity_checking:
+                self.log(f"{eval_type}/loss", loss, prog_bar=True, sync_dist=True)
+        for spec in self._eval_specs(eval_type):
+            spec.task.evaluation_step(self, batch, batch_idx)
+        return loss
+
+    def _on_eval_epoch_end(self, eval_type: Literal["val", "test"]) -> None:
+        for spec in self._eval_specs(eval_type):
+            spec.task.on_evaluation_epoch_end(self)
+
+
+def _is_eval_hooks(obj: Any) -> bool:
+    """Accept mmlearn's own EvaluationHooks subclasses when mmlearn is installed next to this package."""
+    return all(hasattr(obj, m) for m in ("on_evaluation_epoch_start", "evaluation_step", "on_evaluation_epoch_end"))

@@ -1,0 +1,113 @@
+"""CPU tests of the host-side logic: mask generator RNG sequence (golden G7), modality registry,
+registry wiring, task construction contracts."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden
+
+MASKS = Golden("g7_masks")
+
+
+@pytest.mark.parametrize("name", MASKS.names())
+def test_mask_generator_vs_reference(name):
+    from mmlearn_amd.masking import IJEPAMaskGenerator
+
+    c = MASKS[name]
+    if name.startswith("seed"):
+        seed, b = name[4:].split("_b")
+        torch.manual_seed(int(seed))
+        b = int(b)
+        m = IJEPAMaskGenerator()(batch_size=b)
+    else:
+        torch.manual_seed(4)
+        b = 2
+        m = IJEPAMaskGenerator(input_size=(96, 128), patch_size=8, npred=2, nenc=2)(batch_size=b)
+    after = torch.randint(0, 2**31, (1,)).item()
+    np.testing.assert_array_equal(torch.stack(m["encoder_masks"]).numpy(), c["enc"])
+    np.testing.assert_array_equal(torch.stack(m["predictor_masks"]).numpy(), c["pred"])
+    assert after == int(c["rng_after"])  # the global RNG advanced exactly as in the reference
+    # the index form equals nonzero() of the mask form
+    for masks, idx in ((m["encoder_masks"], m["encoder_indices"]), (m["predictor_masks"], m["predictor_indices"])):
+        for k, mk in enumerate(masks):
+            assert mk.dtype == torch.int32 and mk.shape[0] == b
+            np.testing.assert_array_equal(idx[k, 0].numpy(), np.nonzero(mk[0].numpy())[0])
+
+
+def test_masks_to_indices_host_path():
+    from mmlearn_amd import ops
+
+    m = torch.zeros(3, 20, dtype=torch.int32)
+    m[:, [2, 5, 7]] = 1
+    idx = ops.masks_to_indices([m, m[0]], 3, torch.device("cpu"))
+    assert idx.shape == (2, 1, 3) and idx.dtype == torch.int32
+    assert idx[0, 0].tolist() == [2, 5, 7]
+    per = torch.zeros(3, 20, dtype=torch.int32)
+    per[0, [1, 2]] = 1; per[1, [3, 4]] = 1; per[2, [5, 19]] = 1
+    assert ops.masks_to_indices([per], 3, torch.device("cpu"))[0].tolist() == [[1, 2], [3, 4], [5, 19]]
+    bad = per.clone(); bad[0, 9] = 1
+    with pytest.raises(ValueError):
+        ops.masks_to_indices([bad], 3, torch.device("cpu"))
+    with pytest.raises(ValueError):
+        ops.masks_to_indices([m[:2]], 3, torch.device("cpu"))
+
+
+def test_modalities_and_registry():
+    from mmlearn_amd import Modalities, registry
+
+    rgb = Modalities.get_modality("RGB")
+    assert (rgb.name, rgb.embedding, rgb.mask, rgb.target) == ("rgb", "rgb_embedding", "rgb_mask", "rgb_target")
+    assert Modalities.has_modality("audio") and not Modalities.has_modality("smell")
+    assert Modalities.rgb is rgb
+    import mmlearn_amd.tasks  # noqa: F401
+
+    keys = set(registry.REGISTERED)
+    assert {("modules/losses", "ContrastiveLossHIP"), ("task", "ContrastivePretrainingHIP"), ("task", "IJEPAHIP")} <= keys
+
+
+def test_loss_constructor_contract():
+    from mmlearn_amd import ContrastiveLoss
+
+    l = ContrastiveLoss(l2_normalize=True, local_loss=True, gather_with_grad=True, cache_labels=True)
+    assert (l.l2_normalize, l.local_loss, l.gather_with_grad, l.cache_labels) == (True, True, True, True)
+    with pytest.raises(NotImplementedError):
+        ContrastiveLoss(modality_alignment=True)
+    with pytest.raises(ValueError):
+        ContrastiveLoss(compute_dtype=torch.float16)
+
+
+def test_ema_requires_gpu_and_configure():
+    from mmlearn_amd import ExponentialMovingAverage
+
+    net = torch.nn.Linear(3, 2)
+    ema = ExponentialMovingAverage(net, 0.9, 1.0, 10)
+    with pytest.raises(RuntimeError, match="not configured"):
+        ema.step(net)
+    ema.configure_model("cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ema.step(net)
+    assert ExponentialMovingAverage.get_annealed_rate(0.996, 1.0, 500, 1000) == pytest.approx(0.998)
+
+
+def test_training_task_optimizer_split():
+    from functools import partial
+
+    from mmlearn_amd.tasks import TrainingTask
+
+    class T(TrainingTask):
+        def __init__(self, **kw):
+            super().__init__(**kw)
+            self.net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.LayerNorm(4))
+
+    t = T(optimizer=partial(torch.optim.AdamW, lr=1e-3, weight_decay=0.2), loss_fn=lambda a, b: a,
+          lr_scheduler={"scheduler": partial(torch.optim.lr_scheduler.StepLR, step_size=1), "extras": {"interval": "step"}})
+    out = t.configure_optimizers()
+    groups = {g["name"]: g for g in out["optimizer"].param_groups}
+    assert groups["weight_decay_params"]["weight_decay"] == 0.2 and len(groups["weight_decay_params"]["params"]) == 1
+    assert groups["no_weight_decay_params"]["weight_decay"] == 0.0 and len(groups["no_weight_decay_params"]["params"]) == 3
+    assert out["lr_scheduler"]["interval"] == "step"
+    with pytest.raises(ValueError):
+        T()
+    with pytest.warns(UserWarning):
+        assert T(loss_fn=lambda a, b: a).configure_optimizers() is None

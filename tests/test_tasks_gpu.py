@@ -1,0 +1,193 @@
+"""GPU parity of whole task steps against the reference's own outputs (golden g5_task / g6_ijepa "step"):
+same tiny encoders (tests/golden/tiny_models.py), same weights, same inputs and RNG seeds."""
+
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _ids(n, dev):
+    return torch.stack([torch.zeros(n, dtype=torch.long), torch.arange(n)], 1).to(dev)
+
+
+@pytest.mark.parametrize("name", ["default", "clamp_hi", "clamp_lo"])
+def test_contrastive_training_step_vs_reference(name):
+    import tiny_models
+    from mmlearn_amd import ContrastiveLoss
+    from mmlearn_amd.tasks import ContrastivePretraining
+
+    c = Golden("g5_task")[name]
+    dev = _dev()
+    B, D = 16, 32
+    enc = {"rgb": tiny_models.FlatMLPEncoder("rgb", 3 * 8 * 8, 48, D), "text": tiny_models.TokenMLPEncoder("text", 50, 24, D)}
+    task = ContrastivePretraining(encoders=enc, loss=ContrastiveLoss(), compute_validation_loss=False, compute_test_loss=False)
+    task.load_state_dict({k[3:]: torch.tensor(v) for k, v in c.items() if k.startswith("w::")})
+    task.to(dev)
+    batch = {"rgb": torch.tensor(c["rgb"], device=dev), "text": torch.tensor(c["text"], device=dev),
+             "example_ids": {"rgb": _ids(B, dev), "text": _ids(B, dev)}}
+    loss = task.training_step(batch, 0)
+    loss.backward()
+    assert abs(loss.item() - float(c["loss"])) <= 1e-3 * max(1.0, abs(float(c["loss"])))
+    # clamp happened in place, before the loss read exp() (Q6)
+    assert abs(task.log_logit_scale.item() - float(c["log_logit_scale_after"])) < 1e-6
+    assert abs(float(task.logged["train/logit_scale"]) - float(c["logged_logit_scale"])) <= 1e-4 * float(c["logged_logit_scale"])
+    assert abs(float(task.logged["train/loss"]) - float(c["logged_loss"])) <= 1e-3 * max(1.0, abs(float(c["logged_loss"])))
+    for k, p in task.named_parameters():
+        ref = c[f"g::{k}"]
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
+        assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6) + 1e-7, k
+
+
+def test_contrastive_task_surface():
+    import tiny_models
+    from mmlearn_amd import ContrastiveLoss, LearnableLogitScaling, Modalities
+    from mmlearn_amd.tasks import ContrastivePretraining, LossPairSpec, ModuleKeySpec
+
+    dev = _dev()
+    D = 16
+    mk = lambda: tiny_models.FlatMLPEncoder("x", 12, 8, D)  # noqa: E731
+
+    class Enc(torch.nn.Module):
+        def __init__(self, key):
+            super().__init__()
+            self.key, self.lin = key, torch.nn.Linear(12, D)
+
+        def forward(self, inputs):
+            return (self.lin(inputs[self.key]),)
+
+    shared = {"proj": torch.nn.Linear(D, D), "scale": LearnableLogitScaling()}
+    task = ContrastivePretraining(
+        encoders={"rgb": Enc("rgb"), "text": Enc("text"), "audio": Enc("audio")},
+        heads={"shared": shared},
+        modality_module_mapping={m: ModuleKeySpec(encoder_key=m, head_key="shared") for m in ("rgb", "text", "audio")},
+        loss=ContrastiveLoss(), optimizer=partial(torch.optim.AdamW, lr=1e-3),
+        modality_loss_pairs=[LossPairSpec(("rgb", "text")), LossPairSpec(("rgb", "audio"), 0.5), LossPairSpec(("text", "audio"), 0.25)],
+        compute_validation_loss=True, compute_test_loss=False).to(dev)
+    # dict heads become Sequentials over the SAME module instances (Q5)
+    assert task.heads["rgb"][0] is task.heads["text"][0] is task.heads["audio"][0]
+    B = 24
+    batch = {m: torch.randn(B, 12, device=dev) for m in ("rgb", "text", "audio")}
+    batch["example_ids"] = {m: _ids(B, dev) for m in ("rgb", "text", "audio")}
+    out = task(batch)
+    assert set(out) == {"rgb_embedding", "text_embedding", "audio_embedding"}
+    for v in out.values():
+        np.testing.assert_allclose(v.norm(dim=-1).detach().cpu().numpy(), 1.0, atol=1e-5)
+    opt = task.configure_optimizers()
+    names = {g["name"]: len(g["params"]) for g in opt.param_groups}
+    assert names["no_weight_decay_params"] > 0 and names["weight_decay_params"] > 0
+    loss = task.training_step(batch, 0)
+    loss.backward()
+    opt.step()
+    assert torch.isfinite(loss)
+    # logit-scaling head is cancelled by the normalisation: ~zero gradient (Q5)
+    assert task.heads["rgb"][1].log_logit_scale.grad.abs().item() < 1e-4
+    vloss = task.validation_step(batch, 0)
+    assert torch.isfinite(vloss) and "val/loss" in task.logged
+    assert task.test_step(batch, 0) is None
+    # dimension mismatch -> ValueError like the reference
+    bad = ContrastivePretraining(encoders={"rgb": Enc("rgb"), "text": torch.nn.Sequential()}, loss=ContrastiveLoss(),
+                                 compute_validation_loss=False, compute_test_loss=False)
+    bad.encoders["text"] = type("E", (torch.nn.Module,), {"forward": lambda self, i: (torch.zeros(B, D + 1, device=dev),)})()
+    with pytest.raises(ValueError, match="same dimension"):
+        bad.to(dev)(batch)
+    with pytest.raises(ValueError, match="unsupported modality"):
+        ContrastivePretraining(encoders={"rgb": mk(), "smell": mk()}, loss=ContrastiveLoss())
+    with pytest.raises(ValueError, match="Loss function must be provided"):
+        ContrastivePretraining(encoders={"rgb": mk(), "text": mk()})
+    assert Modalities.get_modality("rgb").embedding == "rgb_embedding"
+
+
+def test_ijepa_training_step_vs_reference():
+    import tiny_models
+    from mmlearn_amd import ops
+    from mmlearn_amd.tasks import IJEPA
+
+    c = Golden("g6_ijepa")["step"]
+    dev = _dev()
+    enc = tiny_models.TinyPatchEncoder(embed_dim=32, mask_fn=ops.apply_masks)
+    pred = tiny_models.SimplePredictor(196, 32, 16)
+    task = IJEPA(encoder=enc, predictor=pred)
+    sd = {k[3:]: torch.tensor(v) for k, v in c.items() if k.startswith("w::")}
+    task.load_state_dict(sd)
+    task.target_encoder.model.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")})
+    task.to(dev)
+    task.configure_model()
+    imgs = torch.tensor(c["images"].astype(np.float32), device=dev)
+    torch.manual_seed(int(c["mask_seed"]))
+    loss = task.training_step({"rgb": imgs}, 0)
+    loss.backward()
+    # images were stored as fp16 -> compare at 2e-3
+    assert abs(loss.item() - float(c["loss"])) <= 2e-3 * max(1.0, float(c["loss"])), (loss.item(), float(c["loss"]))
+    assert float(task.logged["train/ema_decay"]) == float(c["ema_decay_logged"])
+    ref = dict(s.split("=") for s in c["grad_abs_sums"].tolist())
+    for k, p in task.named_parameters():
+        if p.grad is None:
+            continue
+        r = float(ref[k])
+        assert abs(p.grad.abs().sum().item() - r) <= 2e-2 * max(r, 1e-6), (k, p.grad.abs().sum().item(), r)
+    # EMA hook + checkpoint hooks
+    before = task.target_encoder.num_updates
+    task.on_before_zero_grad(None)
+    assert task.target_encoder.num_updates == before + 1
+    for (k, t), (_, s) in zip(task.target_encoder.model.state_dict().items(), task.encoder.state_dict().items()):
+        assert torch.equal(t, s), k   # copy quirk (Q1)
+    ckpt = {}
+    task.on_save_checkpoint(ckpt)
+    assert set(ckpt["ema_params"]) == {"decay", "num_updates"}
+    task.on_load_checkpoint(dict(ckpt))
+    # user loss_fn path: HIP target + arbitrary callable
+    task2 = IJEPA(encoder=enc, predictor=pred, loss_fn=lambda p, t: (p - t).abs().mean())
+    task2.to(dev)
+    task2.configure_model()
+    l2 = task2.training_step({"rgb": imgs}, 0)
+    assert torch.isfinite(l2) and l2.requires_grad
+
+
+def test_contrastive_with_ijepa_auxiliary():
+    import tiny_models
+    from mmlearn_amd import ContrastiveLoss, ops
+    from mmlearn_amd.tasks import IJEPA, AuxiliaryTaskSpec, ContrastivePretraining
+
+    dev = _dev()
+    torch.manual_seed(0)
+
+    rgb = tiny_models.TinyPatchEncoder(embed_dim=32, mask_fn=ops.apply_masks)
+
+    class RgbForContrastive(torch.nn.Module):
+        """contrastive branch pools the tokens; the I-JEPA branches (mask given, or teacher) see tokens"""
+
+        def __init__(self, enc):
+            super().__init__()
+            self.enc = enc
+            self.patch_embed, self.embed_dim, self.num_heads = enc.patch_embed, enc.embed_dim, enc.num_heads
+
+        def forward(self, inputs):
+            x = self.enc(inputs)[0]
+            return (x if "rgb_mask" in inputs or getattr(self, "tokens", False) else x.mean(1), None)
+
+    wrapped = RgbForContrastive(rgb)
+    aux = partial(IJEPA, predictor=tiny_models.SimplePredictor(196, 32, 16), loss_fn=None)
+    task = ContrastivePretraining(
+        encoders={"rgb": wrapped, "text": tiny_models.TokenMLPEncoder("text", 50, 24, 32)},
+        loss=ContrastiveLoss(), auxiliary_tasks={"ijepa": AuxiliaryTaskSpec(modality="rgb", task=aux, loss_weight=0.5)},
+        log_auxiliary_tasks_loss=True, compute_validation_loss=False, compute_test_loss=False).to(dev)
+    task.configure_model()
+    task.auxiliary_tasks["ijepa"].target_encoder.model.tokens = True
+    B = 8
+    batch = {"rgb": torch.rand(B, 3, 224, 224, device=dev), "text": torch.randint(0, 50, (B, 77), device=dev),
+             "example_ids": {"rgb": _ids(B, dev), "text": _ids(B, dev)}}
+    loss = task.training_step(batch, 0)
+    loss.backward()
+    assert torch.isfinite(loss) and "train/ijepa_loss" in task.logged
+    task.on_before_zero_grad(None)
+    assert task.auxiliary_tasks["ijepa"].target_encoder.num_updates == 1

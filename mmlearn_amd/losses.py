@@ -109,6 +109,14 @@ def _slice_rows(t: torch.Tensor, p0: int) -> torch.Tensor:
     return t[p0:] if p0 else t
 
 
+def _all_gather(t: torch.Tensor, world: int) -> torch.Tensor:
+    """One all-gather of a contiguous tensor -> [world, *t.shape] (flat buffers: valid for RCCL and gloo)."""
+    flat = t.contiguous().view(-1)
+    out = torch.empty(world * flat.numel(), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, flat)
+    return out.view(world, *t.shape)
+
+
 class _Run:
     """One evaluation of the loss: forward state kept for the backward pass."""
 
@@ -171,9 +179,7 @@ class _Run:
             counts = {n: [t.shape[0]] * W for n, t in local.items()}
         else:
             header = torch.tensor([local[n].shape[0] if n in local else -1 for n in names_all] + [d], dtype=torch.int64, device=dev)
-            gathered = torch.empty((W, header.numel()), dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(gathered, header)
-            table = gathered.tolist()
+            table = _all_gather(header, W).tolist()
             if any(row[-1] != d for row in table):
                 raise ValueError("embedding dimension differs across ranks")
             counts = {n: [max(table[r][i], 0) for r in range(W)] for i, n in enumerate(names_all)
@@ -189,10 +195,8 @@ class _Run:
         for n, t in local.items():
             send_e[roff[n]: roff[n] + t.shape[0]].copy_(t.detach())
             send_i[roff[n]: roff[n] + t.shape[0]].copy_(self.example_ids[n])
-        all_e = torch.empty((W * tot, d), dtype=dt, device=dev)
-        all_i = torch.empty((W * tot, 2), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(all_e, send_e)
-        dist.all_gather_into_tensor(all_i, send_i)
+        all_e = _all_gather(send_e, W).view(W * tot, d)
+        all_i = _all_gather(send_i, W).view(W * tot, 2)
         views = {}
         for n in names:
             rows_np = np.concatenate([np.arange(counts[n][r], dtype=np.int32) + (r * tot + roff[n]) for r in range(W)]) \
@@ -242,9 +246,7 @@ class _Run:
         if local_mode and self.pairs:
             # per-rank row counts of every pair (the reference all-gathers them per pair, contrastive.py:196-206)
             mine = torch.tensor([p.ml.n for p in self.pairs], dtype=torch.int64, device=dev)
-            allc = torch.empty((W, len(self.pairs)), dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(allc, mine)
-            table = allc.tolist()
+            table = _all_gather(mine, W).tolist()
             for k, p in enumerate(self.pairs):
                 p.local_sizes = [table[r][k] for r in range(W)]
 

@@ -1,0 +1,126 @@
+"""TEST DOUBLE of ``mmlearn_amd.kernels`` on CPU tensors (float64), used ONLY by the multi-process gloo
+tests to exercise the host-side sharding / exchange logic of ``mmlearn_amd.losses`` without a GPU.
+
+It restates the *contract* of each kernel entry point (include/mmlearn_hip.h) with plain torch ops; it
+is installed by monkeypatching ``mmlearn_amd.losses.K`` from the tests and is never importable from
+the product.  The HIP kernels themselves are checked against the oracle in the ``-m gpu`` tests.
+"""
+
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from mmlearn_amd.kernels import Direction, Match  # dataclasses only  # noqa: F401
+from oracle import clip_oracle as co
+
+MAX_DIRS_PER_CALL = 8
+CALLS = {"pack_rows": 0, "clip_forward": 0, "clip_backward": 0, "match_ids": 0}
+
+
+def require_gpu(t, what="tensor"):
+    return None
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+def match_ids(ids_a: torch.Tensor, ids_b: torch.Tensor) -> Match:
+    CALLS["match_ids"] += 1
+    n_a, n_b = ids_a.shape[0], ids_b.shape[0]
+    if n_a == 0 or n_b == 0:
+        return Match(0, False, torch.empty(0, dtype=torch.int32), torch.empty(0, dtype=torch.int32))
+    ia, ib = co.find_matching_indices(ids_a.numpy(), ids_b.numpy())
+    n = len(ia)
+    ident = n == n_a == n_b and (ia == range(n)).all() and (ib == range(n)).all()
+    if ident:
+        return Match(n, True, None, None)
+    rep_a = len(set(ia.tolist())) < n
+    rep_b = len(set(ib.tolist())) < n
+    return Match(n, False, torch.from_numpy(ia).int(), torch.from_numpy(ib).int(), rep_a, rep_b)
+
+
+def pack_rows(src, idx, r, normalize, compute, want_transpose):
+    CALLS["pack_rows"] += 1
+    n_src, d = src.shape
+    rows = src.detach().double()
+    rows = rows[idx[:r].long()] if idx is not None else rows[:r]
+    if normalize:
+        rows = rows / rows.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    r_pad, k_pad = round_up(max(r, 1), 128), round_up(d, 64)
+    dst = torch.zeros(r_pad, k_pad, dtype=torch.float64)
+    dst[:r, :d] = rows
+    return dst, (dst.T.contiguous() if want_transpose else None)
+
+
+def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.Tensor) -> None:
+    CALLS["clip_forward"] += 1
+    s = scale.double().item()
+    for dr in dirs:
+        t = dr.x[: dr.r] @ dr.y[: dr.c].T
+        v = s * t
+        lse = torch.logsumexp(v, dim=1)
+        lab = dr.label_off + torch.arange(dr.r)
+        dr.lse = lse.float()
+        dr.diag = v[torch.arange(dr.r), lab].float()
+        per = lse - v[torch.arange(dr.r), lab]
+        nb = (dr.r + 255) // 256
+        dr.loss_part = torch.stack([per[k * 256:(k + 1) * 256].sum() for k in range(nb)]).float()
+
+
+def reduce_sums(parts, weights, separate=False, out: Optional[torch.Tensor] = None):
+    vals = [float(w) * p.double().sum() for p, w in zip(parts, weights)]
+    if separate:
+        res = torch.stack(vals).float()
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+    res = torch.stack(vals).sum().float()
+    if out is not None:
+        out.copy_(res.reshape(out.shape))
+        return out
+    return res
+
+
+def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale, upstream, dscale) -> None:
+    CALLS["clip_backward"] += 1
+    s = scale.double().item()
+    up = upstream.double().item()
+    for dr in dirs:
+        x, y = dr.x[: dr.r], dr.y[: dr.c]
+        assert torch.equal(dr.y_t[:, : dr.c], y.T), "yT must be the transpose of y"
+        t = x @ y.T
+        v = s * t
+        p_row = torch.exp(v - dr.lse.double()[:, None])
+        p_col = torch.exp(v - dr.lse_col.double()[None, :]) if (dr.c_col or dr.s_col) else torch.zeros_like(v)
+        delta = torch.zeros_like(v)
+        delta[torch.arange(dr.r), dr.label_off + torch.arange(dr.r)] = 1.0
+        g = dr.c_row * p_row + dr.c_col * p_col - dr.c_diag * delta
+        gs = dr.s_row * p_row + dr.s_col * p_col - dr.s_diag * delta
+        if dscale is not None:
+            dscale += float(up * dr.ds_kappa * (gs * t).sum())
+        dx = (up * dr.kappa * s) * (g @ y)[:, :d]
+        rows = dr.dx_rows.long() if dr.dx_rows is not None else torch.arange(dr.r)
+        if dr.normalize:
+            src = dr.src.double()[rows]
+            nrm = src.norm(dim=-1, keepdim=True)
+            inv = 1.0 / nrm.clamp_min(1e-12)
+            yv = src * inv
+            dx = (dx - yv * (yv * dx).sum(-1, keepdim=True)) * inv
+        if dr.dx_accumulate:
+            dr.dx.index_add_(0, rows, dx.to(dr.dx.dtype))
+        else:
+            dr.dx[rows] = dx.to(dr.dx.dtype)
+
+
+def l2norm_fwd(x):
+    inv = 1.0 / x.norm(dim=-1).clamp_min(1e-12)
+    return x * inv[..., None], inv
+
+
+def l2norm_bwd(x, dy, inv):
+    y = x * inv[..., None]
+    return (dy - y * (y * dy).sum(-1, keepdim=True)) * inv[..., None]

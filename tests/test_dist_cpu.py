@@ -1,0 +1,117 @@
+"""World-size > 1 tests on CPU (gloo): the row-sharded orchestration of ``mmlearn_amd.losses`` (packed
+all-gather, ownership, label offsets, LSE/loss all-reduce, per-flag gradient recipes) against the
+per-rank outputs of the REFERENCE itself under torch.distributed (golden g3_clip_dist).
+
+The kernels are replaced by the CPU test double ``tests/fake_kernels.py`` (monkeypatched into
+``mmlearn_amd.losses.K`` inside the worker processes only); the HIP kernels are covered by -m gpu tests.
+"""
+
+import os
+import sys
+import traceback
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import Golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIST = Golden("g3_clip_dist")
+
+
+def _worker(rank, world, port, case_names, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import fake_kernels
+        import mmlearn_amd.losses as L
+        from conftest import Golden as G
+
+        L.K = fake_kernels  # test seam: CPU double of the kernel layer
+        gold = G("g3_clip_dist")
+        results = {}
+        for name in case_names:
+            c = gold[name]
+            mods = sorted(k[len(f"r{rank}_in_"):] for k in c if k.startswith(f"r{rank}_in_"))
+            embs = {f"{m}_embedding": torch.tensor(c[f"r{rank}_in_{m}"]).requires_grad_(True) for m in mods}
+            ids = {m: torch.tensor(c[f"r{rank}_ids_{m}"]) for m in mods}
+            s = torch.tensor(float(c["scale"]), requires_grad=True)
+            for static in ((False, True) if "uneven" not in name and "missing" not in name else (False,)):
+                for t in embs.values():
+                    t.grad = None
+                s.grad = None
+                fn = L.ContrastiveLoss(local_loss=bool(c["local_loss"]), gather_with_grad=bool(c["gather_with_grad"]),
+                                       static_shapes=static)
+                loss = fn(embs, ids, s, [L.LossPairSpec(("rgb", "text"))])
+                rec = {"loss": float(loss.detach()), "requires_grad": loss.requires_grad}
+                if loss.requires_grad:
+                    loss.backward()
+                rec["grads"] = {m: (embs[f"{m}_embedding"].grad.numpy().copy() if embs[f"{m}_embedding"].grad is not None
+                                    else np.zeros_like(c[f"r{rank}_in_{m}"])) for m in mods}
+                rec["dscale"] = float(s.grad) if s.grad is not None else 0.0
+                results[(name, static)] = rec
+        q.put((rank, results, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # surface the traceback in the parent
+        q.put((rank, None, traceback.format_exc()))
+
+
+def _run(world, case_names, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case_names, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in procs:
+        rank, res, err = q.get(timeout=240)
+        assert err is None, f"rank {rank} failed:\n{err}"
+        out[rank] = res
+    for p in procs:
+        p.join(timeout=60)
+    return out
+
+
+def _check(world, case_names, out):
+    for name in case_names:
+        c = DIST[name]
+        local = bool(c["local_loss"])
+        for rank in range(world):
+            for static in (False, True):
+                if (name, static) not in out[rank]:
+                    continue
+                got = out[rank][(name, static)]
+                tag = (name, rank, static)
+                ref_loss = float(c[f"r{rank}_out_loss"])
+                ref_has_graph = bool(c[f"r{rank}_out_loss_requires_grad"])
+                assert abs(got["loss"] - ref_loss) <= 2e-5 * max(1.0, abs(ref_loss)), (tag, got["loss"], ref_loss)
+                assert got["requires_grad"] or not ref_has_graph, tag
+                for m, g in got["grads"].items():
+                    ref = c[f"r{rank}_out_grad_{m}"] if ref_has_graph else np.zeros_like(g)
+                    assert np.abs(g - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-3), (tag, m, np.abs(g - ref).max())
+                ref_ds = float(c[f"r{rank}_out_grad_scale"]) if ref_has_graph else 0.0
+                assert abs(got["dscale"] - ref_ds) <= 2e-5 * max(1.0, abs(ref_ds)), (tag, got["dscale"], ref_ds, local)
+
+
+@pytest.mark.timeout(300)
+def test_world2_all_flag_cells_uneven_and_missing_modality():
+    names = [n for n in DIST.names() if n.startswith("w2_")]
+    assert len(names) == 9
+    out = _run(2, names, 29711)
+    _check(2, names, out)
+
+
+@pytest.mark.timeout(300)
+def test_world4_all_flag_cells():
+    names = [n for n in DIST.names() if n.startswith("w4_")]
+    assert len(names) == 4
+    out = _run(4, names, 29712)
+    _check(4, names, out)

@@ -16,7 +16,10 @@
 // Data layout: operands are [rows][k_pad] with k_pad a multiple of one 128-byte LDS row
 // (64 bf16 / 32 f32).  LDS tiles are [rows][128 B], 16-byte chunks XOR-swizzled with
 // (row>>1)&7 so that the 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots.
+#include <stdlib.h>
+
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -86,15 +89,34 @@ struct ProbBatch {
 };
 
 // ------------------------------------------------------------------ main loop
-template <typename T, int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const ProbBatch batch, const float* __restrict__ scale_ptr) {
+// LOADER 0: global -> VGPR -> ds_write_b128 staging (2 LDS stages).
+// LOADER 1: LDS-DMA (global_load_lds_dwordx4): each wave-instruction lands 1 KiB = 8 tile rows linearly in
+//           LDS; the XOR swizzle is applied to the per-lane SOURCE chunk instead (the read side is unchanged).
+//           NSTAGE LDS stages, counted s_waitcnt vmcnt(N) + raw s_barrier so prefetches stay in flight.
+enum { LOADER_REG = 0, LOADER_DMA = 1 };
+
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// raw v_exp_f32 (2^x); arguments here are <= 0 up to rounding, tiny results may flush -- harmless in a softmax sum
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int EPI, int LOADER, int NSTAGE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, const float* __restrict__ scale_ptr) {
   typedef Atom<T> A;
   typedef typename A::Frag Frag;
   constexpr int MT = BM / 64, NT = BN / 64;          // 32x32 MFMA tiles per wave per dim (2x2 waves)
   constexpr int ROWS = BM + BN;
-  constexpr int CPT = ROWS * 8 / 256;                // 16-byte chunks per thread per stage
+  constexpr int CPT = ROWS * 8 / 256;                // 16-byte chunks per thread per stage (= DMA instr per wave)
   constexpr int STAGE_BYTES = ROWS * 128;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // NSTAGE * STAGE_BYTES (dynamic: may exceed 64 KiB)
 
   const int zsplit = (EPI == EPI_PLAIN) ? (blockIdx.z % batch.n_split) : 0;
   const int zprob = (EPI == EPI_PLAIN) ? (blockIdx.z / batch.n_split) : blockIdx.z;
@@ -114,13 +136,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const ProbBatch batch, con
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1, r = lane & 31, h = lane >> 5;
 
-  // ---- global -> register staging assignment (chunk c = tid + 256*u; 8 chunks per row)
+  // ---- staging assignment.  REG: chunk c = tid + 256*u (8 chunks per row), swizzled LDS destination.
+  //      DMA: wave-instruction u of wave w covers tile rows 8*(w*CPT+u) .. +7; lane L lands at LDS row
+  //      8g + (L>>3), slot L&7 and therefore fetches source chunk (L&7) ^ swizzle(row).
   const char* gsrc[CPT];
   int lds_off[CPT];
 #pragma unroll
   for (int u = 0; u < CPT; ++u) {
-    const int c = tid + 256 * u;
-    const int row = c >> 3, ch = c & 7;
+    int row, ch;
+    if (LOADER == LOADER_REG) {
+      const int c = tid + 256 * u;
+      row = c >> 3;
+      ch = c & 7;
+      lds_off[u] = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+    } else {
+      const int g = wave * CPT + u;
+      row = 8 * g + (lane >> 3);
+      ch = (lane & 7) ^ ((row >> 1) & 7);
+      lds_off[u] = g * 1024;  // wave-uniform base of this instruction's 1 KiB
+    }
     const char* base;
     if (row < BM) {
       const int g = min(m0 + row, p.M - 1);
@@ -130,7 +164,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const ProbBatch batch, con
       base = p.Q + ((size_t)g * p.ldq + k_begin) * sizeof(T);
     }
     gsrc[u] = base + ch * 16;
-    lds_off[u] = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
   }
 
   f32x16 acc[MT][NT];
@@ -140,15 +173,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const ProbBatch batch, con
     for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-  uint4 stage[CPT];
-  if (nk > 0) {
-#pragma unroll
-    for (int u = 0; u < CPT; ++u) stage[u] = *reinterpret_cast<const uint4*>(gsrc[u]);
-#pragma unroll
-    for (int u = 0; u < CPT; ++u) *reinterpret_cast<uint4*>(smem + lds_off[u]) = stage[u];
-  }
-  __syncthreads();
 
   // fragment read offsets (row-dependent swizzle is constant over k)
   int p_off[MT], q_off[NT], p_sw[MT], q_sw[NT];
@@ -165,14 +189,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const ProbBatch batch, con
     q_sw[b] = (row >> 1) & 7;
   }
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* cur = smem + (kt & 1) * STAGE_BYTES;
-    const bool more = kt + 1 < nk;
-    if (more) {
-#pragma unroll
-      for (int u = 0; u < CPT; ++u)
-        stage[u] = *reinterpret_cast<const uint4*>(gsrc[u] + (size_t)(kt + 1) * 128);
-    }
+  auto compute_stage = [&](const char* cur) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       Frag fa[MT], fb[NT];
@@ -186,94 +203,202 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const ProbBatch batch, con
 #pragma unroll
         for (int b = 0; b < NT; ++b) A::mma(fa[a], fb[b], acc[a][b]);
     }
-    if (more) {
-      char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+  };
+
+  if (LOADER == LOADER_REG) {
+    uint4 stage[CPT];
+    if (nk > 0) {
 #pragma unroll
-      for (int u = 0; u < CPT; ++u) *reinterpret_cast<uint4*>(nxt + lds_off[u]) = stage[u];
+      for (int u = 0; u < CPT; ++u) stage[u] = *reinterpret_cast<const uint4*>(gsrc[u]);
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) *reinterpret_cast<uint4*>(smem + lds_off[u]) = stage[u];
     }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* cur = smem + (kt & 1) * STAGE_BYTES;
+      const bool more = kt + 1 < nk;
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) stage[u] = *reinterpret_cast<const uint4*>(gsrc[u] + (size_t)(kt + 1) * 128);
+      }
+      compute_stage(cur);
+      if (more) {
+        char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) *reinterpret_cast<uint4*>(nxt + lds_off[u]) = stage[u];
+      }
+      __syncthreads();
+    }
+  } else {
+    // prologue: NSTAGE-1 stages in flight (empty ones are still "issued" as no-ops by skipping: counts below
+    // assume exactly CPT DMA instructions per issued stage, so issue only real stages and clamp the wait)
+    auto issue = [&](int kt) {
+      char* dst = smem + (kt % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) glds16(gsrc[u] + (size_t)kt * 128, dst + lds_off[u]);
+    };
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; ++st)
+      if (st < nk) issue(st);
+    for (int kt = 0; kt < nk; ++kt) {
+      // stage kt has landed when at most the younger issued stages remain outstanding
+      const int younger = min(nk - 1, kt + NSTAGE - 2) - kt;  // stages issued after kt so far
+      if (younger >= 2) wait_vmcnt<2 * CPT>();
+      else if (younger == 1) wait_vmcnt<CPT>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();  // every wave's share of stage kt is in LDS; stage kt-1 fully consumed
+      if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);  // refill the buffer that stage kt-1 just released
+      compute_stage(smem + (kt % NSTAGE) * STAGE_BYTES);
+    }
+    wait_vmcnt<0>();
     __syncthreads();
   }
 
   // -------------------------------------------------------------- epilogues
   // element (a, b, e): m = m0 + wm*BM/2 + a*32 + (e&3) + 8*(e>>2) + 4*h ; n = n0 + wn*BN/2 + b*32 + r
+  constexpr float LOG2E = 1.4426950408889634f;
   if (EPI == EPI_STATS) {
+    // All softmax arithmetic runs in the log2 domain (u = s*log2e*t): one v_fma/v_sub + v_exp per element.
+    // The per-tile partial (max2, sum) is converted back by the reduce kernel.  INTERIOR tiles (all BM
+    // columns valid) skip the column mask; only the tile that holds the labels looks for the positive.
     const float s = *scale_ptr;
+    const float s2 = s * LOG2E;
+    const bool interior = (m0 + BM <= p.M);
+    const bool has_diag = (m0 < p.label_off + n0 + BN) && (m0 + BM > p.label_off + n0);
     float2* red = reinterpret_cast<float2*>(smem);  // [2][BN]
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
       const int nl = wn * (BN / 2) + b * 32 + r;
       const int i = n0 + nl;
-      const int lab = p.label_off + i;
-      float vmax = -INFINITY;
-#pragma unroll
-      for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int j = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const float v = (j < p.M) ? s * acc[a][b][e] : -INFINITY;
-          acc[a][b][e] = v;
-          vmax = fmaxf(vmax, v);
-          if (j == lab && i < p.N && j < p.M) p.diag[i] = v;
-        }
-      vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
-      float sum = 0.f;
-      if (vmax > -INFINITY) {
+      if (has_diag) {
+        const int lab = p.label_off + i;
 #pragma unroll
         for (int a = 0; a < MT; ++a)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) sum += __expf(acc[a][b][e] - vmax);
+          for (int e = 0; e < 16; ++e) {
+            const int j = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (j == lab && i < p.N && j < p.M) p.diag[i] = s * acc[a][b][e];
+          }
+      }
+      float sum = 0.f, m2;
+      if (interior && s2 >= 0.f) {  // fast path: every column valid, max of s*t is at max of t
+        float vmax = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) vmax = fmaxf(vmax, acc[a][b][e]);
+        vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+        m2 = vmax * s2;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sum += fast_exp2(fmaf(acc[a][b][e], s2, -m2));
+      } else {  // edge tiles / negative scale: masked extremum of u = s2*t, masked sum
+        float umax = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int j = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float u = (j < p.M) ? acc[a][b][e] * s2 : -INFINITY;
+            acc[a][b][e] = u;
+            umax = fmaxf(umax, u);
+          }
+        umax = fmaxf(umax, __shfl_xor(umax, 32));
+        m2 = umax;
+        if (umax > -INFINITY) {
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sum += (acc[a][b][e] > -INFINITY) ? fast_exp2(acc[a][b][e] - umax) : 0.f;
+        }
       }
       sum += __shfl_xor(sum, 32);
-      if (h == 0) red[wm * BN + nl] = make_float2(vmax, sum);
+      if (h == 0) red[wm * BN + nl] = make_float2(m2, sum);
     }
     __syncthreads();
     if (tid < BN) {
       const float2 x = red[tid], y = red[BN + tid];
       const float mx = fmaxf(x.x, y.x);
       float l = 0.f;
-      if (x.x > -INFINITY) l += x.y * __expf(x.x - mx);
-      if (y.x > -INFINITY) l += y.y * __expf(y.x - mx);
+      if (x.x > -INFINITY) l += x.y * fast_exp2(x.x - mx);
+      if (y.x > -INFINITY) l += y.y * fast_exp2(y.x - mx);
       const int i = n0 + tid;
-      if (i < p.N) p.part[(size_t)tm * p.part_ld + i] = make_float2(mx, l);
+      if (i < p.N) p.part[(size_t)tm * p.part_ld + i] = make_float2(mx, l);  // log2 domain
     }
   } else if (EPI == EPI_GRAD) {
     const float s = *scale_ptr;
+    const float s2 = s * LOG2E;
     const bool use_col = (p.c_col != 0.f) || (p.s_col != 0.f);
+    const bool use_ds = (p.s_row != 0.f) || (p.s_col != 0.f) || (p.s_diag != 0.f);
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    const bool has_diag = (m0 < p.label_off + n0 + BN) && (m0 + BM > p.label_off + n0);
     float ds_acc = 0.f;
+    // G leaves through a wave-private LDS staging tile so that global stores are whole row segments
+    // (COLS*sizeof(T) = 128/256 B contiguous per row) instead of 8/16-byte pieces scattered over 32 rows.
+    constexpr int COLS = BM / 2;                   // j (columns of G) per wave
+    constexpr int PB = 4 * (int)sizeof(T);         // bytes of one 4-element piece
+    constexpr int RB = COLS * (int)sizeof(T);      // bytes of one staged row
+    constexpr int STRIDE = RB + PB;                // padded: conflict-free piece writes, aligned piece reads
+    constexpr int LPR = COLS / 4;                  // lanes per row on read-back
+    constexpr int RPI = 64 / LPR;                  // rows per read-back instruction
+    typedef typename std::conditional<sizeof(T) == 2, uint2, uint4>::type Piece;
+    char* stg = smem + wave * (32 * STRIDE);
 #pragma unroll
     for (int b = 0; b < NT; ++b) {
       const int i = n0 + wn * (BN / 2) + b * 32 + r;
       const bool iv = i < p.N;
-      const float lr = iv ? p.lse_row[i] : 0.f;
+      const float lr2 = (iv ? p.lse_row[i] : 0.f) * LOG2E;
       const int lab = p.label_off + i;
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int jb = m0 + wm * (BM / 2) + a * 32 + 8 * q + 4 * h;
+          const int jl = a * 32 + 8 * q + 4 * h;  // column inside the wave's strip
+          const int jb = m0 + wm * (BM / 2) + jl;
+          float lc2[4] = {0.f, 0.f, 0.f, 0.f};
+          if (use_col) {
+            if (jb + 3 < p.M) {
+              const float4 t4 = *reinterpret_cast<const float4*>(p.lse_col + jb);
+              lc2[0] = t4.x * LOG2E; lc2[1] = t4.y * LOG2E; lc2[2] = t4.z * LOG2E; lc2[3] = t4.w * LOG2E;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (jb + e < p.M) lc2[e] = p.lse_col[jb + e] * LOG2E;
+            }
+          }
           float g4[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int j = jb + e;
             const float t = acc[a][b][4 * q + e];
-            const float v = s * t;
-            const bool valid = iv && (j < p.M);
-            const float pr = __expf(v - lr);
-            const float pc = (use_col && valid) ? __expf(v - p.lse_col[j]) : 0.f;
-            const float d = (j == lab) ? 1.f : 0.f;
-            float g = p.c_row * pr + p.c_col * pc - p.c_diag * d;
-            float gs = p.s_row * pr + p.s_col * pc - p.s_diag * d;
-            if (!valid) {
+            const float pr = fast_exp2(fmaf(t, s2, -lr2));
+            const float pc = use_col ? fast_exp2(fmaf(t, s2, -lc2[e])) : 0.f;
+            float g = p.c_row * pr + p.c_col * pc;
+            float gs = p.s_row * pr + p.s_col * pc;
+            if (has_diag && (jb + e == lab)) {
+              g -= p.c_diag;
+              gs -= p.s_diag;
+            }
+            if (!interior && !(iv && (jb + e < p.M))) {
               g = 0.f;
               gs = 0.f;
             }
-            ds_acc += gs * t;
+            if (use_ds) ds_acc = fmaf(gs, t, ds_acc);
             g4[e] = g;
           }
-          T* dst = reinterpret_cast<T*>(p.G) + (size_t)i * p.ldg + jb;
-          Vec4<T>::store(dst, make_float4(g4[0], g4[1], g4[2], g4[3]));
+          Vec4<T>::store(reinterpret_cast<T*>(stg + r * STRIDE) + jl, make_float4(g4[0], g4[1], g4[2], g4[3]));
         }
+      // read the 32 staged rows back as whole rows and stream them out
+#pragma unroll
+      for (int t = 0; t < 32 / RPI; ++t) {
+        const int row = t * RPI + lane / LPR, c4 = lane % LPR;
+        const Piece v = *reinterpret_cast<const Piece*>(stg + row * STRIDE + c4 * PB);
+        const int gi = n0 + wn * (BN / 2) + b * 32 + row;
+        const int gj = m0 + wm * (BM / 2) + c4 * 4;
+        *reinterpret_cast<Piece*>(reinterpret_cast<T*>(p.G) + (size_t)gi * p.ldg + gj) = v;
+      }
     }
+    __syncthreads();  // staging tiles are dead; reuse LDS for the d/dscale reduction
     ds_acc = wave_sum(ds_acc);
     float* red = reinterpret_cast<float*>(smem);
     if (lane == 0) red[wave] = ds_acc;
@@ -322,9 +447,9 @@ __global__ __launch_bounds__(256) void lse_reduce_kernel(const ReduceBatch batch
     float l = 0.f;
     for (int t = 0; t < p.tiles_m; ++t) {
       const float2 v = p.part[(size_t)t * p.part_ld + i];
-      if (v.x > -INFINITY) l += v.y * __expf(v.x - mx);
+      if (v.x > -INFINITY) l += v.y * exp2f(v.x - mx);
     }
-    const float lse = mx + logf(l);
+    const float lse = (mx + log2f(l)) * 0.6931471805599453f;  // partials are in the log2 domain
     p.lse[i] = lse;
     local = lse - p.diag[i];
   }
@@ -528,15 +653,51 @@ static Plan make_plan(int r_max, int c_max, int k_pad, int n_dirs, int compute) 
   return pl;
 }
 
+// loader / pipeline depth selection (MMK_LOADER=reg|dma, MMK_STAGES=2|3|4 override the defaults; used for A/B runs)
+struct LoaderCfg {
+  int loader, stages;
+};
+static LoaderCfg loader_cfg() {
+  static LoaderCfg cfg = [] {
+    LoaderCfg c{LOADER_DMA, 2};
+    if (const char* e = getenv("MMK_LOADER")) c.loader = (e[0] == 'r') ? LOADER_REG : LOADER_DMA;
+    if (const char* e = getenv("MMK_STAGES")) c.stages = atoi(e);
+    if (c.loader == LOADER_REG) c.stages = 2;
+    if (c.stages < 2 || c.stages > 4) c.stages = 2;
+    return c;
+  }();
+  return cfg;
+}
+
+template <typename T, int BT, int EPI, int LOADER, int NSTAGE>
+static int launch_one(const ProbBatch& b, dim3 grid, const float* scale, hipStream_t st) {
+  constexpr int bytes = NSTAGE * (2 * BT) * 128;
+  auto kern = gemm_nt_kernel<T, BT, BT, EPI, LOADER, NSTAGE>;
+  static bool attr_set = false;
+  if (bytes > 64 * 1024 && !attr_set) {
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), bytes, st, b, scale);
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T, int BT, int EPI>
+static int launch_tile(const ProbBatch& b, dim3 grid, const float* scale, hipStream_t st) {
+  const LoaderCfg c = loader_cfg();
+  if (c.loader == LOADER_REG) return launch_one<T, BT, EPI, LOADER_REG, 2>(b, grid, scale, st);
+  // 128^2 tiles: 32 KiB per stage -> at most 4 stages in 160 KiB; 64^2 tiles: 16 KiB per stage
+  if (c.stages == 2) return launch_one<T, BT, EPI, LOADER_DMA, 2>(b, grid, scale, st);
+  if (c.stages == 3) return launch_one<T, BT, EPI, LOADER_DMA, 3>(b, grid, scale, st);
+  return launch_one<T, BT, EPI, LOADER_DMA, 4>(b, grid, scale, st);
+}
+
 template <typename T, int EPI>
 static int launch_gemm(const ProbBatch& b, int n_probs, int bt, int max_tiles, const float* scale, hipStream_t st) {
   dim3 grid(max_tiles, 1, n_probs * (EPI == EPI_PLAIN ? b.n_split : 1));
-  if (bt == 128)
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 128, 128, EPI>), grid, dim3(256), 0, st, b, scale);
-  else
-    hipLaunchKernelGGL((gemm_nt_kernel<T, 64, 64, EPI>), grid, dim3(256), 0, st, b, scale);
-  MMK_LAUNCH_CHECK();
-  return 0;
+  if (bt == 128) return launch_tile<T, 128, EPI>(b, grid, scale, st);
+  return launch_tile<T, 64, EPI>(b, grid, scale, st);
 }
 
 template <typename T>

@@ -115,6 +115,12 @@ typedef struct {
   const void* src;    /* original rows [n_src, d] (only when normalize=1, for the L2-norm backward) */
   int32_t src_dtype;
   int32_t normalize;
+  /* mode 0: cross-entropy direction (above).  mode 1: modality-alignment BCE rows
+   * (_compute_modality_alignment_loss, contrastive.py:344-413): y = all concatenated features [c rows], x = the
+   * owned rows label_off .. label_off + r of y, hmax[row] = end of the positive columns [row, hmax[row]);
+   * loss_part = block sums of (pos_r/npos_r + neg_r/nneg_r); backward writes the symmetrised d/dlogits. */
+  int32_t mode;
+  const int32_t* hmax;
 } mmk_clip_dir;
 
 /* tile configuration query: n_col_tiles for `part`, blocks for `ds_part`, split-K factor for `slab` */

@@ -44,6 +44,7 @@ class ClipDir(C.Structure):
         ("slab", C.c_void_p), ("ds_part", C.c_void_p),
         ("dx", C.c_void_p), ("dx_rows", C.c_void_p), ("dx_dtype", C.c_int32), ("dx_accumulate", C.c_int32),
         ("src", C.c_void_p), ("src_dtype", C.c_int32), ("normalize", C.c_int32),
+        ("mode", C.c_int32), ("hmax", C.c_void_p),
     ]
 
 
@@ -143,7 +144,11 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of torch's current stream on the current device (fast path: no Stream object)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:  # private API moved: fall back to the public one
+        return torch.cuda.current_stream().cuda_stream
 
 
 # ------------------------------------------------------------------ profiling

@@ -55,7 +55,7 @@ struct Atom<float> {
   }
 };
 
-enum { EPI_STATS = 0, EPI_GRAD = 1, EPI_PLAIN = 2 };
+enum { EPI_STATS = 0, EPI_GRAD = 1, EPI_PLAIN = 2, EPI_ALIGN_STATS = 3, EPI_ALIGN_GRAD = 4 };
 constexpr int MAX_PROBS = 8;
 
 struct Prob {
@@ -77,6 +77,8 @@ struct Prob {
   int ldg;
   float c_row, c_col, c_diag, s_row, s_col, s_diag;
   float* ds_part;        // [tiles_m * tiles_n]
+  // EPI_ALIGN_*: Q row i is row (label_off + i) of the concatenated feature matrix P (M rows)
+  const int* hmax;       // [M]: positives of row r are the columns [r, hmax[r])
   // EPI_PLAIN (split-K)
   float* slab;           // [n_split][slab_rows][slab_ld]
   int slab_ld;
@@ -404,6 +406,105 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
     if (lane == 0) red[wave] = ds_acc;
     __syncthreads();
     if (tid == 0) p.ds_part[tile] = red[0] + red[1] + red[2] + red[3];
+  } else if (EPI == EPI_ALIGN_STATS) {
+    // modality-alignment BCE (contrastive.py:387-413): per row r sums of BCE-with-logits over its positive
+    // columns [r, hmax[r]) and over the rest; pointwise, so tile partials simply add.
+    const float s = *scale_ptr;
+    float2* red = reinterpret_cast<float2*>(smem);  // [2][BN]
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int nl = wn * (BN / 2) + b * 32 + r;
+      const int i = n0 + nl;
+      const int row = p.label_off + i;
+      const int hm = (i < p.N) ? p.hmax[row] : 0;
+      float pos = 0.f, neg = 0.f;
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int c = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const float v = s * acc[a][b][e];
+          const bool y = (c >= row) && (c < hm);
+          // max(v,0) - v*y + log1p(exp(-|v|))
+          const float bce = fmaxf(v, 0.f) - (y ? v : 0.f) + log1pf(__expf(-fabsf(v)));
+          if (c < p.M) {
+            if (y) pos += bce; else neg += bce;
+          }
+        }
+      pos += __shfl_xor(pos, 32);
+      neg += __shfl_xor(neg, 32);
+      if (h == 0) red[wm * BN + nl] = make_float2(pos, neg);
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const float2 x = red[tid], y = red[BN + tid];
+      const int i = n0 + tid;
+      if (i < p.N) p.part[(size_t)tm * p.part_ld + i] = make_float2(x.x + y.x, x.y + y.y);
+    }
+  } else if (EPI == EPI_ALIGN_GRAD) {
+    // d/dlogits of the alignment loss, symmetrised because logits = s F F^T:  G[r][c] = a_rc + a_cr with
+    // a_rc = (sigmoid(v) - y_rc) * (y_rc ? 1/npos_r : 1/nneg_r);  d/dscale uses a_rc only (each (r,c) once).
+    const float s = *scale_ptr;
+    float ds_acc = 0.f;
+    constexpr int COLS = BM / 2;
+    constexpr int PB = 4 * (int)sizeof(T);
+    constexpr int RB = COLS * (int)sizeof(T);
+    constexpr int STRIDE = RB + PB;
+    constexpr int LPR = COLS / 4;
+    constexpr int RPI = 64 / LPR;
+    typedef typename std::conditional<sizeof(T) == 2, uint2, uint4>::type Piece;
+    char* stg = smem + wave * (32 * STRIDE);
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      const int i = n0 + wn * (BN / 2) + b * 32 + r;
+      const bool iv = i < p.N;
+      const int row = p.label_off + i;
+      const int hm_r = iv ? p.hmax[row] : row + 1;
+      const float ipos_r = 1.f / (float)(hm_r - row);
+      const float ineg_r = 1.f / (float)(p.M - (hm_r - row));
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int jl = a * 32 + 8 * q + 4 * h;
+          const int cb = m0 + wm * (BM / 2) + jl;
+          float g4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = cb + e;
+            const bool cv = c < p.M;
+            const int hm_c = cv ? p.hmax[c] : c + 1;
+            const float t = acc[a][b][4 * q + e];
+            const float v = s * t;
+            const float sig = 1.f / (1.f + __expf(-v));
+            const bool y_rc = (c >= row) && (c < hm_r);
+            const bool y_cr = (row >= c) && (row < hm_c);
+            const float w_rc = y_rc ? ipos_r : ineg_r;
+            const float w_cr = y_cr ? 1.f / (float)(hm_c - c) : 1.f / (float)(p.M - (hm_c - c));
+            const float a_rc = (sig - (y_rc ? 1.f : 0.f)) * w_rc;
+            const float a_cr = (sig - (y_cr ? 1.f : 0.f)) * w_cr;
+            float g = a_rc + a_cr;
+            if (!(iv && cv)) g = 0.f;
+            else ds_acc = fmaf(a_rc, t, ds_acc);
+            g4[e] = g;
+          }
+          Vec4<T>::store(reinterpret_cast<T*>(stg + r * STRIDE) + jl, make_float4(g4[0], g4[1], g4[2], g4[3]));
+        }
+#pragma unroll
+      for (int t = 0; t < 32 / RPI; ++t) {
+        const int srow = t * RPI + lane / LPR, c4 = lane % LPR;
+        const Piece v = *reinterpret_cast<const Piece*>(stg + srow * STRIDE + c4 * PB);
+        const int gi = n0 + wn * (BN / 2) + b * 32 + srow;
+        const int gj = m0 + wm * (BM / 2) + c4 * 4;
+        *reinterpret_cast<Piece*>(reinterpret_cast<T*>(p.G) + (size_t)gi * p.ldg + gj) = v;
+      }
+    }
+    __syncthreads();
+    ds_acc = wave_sum(ds_acc);
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane == 0) red[wave] = ds_acc;
+    __syncthreads();
+    if (tid == 0) p.ds_part[tile] = red[0] + red[1] + red[2] + red[3];
   } else {  // EPI_PLAIN: slab[split][n][m] = acc
     float* slab = p.slab + (size_t)zsplit * p.slab_split_stride;
 #pragma unroll
@@ -452,6 +553,39 @@ __global__ __launch_bounds__(256) void lse_reduce_kernel(const ReduceBatch batch
     const float lse = (mx + log2f(l)) * 0.6931471805599453f;  // partials are in the log2 domain
     p.lse[i] = lse;
     local = lse - p.diag[i];
+  }
+  __shared__ float red[4];
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) p.loss_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// alignment: loss_r = pos/npos + neg/nneg per owned row; block sums to loss_part (the caller scales by 1/M)
+struct AlignReduceProb {
+  const float2* part;
+  int part_ld, tiles_m, N, M, row0;
+  const int* hmax;
+  float* loss_part;
+};
+struct AlignReduceBatch {
+  AlignReduceProb p[MAX_PROBS];
+};
+__global__ __launch_bounds__(256) void align_reduce_kernel(const AlignReduceBatch batch) {
+  const AlignReduceProb& p = batch.p[blockIdx.y];
+  if (blockIdx.x * 256 >= p.N) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float local = 0.f;
+  if (i < p.N) {
+    float pos = 0.f, neg = 0.f;
+    for (int t = 0; t < p.tiles_m; ++t) {
+      const float2 v = p.part[(size_t)t * p.part_ld + i];
+      pos += v.x;
+      neg += v.y;
+    }
+    const int row = p.row0 + i;
+    const float npos = (float)(p.hmax[row] - row);
+    local = pos / npos + neg / ((float)p.M - npos);
   }
   __shared__ float red[4];
   local = wave_sum(local);
@@ -710,6 +844,7 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
   const Plan pl = make_plan(r_max, c_max, k_pad, n_dirs, sizeof(T) == 2 ? MMK_COMPUTE_BF16 : MMK_COMPUTE_F32);
   ProbBatch b;
   ReduceBatch rb;
+  AlignReduceBatch ab;
   int max_tiles = 0;
   for (int k = 0; k < n_dirs; ++k) {
     const mmk_clip_dir& d = dirs[k];
@@ -727,18 +862,25 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
     p.part_ld = d.r;
     p.diag = d.diag;
     p.label_off = d.label_off;
+    p.hmax = d.hmax;
     max_tiles = std::max(max_tiles, p.tiles_m * p.tiles_n);
     rb.p[k] = ReduceProb{p.part, p.part_ld, p.tiles_m, d.r, d.diag, d.lse, d.loss_part};
+    ab.p[k] = AlignReduceProb{p.part, p.part_ld, p.tiles_m, d.r, d.c, d.label_off, d.hmax, d.loss_part};
   }
   b.n_split = 1;
+  const bool align = dirs[0].mode == 1;
   {
     ProfScope ps(MMK_K_SIM_STATS, st);
-    int rc = launch_gemm<T, EPI_STATS>(b, n_dirs, pl.bt, max_tiles, scale, st);
+    int rc = align ? launch_gemm<T, EPI_ALIGN_STATS>(b, n_dirs, pl.bt, max_tiles, scale, st)
+                   : launch_gemm<T, EPI_STATS>(b, n_dirs, pl.bt, max_tiles, scale, st);
     if (rc) return rc;
   }
   {
     ProfScope ps(MMK_K_LSE_REDUCE, st);
-    hipLaunchKernelGGL(lse_reduce_kernel, dim3(cdiv(r_max, 256), n_dirs), dim3(256), 0, st, rb);
+    if (align)
+      hipLaunchKernelGGL(align_reduce_kernel, dim3(cdiv(r_max, 256), n_dirs), dim3(256), 0, st, ab);
+    else
+      hipLaunchKernelGGL(lse_reduce_kernel, dim3(cdiv(r_max, 256), n_dirs), dim3(256), 0, st, rb);
     MMK_LAUNCH_CHECK();
   }
   return 0;
@@ -783,7 +925,8 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
     p.c_row = d.c_row; p.c_col = d.c_col; p.c_diag = d.c_diag;
     p.s_row = d.s_row; p.s_col = d.s_col; p.s_diag = d.s_diag;
     p.ds_part = d.ds_part;
-    MMK_REQUIRE(d.lse_col != nullptr || (d.c_col == 0.f && d.s_col == 0.f), "lse_col required when c_col/s_col != 0");
+    p.hmax = d.hmax;
+    MMK_REQUIRE(d.mode == 1 || d.lse_col != nullptr || (d.c_col == 0.f && d.s_col == 0.f), "lse_col required when c_col/s_col != 0");
     max_tiles_g = std::max(max_tiles_g, p.tiles_m * p.tiles_n);
     db.part[k] = d.ds_part;
     db.n[k] = p.tiles_m * p.tiles_n;
@@ -815,7 +958,8 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
   db.n_probs = n_dirs;
   {
     ProfScope ps(MMK_K_SIM_GRAD, st);
-    int rc = launch_gemm<T, EPI_GRAD>(gb, n_dirs, pl.bt, max_tiles_g, scale, st);
+    int rc = dirs[0].mode == 1 ? launch_gemm<T, EPI_ALIGN_GRAD>(gb, n_dirs, pl.bt, max_tiles_g, scale, st)
+                               : launch_gemm<T, EPI_GRAD>(gb, n_dirs, pl.bt, max_tiles_g, scale, st);
     if (rc) return rc;
   }
   {
@@ -898,7 +1042,9 @@ static int check_dirs(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int compu
     const mmk_clip_dir& d = dirs[k];
     MMK_REQUIRE(d.x && d.y, "null operand");
     MMK_REQUIRE(d.r > 0 && d.c > 0, "empty direction");
-    MMK_REQUIRE(d.label_off >= 0 && d.label_off + d.r <= d.c, "labels out of range");
+    MMK_REQUIRE(d.label_off >= 0 && d.label_off + d.r <= d.c, "labels / row offset out of range");
+    MMK_REQUIRE(d.mode == dirs[0].mode && (d.mode == 0 || d.mode == 1), "all directions of one call must share mode 0 or 1");
+    MMK_REQUIRE(d.mode == 0 || d.hmax != nullptr, "alignment mode needs hmax");
   }
   return 0;
 }
@@ -909,7 +1055,7 @@ int mmk_clip_forward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int
   if (rc) return rc;
   MMK_REQUIRE(scale, "null scale");
   for (int k = 0; k < n_dirs; ++k)
-    MMK_REQUIRE(dirs[k].part && dirs[k].diag && dirs[k].lse && dirs[k].loss_part, "null forward buffer");
+    MMK_REQUIRE(dirs[k].part && dirs[k].loss_part && (dirs[k].mode == 1 || (dirs[k].diag && dirs[k].lse)), "null forward buffer");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (compute == MMK_COMPUTE_BF16) return clip_forward_impl<bf16_t>(dirs, n_dirs, k_pad, scale, st);
   return clip_forward_impl<float>(dirs, n_dirs, k_pad, scale, st);
@@ -942,7 +1088,7 @@ int mmk_clip_backward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, in
   const int dt = dirs[0].dx_dtype;
   for (int k = 0; k < n_dirs; ++k) {
     const mmk_clip_dir& q = dirs[k];
-    MMK_REQUIRE(q.yT && q.lse && q.g && q.slab && q.ds_part && q.dx, "null backward buffer");
+    MMK_REQUIRE(q.yT && (q.lse || q.mode == 1) && q.g && q.slab && q.ds_part && q.dx, "null backward buffer");
     MMK_REQUIRE(q.dx_dtype == dt, "all directions of one call must share dx_dtype");
     MMK_REQUIRE(!q.dx_accumulate || q.dx_dtype == MMK_F32, "accumulating scatter needs an f32 gradient buffer");
     MMK_REQUIRE(!q.normalize || (q.src && q.src_dtype == q.dx_dtype), "normalize backward needs src of dx dtype");

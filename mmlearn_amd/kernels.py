@@ -115,6 +115,8 @@ class Direction:
     dx_accumulate: bool = False
     src: Optional[torch.Tensor] = None       # original rows when normalize=True
     normalize: bool = False
+    mode: int = 0                            # 0: cross-entropy direction, 1: modality-alignment BCE rows
+    hmax: Optional[torch.Tensor] = None      # int32[c] (mode 1)
     _keep: list = field(default_factory=list)
 
 
@@ -136,13 +138,15 @@ def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.T
             assert dr.x.shape[1] == k_pad and dr.y.shape[1] == k_pad
             n_col_tiles, _, _ = _plan(dr.r, dr.c, k_pad, compute)
             part = torch.empty((n_col_tiles, dr.r, 2), dtype=torch.float32, device=dev)
-            dr.lse = torch.empty(dr.r, dtype=torch.float32, device=dev)
-            dr.diag = torch.empty(dr.r, dtype=torch.float32, device=dev)
+            if dr.mode == 0:
+                dr.lse = torch.empty(dr.r, dtype=torch.float32, device=dev)
+                dr.diag = torch.empty(dr.r, dtype=torch.float32, device=dev)
             dr.loss_part = torch.empty((dr.r + 255) // 256, dtype=torch.float32, device=dev)
             dr._keep.append(part)
             e = arr[k]
             e.x, e.y, e.r, e.c, e.label_off = ptr(dr.x), ptr(dr.y), dr.r, dr.c, dr.label_off
             e.part, e.diag, e.lse, e.loss_part = ptr(part), ptr(dr.diag), ptr(dr.lse), ptr(dr.loss_part)
+            e.mode, e.hmax = dr.mode, ptr(dr.hmax)
         check(_lib.lib().mmk_clip_forward(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), stream()))
 
 
@@ -194,6 +198,7 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.
             e.dx, e.dx_rows, e.dx_dtype = ptr(dr.dx), ptr(dr.dx_rows), dtype_tag(dr.dx.dtype)
             e.dx_accumulate = int(dr.dx_accumulate)
             e.src, e.normalize = ptr(dr.src), int(dr.normalize)
+            e.mode, e.hmax = dr.mode, ptr(dr.hmax)
             e.src_dtype = dtype_tag(dr.src.dtype) if dr.src is not None else 0
         check(_lib.lib().mmk_clip_backward(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), ptr(upstream),
                                            ptr(dscale), stream()))

@@ -256,10 +256,62 @@ class _Run:
             dirs_all += p.dirs
         if dirs_all:
             K.clip_forward(dirs_all, self.d, self.compute, self.scale32)
+        self.align_dirs = []
+        if o.modality_alignment:
+            self._build_alignment(views, dev)
 
-        if not self.pairs:
+        if not self.pairs and not o.modality_alignment:
             return None
-        return self._finish_forward(dev)
+        loss = self._finish_forward(dev) if self.pairs else None
+        if o.modality_alignment:
+            # (1/M) * sum over ALL rows of (pos_r/npos_r + neg_r/nneg_r); every rank holds its own rows' share
+            if self.align_dirs:
+                al = K.reduce_sums([d.loss_part for d in self.align_dirs], [1.0 / self.align_m] * len(self.align_dirs))
+            else:
+                al = torch.zeros((), dtype=torch.float32, device=dev)
+            if W > 1:
+                dist.all_reduce(al)
+            loss = al if loss is None else loss + al
+        return loss
+
+    def _build_alignment(self, views: dict, dev) -> None:
+        """Rows of the modality-alignment BCE (contrastive.py:344-413) owned by this rank: one problem per modality.
+        The concatenation follows the reference's dict order (insertion order at W = 1, sorted keys after a gather)
+        and the positives use its non-cumulative block offsets (quirk Q2)."""
+        o, W, rank = self.o, self.world, self.rank
+        order = list(views) if W == 1 else sorted(views, key=lambda n: Modalities.get_modality(n).embedding
+                                                  if Modalities.has_modality(n) else n)
+        sizes = [sum(views[n].counts) for n in order]
+        m_total = sum(sizes)
+        self.align_m = m_total
+        self.align_order = order
+        hmax = np.arange(1, m_total + 1, dtype=np.int32)
+        for k, n in enumerate(sizes):
+            off = 0 if k == 0 else sizes[k - 1]
+            hmax[off: off + n] = np.maximum(hmax[off: off + n], off + n)
+        hmax_t = torch.from_numpy(hmax).to(dev)
+        if W == 1:
+            src = torch.cat([views[n].src for n in order], 0)
+            idx = None
+        else:
+            src = views[order[0]].src
+            idx = torch.cat([views[n].rows for n in order]).contiguous()
+        f_all, f_all_t = K.pack_rows(src, idx, m_total, o.l2_normalize, self.compute, self.needs_grad)
+        # gradient multiplier of the gathered shards (SURVEY 8(a) A4): own shard re-inserted x1, dist_nn gather xW,
+        # no gradient path in the (local_loss, no gather_with_grad) cell
+        mult = 1.0 if W == 1 else (float(W) if o.gather_with_grad else (0.0 if o.local_loss else 1.0))
+        off = 0
+        for n, size in zip(order, sizes):
+            v = views[n]
+            if v.local is not None and v.local.shape[0] > 0:
+                lo, hi = v.my_range(rank)
+                dr = K.Direction(x=_slice_rows(f_all, off + lo), y=f_all, y_t=f_all_t, r=hi - lo, c=m_total, label_off=off + lo,
+                                 kappa=mult / m_total, ds_kappa=1.0 / m_total, mode=1, hmax=hmax_t)
+                dr.modality = n
+                self.align_dirs.append(dr)
+            off += size
+        if self.align_dirs:
+            K.clip_forward(self.align_dirs, self.d, self.compute, self.scale32)
 
     def _own_rows(self, view: _View, idx: Optional[torch.Tensor], n: int):
         """Rows p of the matched list whose `view` row belongs to this rank -> (contiguous?, p0, p1 | index array)."""
@@ -413,8 +465,12 @@ class _Run:
             for role in p.roles:
                 n = p.ma if role == "a" else p.mb
                 writers[n] = writers.get(n, 0) + 1
+        for dr in self.align_dirs:
+            writers[dr.modality] = writers.get(dr.modality, 0) + 1
         grads: dict[str, torch.Tensor] = {}
         accumulate: dict[str, bool] = {}
+        for dr in self.align_dirs:
+            accumulate[dr.modality] = writers[dr.modality] > 1
         for p in self.pairs:
             for role in p.roles:
                 n = p.ma if role == "a" else p.mb
@@ -442,9 +498,24 @@ class _Run:
                     dr.normalize = True
                     dr.src = self.embeddings[key_of[n]].detach().contiguous()
                 dirs_all.append(dr)
+        for dr in self.align_dirs:
+            dr.dx = grads[dr.modality]
+            dr.dx_accumulate = accumulate[dr.modality]
+            if o.l2_normalize:
+                dr.normalize = True
+                dr.src = self.embeddings[key_of[dr.modality]].detach().contiguous()
         dscale = torch.zeros(1, dtype=torch.float32, device=dev)
+        dscale_align = torch.zeros(1, dtype=torch.float32, device=dev) if self.align_dirs or o.modality_alignment else None
+        every = dirs_all + self.align_dirs
+        if every:
+            deferred_norm = o.l2_normalize and any(d.dx_accumulate for d in every)
+            if deferred_norm:
+                for d_ in every:
+                    d_.normalize = False
+            if self.align_dirs:
+                K.clip_backward(self.align_dirs, self.d, self.compute, self.scale32, upstream, dscale_align)
         if dirs_all:
-            if o.l2_normalize and any(d.dx_accumulate for d in dirs_all):
+            if o.l2_normalize and any(d.dx_accumulate for d in every):
                 # the normalise-backward of an accumulating scatter needs the summed upstream gradient first:
                 # run un-normalised, then apply the projection once per row.
                 for d_ in dirs_all:
@@ -458,8 +529,17 @@ class _Run:
                     grads[n] = K.l2norm_bwd(src.float(), g.float(), inv)
             else:
                 K.clip_backward(dirs_all, self.d, self.compute, self.scale32, upstream, dscale)
+        elif every and o.l2_normalize and any(d.dx_accumulate for d in every):
+            for n in grads:  # alignment only: apply the deferred normalise-backward
+                src = self.embeddings[key_of[n]].detach()
+                _, inv = K.l2norm_fwd(src.float())
+                grads[n] = K.l2norm_bwd(src.float(), grads[n].float(), inv)
         if W > 1 and not self.local_mode:
             dist.all_reduce(dscale)  # every rank returns the full d loss / d scale (reference: identical graphs)
+        if dscale_align is not None:
+            if W > 1:
+                dist.all_reduce(dscale_align)  # each rank summed its own rows of the (replicated) alignment term
+            dscale = dscale + dscale_align
         out = []
         for key, t in self.embeddings.items():
             name = next(n for n, k in key_of.items() if k == key)
@@ -496,8 +576,9 @@ class ContrastiveLoss(nn.Module):
     ----------
     l2_normalize, local_loss, gather_with_grad, modality_alignment, cache_labels
         As in the reference.  ``cache_labels`` is accepted and ignored (labels are never
-        materialised: label(i) = offset + i inside the kernels).  ``modality_alignment=True`` is not
-        implemented yet and raises.
+        materialised: label(i) = offset + i inside the kernels).  ``modality_alignment=True`` adds the
+        reference's BCE term over the concatenated modalities, including its non-cumulative positive
+        offsets for the 3rd+ modality.
     compute_dtype : torch.dtype, optional
         Force the arithmetic of the similarity products (``torch.bfloat16`` -> bf16 MFMA,
         ``torch.float32`` -> exact-f32 MFMA).  Default: bf16 for bf16 inputs or under bf16 autocast,
@@ -511,10 +592,6 @@ class ContrastiveLoss(nn.Module):
                  modality_alignment: bool = False, cache_labels: bool = False, compute_dtype: Optional[torch.dtype] = None,
                  static_shapes: bool = False):
         super().__init__()
-        if modality_alignment:
-            raise NotImplementedError(
-                "modality_alignment=True (contrastive.py:344-413) is not implemented in mmlearn_amd yet; "
-                "it is off by default in the reference.")
         if compute_dtype not in (None, torch.bfloat16, torch.float32):
             raise ValueError("compute_dtype must be None, torch.bfloat16 or torch.float32")
         self.l2_normalize = l2_normalize
@@ -541,9 +618,9 @@ class ContrastiveLoss(nn.Module):
                 loss = run.forward()
         else:
             loss = _ContrastiveFn.apply(run, logit_scale, *embeddings.values())
-            if not run.pairs:
+            if not run.pairs and not self.modality_alignment:
                 loss = None
-        if loss is None or not run.pairs:
+        if loss is None:
             # no loss to compute (e.g. no paired data in batch): constant zero, contrastive.py:151-158
             return torch.tensor(0.0, device=logit_scale.device, dtype=first.dtype)
         # CE runs in f32 under autocast; without it the reference's loss has the embeddings' dtype

@@ -78,9 +78,48 @@ def cross_entropy_rows(logits: np.ndarray, labels: np.ndarray):
 
 
 # ----------------------------------------------------------------------------
+# losses/contrastive.py:344-413 (_compute_modality_alignment_loss)
+def alignment_hmax(sizes):
+    """Positive set of row r is {r} + (r, hmax[r]): every modality block k contributes the strict upper triangle
+    of [o_k, o_k + n_k) with the reference's NON-cumulative offsets o_0 = 0, o_k = n_{k-1} (quirk Q2, :374-386)."""
+    m = int(sum(sizes))
+    hmax = np.arange(1, m + 1)
+    for k, n in enumerate(sizes):
+        o = 0 if k == 0 else sizes[k - 1]
+        rows = np.arange(o, o + n)
+        hmax[rows] = np.maximum(hmax[rows], o + n)
+    return hmax
+
+
+def alignment_loss(feats, scale):
+    """feats: list of [n_k, D] arrays in the reference's dict order.  Returns loss, d/dfeats (list), d/dscale."""
+    f = np.concatenate(feats, 0)
+    sizes = [len(x) for x in feats]
+    m = len(f)
+    hmax = alignment_hmax(sizes)
+    c = np.arange(m)
+    target = ((c[None, :] >= c[:, None]) & (c[None, :] < hmax[:, None])).astype(f.dtype)
+    t = _safe_matmul(f, f)
+    v = scale * t
+    bce = np.maximum(v, 0) - v * target + np.log1p(np.exp(-np.abs(v)))
+    num_pos = target.sum(1)
+    num_neg = m - num_pos
+    loss = ((bce * target).sum(1) / num_pos + (bce * (1 - target)).sum(1) / num_neg).mean()
+    w = np.where(target > 0, 1.0 / num_pos[:, None], 1.0 / num_neg[:, None]) / m
+    dv = (1.0 / (1.0 + np.exp(-v)) - target) * w
+    df = scale * ((dv + dv.T) @ f)
+    ds = (dv * t).sum()
+    out, o = [], 0
+    for n in sizes:
+        out.append(df[o:o + n])
+        o += n
+    return float(loss), out, float(ds)
+
+
+# ----------------------------------------------------------------------------
 # losses/contrastive.py:59-160 with world_size == 1
 def contrastive_loss(embeddings: dict, example_ids: dict, scale: float, pairs, l2norm: bool = False,
-                     dtype=np.float64):
+                     dtype=np.float64, modality_alignment: bool = False):
     """Single-process ContrastiveLoss.forward.
 
     embeddings: {modality_name: [B_m, D]}, example_ids: {modality_name: int64[B_m, 2]},
@@ -112,6 +151,14 @@ def contrastive_loss(embeddings: dict, example_ids: dict, scale: float, pairs, l
         np.add.at(grads[ma], ia, scale * (g @ fb))
         np.add.at(grads[mb], ib, scale * (g.T @ fa))
         n_terms += 1
+    if modality_alignment:  # :146-149, over the embeddings dict in insertion order
+        order = list(emb)
+        la, dfs, ds = alignment_loss([emb[k] for k in order], scale)
+        loss += la
+        dscale += ds
+        for k, g in zip(order, dfs):
+            grads[k] += g
+        n_terms += 1
     if l2norm:
         grads = {k: l2_normalize_bwd(raw[k], grads[k]) for k in grads}
     return {"loss": float(loss), "grads": grads, "dscale": float(dscale), "has_graph": n_terms > 0}
@@ -120,7 +167,7 @@ def contrastive_loss(embeddings: dict, example_ids: dict, scale: float, pairs, l
 # ----------------------------------------------------------------------------
 # losses/contrastive.py with world_size > 1, restated for all ranks at once
 def contrastive_loss_dist(rank_embeddings, rank_ids, scale: float, pairs, local_loss: bool,
-                          gather_with_grad: bool, l2norm: bool = False, dtype=np.float64):
+                          gather_with_grad: bool, l2norm: bool = False, dtype=np.float64, modality_alignment: bool = False):
     """Per-rank results of ContrastiveLoss.forward under torch.distributed.
 
     rank_embeddings[r] / rank_ids[r] are rank r's dicts.  Returns a list (one
@@ -209,6 +256,20 @@ def contrastive_loss_dist(rank_embeddings, rank_ids, scale: float, pairs, local_
                     sel = owner[mb][ib] == r
                     if mb in emb[r]:
                         np.add.at(out[r]["grads"][mb], local_row[mb][ib[sel]], dfb_g_tot[sel])
+    if modality_alignment:
+        # every rank evaluates the same term on the gathered dict (sorted keys, :466); gradients reach the local
+        # rows only where the gathered shards carry grad: own shard re-inserted (F,F) x1, dist_nn gather (.,T) xW,
+        # none in (T,F) (:491-492)
+        la, dfs, ds = alignment_loss([all_emb[k] for k in keys], scale)
+        mult = float(W) if gather_with_grad else (0.0 if local_loss else 1.0)
+        for r in range(W):
+            out[r]["loss"] += la
+            out[r]["dscale"] += ds
+            out[r]["has_graph"] = True
+            for k, g in zip(keys, dfs):
+                if k in emb[r]:
+                    sel = owner[k] == r
+                    out[r]["grads"][k][local_row[k][sel]] += mult * g[sel]
     if l2norm:
         for r in range(W):
             out[r]["grads"] = {k: l2_normalize_bwd(emb_raw[r][k], g) for k, g in out[r]["grads"].items()}

@@ -61,6 +61,11 @@ def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.T
     for dr in dirs:
         t = dr.x[: dr.r] @ dr.y[: dr.c].T
         v = s * t
+        if dr.mode == 1:
+            per = _align_rows(dr, v)[0]
+            nb = (dr.r + 255) // 256
+            dr.loss_part = torch.stack([per[k * 256:(k + 1) * 256].sum() for k in range(nb)]).float()
+            continue
         lse = torch.logsumexp(v, dim=1)
         lab = dr.label_off + torch.arange(dr.r)
         dr.lse = lse.float()
@@ -68,6 +73,21 @@ def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.T
         per = lse - v[torch.arange(dr.r), lab]
         nb = (dr.r + 255) // 256
         dr.loss_part = torch.stack([per[k * 256:(k + 1) * 256].sum() for k in range(nb)]).float()
+
+
+def _align_rows(dr, v):
+    """per-row alignment loss and the (unsymmetrised) d/dlogits weights for the owned rows of `dr`"""
+    m = dr.c
+    hmax = dr.hmax.long()
+    rows = dr.label_off + torch.arange(dr.r)
+    cols = torch.arange(m)
+    y = ((cols[None, :] >= rows[:, None]) & (cols[None, :] < hmax[rows][:, None])).double()
+    bce = torch.clamp(v, min=0) - v * y + torch.log1p(torch.exp(-v.abs()))
+    npos = (hmax[rows] - rows).double()
+    nneg = m - npos
+    per = (bce * y).sum(1) / npos + (bce * (1 - y)).sum(1) / nneg
+    w = torch.where(y > 0, 1.0 / npos[:, None], 1.0 / nneg[:, None])
+    return per, y, w
 
 
 def reduce_sums(parts, weights, separate=False, out: Optional[torch.Tensor] = None):
@@ -94,6 +114,28 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale, upstre
         assert torch.equal(dr.y_t[:, : dr.c], y.T), "yT must be the transpose of y"
         t = x @ y.T
         v = s * t
+        if dr.mode == 1:
+            _, yy, w = _align_rows(dr, v)
+            sig = torch.sigmoid(v)
+            a_rc = (sig - yy) * w
+            # transposed term a_cr for (c, r): needs the weights of every column's own row
+            m = dr.c
+            hmax = dr.hmax.long()
+            rows = dr.label_off + torch.arange(dr.r)
+            cols = torch.arange(m)
+            y_cr = ((rows[:, None] >= cols[None, :]) & (rows[:, None] < hmax[cols][None, :])).double()
+            npos_c = (hmax[cols] - cols).double()
+            w_cr = torch.where(y_cr > 0, 1.0 / npos_c[None, :], 1.0 / (m - npos_c)[None, :])
+            g = a_rc + (sig - y_cr) * w_cr
+            if dscale is not None:
+                dscale += float(up * dr.ds_kappa * (a_rc * t).sum())
+            dx = (up * dr.kappa * s) * (g @ y)[:, :d]
+            rws = torch.arange(dr.r)
+            if dr.dx_accumulate:
+                dr.dx.index_add_(0, rws, dx.to(dr.dx.dtype))
+            else:
+                dr.dx[rws] = dx.to(dr.dx.dtype)
+            continue
         p_row = torch.exp(v - dr.lse.double()[:, None])
         p_col = torch.exp(v - dr.lse_col.double()[None, :]) if (dr.c_col or dr.s_col) else torch.zeros_like(v)
         delta = torch.zeros_like(v)

@@ -364,6 +364,72 @@ def gen_ema(R):
     return cases
 
 
+# ------------------------------------------------------------------------ G9
+def _align_worker(rank, world, port, cfg, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    warnings.filterwarnings("ignore")
+    R = ref_shim.load()
+    torch.manual_seed(300 + rank)
+    embs = {m: F.normalize(torch.randn(n, cfg["D"]), dim=-1) for m, n in cfg["sizes"].items()}
+    ids = {m: _ids(range(rank * 50, rank * 50 + n)) for m, n in cfg["sizes"].items()}
+    out = _run_loss(R, embs, ids, cfg["scale"], cfg["pairs"], modality_alignment=True,
+                    local_loss=cfg["local_loss"], gather_with_grad=cfg["gather_with_grad"])
+    rec = {f"in_{k}": _np(v) for k, v in embs.items()}
+    rec.update({f"ids_{k}": _np(v) for k, v in ids.items()})
+    rec.update({f"out_{k}": v for k, v in out.items()})
+    q.put((rank, rec))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gen_align(R):
+    """modality_alignment=True (contrastive.py:344-413) incl. the non-cumulative offset quirk (Q2)."""
+    cases = {}
+    g = torch.Generator().manual_seed(99)
+    for name, sizes, pairs, scale in (
+        ("m2_6x6", {"rgb": 6, "text": 6}, [(("rgb", "text"), 1.0)], 1 / 0.07),
+        ("m3_5x7x4", {"rgb": 5, "text": 7, "audio": 4}, [(("rgb", "text"), 1.0), (("rgb", "audio"), 0.5)], 10.0),
+        ("m3_equal_8", {"rgb": 8, "text": 8, "audio": 8}, [(("rgb", "text"), 1.0), (("text", "audio"), 1.0)], 5.0),
+        ("m2_40x33_d24", {"rgb": 40, "text": 33}, [(("rgb", "text"), 1.0)], 3.0),
+    ):
+        d = 24 if "d24" in name else 16
+        embs = {m: F.normalize(torch.randn(n, d, generator=g), dim=-1) for m, n in sizes.items()}
+        ids = {m: _ids(range(n)) for m, n in sizes.items()}
+        out = _run_loss(R, embs, ids, scale, pairs, modality_alignment=True)
+        rec = {f"in_{k}": _np(v) for k, v in embs.items()}
+        rec.update({f"ids_{k}": _np(v) for k, v in ids.items()})
+        rec["scale"] = np.array(scale)
+        rec["pairs"] = np.array([f"{p[0][0]}|{p[0][1]}|{p[1]}" for p in pairs])
+        rec["order"] = np.array(list(sizes))
+        rec.update({f"out_{k}": v for k, v in out.items()})
+        # the alignment term alone (no pairs -> only the alignment loss is appended)
+        only = _run_loss(R, embs, ids, scale, [], modality_alignment=True)
+        rec.update({f"only_{k}": v for k, v in only.items()})
+        cases[name] = rec
+    ctx = mp.get_context("spawn")
+    port = 29660
+    for ll, gwg in ((False, False), (False, True), (True, False), (True, True)):
+        port += 1
+        cfg = dict(D=16, sizes={"rgb": 6, "text": 6}, scale=8.0, pairs=[(("rgb", "text"), 1.0)], local_loss=ll, gather_with_grad=gwg)
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_align_worker, args=(r, 2, port, cfg, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=180) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+        rec = {"world": np.array(2), "local_loss": np.array(ll), "gather_with_grad": np.array(gwg), "scale": np.array(8.0),
+               "order": np.array(["rgb", "text"])}
+        for r, dd in res.items():
+            for k, v in dd.items():
+                rec[f"r{r}_{k}"] = v
+        cases[f"w2_local{int(ll)}_gwg{int(gwg)}"] = rec
+        print("  align dist", ll, gwg, [float(res[r]["out_loss"]) for r in sorted(res)])
+    return cases
+
+
 def _save(name, cases):
     flat = {}
     for c, rec in cases.items():
@@ -376,7 +442,7 @@ def _save(name, cases):
 
 def main():
     R = ref_shim.load()
-    which = sys.argv[1:] or ["clip", "match", "task", "ijepa", "masks", "ema", "dist"]
+    which = sys.argv[1:] or ["clip", "match", "task", "ijepa", "masks", "ema", "dist", "align"]
     if "clip" in which:
         _save("g1_g2_clip", gen_clip(R))
     if "match" in which:
@@ -391,6 +457,8 @@ def main():
         _save("g8_ema", gen_ema(R))
     if "dist" in which:
         _save("g3_clip_dist", gen_dist())
+    if "align" in which:
+        _save("g9_align", gen_align(R))
 
 
 if __name__ == "__main__":

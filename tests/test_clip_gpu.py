@@ -200,3 +200,32 @@ def test_match_large_and_errors():
         find_matching_indices([(0, 0)], b.to(dev))
     with pytest.raises(ValueError):
         find_matching_indices(torch.zeros(3, device=dev), b.to(dev))
+
+
+ALIGN = Golden("g9_align")
+
+
+@pytest.mark.parametrize("name", [n for n in ALIGN.names() if not n.startswith("w2_")])
+def test_golden_modality_alignment(name):
+    c = ALIGN[name]
+    order = c["order"].tolist()
+    embs = {m: c[f"in_{m}"] for m in order}       # dict order matters: the reference concatenates in insertion order
+    ids = {m: c[f"ids_{m}"] for m in order}
+    for prefix, pairs in (("out", parse_pairs(c["pairs"])), ("only", [])):
+        res = _run_hip(embs, ids, float(c["scale"]), pairs, modality_alignment=True)
+        _check(res, float(c[f"{prefix}_loss"]), {m: c[f"{prefix}_grad_{m}"] for m in order}, float(c[f"{prefix}_grad_scale"]), 1e-3,
+               f"{name}:{prefix}")
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_modality_alignment_seeded_three_modalities(dtype):
+    g = np.random.default_rng(11)
+    sizes = {"rgb": 300, "text": 257, "audio": 190}
+    embs = {m: (lambda x: x / np.linalg.norm(x, axis=1, keepdims=True))(g.standard_normal((n, 80)).astype(np.float32)) for m, n in sizes.items()}
+    if dtype == "bfloat16":
+        embs = {m: torch.tensor(v).bfloat16().float().numpy() for m, v in embs.items()}
+    ids = {m: np.stack([np.zeros(n, np.int64), np.arange(n)], 1) for m, n in sizes.items()}
+    pairs = [(("rgb", "text"), 1.0), (("text", "audio"), 0.5)]
+    res = _run_hip(embs, ids, 6.0, pairs, dtype=dtype, modality_alignment=True, l2_normalize=(dtype == "float32"))
+    orc = co.contrastive_loss(embs, ids, 6.0, pairs, modality_alignment=True, l2norm=(dtype == "float32"))
+    _check(res, orc["loss"], orc["grads"], orc["dscale"], TOL[dtype], f"align3:{dtype}")

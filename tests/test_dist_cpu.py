@@ -109,6 +109,65 @@ def test_world2_all_flag_cells_uneven_and_missing_modality():
     _check(2, names, out)
 
 
+def _align_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import fake_kernels
+        import mmlearn_amd.losses as L
+        from conftest import Golden as G
+
+        L.K = fake_kernels
+        gold = G("g9_align")
+        results = {}
+        for name in [n for n in gold.names() if n.startswith("w2_")]:
+            c = gold[name]
+            embs = {f"{m}_embedding": torch.tensor(c[f"r{rank}_in_{m}"]).requires_grad_(True) for m in ("rgb", "text")}
+            ids = {m: torch.tensor(c[f"r{rank}_ids_{m}"]) for m in ("rgb", "text")}
+            s = torch.tensor(float(c["scale"]), requires_grad=True)
+            fn = L.ContrastiveLoss(local_loss=bool(c["local_loss"]), gather_with_grad=bool(c["gather_with_grad"]),
+                                   modality_alignment=True)
+            loss = fn(embs, ids, s, [L.LossPairSpec(("rgb", "text"))])
+            loss.backward()
+            results[name] = {"loss": float(loss.detach()), "dscale": float(s.grad),
+                             "grads": {m: embs[f"{m}_embedding"].grad.numpy().copy() for m in ("rgb", "text")}}
+        q.put((rank, results, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, None, traceback.format_exc()))
+
+
+@pytest.mark.timeout(300)
+def test_world2_modality_alignment_all_flag_cells():
+    gold = Golden("g9_align")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_align_worker, args=(r, 2, 29713, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in procs:
+        rank, res, err = q.get(timeout=240)
+        assert err is None, f"rank {rank} failed:\n{err}"
+        out[rank] = res
+    for p in procs:
+        p.join(timeout=60)
+    for name in [n for n in gold.names() if n.startswith("w2_")]:
+        c = gold[name]
+        for rank in range(2):
+            got = out[rank][name]
+            assert abs(got["loss"] - float(c[f"r{rank}_out_loss"])) <= 2e-5 * abs(got["loss"]), (name, rank)
+            for m in ("rgb", "text"):
+                ref = c[f"r{rank}_out_grad_{m}"]
+                assert np.abs(got["grads"][m] - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-3), (name, rank, m)
+            assert abs(got["dscale"] - float(c[f"r{rank}_out_grad_scale"])) <= 2e-5 * max(1.0, abs(got["dscale"])), (name, rank)
+
+
 @pytest.mark.timeout(300)
 def test_world4_all_flag_cells():
     names = [n for n in DIST.names() if n.startswith("w4_")]

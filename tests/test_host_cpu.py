@@ -71,8 +71,7 @@ def test_loss_constructor_contract():
 
     l = ContrastiveLoss(l2_normalize=True, local_loss=True, gather_with_grad=True, cache_labels=True)
     assert (l.l2_normalize, l.local_loss, l.gather_with_grad, l.cache_labels) == (True, True, True, True)
-    with pytest.raises(NotImplementedError):
-        ContrastiveLoss(modality_alignment=True)
+    assert ContrastiveLoss(modality_alignment=True).modality_alignment is True
     with pytest.raises(ValueError):
         ContrastiveLoss(compute_dtype=torch.float16)
 

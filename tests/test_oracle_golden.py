@@ -137,3 +137,33 @@ def test_ema_oracle_vs_reference():
     np.testing.assert_allclose(decays, c["decays"], rtol=0, atol=1e-15)
     np.testing.assert_array_equal(nups, c["num_updates"])
     np.testing.assert_allclose([io.annealed_rate(0.996, 1.0, s, 1000) for s in (0, 1, 10, 500, 999, 1000)], c["annealed"], atol=1e-15)
+
+
+ALIGN = Golden("g9_align")
+
+
+@pytest.mark.parametrize("name", ALIGN.names())
+def test_alignment_oracle_vs_reference(name):
+    c = ALIGN[name]
+    order = c["order"].tolist()
+    if name.startswith("w2_"):
+        embs = [{m: c[f"r{r}_in_{m}"] for m in order} for r in range(2)]
+        ids = [{m: c[f"r{r}_ids_{m}"] for m in order} for r in range(2)]
+        res = co.contrastive_loss_dist(embs, ids, float(c["scale"]), [(("rgb", "text"), 1.0)], bool(c["local_loss"]),
+                                       bool(c["gather_with_grad"]), modality_alignment=True)
+        for r in range(2):
+            assert abs(res[r]["loss"] - float(c[f"r{r}_out_loss"])) <= 2e-5 * abs(res[r]["loss"])
+            for m in order:
+                ref = c[f"r{r}_out_grad_{m}"]
+                assert np.abs(res[r]["grads"][m] - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-3), (name, r, m)
+            assert abs(res[r]["dscale"] - float(c[f"r{r}_out_grad_scale"])) <= 2e-5 * max(1.0, abs(res[r]["dscale"]))
+        return
+    embs = {m: c[f"in_{m}"] for m in order}
+    ids = {m: c[f"ids_{m}"] for m in order}
+    for prefix, pairs in (("out", parse_pairs(c["pairs"])), ("only", [])):
+        res = co.contrastive_loss(embs, ids, float(c["scale"]), pairs, modality_alignment=True)
+        assert abs(res["loss"] - float(c[f"{prefix}_loss"])) <= 2e-5 * abs(res["loss"]), (name, prefix)
+        for m in order:
+            ref = c[f"{prefix}_grad_{m}"]
+            assert np.abs(res["grads"][m] - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-3), (name, prefix, m)
+        assert abs(res["dscale"] - float(c[f"{prefix}_grad_scale"])) <= 2e-5 * max(1.0, abs(res["dscale"]))

@@ -93,12 +93,20 @@ def synthetic_batch(b: int, rank: int, device):
     }
 
 
-def build_task(loss, small: bool):
+def build_task(loss, small: bool, fused: bool = False):
     from mmlearn_amd.tasks.contrastive_pretraining import ContrastivePretraining
 
     torch.manual_seed(0)
+    rgb, text = VisionEncoder(small), TextEncoder(small)
+    if fused:  # HIP LayerNorm / quick-GELU inside the encoders (same parameters, same math)
+        from mmlearn_amd.fused import accelerate_encoder
+
+        # CLIP is pre-LN: these LayerNorms feed autocast Linears only, so they may emit bf16 directly;
+        # BERT is post-LN (the LN output is the residual stream) and keeps f32 outputs.
+        accelerate_encoder(rgb, low_precision_ln=("layer_norm1", "layer_norm2", "post_layernorm"))
+        accelerate_encoder(text)
     return ContrastivePretraining(
-        encoders={"rgb": VisionEncoder(small), "text": TextEncoder(small)},
+        encoders={"rgb": rgb, "text": text},
         loss=loss,
         optimizer=partial(torch.optim.AdamW, lr=1e-4, weight_decay=0.1),
         compute_validation_loss=False,
@@ -150,6 +158,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch (BASELINE: 1024)")
     ap.add_argument("--small", action="store_true", help="tiny encoders (debug only; invalid as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-encoder-ops", action="store_true", help="keep torch LayerNorm / HF quick-GELU in the encoders")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,7 +174,7 @@ def main():
     from mmlearn_amd import ContrastiveLoss, _lib
 
     _lib.check(_lib.lib().mmk_device_check())
-    task = build_task(ContrastiveLoss(static_shapes=True), args.small).to(dev)
+    task = build_task(ContrastiveLoss(static_shapes=True), args.small, fused=not args.no_fused_encoder_ops).to(dev)
     opt = task.configure_optimizers()
     stepper = _Step(task)
     if world > 1:
@@ -242,6 +251,7 @@ def main():
                                    f"per-GPU batch {args.batch}, {'local' if world == 1 else 'global-batch (all-gather)'} negatives"
                                    + (" [DEBUG small encoders]" if args.small else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": "mmlearn_amd.ContrastiveLoss (HIP)",
+                       "encoder_ops": "torch" if args.no_fused_encoder_ops else "HIP LayerNorm + quick-GELU (mmlearn_amd.fused)",
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline,
         }

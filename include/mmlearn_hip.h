@@ -46,7 +46,7 @@ enum {
   MMK_K_MATCH = 0, MMK_K_PACK, MMK_K_TRANSPOSE, MMK_K_SIM_STATS, MMK_K_LSE_REDUCE, MMK_K_LOSS_COMBINE,
   MMK_K_SIM_GRAD, MMK_K_GRAD_GEMM, MMK_K_GRAD_FINALIZE, MMK_K_L2NORM, MMK_K_IJEPA_LOSS_FWD,
   MMK_K_IJEPA_LOSS_BWD, MMK_K_GATHER_ROWS, MMK_K_SCATTER_ROWS, MMK_K_PRED_ASSEMBLE, MMK_K_PRED_ASSEMBLE_BWD,
-  MMK_K_EMA, MMK_K_MASK_INDEX, MMK_K_COUNT
+  MMK_K_EMA, MMK_K_MASK_INDEX, MMK_K_LAYERNORM_FWD, MMK_K_LAYERNORM_BWD, MMK_K_ACT, MMK_K_COUNT
 };
 int mmk_profile_enable(int on);          /* on=1 start recording (clears), on=0 stop */
 /* resolve recorded events (synchronises on them); fills count[k] and total_ms[k] for k < MMK_K_COUNT */
@@ -200,6 +200,20 @@ typedef struct {
 } mmk_ema_entry;
 int mmk_ema_update(const mmk_ema_entry* table, int n_tensors, int64_t max_numel, float decay, int mode,
                    void* stream);
+
+/* ------------------------------------------------------------------ encoder-side row ops
+ * torch.nn.LayerNorm inside the encoders the tasks drive (mmlearn/modules/encoders/{clip,text,vision}.py):
+ * F.layer_norm forward / backward with f32 statistics.  x: [rows, d]; w, b: f32[d] or NULL; mean/rstd: f32[rows].
+ * fwd dtype = x dtype | (y dtype << 4);  bwd dtype = x(=dx) dtype | (dy dtype << 4).
+ * bwd workspaces: part f32[mmk_layernorm_part_blocks(rows), 2, d], part2 f32[64, 2, d]; dw/db f32[d] or both NULL. */
+int mmk_layernorm_part_blocks(long rows);
+int mmk_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int64_t rows, int d,
+                      float eps, int dtype, void* stream);
+int mmk_layernorm_bwd(const void* x, const void* dy, const float* w, const float* mean, const float* rstd, void* dx, float* part,
+                      float* part2, float* dw, float* db, int64_t rows, int d, int dtype, void* stream);
+/* HF QuickGELUActivation  x * sigmoid(1.702 x)  (CLIP MLP), forward and backward, n elements (multiple of 4) */
+int mmk_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
+int mmk_quick_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ _DTYPE_TAG = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 KERNEL_NAMES = [
     "match_ids", "pack_rows", "transpose", "sim_stats", "lse_reduce", "loss_combine", "sim_grad", "grad_gemm",
     "grad_finalize", "l2norm", "ijepa_loss_fwd", "ijepa_loss_bwd", "gather_rows", "scatter_rows", "pred_assemble",
-    "pred_assemble_bwd", "ema_update", "mask_to_index",
+    "pred_assemble_bwd", "ema_update", "mask_to_index", "layernorm_fwd", "layernorm_bwd", "activation",
 ]
 
 
@@ -81,6 +81,11 @@ _SIGNATURES = {
     "mmk_pred_assemble": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "mmk_pred_assemble_bwd": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
     "mmk_ema_update": [_vp, _i, C.c_int64, _f, _i, _vp],
+    "mmk_layernorm_part_blocks": [C.c_long],
+    "mmk_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _f, _i, _vp],
+    "mmk_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _vp],
+    "mmk_quick_gelu_fwd": [_vp, _vp, C.c_int64, _i, _vp],
+    "mmk_quick_gelu_bwd": [_vp, _vp, _vp, C.c_int64, _i, _vp],
 }
 _STR_FUNCS = {"mmk_last_error": [], "mmk_kernel_name": [_i]}
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_STR_FUNCS))

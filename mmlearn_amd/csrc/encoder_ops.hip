@@ -1,0 +1,283 @@
+// SURVEY 8(f1) -- first widening into the encoder step: the HBM-bound row / elementwise ops that dominate the
+// non-GEMM time of the ViT-B/16 + BERT-base step under bf16 autocast (rocprof: LayerNorm fwd+bwd ~126 ms and the
+// unfused quick-GELU chain ~100 ms of a 425 ms step).  Replaces, inside the encoders the reference instantiates
+// (mmlearn/modules/encoders/clip.py, text.py, vision.py -> torch.nn.LayerNorm / HF activations):
+//   * F.layer_norm forward + backward (3 ATen kernels in backward) -> one forward kernel, one fused backward kernel
+//     (dx + per-block partial dgamma/dbeta) + a tiny column reduce;
+//   * x * sigmoid(1.702 x)  (3 elementwise kernels forward, ~6 backward) -> one kernel each way.
+// All are "one wave per row" / 16-byte-per-lane streaming kernels: coalesced HBM traffic, wave-shuffle reductions.
+#include <algorithm>
+
+#include "common.h"
+
+namespace mmk {
+
+constexpr int LN_ROWS_PER_WAVE = 16;  // rows each wave walks in the backward kernel (64 rows per block partial)
+constexpr int LN_MAX_VEC = 8;        // float4 per lane held in registers: D <= 64*4*8 = 2048 (VEC = 4 when D <= 1024)
+
+// ------------------------------------------------------------------ LayerNorm forward
+// y = (x - mean) * rstd * w + b, statistics in f32 over the row held in registers (two-pass variance).
+template <typename X, typename Y, int VEC>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const X* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, Y* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows,
+                                                            int d, float eps) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const X* xr = x + row * d;
+  Y* yr = y + row * d;
+  float4 v[VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int c = (lane + 64 * k) * 4;
+    if (c < d) {
+      v[k] = Vec4<X>::load(xr + c);
+      s += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
+  }
+  const float mean = wave_sum(s) / d;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int c = (lane + 64 * k) * 4;
+    if (c < d) {
+      const float a0 = v[k].x - mean, a1 = v[k].y - mean, a2 = v[k].z - mean, a3 = v[k].w - mean;
+      ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / d + eps);
+  if (lane == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int c = (lane + 64 * k) * 4;
+    if (c < d) {
+      float4 g = make_float4(1.f, 1.f, 1.f, 1.f), o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (w) g = *reinterpret_cast<const float4*>(w + c);
+      if (b) o = *reinterpret_cast<const float4*>(b + c);
+      float4 r;
+      r.x = (v[k].x - mean) * rstd * g.x + o.x;
+      r.y = (v[k].y - mean) * rstd * g.y + o.y;
+      r.z = (v[k].z - mean) * rstd * g.z + o.z;
+      r.w = (v[k].w - mean) * rstd * g.w + o.w;
+      Vec4<Y>::store(yr + c, r);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward (fused)
+// per row: xhat = (x-mean)*rstd, gy = dy*w, dx = rstd*(gy - mean(gy) - xhat*mean(gy*xhat));
+// per block: partial dgamma = sum dy*xhat, dbeta = sum dy over its rows -> part[block][2][d]
+template <typename X, typename G, int VEC>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const X* __restrict__ x, const G* __restrict__ dy,
+                                                            const float* __restrict__ w, const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in, X* __restrict__ dx,
+                                                            float* __restrict__ part, long rows, int d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][2][d]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4 dg[VEC], db[VEC], wv[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    dg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = (lane + 64 * k) * 4;
+    wv[k] = (w && c < d) ? *reinterpret_cast<const float4*>(w + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+  }
+  const long row0 = ((long)blockIdx.x * 4 + wave) * LN_ROWS_PER_WAVE;
+  for (int q = 0; q < LN_ROWS_PER_WAVE; ++q) {
+    const long row = row0 + q;
+    if (row >= rows) break;
+    const X* xr = x + row * d;
+    const G* gr = dy + row * d;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float4 xh[VEC], gy[VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int c = (lane + 64 * k) * 4;
+      if (c < d) {
+        const float4 xv = Vec4<X>::load(xr + c);
+        const float4 g = Vec4<G>::load(gr + c);
+        xh[k] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        gy[k] = make_float4(g.x * wv[k].x, g.y * wv[k].y, g.z * wv[k].z, g.w * wv[k].w);
+        s1 += gy[k].x + gy[k].y + gy[k].z + gy[k].w;
+        s2 += gy[k].x * xh[k].x + gy[k].y * xh[k].y + gy[k].z * xh[k].z + gy[k].w * xh[k].w;
+        dg[k].x += g.x * xh[k].x; dg[k].y += g.y * xh[k].y; dg[k].z += g.z * xh[k].z; dg[k].w += g.w * xh[k].w;
+        db[k].x += g.x; db[k].y += g.y; db[k].z += g.z; db[k].w += g.w;
+      }
+    }
+    const float m1 = wave_sum(s1) / d, m2 = wave_sum(s2) / d;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int c = (lane + 64 * k) * 4;
+      if (c < d) {
+        float4 r;
+        r.x = rstd * (gy[k].x - m1 - xh[k].x * m2);
+        r.y = rstd * (gy[k].y - m1 - xh[k].y * m2);
+        r.z = rstd * (gy[k].z - m1 - xh[k].z * m2);
+        r.w = rstd * (gy[k].w - m1 - xh[k].w * m2);
+        Vec4<X>::store(dx + row * d + c, r);
+      }
+    }
+  }
+  if (part == nullptr) return;
+  // combine the 4 waves' column partials through LDS, one [2][d] slab per block
+  float* mine = lds + (size_t)wave * 2 * d;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int c = (lane + 64 * k) * 4;
+    if (c < d) {
+      *reinterpret_cast<float4*>(mine + c) = dg[k];
+      *reinterpret_cast<float4*>(mine + d + c) = db[k];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * d; c += 256)
+    part[(size_t)blockIdx.x * 2 * d + c] = lds[c] + lds[2 * d + c] + lds[4 * d + c] + lds[6 * d + c];
+}
+
+// dgamma/dbeta = column sums of the block partials: grid over column chunks x row slices, then atomics-free 2nd stage
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int n_rows, int n_cols,
+                                                     float* __restrict__ out, int rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n_cols) return;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(n_rows, r0 + rows_per_block);
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) s += part[(size_t)r * n_cols + c];
+  out[(size_t)blockIdx.y * n_cols + c] = s;
+}
+
+// ------------------------------------------------------------------ quick-GELU (x * sigmoid(1.702 x))
+template <typename T>
+__global__ __launch_bounds__(256) void quick_gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 v = Vec4<T>::load(x + i * 4);
+    v.x = v.x / (1.f + __expf(-1.702f * v.x));
+    v.y = v.y / (1.f + __expf(-1.702f * v.y));
+    v.z = v.z / (1.f + __expf(-1.702f * v.z));
+    v.w = v.w / (1.f + __expf(-1.702f * v.w));
+    Vec4<T>::store(y + i * 4, v);
+  }
+}
+__device__ __forceinline__ float quick_gelu_grad(float x, float g) {
+  const float s = 1.f / (1.f + __expf(-1.702f * x));
+  return g * s * (1.f + 1.702f * x * (1.f - s));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void quick_gelu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                             long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = Vec4<T>::load(x + i * 4), g = Vec4<T>::load(dy + i * 4);
+    Vec4<T>::store(dx + i * 4, make_float4(quick_gelu_grad(v.x, g.x), quick_gelu_grad(v.y, g.y), quick_gelu_grad(v.z, g.z),
+                                           quick_gelu_grad(v.w, g.w)));
+  }
+}
+
+}  // namespace mmk
+
+using namespace mmk;
+
+extern "C" {
+
+int mmk_layernorm_part_blocks(long rows) { return (int)((rows + 4 * LN_ROWS_PER_WAVE - 1) / (4 * LN_ROWS_PER_WAVE)); }
+
+int mmk_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int64_t rows, int d,
+                      float eps, int dtype, void* stream) {
+  // dtype packs (x dtype) | (y dtype << 4)
+  MMK_REQUIRE(x && y && mean && rstd && rows >= 0 && d > 0, "bad arguments");
+  MMK_REQUIRE(d % 4 == 0 && d <= 64 * 4 * LN_MAX_VEC, "layernorm: d must be a multiple of 4 and <= 2048");
+  if (rows == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope ps(MMK_K_LAYERNORM_FWD, st);
+  int rc = MMK_DISPATCH_DTYPE(dtype & 15, X, [&]() -> int {
+    return MMK_DISPATCH_DTYPE((dtype >> 4) & 15, Y, [&]() -> int {
+      if (d <= 1024)
+        hipLaunchKernelGGL((layernorm_fwd_kernel<X, Y, 4>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st,
+                           static_cast<const X*>(x), w, b, static_cast<Y*>(y), mean, rstd, (long)rows, d, eps);
+      else
+        hipLaunchKernelGGL((layernorm_fwd_kernel<X, Y, 8>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st,
+                           static_cast<const X*>(x), w, b, static_cast<Y*>(y), mean, rstd, (long)rows, d, eps);
+      return 0;
+    });
+  });
+  if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+int mmk_layernorm_bwd(const void* x, const void* dy, const float* w, const float* mean, const float* rstd, void* dx, float* part,
+                      float* part2, float* dw, float* db, int64_t rows, int d, int dtype, void* stream) {
+  // dtype packs (x / dx dtype) | (dy dtype << 4).  part: float[n_blocks, 2, d]; part2: float[64, 2, d] (second stage)
+  MMK_REQUIRE(x && dy && mean && rstd && dx && rows >= 0 && d > 0, "bad arguments");
+  MMK_REQUIRE(d % 4 == 0 && d <= 64 * 4 * LN_MAX_VEC, "layernorm: d must be a multiple of 4 and <= 2048");
+  MMK_REQUIRE((dw == nullptr && db == nullptr) || (part && part2 && dw && db), "dgamma/dbeta need both outputs and the workspaces");
+  if (rows == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope ps(MMK_K_LAYERNORM_BWD, st);
+  const int n_blocks = mmk_layernorm_part_blocks(rows);
+  int rc = MMK_DISPATCH_DTYPE(dtype & 15, X, [&]() -> int {
+    return MMK_DISPATCH_DTYPE((dtype >> 4) & 15, G, [&]() -> int {
+      if (d <= 1024)
+        hipLaunchKernelGGL((layernorm_bwd_kernel<X, G, 4>), dim3(n_blocks), dim3(256), dw ? 8 * d * sizeof(float) : 0, st,
+                           static_cast<const X*>(x), static_cast<const G*>(dy), w, mean, rstd, static_cast<X*>(dx),
+                           dw ? part : nullptr, (long)rows, d);
+      else
+        hipLaunchKernelGGL((layernorm_bwd_kernel<X, G, 8>), dim3(n_blocks), dim3(256), dw ? 8 * d * sizeof(float) : 0, st,
+                           static_cast<const X*>(x), static_cast<const G*>(dy), w, mean, rstd, static_cast<X*>(dx),
+                           dw ? part : nullptr, (long)rows, d);
+      return 0;
+    });
+  });
+  if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  if (dw) {
+    // part is [n_blocks][2*d]: stage 1 -> 64 row slices, stage 2 -> 1
+    const int slices = std::min(64, n_blocks);
+    const int rpb = (n_blocks + slices - 1) / slices;
+    hipLaunchKernelGGL(colsum_kernel, dim3((2 * d + 255) / 256, slices), dim3(256), 0, st, part, n_blocks, 2 * d, part2, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3((2 * d + 255) / 256, 1), dim3(256), 0, st, part2, slices, 2 * d, part, slices);
+    MMK_LAUNCH_CHECK();
+    MMK_HIP(hipMemcpyAsync(dw, part, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
+    MMK_HIP(hipMemcpyAsync(db, part + d, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
+  }
+  return 0;
+}
+
+int mmk_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
+  MMK_REQUIRE(x && y && n >= 0 && n % 4 == 0, "quick_gelu: n must be a multiple of 4");
+  if (n == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope ps(MMK_K_ACT, st);
+  const long n4 = n / 4;
+  const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 256 * 16);
+  int rc = MMK_DISPATCH_DTYPE(dtype, T, [&]() -> int {
+    hipLaunchKernelGGL((quick_gelu_fwd_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(x), static_cast<T*>(y), n4);
+    return 0;
+  });
+  if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+int mmk_quick_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream) {
+  MMK_REQUIRE(x && dy && dx && n >= 0 && n % 4 == 0, "quick_gelu: n must be a multiple of 4");
+  if (n == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope ps(MMK_K_ACT, st);
+  const long n4 = n / 4;
+  const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 256 * 16);
+  int rc = MMK_DISPATCH_DTYPE(dtype, T, [&]() -> int {
+    hipLaunchKernelGGL((quick_gelu_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(x), static_cast<const T*>(dy),
+                       static_cast<T*>(dx), n4);
+    return 0;
+  });
+  if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+"""Encoder-side fused ops (the first "next" row): drop-in HIP replacements for the
+HBM-bound modules that dominate the non-GEMM time of the encoder step under bf16 autocast.
+
+* :class:`LayerNorm` -- ``torch.nn.LayerNorm`` subclass (same parameters / state_dict) whose forward and backward
+  are one HIP kernel each (f32 statistics, fused dx + dgamma/dbeta).  Under autocast ``F.layer_norm`` returns
+  f32 and the following ``Linear`` re-casts it to bf16 in a separate kernel; ``low_precision_out=True`` emits the
+  autocast dtype directly -- bit-identical for consumers that are autocast ``Linear`` layers (pre-LN blocks such as
+  CLIP's ``layer_norm1/2``), not for post-LN residual streams (BERT), where it must stay off.
+* :class:`QuickGELU` -- HF ``QuickGELUActivation`` (``x * sigmoid(1.702 x)``: 3 ATen kernels forward, ~6 backward)
+  as one kernel each way.
+* :func:`accelerate_encoder` swaps those modules in place inside any encoder (HF CLIP / BERT, mmlearn's own ViT).
+
+There is no CPU path: CPU tensors raise.
+"""
+
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+from torch import nn
+
+from . import kernels as K
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        d = x.shape[-1]
+        x2 = x.contiguous().view(-1, d)
+        w32 = None if weight is None else weight.detach().float().contiguous()
+        b32 = None if bias is None else bias.detach().float().contiguous()
+        y, mean, rstd = K.layernorm_fwd(x2, w32, b32, eps, out_dtype)
+        ctx.save_for_backward(x2, w32, mean, rstd)
+        ctx.shape = x.shape
+        ctx.wb = (weight is not None and weight.requires_grad, bias is not None and bias.requires_grad,
+                  None if weight is None else weight.dtype, None if bias is None else bias.dtype)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w32, mean, rstd = ctx.saved_tensors
+        need_w, need_b, wdt, bdt = ctx.wb
+        dy2 = dy.contiguous().view(x2.shape)
+        dx, dw, db = K.layernorm_bwd(x2, dy2, w32, mean, rstd, need_w or need_b)
+        return (dx.view(ctx.shape), dw.to(wdt) if need_w else None, db.to(bdt) if need_b else None, None, None)
+
+
+def layer_norm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], eps: float = 1e-5,
+               low_precision_out: bool = False) -> torch.Tensor:
+    """``F.layer_norm(x, x.shape[-1:], weight, bias, eps)`` on MI355X.  Output dtype: f32 under autocast (like torch) or
+    the autocast dtype when ``low_precision_out``; ``x.dtype`` outside autocast."""
+    K.require_gpu(x)
+    d = x.shape[-1]
+    if d % 4 or d > 2048:
+        raise ValueError(f"mmlearn_amd.fused.layer_norm supports a normalised dim that is a multiple of 4 and <= 2048, got {d}")
+    if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise TypeError(f"unsupported dtype {x.dtype}")
+    if torch.is_autocast_enabled():
+        out_dtype = torch.get_autocast_dtype("cuda") if low_precision_out else torch.float32
+    else:
+        out_dtype = x.dtype
+    return _LayerNormFn.apply(x, weight, bias, eps, out_dtype)
+
+
+class LayerNorm(nn.LayerNorm):
+    """``torch.nn.LayerNorm`` over the last dimension with HIP forward/backward kernels."""
+
+    low_precision_out: bool = False
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if len(self.normalized_shape) != 1:
+            raise ValueError("mmlearn_amd.fused.LayerNorm normalises the last dimension only")
+        return layer_norm(x, self.weight, self.bias, self.eps, self.low_precision_out)
+
+    @classmethod
+    def from_torch(cls, ln: nn.LayerNorm, low_precision_out: bool = False) -> "LayerNorm":
+        new = cls.__new__(cls)
+        nn.Module.__init__(new)
+        new.normalized_shape, new.eps, new.elementwise_affine = ln.normalized_shape, ln.eps, ln.elementwise_affine
+        new.weight, new.bias = ln.weight, ln.bias      # the SAME Parameter objects: optimizers / checkpoints are unaffected
+        new.low_precision_out = low_precision_out
+        new.train(ln.training)
+        return new
+
+
+class _QuickGELUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return K.quick_gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.quick_gelu_bwd(x, dy.contiguous().to(x.dtype))
+
+
+class QuickGELU(nn.Module):
+    """``x * sigmoid(1.702 * x)`` (HF ``QuickGELUActivation``) as one HIP kernel per direction."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        K.require_gpu(x)
+        if x.numel() % 4:
+            raise ValueError("QuickGELU kernel needs a multiple of 4 elements")
+        return _QuickGELUFn.apply(x)
+
+
+def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = ()) -> dict:
+    """Swap ``nn.LayerNorm`` -> :class:`LayerNorm` and quick-GELU activations -> :class:`QuickGELU` inside ``module`` (in place).
+
+    ``low_precision_ln``: substrings of qualified module names whose LayerNorm may emit the autocast dtype directly
+    (only LayerNorms that feed autocast ``Linear`` layers, e.g. ``("layer_norm1", "layer_norm2", "post_layernorm")``
+    for HF CLIP).  Returns the number of modules swapped per kind.
+    """
+    swapped = {"layernorm": 0, "quick_gelu": 0}
+    low = tuple(low_precision_ln)
+    for name, parent in list(module.named_modules()):
+        for child_name, child in list(parent.named_children()):
+            full = f"{name}.{child_name}" if name else child_name
+            if type(child) is nn.LayerNorm and len(child.normalized_shape) == 1 and child.normalized_shape[0] % 4 == 0 \
+                    and child.normalized_shape[0] <= 2048:
+                setattr(parent, child_name, LayerNorm.from_torch(child, any(s in full for s in low)))
+                swapped["layernorm"] += 1
+            elif type(child).__name__ in ("QuickGELUActivation", "QuickGELU") and not isinstance(child, QuickGELU):
+                setattr(parent, child_name, QuickGELU())
+                swapped["quick_gelu"] += 1
+    return swapped

@@ -336,3 +336,46 @@ def ema_table(teacher: Sequence[torch.Tensor], student: Sequence[torch.Tensor]):
 
 def ema_update(table: torch.Tensor, n: int, max_numel: int, decay: float, true_ema: bool) -> None:
     check(_lib.lib().mmk_ema_update(ptr(table), n, max_numel, float(decay), int(true_ema), stream()))
+
+
+# ------------------------------------------------------------------ encoder-side row ops
+def layernorm_fwd(x2: torch.Tensor, w: Optional[torch.Tensor], b: Optional[torch.Tensor], eps: float, out_dtype: torch.dtype):
+    """x2 [rows, d] contiguous; w/b f32[d] or None -> (y [rows, d] of out_dtype, mean f32[rows], rstd f32[rows])."""
+    require_gpu(x2)
+    rows, d = x2.shape
+    y = torch.empty((rows, d), dtype=out_dtype, device=x2.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    dt = dtype_tag(x2.dtype) | (dtype_tag(out_dtype) << 4)
+    check(_lib.lib().mmk_layernorm_fwd(ptr(x2), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, d, float(eps), dt, stream()))
+    return y, mean, rstd
+
+
+def layernorm_bwd(x2: torch.Tensor, dy2: torch.Tensor, w: Optional[torch.Tensor], mean: torch.Tensor, rstd: torch.Tensor, need_wb: bool):
+    rows, d = x2.shape
+    dev = x2.device
+    dx = torch.empty_like(x2)
+    part = part2 = dw = db = None
+    if need_wb:
+        nb = _lib.lib().mmk_layernorm_part_blocks(rows)
+        part = torch.empty((max(nb, 1), 2, d), dtype=torch.float32, device=dev)
+        part2 = torch.empty((64, 2, d), dtype=torch.float32, device=dev)
+        dw = torch.empty(d, dtype=torch.float32, device=dev)
+        db = torch.empty(d, dtype=torch.float32, device=dev)
+    dt = dtype_tag(x2.dtype) | (dtype_tag(dy2.dtype) << 4)
+    check(_lib.lib().mmk_layernorm_bwd(ptr(x2), ptr(dy2), ptr(w), ptr(mean), ptr(rstd), ptr(dx), ptr(part), ptr(part2), ptr(dw), ptr(db),
+                                       rows, d, dt, stream()))
+    return dx, dw, db
+
+
+def quick_gelu_fwd(x: torch.Tensor) -> torch.Tensor:
+    require_gpu(x)
+    y = torch.empty_like(x)
+    check(_lib.lib().mmk_quick_gelu_fwd(ptr(x), ptr(y), x.numel(), dtype_tag(x.dtype), stream()))
+    return y
+
+
+def quick_gelu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    dx = torch.empty_like(x)
+    check(_lib.lib().mmk_quick_gelu_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), dtype_tag(x.dtype), stream()))
+    return dx

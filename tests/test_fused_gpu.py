@@ -1,0 +1,126 @@
+"""GPU parity of the encoder-side fused ops against plain PyTorch f32 references of the same op."""
+
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("rows,d,dtype", [(1000, 768, torch.float32), (17, 64, torch.float32), (33, 2048, torch.float32),
+                                          (513, 1024, torch.bfloat16), (64, 384, torch.float16), (4099, 768, torch.bfloat16)])
+def test_layernorm_fwd_bwd_vs_torch(rows, d, dtype):
+    from mmlearn_amd import fused
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(rows + d)
+    x = (torch.randn(rows, d, generator=g) * 2 + 0.3).to(dtype)
+    w = torch.randn(d, generator=g) * 0.5 + 1
+    b = torch.randn(d, generator=g) * 0.1
+    dy = torch.randn(rows, d, generator=g).to(dtype)
+    xr = x.float().clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (d,), wr, br, 1e-5)
+    yr.backward(dy.float())
+    xd = x.to(dev).requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = fused.layer_norm(xd, wd, bd, 1e-5)
+    assert y.dtype == dtype
+    y.backward(dy.to(dev))
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert (y.float().cpu() - yr.detach()).abs().max() <= tol * max(1.0, yr.abs().max().item())
+    assert (xd.grad.float().cpu() - xr.grad).abs().max() <= (1e-4 if dtype == torch.float32 else 2e-2) * xr.grad.abs().max()
+    assert (wd.grad.cpu() - wr.grad).abs().max() <= (1e-4 if dtype == torch.float32 else 2e-2) * wr.grad.abs().max()
+    assert (bd.grad.cpu() - br.grad).abs().max() <= (1e-4 if dtype == torch.float32 else 2e-2) * br.grad.abs().max()
+
+
+def test_layernorm_autocast_dtypes_and_module():
+    from mmlearn_amd import fused
+
+    dev = _dev()
+    ln = torch.nn.LayerNorm(768).to(dev)
+    with torch.no_grad():
+        ln.weight.normal_(1, 0.2)
+        ln.bias.normal_(0, 0.2)
+    hip = fused.LayerNorm.from_torch(ln)
+    assert hip.weight is ln.weight and hip.bias is ln.bias
+    assert set(hip.state_dict()) == set(ln.state_dict())
+    x = torch.randn(8, 197, 768, device=dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y_ref = ln(x)
+        y = hip(x)
+        hip.low_precision_out = True
+        y_lp = hip(x)
+    assert y.dtype == torch.float32 == y_ref.dtype and y_lp.dtype == torch.bfloat16
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().cpu().numpy(), atol=2e-5)
+    assert torch.equal(y_lp.detach(), y.detach().bfloat16())  # emitting bf16 == f32 result rounded once (what the next Linear would do)
+    # no affine
+    y0 = fused.layer_norm(x, None, None, 1e-6)
+    np.testing.assert_allclose(y0.detach().cpu().numpy(), F.layer_norm(x, (768,), None, None, 1e-6).cpu().numpy(), atol=2e-5)
+    with pytest.raises(ValueError):
+        fused.layer_norm(torch.randn(4, 6, device=dev), None, None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fused.layer_norm(torch.randn(4, 8), None, None)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_quick_gelu_vs_torch(dtype):
+    from mmlearn_amd import fused
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(37, 3072, generator=g) * 3).to(dtype)
+    dy = torch.randn(37, 3072, generator=g).to(dtype)
+    xr = x.float().clone().requires_grad_(True)
+    yr = xr * torch.sigmoid(1.702 * xr)
+    yr.backward(dy.float())
+    xd = x.to(dev).requires_grad_(True)
+    y = fused.QuickGELU()(xd)
+    y.backward(dy.to(dev))
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert (y.float().cpu() - yr.detach()).abs().max() <= tol * yr.abs().max()
+    assert (xd.grad.float().cpu() - xr.grad).abs().max() <= (1e-5 if dtype == torch.float32 else 2e-2) * xr.grad.abs().max()
+
+
+def test_accelerate_encoder_matches_stock_hf_models():
+    from transformers import BertConfig, BertModel, CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    from mmlearn_amd import fused
+
+    dev = _dev()
+    torch.manual_seed(0)
+    clip = CLIPVisionModelWithProjection(CLIPVisionConfig(patch_size=32, image_size=64, hidden_size=128, intermediate_size=256,
+                                                           num_hidden_layers=2, num_attention_heads=2, projection_dim=64)).to(dev)
+    bert = BertModel(BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, hidden_dropout_prob=0.0,
+                                attention_probs_dropout_prob=0.0), add_pooling_layer=False).to(dev)
+    clip_f, bert_f = copy.deepcopy(clip), copy.deepcopy(bert)
+    n1 = fused.accelerate_encoder(clip_f, ("layer_norm1", "layer_norm2", "post_layernorm"))
+    n2 = fused.accelerate_encoder(bert_f)
+    assert n1 == {"layernorm": 6, "quick_gelu": 2} and n2["layernorm"] == 5
+    px = torch.rand(6, 3, 64, 64, device=dev)
+    tok = torch.randint(0, 30522, (6, 16), device=dev)
+    for autocast, tol in ((False, 2e-4), (True, 3e-2)):
+        outs = []
+        for cm, bm in ((clip, bert), (clip_f, bert_f)):
+            for p in list(cm.parameters()) + list(bm.parameters()):
+                p.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                a = cm(pixel_values=px).image_embeds
+                b = bm(input_ids=tok).last_hidden_state[:, 0]
+                loss = a.float().square().mean() + b.float().square().mean()
+            loss.backward()
+            outs.append((a.float().detach(), b.float().detach(), {n: p.grad.clone() for n, p in cm.named_parameters()},
+                         {n: p.grad.clone() for n, p in bm.named_parameters()}))
+        (a0, b0, g0, h0), (a1, b1, g1, h1) = outs
+        assert (a0 - a1).abs().max() <= tol * a0.abs().max() and (b0 - b1).abs().max() <= tol * b0.abs().max()
+        for ref, got in ((g0, g1), (h0, h1)):
+            gmax = max(v.abs().max().item() for v in ref.values())
+            for n in ref:  # parameters with (numerically) zero gradient, e.g. key biases, are compared on the global scale
+                assert (ref[n] - got[n]).abs().max() <= 3 * tol * max(ref[n].abs().max().item(), 1e-2 * gmax), (autocast, n)

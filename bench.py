@@ -230,8 +230,15 @@ def main():
             cnt, ms = mfma[rep]
             avg_s = ms / cnt * 1e-3
             achieved = algo[rep] / avg_s / 1e12
+            traffic = None  # HBM bytes per launch from rocprofv3 PMC passes of the same kernel and shape (profiles/)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                if world == 1 and args.batch == 1024:
+                    traffic = pmc["n1024_tile64"][rep]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
             roofline = {"bound": "mfma", "kernel": rep, "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                        "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2),
                         "launches": cnt, "dominant_by_time": dom,
                         "loss_path_kernel_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in prof.items()}}
         out = {

@@ -123,8 +123,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
   const int zsplit = (EPI == EPI_PLAIN) ? (blockIdx.z % batch.n_split) : 0;
   const int zprob = (EPI == EPI_PLAIN) ? (blockIdx.z / batch.n_split) : blockIdx.z;
   const Prob& p = batch.p[zprob];
-  const int tile = blockIdx.x;
-  if (tile >= p.tiles_m * p.tiles_n) return;
+  const int n_tiles = p.tiles_m * p.tiles_n;
+  if ((int)blockIdx.x >= n_tiles) return;
+  // XCD-aware tile order (speed only, any placement is correct): workgroups are dealt round-robin over the 8 XCDs,
+  // so XCD x can be given the contiguous tile range [base_x, base_x + cnt_x): neighbours in (tn, tm) order then share
+  // the Q row tile in one L2 instead of it being fetched by all eight (rocprofv3 FETCH_SIZE, N = 8192: 1082 -> 392 MB).
+  int tile = blockIdx.x;
+  if (EPI == EPI_PLAIN) {
+    // gradient GEMM: the k_pad/BM blocks that share a G row tile must meet in one L2 (G does not fit any cache).
+    // The similarity kernels keep the plain order: there each XCD sees every 8th P tile, a 1/8 slice of P that
+    // stays L2-resident while Q streams through once (measured: 142 MB fetched vs 1040 MB with the remap).
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int q = n_tiles >> 3, rr = n_tiles & 7;
+    tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
   const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -544,8 +556,10 @@ __global__ __launch_bounds__(256) void lse_reduce_kernel(const ReduceBatch batch
   float local = 0.f;
   if (i < p.N) {
     float mx = -INFINITY;
+#pragma unroll 8
     for (int t = 0; t < p.tiles_m; ++t) mx = fmaxf(mx, p.part[(size_t)t * p.part_ld + i].x);
     float l = 0.f;
+#pragma unroll 8
     for (int t = 0; t < p.tiles_m; ++t) {
       const float2 v = p.part[(size_t)t * p.part_ld + i];
       if (v.x > -INFINITY) l += v.y * exp2f(v.x - mx);
@@ -711,16 +725,31 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinBatch batch
   float* buf = rowbuf + (size_t)wave * p.slab_ld;
   const int dst_row = p.dx_rows ? p.dx_rows[i] : i;
   const U* x = reinterpret_cast<const U*>(p.src) + (size_t)dst_row * d;
+  const bool vec = (d & 3) == 0;  // 4-element (16/8-byte) lanes; slab rows are k_pad wide, always 16-byte aligned
   float dot = 0.f, ss = 0.f;
-  for (int c = lane; c < d; c += 64) {
-    float v = 0.f;
-    for (int s = 0; s < batch.n_split; ++s) v += p.slab[(size_t)s * p.split_stride + (size_t)i * p.slab_ld + c];
-    v *= coef;
-    buf[c] = v;
+  for (int c = lane * 4; c < d; c += 256) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < batch.n_split; ++s) {
+      const float4 t = *reinterpret_cast<const float4*>(p.slab + (size_t)s * p.split_stride + (size_t)i * p.slab_ld + c);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;
+    *reinterpret_cast<float4*>(buf + c) = v;
     if (p.normalize) {
-      const float xv = to_f32(x[c]);
-      dot += v * xv;
-      ss += xv * xv;
+      float xv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (vec) {
+        const float4 t = Vec4<U>::load(x + c);
+        xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+      } else {
+        for (int e = 0; e < 4; ++e)
+          if (c + e < d) xv[e] = to_f32(x[c + e]);
+      }
+      const float dv[4] = {v.x, v.y, v.z, v.w};
+      for (int e = 0; e < 4; ++e)
+        if (c + e < d) {
+          dot += dv[e] * xv[e];
+          ss += xv[e] * xv[e];
+        }
     }
   }
   float inv = 1.f, proj = 0.f;
@@ -732,13 +761,21 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinBatch batch
     // y = x*inv ; dx = (dy - y (y.dy)) * inv   (norm clamped at eps => constant, no projection)
     proj = (nrm > 1e-12f) ? dot * inv * inv : 0.f;
   }
-  for (int c = lane; c < d; c += 64) {
-    float v = buf[c];
-    if (p.normalize) v = (v - to_f32(x[c]) * proj) * inv;
+  for (int c = lane * 4; c < d; c += 256) {
+    float4 v = *reinterpret_cast<const float4*>(buf + c);
+    float o[4] = {v.x, v.y, v.z, v.w};
+    if (p.normalize) {
+      for (int e = 0; e < 4; ++e)
+        if (c + e < d) o[e] = (o[e] - to_f32(x[c + e]) * proj) * inv;
+    }
     if (p.accumulate) {
-      atomicAdd(reinterpret_cast<float*>(p.dx) + (size_t)dst_row * d + c, v);
+      for (int e = 0; e < 4; ++e)
+        if (c + e < d) atomicAdd(reinterpret_cast<float*>(p.dx) + (size_t)dst_row * d + c + e, o[e]);
+    } else if (vec) {
+      Vec4<U>::store(reinterpret_cast<U*>(p.dx) + (size_t)dst_row * d + c, make_float4(o[0], o[1], o[2], o[3]));
     } else {
-      reinterpret_cast<U*>(p.dx)[(size_t)dst_row * d + c] = from_f32<U>(v);
+      for (int e = 0; e < 4; ++e)
+        if (c + e < d) reinterpret_cast<U*>(p.dx)[(size_t)dst_row * d + c + e] = from_f32<U>(o[e]);
     }
   }
 }
@@ -765,19 +802,32 @@ __global__ __launch_bounds__(256) void ds_reduce_kernel(const DsBatch b, const f
 
 // ------------------------------------------------------------------ host side
 struct Plan {
-  int bt;        // square tile edge for the similarity kernels: 128 or 64
-  int bt_g;      // tile edge for the gradient GEMM
-  int n_split;   // split-K factor of the gradient GEMM
+  int bm, bn;      // tile of the similarity kernels: BM columns (P rows) x BN owned rows (Q rows)
+  int bm_g, bn_g;  // tile of the gradient GEMM: BM_g of the k_pad output columns x BN_g owned rows
+  int n_split;     // split-K factor of the gradient GEMM
 };
+// 128x128 when that gives >= `want` tiles, else 64x64 (small problems are latency-bound: more, smaller blocks win;
+// 128x64 is kept as an experiment override).
+static void pick_tile(long rows_p, long rows_q, int n_probs, long want, int* bm, int* bn) {
+  if (const char* e = getenv("MMK_TILE")) {  // experiment override: 64 | 12864 | 128
+    const int v = atoi(e);
+    *bm = v == 64 ? 64 : 128;
+    *bn = v == 128 ? 128 : 64;
+    return;
+  }
+  const long t128 = cdiv((int)rows_p, 128) * (long)cdiv((int)rows_q, 128) * n_probs;
+  const long t12864 = cdiv((int)rows_p, 128) * (long)cdiv((int)rows_q, 64) * n_probs;
+  (void)t12864;  // measured at N = 1024 (rocprofv3): 64x64 9.2-10.2 us < 128x64 10.2-11.7 us < 128x128 12.7-16.6 us
+  if (t128 >= want) { *bm = 128; *bn = 128; }
+  else { *bm = 64; *bn = 64; }
+}
 static Plan make_plan(int r_max, int c_max, int k_pad, int n_dirs, int compute) {
   Plan pl;
-  const long tiles128 = (long)cdiv(r_max, 128) * cdiv(c_max, 128) * n_dirs;
-  pl.bt = tiles128 >= 256 ? 128 : 64;
+  pick_tile(c_max, r_max, n_dirs, 256, &pl.bm, &pl.bn);
   const int bk = compute == MMK_COMPUTE_BF16 ? 64 : 32;
   const int c_pad = round_up(c_max, 128);
-  const long gt128 = (long)cdiv(k_pad, 128) * cdiv(r_max, 128) * n_dirs;
-  pl.bt_g = gt128 >= 128 ? 128 : 64;
-  const long gt = (long)cdiv(k_pad, pl.bt_g) * cdiv(r_max, pl.bt_g) * n_dirs;
+  pick_tile(k_pad, r_max, n_dirs, 128, &pl.bm_g, &pl.bn_g);
+  const long gt = (long)cdiv(k_pad, pl.bm_g) * cdiv(r_max, pl.bn_g) * n_dirs;
   int split = (int)((768 + gt - 1) / gt);
   const int max_split = c_pad / (2 * bk) > 0 ? c_pad / (2 * bk) : 1;  // >= 2 k-steps per split
   if (split > max_split) split = max_split;
@@ -803,10 +853,10 @@ static LoaderCfg loader_cfg() {
   return cfg;
 }
 
-template <typename T, int BT, int EPI, int LOADER, int NSTAGE>
+template <typename T, int BM, int BN, int EPI, int LOADER, int NSTAGE>
 static int launch_one(const ProbBatch& b, dim3 grid, const float* scale, hipStream_t st) {
-  constexpr int bytes = NSTAGE * (2 * BT) * 128;
-  auto kern = gemm_nt_kernel<T, BT, BT, EPI, LOADER, NSTAGE>;
+  constexpr int bytes = NSTAGE * (BM + BN) * 128;
+  auto kern = gemm_nt_kernel<T, BM, BN, EPI, LOADER, NSTAGE>;
   static bool attr_set = false;
   if (bytes > 64 * 1024 && !attr_set) {
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -817,21 +867,22 @@ static int launch_one(const ProbBatch& b, dim3 grid, const float* scale, hipStre
   return 0;
 }
 
-template <typename T, int BT, int EPI>
+template <typename T, int BM, int BN, int EPI>
 static int launch_tile(const ProbBatch& b, dim3 grid, const float* scale, hipStream_t st) {
   const LoaderCfg c = loader_cfg();
-  if (c.loader == LOADER_REG) return launch_one<T, BT, EPI, LOADER_REG, 2>(b, grid, scale, st);
+  if (c.loader == LOADER_REG) return launch_one<T, BM, BN, EPI, LOADER_REG, 2>(b, grid, scale, st);
   // 128^2 tiles: 32 KiB per stage -> at most 4 stages in 160 KiB; 64^2 tiles: 16 KiB per stage
-  if (c.stages == 2) return launch_one<T, BT, EPI, LOADER_DMA, 2>(b, grid, scale, st);
-  if (c.stages == 3) return launch_one<T, BT, EPI, LOADER_DMA, 3>(b, grid, scale, st);
-  return launch_one<T, BT, EPI, LOADER_DMA, 4>(b, grid, scale, st);
+  if (c.stages == 2) return launch_one<T, BM, BN, EPI, LOADER_DMA, 2>(b, grid, scale, st);
+  if (c.stages == 3) return launch_one<T, BM, BN, EPI, LOADER_DMA, 3>(b, grid, scale, st);
+  return launch_one<T, BM, BN, EPI, LOADER_DMA, 4>(b, grid, scale, st);
 }
 
 template <typename T, int EPI>
-static int launch_gemm(const ProbBatch& b, int n_probs, int bt, int max_tiles, const float* scale, hipStream_t st) {
+static int launch_gemm(const ProbBatch& b, int n_probs, int bm, int bn, int max_tiles, const float* scale, hipStream_t st) {
   dim3 grid(max_tiles, 1, n_probs * (EPI == EPI_PLAIN ? b.n_split : 1));
-  if (bt == 128) return launch_tile<T, 128, EPI>(b, grid, scale, st);
-  return launch_tile<T, 64, EPI>(b, grid, scale, st);
+  if (bm == 128 && bn == 128) return launch_tile<T, 128, 128, EPI>(b, grid, scale, st);
+  if (bm == 128 && bn == 64) return launch_tile<T, 128, 64, EPI>(b, grid, scale, st);
+  return launch_tile<T, 64, 64, EPI>(b, grid, scale, st);
 }
 
 template <typename T>
@@ -856,8 +907,8 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
     p.N = d.r;
     p.K = k_pad;
     p.ldp = p.ldq = k_pad;
-    p.tiles_m = cdiv(d.c, pl.bt);
-    p.tiles_n = cdiv(d.r, pl.bt);
+    p.tiles_m = cdiv(d.c, pl.bm);
+    p.tiles_n = cdiv(d.r, pl.bn);
     p.part = reinterpret_cast<float2*>(d.part);
     p.part_ld = d.r;
     p.diag = d.diag;
@@ -871,8 +922,8 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
   const bool align = dirs[0].mode == 1;
   {
     ProfScope ps(MMK_K_SIM_STATS, st);
-    int rc = align ? launch_gemm<T, EPI_ALIGN_STATS>(b, n_dirs, pl.bt, max_tiles, scale, st)
-                   : launch_gemm<T, EPI_STATS>(b, n_dirs, pl.bt, max_tiles, scale, st);
+    int rc = align ? launch_gemm<T, EPI_ALIGN_STATS>(b, n_dirs, pl.bm, pl.bn, max_tiles, scale, st)
+                   : launch_gemm<T, EPI_STATS>(b, n_dirs, pl.bm, pl.bn, max_tiles, scale, st);
     if (rc) return rc;
   }
   {
@@ -915,8 +966,8 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
     p.N = d.r;
     p.K = k_pad;
     p.ldp = p.ldq = k_pad;
-    p.tiles_m = c_pad / pl.bt;   // cover the zero padding of G up to ldg
-    p.tiles_n = cdiv(d.r, pl.bt);
+    p.tiles_m = c_pad / pl.bm;   // cover the zero padding of G up to ldg
+    p.tiles_n = cdiv(d.r, pl.bn);
     p.label_off = d.label_off;
     p.lse_row = d.lse;
     p.lse_col = d.lse_col;
@@ -941,8 +992,8 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
     x.K = c_pad;
     x.ldp = d.ldt;
     x.ldq = d.ldg;
-    x.tiles_m = cdiv(k_pad, pl.bt_g);
-    x.tiles_n = cdiv(d.r, pl.bt_g);
+    x.tiles_m = cdiv(k_pad, pl.bm_g);
+    x.tiles_n = cdiv(d.r, pl.bn_g);
     x.slab = d.slab;
     x.slab_ld = k_pad;
     x.slab_split_stride = (long)r_pad * k_pad;
@@ -958,13 +1009,13 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
   db.n_probs = n_dirs;
   {
     ProfScope ps(MMK_K_SIM_GRAD, st);
-    int rc = dirs[0].mode == 1 ? launch_gemm<T, EPI_ALIGN_GRAD>(gb, n_dirs, pl.bt, max_tiles_g, scale, st)
-                               : launch_gemm<T, EPI_GRAD>(gb, n_dirs, pl.bt, max_tiles_g, scale, st);
+    int rc = dirs[0].mode == 1 ? launch_gemm<T, EPI_ALIGN_GRAD>(gb, n_dirs, pl.bm, pl.bn, max_tiles_g, scale, st)
+                               : launch_gemm<T, EPI_GRAD>(gb, n_dirs, pl.bm, pl.bn, max_tiles_g, scale, st);
     if (rc) return rc;
   }
   {
     ProfScope ps(MMK_K_GRAD_GEMM, st);
-    int rc = launch_gemm<T, EPI_PLAIN>(xb, n_dirs, pl.bt_g, max_tiles_x, scale, st);
+    int rc = launch_gemm<T, EPI_PLAIN>(xb, n_dirs, pl.bm_g, pl.bn_g, max_tiles_x, scale, st);
     if (rc) return rc;
   }
   {

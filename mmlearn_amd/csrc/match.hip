@@ -12,9 +12,9 @@
 
 namespace mmk {
 
-constexpr int MATCH_CHUNK = 256;  // id pairs of b per block (4 KiB of LDS): a 256 x 256 compare tile per block
+constexpr int MATCH_CHUNK = 128;  // id pairs of b per block (2 KiB of LDS): a 256 x 128 compare tile per block
 
-// MODE 0: cnt[i*n_chunks + chunk] = #{j in chunk : a[i] == b[j]}, cnt_b[j] += 1 per match.
+// MODE 0: cnt[chunk*n_a + i] = #{j in chunk : a[i] == b[j]}, cnt_b[j] += 1 per match.
 // MODE 1: write the pairs of (i, chunk) at offs[i*n_chunks + chunk]; maintain the status flags.
 template <int MODE>
 __global__ __launch_bounds__(256) void match_kernel(const longlong2* __restrict__ a, int n_a, const longlong2* __restrict__ b,
@@ -31,29 +31,43 @@ __global__ __launch_bounds__(256) void match_kernel(const longlong2* __restrict_
   if (i >= n_a) return;
   const longlong2 mine = a[i];
   if (MODE == 0) {
+    // compare 8 LDS entries per step into a bit mask (loads pipeline, no side effects); matches are rare, so the
+    // atomics that feed the "column repeats" flag sit behind an almost-never-taken branch
     int c = 0;
-#pragma unroll 8
-    for (int t = 0; t < len; ++t) {
-      const longlong2 o = sb[t];
-      if (o.x == mine.x && o.y == mine.y) {
-        ++c;
-        atomicAdd(&cnt_b[j0 + t], 1);
+    for (int t0 = 0; t0 < len; t0 += 8) {
+      unsigned mask = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const longlong2 o = sb[min(t0 + e, MATCH_CHUNK - 1)];
+        mask |= (unsigned)(t0 + e < len && o.x == mine.x && o.y == mine.y) << e;
+      }
+      c += __popc(mask);
+      while (mask) {
+        const int e = __ffs(mask) - 1;
+        mask &= mask - 1;
+        atomicAdd(&cnt_b[j0 + t0 + e], 1);
       }
     }
-    cnt[(size_t)i * n_chunks + chunk] = c;
+    cnt[(size_t)chunk * n_a + i] = c;  // [chunk][row]: coalesced for the scan and the fill pass
   } else {
     // row_off[i] = pairs before row i; the chunks of a row are laid out in chunk order behind it
     const int32_t* row_off = cnt + (size_t)n_a * n_chunks;
     int pos = row_off[i];
-    for (int c = 0; c < chunk; ++c) pos += cnt[(size_t)i * n_chunks + c];
+    for (int c = 0; c < chunk; ++c) pos += cnt[(size_t)c * n_a + i];
     if (chunk == 0 && row_off[i + 1] - pos > 1) status[2] = 1;  // row i is in several pairs
-    if (cnt[(size_t)i * n_chunks + chunk] == 0) return;
+    if (cnt[(size_t)chunk * n_a + i] == 0) return;
     bool off_diag = false, col_rep = false;
-#pragma unroll 8
-    for (int t = 0; t < len; ++t) {
-      const longlong2 o = sb[t];
-      if (o.x == mine.x && o.y == mine.y) {
-        const int j = j0 + t;
+    for (int t0 = 0; t0 < len; t0 += 8) {
+      unsigned mask = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const longlong2 o = sb[min(t0 + e, MATCH_CHUNK - 1)];
+        mask |= (unsigned)(t0 + e < len && o.x == mine.x && o.y == mine.y) << e;
+      }
+      while (mask) {  // ascending j: row-major order
+        const int e = __ffs(mask) - 1;
+        mask &= mask - 1;
+        const int j = j0 + t0 + e;
         if (pos < capacity) {
           idx_a[pos] = i;
           idx_b[pos] = j;
@@ -81,7 +95,7 @@ __global__ __launch_bounds__(1024) void match_scan_kernel(const int32_t* __restr
     const int i = base + threadIdx.x;
     int x0 = 0;
     if (i < n)
-      for (int c = 0; c < n_chunks; ++c) x0 += cnt[(size_t)i * n_chunks + c];
+      for (int c = 0; c < n_chunks; ++c) x0 += cnt[(size_t)c * n + i];
     int x = x0;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {

@@ -129,10 +129,21 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const T* __restrict__
     }
     if (lo < keep && ix[lo] == tok) src[n_src++] = (m * b + bi) * keep + lo;
   }
-  for (int c = lane; c < d; c += 64) {
-    float v = 0.f;
-    for (int k = 0; k < n_src; ++k) v += to_f32(dout[(size_t)src[k] * d + c]);
-    o[c] = from_f32<T>(v);
+  if ((d & 3) == 0) {
+    for (int c = lane * 4; c < d; c += 256) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < n_src; ++k) {
+        const float4 t = Vec4<T>::load(dout + (size_t)src[k] * d + c);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      Vec4<T>::store(o + c, v);
+    }
+  } else {
+    for (int c = lane; c < d; c += 64) {
+      float v = 0.f;
+      for (int k = 0; k < n_src; ++k) v += to_f32(dout[(size_t)src[k] * d + c]);
+      o[c] = from_f32<T>(v);
+    }
   }
 }
 
@@ -158,38 +169,69 @@ __global__ __launch_bounds__(256) void ijepa_loss_kernel(const Z* __restrict__ z
     const H* hr = h + ((size_t)bi * n + tok) * d;
     const Z* zr = z + (size_t)row * d;
     float* buf = rowbuf + (size_t)wave * d;
-    float s = 0.f;
-    for (int c = lane; c < d; c += 64) {
-      const float v = to_f32(hr[c]);
-      buf[c] = v;
-      s += v;
-    }
-    const float mean = wave_sum(s) / d;
-    float ss = 0.f;
-    for (int c = lane; c < d; c += 64) {
-      const float v = buf[c] - mean;
-      ss += v * v;
-    }
-    const float rstd = rsqrtf(wave_sum(ss) / d + eps);
     const float gscale = (MODE == 1) ? (*upstream) / ((float)total * (float)d) : 0.f;
-    for (int c = lane; c < d; c += 64) {
-      float t = (buf[c] - mean) * rstd;
-      // the reference materialises the target (F.layer_norm output) in h's dtype before the loss
-      t = to_f32(from_f32<H>(t));
-      if (MODE == 0 && target_out) target_out[(size_t)row * d + c] = from_f32<H>(t);
-      const float diff = to_f32(zr[c]) - t;
+    auto rho = [&](float zv, float t, float& acc, float& g) {
+      const float diff = zv - t;
       if (MODE == 0) {
         if (kind == 0) {
           const float ad = fabsf(diff);
-          local += ad < 1.f ? 0.5f * diff * diff : ad - 0.5f;
+          acc += ad < 1.f ? 0.5f * diff * diff : ad - 0.5f;
         } else {
-          local += diff * diff;
+          acc += diff * diff;
         }
       } else {
-        float g;
-        if (kind == 0) g = fabsf(diff) < 1.f ? diff : (diff > 0.f ? 1.f : -1.f);
-        else g = 2.f * diff;
-        dz[(size_t)row * d + c] = from_f32<Z>(g * gscale);
+        g = (kind == 0 ? (fabsf(diff) < 1.f ? diff : (diff > 0.f ? 1.f : -1.f)) : 2.f * diff) * gscale;
+      }
+    };
+    if ((d & 3) == 0) {  // 16-byte (f32) / 8-byte (bf16) lanes
+      float s = 0.f;
+      for (int c = lane * 4; c < d; c += 256) {
+        const float4 v = Vec4<H>::load(hr + c);
+        *reinterpret_cast<float4*>(buf + c) = v;
+        s += v.x + v.y + v.z + v.w;
+      }
+      const float mean = wave_sum(s) / d;
+      float ss = 0.f;
+      for (int c = lane * 4; c < d; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(buf + c);
+        const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+        ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+      }
+      const float rstd = rsqrtf(wave_sum(ss) / d + eps);
+      for (int c = lane * 4; c < d; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(buf + c);
+        // the reference materialises the target (F.layer_norm output) in h's dtype before the loss
+        float4 t = make_float4(to_f32(from_f32<H>((v.x - mean) * rstd)), to_f32(from_f32<H>((v.y - mean) * rstd)),
+                               to_f32(from_f32<H>((v.z - mean) * rstd)), to_f32(from_f32<H>((v.w - mean) * rstd)));
+        if (MODE == 0 && target_out) Vec4<H>::store(target_out + (size_t)row * d + c, t);
+        const float4 zv = Vec4<Z>::load(zr + c);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        rho(zv.x, t.x, local, g.x);
+        rho(zv.y, t.y, local, g.y);
+        rho(zv.z, t.z, local, g.z);
+        rho(zv.w, t.w, local, g.w);
+        if (MODE == 1) Vec4<Z>::store(dz + (size_t)row * d + c, g);
+      }
+    } else {
+      float s = 0.f;
+      for (int c = lane; c < d; c += 64) {
+        const float v = to_f32(hr[c]);
+        buf[c] = v;
+        s += v;
+      }
+      const float mean = wave_sum(s) / d;
+      float ss = 0.f;
+      for (int c = lane; c < d; c += 64) {
+        const float v = buf[c] - mean;
+        ss += v * v;
+      }
+      const float rstd = rsqrtf(wave_sum(ss) / d + eps);
+      for (int c = lane; c < d; c += 64) {
+        const float t = to_f32(from_f32<H>((buf[c] - mean) * rstd));
+        if (MODE == 0 && target_out) target_out[(size_t)row * d + c] = from_f32<H>(t);
+        float g = 0.f;
+        rho(to_f32(zr[c]), t, local, g);
+        if (MODE == 1) dz[(size_t)row * d + c] = from_f32<Z>(g);
       }
     }
   }
@@ -236,15 +278,27 @@ __global__ __launch_bounds__(256) void pred_assemble_kernel(const X* __restrict_
     const int pt = enc_idx[((size_t)e * enc_idx_b + (enc_idx_b == 1 ? 0 : bi)) * n_ctxt + t];
     const X* xr = x + ((size_t)r * n_ctxt + t) * d;
     const float* pr = pos + (size_t)pt * d;
-    for (int c = lane; c < d; c += 64) {
-      // the reference adds in place into x (x's dtype), then torch.cat promotes
-      const float v = to_f32(from_f32<X>(to_f32(xr[c]) + pr[c]));
-      o[c] = from_f32<O>(v);
+    // the reference adds in place into x (x's dtype), then torch.cat promotes
+    if ((d & 3) == 0) {
+      for (int c = lane * 4; c < d; c += 256) {
+        const float4 a = Vec4<X>::load(xr + c), q = *reinterpret_cast<const float4*>(pr + c);
+        Vec4<O>::store(o + c, make_float4(to_f32(from_f32<X>(a.x + q.x)), to_f32(from_f32<X>(a.y + q.y)),
+                                          to_f32(from_f32<X>(a.z + q.z)), to_f32(from_f32<X>(a.w + q.w))));
+      }
+    } else {
+      for (int c = lane; c < d; c += 64) o[c] = from_f32<O>(to_f32(from_f32<X>(to_f32(xr[c]) + pr[c])));
     }
   } else {
     const int pt = pred_idx[((size_t)m * pred_idx_b + (pred_idx_b == 1 ? 0 : bi)) * n_pred + (t - n_ctxt)];
     const float* pr = pos + (size_t)pt * d;
-    for (int c = lane; c < d; c += 64) o[c] = from_f32<O>(tok[c] + pr[c]);
+    if ((d & 3) == 0) {
+      for (int c = lane * 4; c < d; c += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(tok + c), q = *reinterpret_cast<const float4*>(pr + c);
+        Vec4<O>::store(o + c, make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w));
+      }
+    } else {
+      for (int c = lane; c < d; c += 64) o[c] = from_f32<O>(tok[c] + pr[c]);
+    }
   }
 }
 
@@ -258,10 +312,21 @@ __global__ __launch_bounds__(256) void pred_assemble_bwd_x_kernel(const O* __res
   if (row >= (long)rows_x * n_ctxt) return;
   const int t = row % n_ctxt;
   const long r = row / n_ctxt;
-  for (int c = lane; c < d; c += 64) {
-    float v = 0.f;
-    for (int m = 0; m < n_pm; ++m) v += to_f32(dseq[(((size_t)m * rows_x + r) * L + t) * d + c]);
-    dx[(size_t)row * d + c] = from_f32<X>(v);
+  if ((d & 3) == 0) {
+    for (int c = lane * 4; c < d; c += 256) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int m = 0; m < n_pm; ++m) {
+        const float4 q = Vec4<O>::load(dseq + (((size_t)m * rows_x + r) * L + t) * d + c);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      Vec4<X>::store(dx + (size_t)row * d + c, v);
+    }
+  } else {
+    for (int c = lane; c < d; c += 64) {
+      float v = 0.f;
+      for (int m = 0; m < n_pm; ++m) v += to_f32(dseq[(((size_t)m * rows_x + r) * L + t) * d + c]);
+      dx[(size_t)row * d + c] = from_f32<X>(v);
+    }
   }
 }
 
@@ -275,6 +340,7 @@ __global__ __launch_bounds__(256) void pred_assemble_bwd_tok_kernel(const O* __r
   const long r1 = min(total, r0 + rows_per_block);
   for (int c = threadIdx.x; c < d; c += 256) {
     float v = 0.f;
+#pragma unroll 8
     for (long q = r0; q < r1; ++q) {
       const long sq = q / n_pred;
       const int p = q % n_pred;
@@ -287,6 +353,7 @@ __global__ __launch_bounds__(256) void sum_cols_kernel(const float* __restrict__
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= d) return;
   float v = 0.f;
+#pragma unroll 8
   for (int k = 0; k < n_blocks; ++k) v += part[(size_t)k * d + c];
   out[c] = v;
 }
@@ -474,7 +541,7 @@ int mmk_ijepa_loss_bwd(const void* z, const void* h, const int32_t* idx, int b, 
   return 0;
 }
 
-int mmk_pred_tok_blocks(int rows) { return std::min(1024, std::max(1, cdiv(rows, 64))); }
+int mmk_pred_tok_blocks(int rows) { return std::min(256, std::max(1, cdiv(rows, 16))); }
 
 int mmk_pred_assemble(const void* x, const void* pos, const void* mask_token, const int32_t* enc_idx, const int32_t* pred_idx,
                       int b, int n, int d, int n_enc, int n_pred_masks, int enc_idx_b, int pred_idx_b, int n_ctxt, int n_pred,

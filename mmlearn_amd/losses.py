@@ -172,6 +172,14 @@ class _Run:
         for n in local:
             if n not in names_all:
                 raise ValueError(f"modality {n!r} is not registered")
+        pre = self.o._take_prefetched(local)
+        if pre is not None:  # gathers were started right after each encoder (overlapped with the next one)
+            views = {}
+            for n, (all_e, all_i, works) in pre.items():
+                for w in works:
+                    w.wait()  # stream-level wait on the collective's stream, no host block
+                views[n] = _View(n, local[n], all_e, all_i, None, [local[n].shape[0]] * self.world)
+            return views
         any_t = next(iter(local.values()))
         dev, dt, d = any_t.device, any_t.dtype, any_t.shape[1]
         W, rank = self.world, self.rank
@@ -601,6 +609,34 @@ class ContrastiveLoss(nn.Module):
         self.cache_labels = cache_labels
         self.compute_dtype = compute_dtype
         self.static_shapes = static_shapes
+        self._pending: dict[str, tuple] = {}
+
+    # ------------------------------------------------------------------ gather / encoder overlap
+    def prefetch_gather(self, modality: str, embedding: torch.Tensor, example_ids: torch.Tensor) -> None:
+        """Start this modality's all-gather now (asynchronously, on the process group's own stream) so that it
+        overlaps with the encoders that still have to run; ``forward`` picks the result up.  Called by
+        ``ContrastivePretraining.forward`` after each ``encode``.  Only with ``static_shapes=True`` (all ranks hold
+        the same modalities and batch size); otherwise a no-op and the packed gather in ``forward`` is used."""
+        if not (self.static_shapes and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        world = dist.get_world_size()
+        e = embedding.detach().contiguous()
+        i = example_ids.to(torch.int64).contiguous()
+        all_e = torch.empty((world * e.shape[0], e.shape[1]), dtype=e.dtype, device=e.device)
+        all_i = torch.empty((world * i.shape[0], 2), dtype=torch.int64, device=i.device)
+        works = [dist.all_gather_into_tensor(all_e.view(-1), e.view(-1), async_op=True),
+                 dist.all_gather_into_tensor(all_i.view(-1), i.view(-1), async_op=True)]
+        self._pending[modality] = (embedding, all_e, all_i, works, (e, i))
+
+    def _take_prefetched(self, local: dict[str, torch.Tensor]):
+        """Prefetched gathers, if there is one for every local modality and it belongs to exactly these tensors."""
+        pending, self._pending = self._pending, {}
+        if not pending or set(pending) != set(local) or any(pending[n][0] is not local[n] for n in local):
+            for _, _, _, works, _ in pending.values():
+                for w in works:
+                    w.wait()  # never leave a collective un-joined
+            return None
+        return {n: (p[1], p[2], p[3]) for n, p in pending.items()}
 
     def forward(self, embeddings: dict[str, torch.Tensor], example_ids: dict[str, torch.Tensor], logit_scale: torch.Tensor,
                 modality_loss_pairs: Sequence[Any]) -> torch.Tensor:

@@ -4,9 +4,10 @@
 Differences from the reference, all inside the hot path:
 
 * ``encode(..., normalize=True)`` normalises with the HIP ``l2_normalize`` op;
-* the default ``loss`` is this package's :class:`~mmlearn_amd.losses.ContrastiveLoss`
-  (any module with the documented ``forward(embeddings, example_ids, logit_scale,
-  modality_loss_pairs)`` signature is accepted, as in the reference).
+* ``forward`` hands every finished embedding to ``loss.prefetch_gather`` (when the loss has one): the
+  global-batch all-gather of modality k runs on the RCCL stream while the encoder of modality k+1 runs;
+* ``loss`` is any module with the documented ``forward(embeddings, example_ids, logit_scale,
+  modality_loss_pairs)`` signature, as in the reference (use :class:`~mmlearn_amd.losses.ContrastiveLoss`).
 """
 
 from __future__ import annotations
@@ -183,7 +184,15 @@ class ContrastivePretraining(TrainingTask):
         return output
 
     def forward(self, inputs: dict[str, Any]) -> dict[str, torch.Tensor]:
-        outputs = {m.embedding: self.encode(inputs, m, normalize=True) for m in self._available_modalities if m.name in inputs}
+        outputs = {}
+        prefetch = getattr(self.loss_fn, "prefetch_gather", None) if "example_ids" in inputs else None
+        for m in self._available_modalities:
+            if m.name not in inputs:
+                continue
+            outputs[m.embedding] = self.encode(inputs, m, normalize=True)
+            if prefetch is not None and m.name in inputs["example_ids"]:
+                # start the global-batch all-gather of this modality while the next encoder runs (RCCL stream)
+                prefetch(m.name, outputs[m.embedding], inputs["example_ids"][m.name])
         dims = {o.size(-1) for o in outputs.values()}
         if len(dims) > 1:
             raise ValueError("Expected all model outputs to have the same dimension.")

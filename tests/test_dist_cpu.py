@@ -49,7 +49,12 @@ def _worker(rank, world, port, case_names, q):
                 s.grad = None
                 fn = L.ContrastiveLoss(local_loss=bool(c["local_loss"]), gather_with_grad=bool(c["gather_with_grad"]),
                                        static_shapes=static)
+                if static:  # the task starts the gathers right after each encoder; the loss must pick them up
+                    for m in mods:
+                        fn.prefetch_gather(m, embs[f"{m}_embedding"], ids[m])
+                    assert set(fn._pending) == set(mods)
                 loss = fn(embs, ids, s, [L.LossPairSpec(("rgb", "text"))])
+                assert not fn._pending
                 rec = {"loss": float(loss.detach()), "requires_grad": loss.requires_grad}
                 if loss.requires_grad:
                     loss.backward()

@@ -116,14 +116,16 @@ def build_task(loss, small: bool, fused: bool = False):
 
 def cpu_baseline(seconds_budget: float = 25.0):
     """The reference's step on the host cores: same encoders (f32), eager torch ops, the reference's loss op
-    sequence (oracle/eager_torch.py).  Bounded sample: batches of 16 pairs until the budget is spent."""
+    sequence (oracle/eager_torch.py).  Bounded sample: batches of 8 pairs until the time budget is spent (at most 32 threads)."""
     from oracle.eager_torch import EagerContrastiveLoss
 
     import mmlearn_amd.tasks.contrastive_pretraining as cp
 
-    cores = os.cpu_count() or 1
+    # many-core hosts: torch eager on ~200 threads is slower than on 32 (measured on the 256-core MI355X box:
+    # 16 pairs took ~7 min at 256 threads); use at most 32 and report what was used
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    b = 16
+    b = 8
     saved = cp.l2_normalize
     cp.l2_normalize = lambda x: torch.nn.functional.normalize(x, p=2, dim=-1)  # the reference's K1 on CPU (baseline leg only)
     try:
@@ -137,17 +139,21 @@ def cpu_baseline(seconds_budget: float = 25.0):
             loss.backward()
             opt.step()
 
-        step()  # warm-up
         t0 = time.perf_counter()
-        n = 0
-        while n < 1 or (time.perf_counter() - t0) < seconds_budget and n < 50:
-            step()
-            n += 1
-        dt = time.perf_counter() - t0
+        step()  # first step (includes one-time allocator / thread-pool start-up)
+        first = time.perf_counter() - t0
+        n, dt = 1, first
+        if first < seconds_budget / 2:  # time steady-state steps while the budget lasts
+            t0 = time.perf_counter()
+            n = 0
+            while n < 1 or ((time.perf_counter() - t0) + first < seconds_budget and n < 50):
+                step()
+                n += 1
+            dt = time.perf_counter() - t0
     finally:
         cp.l2_normalize = saved
     return {"value": round(b * n / dt, 3), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of {b} pairs (ViT-B/16 + BERT-base, f32, torch eager on host cores, reference loss op sequence)"}
+            "sample": f"{n} steps of {b} pairs (ViT-B/16 + BERT-base, f32, torch eager on {cores} host threads, reference loss op sequence)"}
 
 
 def main():

@@ -16,6 +16,7 @@
 // Data layout: operands are [rows][k_pad] with k_pad a multiple of one 128-byte LDS row
 // (64 bf16 / 32 f32).  LDS tiles are [rows][128 B], 16-byte chunks XOR-swizzled with
 // (row>>1)&7 so that the 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots.
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -862,7 +863,12 @@ static int launch_one(const ProbBatch& b, dim3 grid, const float* scale, hipStre
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), bytes, st, b, scale);
+  {
+    constexpr int kid = (EPI == EPI_STATS || EPI == EPI_ALIGN_STATS) ? MMK_K_SIM_STATS
+                        : (EPI == EPI_GRAD || EPI == EPI_ALIGN_GRAD) ? MMK_K_SIM_GRAD : MMK_K_GRAD_GEMM;
+    ProfEvents pe(kid);  // null events unless profiling: then the dispatch itself is time-stamped
+    hipExtLaunchKernelGGL(kern, grid, dim3(256), bytes, st, pe.start, pe.stop, 0, b, scale);
+  }
   MMK_LAUNCH_CHECK();
   return 0;
 }
@@ -921,7 +927,6 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
   b.n_split = 1;
   const bool align = dirs[0].mode == 1;
   {
-    ProfScope ps(MMK_K_SIM_STATS, st);
     int rc = align ? launch_gemm<T, EPI_ALIGN_STATS>(b, n_dirs, pl.bm, pl.bn, max_tiles, scale, st)
                    : launch_gemm<T, EPI_STATS>(b, n_dirs, pl.bm, pl.bn, max_tiles, scale, st);
     if (rc) return rc;
@@ -1008,13 +1013,11 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
   fb.d = d_user;
   db.n_probs = n_dirs;
   {
-    ProfScope ps(MMK_K_SIM_GRAD, st);
     int rc = dirs[0].mode == 1 ? launch_gemm<T, EPI_ALIGN_GRAD>(gb, n_dirs, pl.bm, pl.bn, max_tiles_g, scale, st)
                                : launch_gemm<T, EPI_GRAD>(gb, n_dirs, pl.bm, pl.bn, max_tiles_g, scale, st);
     if (rc) return rc;
   }
   {
-    ProfScope ps(MMK_K_GRAD_GEMM, st);
     int rc = launch_gemm<T, EPI_PLAIN>(xb, n_dirs, pl.bm_g, pl.bn_g, max_tiles_x, scale, st);
     if (rc) return rc;
   }

@@ -41,6 +41,16 @@ struct ProfScope {
   ~ProfScope();
 };
 
+// Event pair handed to hipExtLaunchKernelGGL: HIP stamps them with the dispatch's own begin/end, so the elapsed time
+// is the kernel duration (what rocprofv3 reports), free of the enqueue gap a record-before/record-after pair includes
+// when the stream is starved.  Null events when profiling is off.
+struct ProfEvents {
+  int id;
+  hipEvent_t start, stop;
+  explicit ProfEvents(int kernel_id);
+  ~ProfEvents();
+};
+
 #define MMK_LAUNCH_CHECK()                                                                 \
   do {                                                                                     \
     hipError_t _e = hipGetLastError();                                                     \

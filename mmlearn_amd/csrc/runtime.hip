@@ -51,6 +51,19 @@ ProfScope::~ProfScope() {
   delete p;
 }
 
+ProfEvents::ProfEvents(int kernel_id) : id(kernel_id), start(nullptr), stop(nullptr) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  start = get_event();
+  stop = get_event();
+  if (!start || !stop) start = stop = nullptr;
+}
+ProfEvents::~ProfEvents() {
+  if (!start) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_events.push_back(EventPair{id, start, stop});
+}
+
 static void resolve_locked() {
   for (auto& e : g_events) {
     float ms = 0.f;

@@ -298,10 +298,10 @@ class _Run:
             off = 0 if k == 0 else sizes[k - 1]
             hmax[off: off + n] = np.maximum(hmax[off: off + n], off + n)
         hmax_t = torch.from_numpy(hmax).to(dev)
-        if W == 1:
+        if all(views[n].rows is None for n in order):  # one compact matrix per modality (W = 1, or prefetched gathers)
             src = torch.cat([views[n].src for n in order], 0)
             idx = None
-        else:
+        else:  # one packed gather holding every modality: select the rows
             src = views[order[0]].src
             idx = torch.cat([views[n].rows for n in order]).contiguous()
         f_all, f_all_t = K.pack_rows(src, idx, m_total, o.l2_normalize, self.compute, self.needs_grad)

@@ -124,3 +124,78 @@ def test_multi_rank_hip_path_vs_reference(world):
             assert abs(got["dscale"] - ref_ds) <= 1e-3 * max(1.0, abs(ref_ds)), (tag, got["dscale"], ref_ds)
             n_checked += 1
     assert n_checked >= (13 if world == 2 else 8) * world // 2
+
+
+def _seeded_inputs(rank, b, d, dtype):
+    g = torch.Generator().manual_seed(500 + rank)
+    a = torch.nn.functional.normalize(torch.randn(b, d, generator=g), dim=-1)
+    t = torch.nn.functional.normalize(0.5 * a + 0.5 * torch.nn.functional.normalize(torch.randn(b, d, generator=g), dim=-1), dim=-1)
+    ids = torch.stack([torch.zeros(b, dtype=torch.long), torch.arange(rank * b, (rank + 1) * b)], 1)
+    if dtype == "bfloat16":
+        a, t = a.bfloat16().float(), t.bfloat16().float()
+    return a, t, ids
+
+
+def _seeded_worker(rank, world, port, b, d, dtype, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        _stage_collectives_through_host()
+        import mmlearn_amd.losses as L
+
+        dev = torch.device("cuda", 0)
+        tdt = torch.bfloat16 if dtype == "bfloat16" else torch.float32
+        a, t, ids = _seeded_inputs(rank, b, d, dtype)
+        res = {}
+        for ll, gwg in ((False, False), (True, True)):
+            ea, et = a.to(dev, tdt).requires_grad_(True), t.to(dev, tdt).requires_grad_(True)
+            s = torch.tensor(1 / 0.07, device=dev, requires_grad=True)
+            fn = L.ContrastiveLoss(local_loss=ll, gather_with_grad=gwg, static_shapes=True)
+            fn.prefetch_gather("rgb", ea, ids.to(dev))
+            fn.prefetch_gather("text", et, ids.to(dev))
+            loss = fn({"rgb_embedding": ea, "text_embedding": et}, {"rgb": ids.to(dev), "text": ids.to(dev)}, s, [L.LossPairSpec(("rgb", "text"))])
+            loss.float().backward()
+            res[(ll, gwg)] = {"loss": float(loss.detach().float()), "ga": ea.grad.float().cpu().numpy(), "gt": et.grad.float().cpu().numpy(),
+                              "ds": float(s.grad)}
+        q.put((rank, res, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, None, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,b,d,dtype", [(2, 1024, 512, "bfloat16"), (4, 333, 200, "float32")])
+@pytest.mark.timeout(600)
+def test_multi_rank_hip_path_seeded_vs_oracle(world, b, d, dtype):
+    """BASELINE-sized shards (per-rank 1024 x 512 bf16: 128x128 tiles, label offsets, r != c) against the oracle."""
+    from oracle import clip_oracle as co
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_seeded_worker, args=(r, world, 29730 + world, b, d, dtype, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in procs:
+        rank, res, err = q.get(timeout=500)
+        assert err is None, f"rank {rank} failed:\n{err}"
+        out[rank] = res
+    for p in procs:
+        p.join(timeout=60)
+    ins = [_seeded_inputs(r, b, d, dtype) for r in range(world)]
+    embs = [{"rgb": i[0].numpy(), "text": i[1].numpy()} for i in ins]
+    ids = [{"rgb": i[2].numpy(), "text": i[2].numpy()} for i in ins]
+    tol = 1e-2 if dtype == "bfloat16" else 1e-3
+    for ll, gwg in ((False, False), (True, True)):
+        orc = co.contrastive_loss_dist(embs, ids, 1 / 0.07, [(("rgb", "text"), 1.0)], ll, gwg)
+        for r in range(world):
+            got = out[r][(ll, gwg)]
+            assert abs(got["loss"] - orc[r]["loss"]) <= tol * max(1.0, abs(orc[r]["loss"])), (ll, gwg, r)
+            for k, m in (("ga", "rgb"), ("gt", "text")):
+                ref = orc[r]["grads"][m]
+                assert np.abs(got[k] - ref).max() <= tol * np.abs(ref).max(), (ll, gwg, r, m)
+            assert abs(got["ds"] - orc[r]["dscale"]) <= tol * max(1.0, abs(orc[r]["dscale"])), (ll, gwg, r)

@@ -875,9 +875,10 @@ static int launch_one(const ProbBatch& b, dim3 grid, const float* scale, hipStre
 
 template <typename T, int BM, int BN, int EPI>
 static int launch_tile(const ProbBatch& b, dim3 grid, const float* scale, hipStream_t st) {
-  const LoaderCfg c = loader_cfg();
+  LoaderCfg c = loader_cfg();
   if (c.loader == LOADER_REG) return launch_one<T, BM, BN, EPI, LOADER_REG, 2>(b, grid, scale, st);
-  // 128^2 tiles: 32 KiB per stage -> at most 4 stages in 160 KiB; 64^2 tiles: 16 KiB per stage
+  // 2 LDS stages by default: 128^2 tiles then fit 2 blocks/CU (3-4 stages measured 1.4-1.7x slower at N = 8192);
+  // for the latency-bound 64^2 tiles 4 stages were within noise of 2 (N = 512..2048), so keep the smaller footprint.
   if (c.stages == 2) return launch_one<T, BM, BN, EPI, LOADER_DMA, 2>(b, grid, scale, st);
   if (c.stages == 3) return launch_one<T, BM, BN, EPI, LOADER_DMA, 3>(b, grid, scale, st);
   return launch_one<T, BM, BN, EPI, LOADER_DMA, 4>(b, grid, scale, st);

@@ -39,7 +39,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 class VisionEncoder(nn.Module):
     """HF CLIP ViT-B/16 with projection; mmlearn encoder contract: forward(dict) -> (embedding,)"""
 
-    def __init__(self, small: bool = False):
+    def __init__(self, small: bool = False, hip_attention: bool = False):
         super().__init__()
         from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
 
@@ -48,6 +48,10 @@ class VisionEncoder(nn.Module):
         if small:
             cfg = CLIPVisionConfig(patch_size=32, image_size=224, projection_dim=512, hidden_size=128, intermediate_size=256,
                                    num_hidden_layers=2, num_attention_heads=2)
+        if hip_attention:  # whole-sequence-on-chip attention kernel through HF's AttentionInterface
+            from mmlearn_amd.attention import register_hf_attention
+
+            cfg._attn_implementation = register_hf_attention()
         self.model = CLIPVisionModelWithProjection(cfg)
 
     def forward(self, inputs):
@@ -97,7 +101,7 @@ def build_task(loss, small: bool, fused: bool = False):
     from mmlearn_amd.tasks.contrastive_pretraining import ContrastivePretraining
 
     torch.manual_seed(0)
-    rgb, text = VisionEncoder(small), TextEncoder(small)
+    rgb, text = VisionEncoder(small, hip_attention=fused and not small), TextEncoder(small)
     if fused:  # HIP LayerNorm / quick-GELU inside the encoders (same parameters, same math)
         from mmlearn_amd.fused import accelerate_encoder
 
@@ -264,7 +268,7 @@ def main():
                                    f"per-GPU batch {args.batch}, {'local' if world == 1 else 'global-batch (all-gather)'} negatives"
                                    + (" [DEBUG small encoders]" if args.small else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": "mmlearn_amd.ContrastiveLoss (HIP)",
-                       "encoder_ops": "torch" if args.no_fused_encoder_ops else "HIP LayerNorm + quick-GELU (mmlearn_amd.fused)",
+                       "encoder_ops": "torch" if args.no_fused_encoder_ops else "HIP LayerNorm + quick-GELU + ViT attention (mmlearn_amd.fused / .attention)",
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline,
         }

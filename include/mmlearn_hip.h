@@ -46,7 +46,8 @@ enum {
   MMK_K_MATCH = 0, MMK_K_PACK, MMK_K_TRANSPOSE, MMK_K_SIM_STATS, MMK_K_LSE_REDUCE, MMK_K_LOSS_COMBINE,
   MMK_K_SIM_GRAD, MMK_K_GRAD_GEMM, MMK_K_GRAD_FINALIZE, MMK_K_L2NORM, MMK_K_IJEPA_LOSS_FWD,
   MMK_K_IJEPA_LOSS_BWD, MMK_K_GATHER_ROWS, MMK_K_SCATTER_ROWS, MMK_K_PRED_ASSEMBLE, MMK_K_PRED_ASSEMBLE_BWD,
-  MMK_K_EMA, MMK_K_MASK_INDEX, MMK_K_LAYERNORM_FWD, MMK_K_LAYERNORM_BWD, MMK_K_ACT, MMK_K_COUNT
+  MMK_K_EMA, MMK_K_MASK_INDEX, MMK_K_LAYERNORM_FWD, MMK_K_LAYERNORM_BWD, MMK_K_ACT, MMK_K_ATTN_FWD,
+  MMK_K_ATTN_BWD, MMK_K_COUNT
 };
 int mmk_profile_enable(int on);          /* on=1 start recording (clears), on=0 stop */
 /* resolve recorded events (synchronises on them); fills count[k] and total_ms[k] for k < MMK_K_COUNT */
@@ -214,6 +215,19 @@ int mmk_layernorm_bwd(const void* x, const void* dy, const float* w, const float
 /* HF QuickGELUActivation  x * sigmoid(1.702 x)  (CLIP MLP), forward and backward, n elements (multiple of 4) */
 int mmk_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
 int mmk_quick_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
+
+/* Short-sequence self-attention of the encoders' blocks (mmlearn/modules/layers/attention.py:60-75 materialises
+ * softmax(QK^T); HF encoders call SDPA): out = softmax(scale * Q K^T) V per (batch, head), bf16, head_dim 64, L <= 256,
+ * no mask, no dropout.  q/k/v are [B, H, L, 64] views given by element strides {batch, head, row} (last dim contiguous);
+ * out is [B, L, H, 64] contiguous; lse (f32 [B, H, L], natural log of the scaled scores' sum) feeds the backward. */
+int mmk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int L, int dh,
+                 const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, float scale, void* stream);
+
+/* Backward of mmk_attn_fwd: out / dout / dq / dk / dv are [B, L, H, 64] contiguous, lse is the forward's [B, H, L].
+ * Replaces autograd through the same reference expressions (softmax(QK^T)V backward). */
+int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                 void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
+                 const int64_t* k_strides, const int64_t* v_strides, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ _DTYPE_TAG = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 KERNEL_NAMES = [
     "match_ids", "pack_rows", "transpose", "sim_stats", "lse_reduce", "loss_combine", "sim_grad", "grad_gemm",
     "grad_finalize", "l2norm", "ijepa_loss_fwd", "ijepa_loss_bwd", "gather_rows", "scatter_rows", "pred_assemble",
-    "pred_assemble_bwd", "ema_update", "mask_to_index", "layernorm_fwd", "layernorm_bwd", "activation",
+    "pred_assemble_bwd", "ema_update", "mask_to_index", "layernorm_fwd", "layernorm_bwd", "activation", "attn_fwd", "attn_bwd",
 ]
 
 
@@ -86,6 +86,8 @@ _SIGNATURES = {
     "mmk_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _vp],
     "mmk_quick_gelu_fwd": [_vp, _vp, C.c_int64, _i, _vp],
     "mmk_quick_gelu_bwd": [_vp, _vp, _vp, C.c_int64, _i, _vp],
+    "mmk_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp],
+    "mmk_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp],
 }
 _STR_FUNCS = {"mmk_last_error": [], "mmk_kernel_name": [_i]}
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_STR_FUNCS))

@@ -1,0 +1,483 @@
+// SURVEY 8(f1), second step: short-sequence self-attention for the encoders' transformer blocks (ViT-B/16: L = 197,
+// own ViT / I-JEPA: L = 196 or 169, BERT: L = 77; head dim 64).  mmlearn's own block materialises softmax(QK^T) as a
+// [B, h, L, L] tensor (mmlearn/modules/layers/attention.py:60-75); HF CLIP/BERT go through SDPA.  For L <= 256 one
+// workgroup holds a whole (batch, head) problem on chip, so no online softmax is needed:
+//
+//   forward : K, V -> LDS by LDS-DMA as row-major images (128-B rows, 16-B chunks XOR-swizzled so that both the
+//             ds_read_b128 row reads and the ds_read_b64_tr_b16 transposed reads are bank-conflict free); per 32-query
+//             tile a wave computes S^T = K Q^T with the queries on the LANES (v_mfma_f32_32x32x16_bf16, Q fragments
+//             straight from global memory), so max / sum over the keys are lane-local; the exponentiated accumulators
+//             are then used directly as the B operand of O^T = V^T P^T (accumulator-as-operand, k order permuted
+//             accordingly), with V^T fragments delivered by the hardware transpose read.
+//   HBM traffic = Q, K, V read once + O written once (the roofline that bounds it); LSE is kept for the backward.
+#include <hip/hip_ext.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace mmk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ATT_DH = 64;  // head dimension (one 128-byte row of bf16)
+
+struct AttnArgs {
+  const bf16_t* q;
+  const bf16_t* k;
+  const bf16_t* v;
+  bf16_t* out;   // [B, L, H, 64] contiguous
+  float* lse;    // [B, H, L]
+  long q_sb, q_sh, q_sl;  // element strides of [B, H, L, 64] views (last dim contiguous)
+  long k_sb, k_sh, k_sl;
+  long v_sb, v_sh, v_sl;
+  int B, H, L;
+  float scale;
+  int debug;  // experiment switches (MMK_ATTN_DEBUG): 1 skip PV, 2 skip V staging, 4 skip pass 1, 8 skip stores
+};
+
+__device__ __forceinline__ float att_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// ---- LDS image of a [rows][64] bf16 tile: 128-byte rows, the 16-byte chunk index XORed with img_swz(row).
+// img_swz = bit-reversed (row>>1)&7: rows 2t, 2t+1 keep their 128-B bank offset from the row parity, the 8 row pairs of
+// a ds_read_b128 lane group land in 8 different chunks (row reads conflict-free), and rows i, i+2 of an aligned 4-row
+// block sit in opposite 64-B halves (transposed reads conflict-free).
+__device__ __forceinline__ int img_swz(int row) {
+  const int t = row >> 1;
+  return ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1);
+}
+
+// global [L][64] rows (element stride sl) -> image of LP rows; rows >= L repeat row L-1 (finite filler that the
+// callers neutralise).  8 rows = 1 KiB per wave-instruction; the swizzle is applied to the SOURCE chunk.
+__device__ __forceinline__ void img_load(char* img, const bf16_t* base, long sl, int L, int LP, int wave, int nwaves,
+                                         int lane) {
+  for (int g = wave; g < LP / 8; g += nwaves) {
+    const int row = 8 * g + (lane >> 3);
+    const int ch = (lane & 7) ^ img_swz(row);
+    const bf16_t* src = base + (long)min(row, L - 1) * sl + ch * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(img + g * 1024), 16, 0, 0);
+  }
+}
+
+// MFMA operand with k along the 64 columns: lane (r, h) takes row `row`, elements 16kk + 8h .. +7
+__device__ __forceinline__ bf16x8 img_row_frag(const char* img, int row, int kk, int h) {
+  return *reinterpret_cast<const bf16x8*>(img + row * 128 + (((2 * kk + h) ^ img_swz(row)) << 4));
+}
+
+// MFMA operand with k along the ROWS (transposed use of the same image): for the 32x32x16 A operand X^T[c][k] with
+// c = 32ct + (lane&31) and the accumulator-as-operand k order, the lane needs column c of rows r0 .. r0+3 and
+// r0+8 .. r0+11, r0 = 16s + 4h (+ tile base).  ds_read_b64_tr_b16: lane 4q+p of each 16-lane group supplies the address
+// of row q, columns 4p..4p+3 of the group's 4 x 16 block and receives column (lane&15) of the 4 rows.
+__device__ __forceinline__ bf16x4 img_tr4(const char* img, int r0, int ct, int lane) {
+  const int li = lane & 15, q = li >> 2, p = li & 3;
+  const int row = r0 + q;
+  const int ch = 4 * ct + 2 * ((lane >> 4) & 1) + (p >> 1);
+  const char* addr = img + row * 128 + ((ch ^ img_swz(row)) << 4) + 8 * (p & 1);
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  const s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(addr));
+  return __builtin_bit_cast(bf16x4, v);
+}
+__device__ __forceinline__ bf16x8 img_tr_frag(const char* img, int r0, int ct, int lane) {
+  const bf16x4 lo = img_tr4(img, r0, ct, lane);
+  const bf16x4 hi = img_tr4(img, r0 + 8, ct, lane);
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+// NT = number of 32-row tiles covering L (LP = 32*NT <= 256)
+template <int NT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int LP = 32 * NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;             // image of K
+  char* Vs = smem + LP * 128;  // image of V
+
+  const int bh = blockIdx.x;
+  const int b = bh / a.H, hh = bh % a.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const bf16_t* qb = a.q + b * a.q_sb + hh * a.q_sh;
+  const bf16_t* kb = a.k + b * a.k_sb + hh * a.k_sh;
+  const bf16_t* vb = a.v + b * a.v_sb + hh * a.v_sh;
+
+  img_load(Ks, kb, a.k_sl, a.L, LP, wave, 4, lane);
+  if (!(a.debug & 2)) img_load(Vs, vb, a.v_sl, a.L, LP, wave, 4, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float sl2 = a.scale * 1.4426950408889634f;
+  for (int t = wave; t < NT; t += 4) {
+    const int i = t * 32 + r;            // this lane's query row
+    const int ic = min(i, a.L - 1);
+    // Q fragments straight from global: lane (r, h) needs Q[i][16kk + 8h .. +8]
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qb + (long)ic * a.q_sl + 16 * kk + 8 * h);
+
+    // S^T tile jt: acc[reg] = sum_d K[j][d] Q[i][d],  j = 32jt + (reg&3) + 8(reg>>2) + 4h.  Computed TWICE (pass 1: row
+    // maximum, pass 2: exponentials + PV) instead of keeping NT accumulator tiles alive: 16 instead of 16*NT registers,
+    // which is what lets 2-4 workgroups share a CU and overlap their load and compute phases (the kernel is HBM-bound;
+    // the extra QK^T MFMAs are free).
+    auto score_tile = [&](int jt) {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(Ks, jt * 32 + r, kk, h), qf[kk], acc, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int j = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        acc[e] = (j < a.L) ? acc[e] * sl2 : -INFINITY;
+      }
+      return acc;
+    };
+    float m = -INFINITY;
+#pragma unroll 1
+    for (int jt = 0; jt < NT && !(a.debug & 4); ++jt) {
+      const f32x16 x = score_tile(jt);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m = fmaxf(m, x[e]);
+    }
+    if (a.debug & 4) m = 30.f;
+    m = fmaxf(m, __shfl_xor(m, 32));
+
+    // ---- O^T[d][i] = sum_j V^T[d][j] P^T[j][i]: A = V^T fragment, B = the accumulator tile itself
+    // B fragment of k-step s (s = 0,1) of tile jt = regs 8s..8s+7; its element jj is row 16s + 8(jj>>2) + 4h + (jj&3)
+    float sum = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+#pragma unroll 1
+    for (int jt = 0; jt < NT; ++jt) {
+      f32x16 x = score_tile(jt);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        x[e] = att_exp2(x[e] - m);
+        sum += x[e];
+      }
+#pragma unroll
+      for (int s = 0; s < 2 && !(a.debug & 1); ++s) {
+        bf16x8 pf;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)x[8 * s + jj];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(Vs, jt * 32 + 16 * s + 4 * h, dt, lane), pf, o[dt],
+                                                          0, 0, 0);
+      }
+    }
+    sum += __shfl_xor(sum, 32);
+    // ---- epilogue: o[dt][reg] = O^T[d][i], d = 32dt + (reg&3) + 8(reg>>2) + 4h ; normalise, store 4 d at a time
+    if (i < a.L && !(a.debug & 8)) {
+      const float inv = 1.f / sum;
+      bf16_t* orow = a.out + (((long)b * a.L + i) * a.H + hh) * ATT_DH;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          bf16x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(o[dt][4 * q4 + e] * inv);
+          *reinterpret_cast<bf16x4*>(orow + dt * 32 + 8 * q4 + 4 * h) = w;
+        }
+      if (h == 0) a.lse[((long)b * a.H + hh) * a.L + i] = (m + log2f(sum)) * 0.6931471805599453f;
+    }
+  }
+}
+
+template <int NT>
+static int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
+  constexpr int LP = 32 * NT;
+  constexpr int bytes = 2 * LP * 128;
+  auto kern = attn_fwd_kernel<NT>;
+  static bool attr_set = false;
+  if (bytes > 64 * 1024 && !attr_set) {
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr_set = true;
+  }
+  ProfEvents pe(MMK_K_ATTN_FWD);
+  hipExtLaunchKernelGGL(kern, dim3(a.B * a.H), dim3(256), bytes, st, pe.start, pe.stop, 0, a);
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------ backward
+//   P = exp2(c S - lse2) is recomputed from Q, K and the forward's LSE; delta_i = sum_d dO_id O_id.
+//   Q, K, V, dO of one (batch, head) live in LDS as four images (read once from HBM); two phases, no cross-wave sums:
+//     phase 1 (a wave owns 32 KEYS):    S = Q K^T, dP = dO V^T with the key on the lane; the accumulators, turned into
+//                                       P and dS = P (dP - delta), are the B operands of dV^T += dO^T P and
+//                                       dK^T += Q^T dS (A operands = transposed reads of the dO / Q images);
+//     phase 2 (a wave owns 32 QUERIES): S^T = K Q^T, dP^T = V dO^T with the query on the lane, dS^T is the B operand of
+//                                       dQ^T += K^T dS^T (transposed reads of the K image).
+//   Seven MFMA products per tile pair instead of five (S and dP are formed in both orientations) buys a kernel with no
+//   atomics, no dS round trip through LDS and one barrier; the pass is HBM-bound (5 reads + 3 writes of [L, 64]).
+struct AttnBwdArgs {
+  const bf16_t* q;
+  const bf16_t* k;
+  const bf16_t* v;
+  const bf16_t* o;     // [B, L, H, 64] contiguous
+  const bf16_t* dout;  // [B, L, H, 64] contiguous
+  const float* lse;    // [B, H, L] (natural log)
+  bf16_t* dq;          // [B, L, H, 64] contiguous
+  bf16_t* dk;
+  bf16_t* dv;
+  long q_sb, q_sh, q_sl;
+  long k_sb, k_sh, k_sl;
+  long v_sb, v_sh, v_sl;
+  int B, H, L;
+  float scale;
+};
+
+// acc[dt][e] = X^T[d][row], d = 32dt + 8(e>>2) + 4h + (e&3), row on the lane: scaled 8-byte stores into [.., 64] rows
+__device__ __forceinline__ void store_t_tile(bf16_t* rowp, const f32x16 (&acc)[2], float mul, int h) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      bf16x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(acc[dt][4 * q4 + e] * mul);
+      *reinterpret_cast<bf16x4*>(rowp + dt * 32 + 8 * q4 + 4 * h) = w;
+    }
+}
+
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdArgs a) {
+  constexpr int LP = 32 * NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* Ks = Qs + LP * 128;
+  char* Vs = Ks + LP * 128;
+  char* Gs = Vs + LP * 128;  // dO
+  float* lse2s = reinterpret_cast<float*>(Gs + LP * 128);
+  float* dls = lse2s + LP;
+
+  const int bh = blockIdx.x;
+  const int b = bh / a.H, hh = bh % a.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const long osl = (long)a.H * ATT_DH;
+  const long obase = ((long)b * a.L * a.H + hh) * ATT_DH;
+  const bf16_t* ob = a.o + obase;
+  const bf16_t* gb = a.dout + obase;
+
+  img_load(Qs, a.q + b * a.q_sb + hh * a.q_sh, a.q_sl, a.L, LP, wave, NW, lane);
+  img_load(Gs, gb, osl, a.L, LP, wave, NW, lane);
+  img_load(Ks, a.k + b * a.k_sb + hh * a.k_sh, a.k_sl, a.L, LP, wave, NW, lane);
+  img_load(Vs, a.v + b * a.v_sb + hh * a.v_sh, a.v_sl, a.L, LP, wave, NW, lane);
+  // delta and the log2-domain LSE per query row (8 lanes per row); padded rows get lse2 = +inf, i.e. P = 0
+  for (int c = tid; c < LP * 8; c += 64 * NW) {
+    const int row = c >> 3, ch = c & 7;
+    float part = 0.f;
+    if (row < a.L) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(ob + row * osl + ch * 8);
+      const bf16x8 y = *reinterpret_cast<const bf16x8*>(gb + row * osl + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part += (float)x[e] * (float)y[e];
+    }
+    part += __shfl_xor(part, 1);
+    part += __shfl_xor(part, 2);
+    part += __shfl_xor(part, 4);
+    if (ch == 0) {
+      dls[row] = part;
+      lse2s[row] = row < a.L ? a.lse[((long)b * a.H + hh) * a.L + row] * 1.4426950408889634f : INFINITY;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float sl2 = a.scale * 1.4426950408889634f;
+
+  // ---------------- phase 1: dK, dV of key tile jt
+  for (int jt = wave; jt < NT; jt += NW) {
+    const int j = jt * 32 + r;
+    const bool jvalid = j < a.L;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      kf[kk] = img_row_frag(Ks, j, kk, h);
+      vf[kk] = img_row_frag(Vs, j, kk, h);
+    }
+    f32x16 dkt[2], dvt[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dkt[dt][e] = dvt[dt][e] = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < NT; ++it) {
+      f32x16 sc, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sc[e] = dp[e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(Qs, it * 32 + r, kk, h), kf[kk], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(Gs, it * 32 + r, kk, h), vf[kk], dp, 0, 0, 0);
+      }
+      bf16x8 pf[2], df[2];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 l2 = *reinterpret_cast<const float4*>(lse2s + it * 32 + 8 * g4 + 4 * h);
+        const float4 dl = *reinterpret_cast<const float4*>(dls + it * 32 + 8 * g4 + 4 * h);
+        const float l2v[4] = {l2.x, l2.y, l2.z, l2.w};
+        const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int e = 4 * g4 + e4;
+          const float p = jvalid ? att_exp2(fmaf(sc[e], sl2, -l2v[e4])) : 0.f;
+          pf[e >> 3][e & 7] = (bf16_t)p;
+          df[e >> 3][e & 7] = (bf16_t)(p * (dp[e] - dlv[e4]));
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(Gs, it * 32 + 16 * s + 4 * h, dt, lane), pf[s],
+                                                            dvt[dt], 0, 0, 0);
+          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(Qs, it * 32 + 16 * s + 4 * h, dt, lane), df[s],
+                                                            dkt[dt], 0, 0, 0);
+        }
+    }
+    if (jvalid) {
+      store_t_tile(a.dk + obase + j * osl, dkt, a.scale, h);
+      store_t_tile(a.dv + obase + j * osl, dvt, 1.f, h);
+    }
+  }
+
+  // ---------------- phase 2: dQ of query tile it
+  for (int it = wave; it < NT; it += NW) {
+    const int i = it * 32 + r;
+    bf16x8 qf[4], gf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      qf[kk] = img_row_frag(Qs, i, kk, h);
+      gf[kk] = img_row_frag(Gs, i, kk, h);
+    }
+    const float l2 = lse2s[i], dl = dls[i];
+    f32x16 dqt[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dqt[dt][e] = 0.f;
+#pragma unroll 1
+    for (int jt = 0; jt < NT; ++jt) {
+      f32x16 sc, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sc[e] = dp[e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(Ks, jt * 32 + r, kk, h), qf[kk], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(Vs, jt * 32 + r, kk, h), gf[kk], dp, 0, 0, 0);
+      }
+      bf16x8 df[2];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int j = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const float p = (j < a.L) ? att_exp2(fmaf(sc[e], sl2, -l2)) : 0.f;
+        df[e >> 3][e & 7] = (bf16_t)(p * (dp[e] - dl));
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(Ks, jt * 32 + 16 * s + 4 * h, dt, lane), df[s],
+                                                            dqt[dt], 0, 0, 0);
+    }
+    if (i < a.L) store_t_tile(a.dq + obase + i * osl, dqt, a.scale, h);
+  }
+}
+
+template <int NT, int NW>
+static int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st) {
+  constexpr int LP = 32 * NT;
+  constexpr int bytes = 4 * LP * 128 + 2 * LP * 4;
+  auto kern = attn_bwd_kernel<NT, NW>;
+  static bool attr_set = false;
+  if (bytes > 64 * 1024 && !attr_set) {
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr_set = true;
+  }
+  ProfEvents pe(MMK_K_ATTN_BWD);
+  hipExtLaunchKernelGGL(kern, dim3(a.B * a.H), dim3(64 * NW), bytes, st, pe.start, pe.stop, 0, a);
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace mmk
+
+using namespace mmk;
+
+extern "C" int mmk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int L, int dh,
+                            const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, float scale,
+                            void* stream) {
+  MMK_REQUIRE(q && k && v && out && lse && q_strides && k_strides && v_strides, "null pointer");
+  MMK_REQUIRE(B > 0 && H > 0 && L > 0, "empty problem");
+  MMK_REQUIRE(dh == ATT_DH, "attention kernel supports head_dim 64");
+  MMK_REQUIRE(L <= 256, "attention kernel supports sequence length <= 256");
+  AttnArgs a;
+  a.q = static_cast<const bf16_t*>(q); a.k = static_cast<const bf16_t*>(k); a.v = static_cast<const bf16_t*>(v);
+  a.out = static_cast<bf16_t*>(out); a.lse = lse;
+  a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sl = q_strides[2];
+  a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sl = k_strides[2];
+  a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sl = v_strides[2];
+  MMK_REQUIRE((a.q_sl % 8 == 0) && (a.k_sl % 8 == 0) && (a.v_sl % 8 == 0) && (a.q_sh % 8 == 0) && (a.k_sh % 8 == 0) &&
+                  (a.v_sh % 8 == 0) && (a.q_sb % 8 == 0) && (a.k_sb % 8 == 0) && (a.v_sb % 8 == 0),
+              "q/k/v rows must be 16-byte aligned");
+  a.B = B; a.H = H; a.L = L; a.scale = scale;
+  {
+    static int dbg = getenv("MMK_ATTN_DEBUG") ? atoi(getenv("MMK_ATTN_DEBUG")) : 0;
+    a.debug = dbg;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch ((L + 31) / 32) {
+    case 1: return launch_attn_fwd<1>(a, st);
+    case 2: return launch_attn_fwd<2>(a, st);
+    case 3: return launch_attn_fwd<3>(a, st);
+    case 4: return launch_attn_fwd<4>(a, st);
+    case 5: return launch_attn_fwd<5>(a, st);
+    case 6: return launch_attn_fwd<6>(a, st);
+    case 7: return launch_attn_fwd<7>(a, st);
+    default: return launch_attn_fwd<8>(a, st);
+  }
+}
+
+extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                            void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
+                            const int64_t* k_strides, const int64_t* v_strides, float scale, void* stream) {
+  MMK_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && q_strides && k_strides && v_strides, "null pointer");
+  MMK_REQUIRE(B > 0 && H > 0 && L > 0, "empty problem");
+  MMK_REQUIRE(dh == ATT_DH, "attention kernel supports head_dim 64");
+  MMK_REQUIRE(L <= 256, "attention kernel supports sequence length <= 256");
+  AttnBwdArgs a;
+  a.q = static_cast<const bf16_t*>(q); a.k = static_cast<const bf16_t*>(k); a.v = static_cast<const bf16_t*>(v);
+  a.o = static_cast<const bf16_t*>(out); a.dout = static_cast<const bf16_t*>(dout); a.lse = lse;
+  a.dq = static_cast<bf16_t*>(dq); a.dk = static_cast<bf16_t*>(dk); a.dv = static_cast<bf16_t*>(dv);
+  a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sl = q_strides[2];
+  a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sl = k_strides[2];
+  a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sl = v_strides[2];
+  MMK_REQUIRE((a.q_sl % 8 == 0) && (a.k_sl % 8 == 0) && (a.v_sl % 8 == 0) && (a.q_sh % 8 == 0) && (a.k_sh % 8 == 0) &&
+                  (a.v_sh % 8 == 0) && (a.q_sb % 8 == 0) && (a.k_sb % 8 == 0) && (a.v_sb % 8 == 0),
+              "q/k/v rows must be 16-byte aligned");
+  a.B = B; a.H = H; a.L = L; a.scale = scale;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch ((L + 31) / 32) {
+    case 1: return launch_attn_bwd<1, 4>(a, st);
+    case 2: return launch_attn_bwd<2, 4>(a, st);
+    case 3: return launch_attn_bwd<3, 4>(a, st);
+    case 4: return launch_attn_bwd<4, 4>(a, st);
+    case 5: return launch_attn_bwd<5, 8>(a, st);
+    case 6: return launch_attn_bwd<6, 8>(a, st);
+    case 7: return launch_attn_bwd<7, 8>(a, st);
+    default: return launch_attn_bwd<8, 8>(a, st);
+  }
+}

@@ -1,0 +1,80 @@
+"""GPU parity of the short-sequence attention kernel against a plain PyTorch f32 reference of the same op."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(q, k, v, scale):
+    s = (q.float() @ k.float().transpose(-1, -2)) * scale
+    p = torch.softmax(s, dim=-1)
+    return (p @ v.float()).transpose(1, 2)  # [B, L, H, dh]
+
+
+@pytest.mark.parametrize("B,H,L", [(3, 4, 197), (2, 12, 77), (2, 2, 256), (1, 3, 32), (2, 2, 169), (5, 1, 1), (2, 3, 100)])
+def test_attention_fwd_bwd_vs_torch(B, H, L):
+    from mmlearn_amd.attention import attention
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    dh = 64
+    # the HF layout: [B, L, H*dh] projections viewed as [B, H, L, dh]
+    def mk():
+        return (torch.randn(B, L, H * dh, generator=g) * 1.5).bfloat16()
+
+    q0, k0, v0 = mk(), mk(), mk()
+    scale = dh ** -0.5
+    qr, kr, vr = (t.float().view(B, L, H, dh).transpose(1, 2).clone().requires_grad_(True) for t in (q0, k0, v0))
+    out_r = _ref(qr, kr, vr, scale)
+    w = torch.randn(B, L, H, dh, generator=g)
+    (out_r * w).sum().backward()
+
+    qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q0, k0, v0))
+    out = attention(qd.view(B, L, H, dh).transpose(1, 2), kd.view(B, L, H, dh).transpose(1, 2), vd.view(B, L, H, dh).transpose(1, 2), scale)
+    assert out.shape == (B, L, H, dh) and out.is_contiguous()
+    err = (out.float().cpu() - out_r.detach()).abs().max().item()
+    assert err <= 2e-2 * max(1.0, out_r.abs().max().item()), err
+    (out.float() * w.to(dev)).sum().backward()
+    for got, ref, name in ((qd.grad, qr.grad, "dq"), (kd.grad, kr.grad, "dk"), (vd.grad, vr.grad, "dv")):
+        ref_l = ref.transpose(1, 2).reshape(B, L, H * dh)
+        e = (got.float().cpu() - ref_l).abs().max().item()
+        assert e <= 3e-2 * max(ref_l.abs().max().item(), 1e-3), (name, e, ref_l.abs().max().item())
+
+
+def test_attention_lse_and_hf_interface():
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    from mmlearn_amd import kernels as K
+    from mmlearn_amd.attention import register_hf_attention
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    q = torch.randn(2, 3, 197, 64, device=dev).bfloat16()
+    k = torch.randn(2, 3, 197, 64, device=dev).bfloat16()
+    v = torch.randn(2, 3, 197, 64, device=dev).bfloat16()
+    _, lse = K.attn_fwd(q, k, v, 0.125)
+    ref = torch.logsumexp((q.float() @ k.float().transpose(-1, -2)) * 0.125, dim=-1)
+    np.testing.assert_allclose(lse.cpu().numpy(), ref.cpu().numpy(), atol=2e-3)
+
+    name = register_hf_attention()
+    cfg = CLIPVisionConfig(patch_size=16, image_size=224, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                           num_attention_heads=2, projection_dim=64)
+    m_ref = CLIPVisionModelWithProjection(cfg).to(dev)
+    cfg2 = CLIPVisionConfig(**{**cfg.to_dict()})
+    cfg2._attn_implementation = name
+    m_hip = CLIPVisionModelWithProjection(cfg2).to(dev)
+    m_hip.load_state_dict(m_ref.state_dict())
+    px = torch.rand(3, 3, 224, 224, device=dev)
+    outs = []
+    for m in (m_ref, m_hip):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            e = m(pixel_values=px).image_embeds
+        e.float().square().mean().backward()
+        outs.append((e.float().detach(), {n: p.grad.clone() for n, p in m.named_parameters()}))
+    (e0, g0), (e1, g1) = outs
+    assert (e0 - e1).abs().max() <= 3e-2 * e0.abs().max()
+    gmax = max(v.abs().max().item() for v in g0.values())
+    for n in g0:
+        assert (g0[n] - g1[n]).abs().max() <= 6e-2 * max(g0[n].abs().max().item(), 1e-2 * gmax), n

@@ -61,13 +61,17 @@ class VisionEncoder(nn.Module):
 class TextEncoder(nn.Module):
     """HF BERT-base (no pooler) + CLS token + Linear(768, 512)."""
 
-    def __init__(self, small: bool = False):
+    def __init__(self, small: bool = False, hip_attention: bool = False):
         super().__init__()
         from transformers import BertConfig, BertModel
 
         cfg = BertConfig()
         if small:
             cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256)
+        if hip_attention:  # same hook as the ViT; BERT's attention-probability dropout (0.1) runs inside the kernel
+            from mmlearn_amd.attention import register_hf_attention
+
+            cfg._attn_implementation = register_hf_attention()
         self.model = BertModel(cfg, add_pooling_layer=False)
         self.proj = nn.Linear(cfg.hidden_size, 512, bias=False)
 
@@ -101,7 +105,7 @@ def build_task(loss, small: bool, fused: bool = False):
     from mmlearn_amd.tasks.contrastive_pretraining import ContrastivePretraining
 
     torch.manual_seed(0)
-    rgb, text = VisionEncoder(small, hip_attention=fused and not small), TextEncoder(small)
+    rgb, text = VisionEncoder(small, hip_attention=fused and not small), TextEncoder(small, hip_attention=fused and not small)
     if fused:  # HIP LayerNorm / quick-GELU inside the encoders (same parameters, same math)
         from mmlearn_amd.fused import accelerate_encoder
 
@@ -268,7 +272,7 @@ def main():
                                    f"per-GPU batch {args.batch}, {'local' if world == 1 else 'global-batch (all-gather)'} negatives"
                                    + (" [DEBUG small encoders]" if args.small else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": "mmlearn_amd.ContrastiveLoss (HIP)",
-                       "encoder_ops": "torch" if args.no_fused_encoder_ops else "HIP LayerNorm + quick-GELU + ViT attention (mmlearn_amd.fused / .attention)",
+                       "encoder_ops": "torch" if args.no_fused_encoder_ops else "HIP LayerNorm + quick-GELU + ViT/BERT attention (mmlearn_amd.fused / .attention)",
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline,
         }

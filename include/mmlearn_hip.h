@@ -219,15 +219,20 @@ int mmk_quick_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int d
 /* Short-sequence self-attention of the encoders' blocks (mmlearn/modules/layers/attention.py:60-75 materialises
  * softmax(QK^T); HF encoders call SDPA): out = softmax(scale * Q K^T) V per (batch, head), bf16, head_dim 64, L <= 256,
  * no mask, no dropout.  q/k/v are [B, H, L, 64] views given by element strides {batch, head, row} (last dim contiguous);
- * out is [B, L, H, 64] contiguous; lse (f32 [B, H, L], natural log of the scaled scores' sum) feeds the backward. */
+ * out is [B, L, H, 64] contiguous; lse (f32 [B, H, L], natural log of the scaled scores' sum) feeds the backward.
+ * dropout_p > 0 applies attention-probability dropout (BERT's attention_probs_dropout_prob) with a counter-based
+ * keep mask that is a pure function of (seed, batch, head, query, key): the backward regenerates it from the same
+ * seed, nothing is stored. */
 int mmk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int L, int dh,
-                 const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, float scale, void* stream);
+                 const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, float scale,
+                 float dropout_p, uint64_t seed, void* stream);
 
 /* Backward of mmk_attn_fwd: out / dout / dq / dk / dv are [B, L, H, 64] contiguous, lse is the forward's [B, H, L].
  * Replaces autograd through the same reference expressions (softmax(QK^T)V backward). */
 int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
                  void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
-                 const int64_t* k_strides, const int64_t* v_strides, float scale, void* stream);
+                 const int64_t* k_strides, const int64_t* v_strides, float scale, float dropout_p, uint64_t seed,
+                 void* stream);
 
 #ifdef __cplusplus
 }

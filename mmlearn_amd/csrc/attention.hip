@@ -11,7 +11,7 @@
 //             accordingly), with V^T fragments delivered by the hardware transpose read.
 //   HBM traffic = Q, K, V read once + O written once (the roofline that bounds it); LSE is kept for the backward.
 #include <hip/hip_ext.h>
-#include <stdlib.h>
+#include <math.h>
 
 #include <algorithm>
 
@@ -36,10 +36,30 @@ struct AttnArgs {
   long v_sb, v_sh, v_sl;
   int B, H, L;
   float scale;
-  int debug;  // experiment switches (MMK_ATTN_DEBUG): 1 skip PV, 2 skip V staging, 4 skip pass 1, 8 skip stores
+  uint32_t seed_lo, seed_hi, drop_thr;  // attention dropout: drop (i, j) when its 16-bit draw < drop_thr (0 = off)
+  float drop_scale;                     // 65536 / (65536 - drop_thr)
 };
 
 __device__ __forceinline__ float att_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// ---- attention dropout: a counter-based mask that forward and backward regenerate instead of storing.
+// One 32-bit word per (query i, key pair j>>1) of a (batch, head) problem; the low / high 16 bits decide keys 2jp and
+// 2jp+1.  Three multiply-xorshift rounds built on the full-rate 24-bit multiply (v_mul_u32_u24; a 32-bit v_mul_lo is
+// quarter rate).  oracle/attention_oracle.py restates it in numpy for the tests.
+__device__ __forceinline__ uint32_t drop_key(uint32_t seed_lo, uint32_t seed_hi, uint32_t bh) {
+  uint32_t h = seed_lo ^ (bh * 0x9E3779B1u);
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h ^ seed_hi;
+}
+__device__ __forceinline__ uint32_t drop_word(uint32_t key, int i, int jp) {
+  uint32_t a = __umul24((uint32_t)(i * 128 + jp), 0x9E3779u) + key;
+  a ^= a >> 16;
+  a = __umul24(a, 0xB5297Au) + 0x1B873593u;
+  a ^= a >> 15;
+  a = __umul24(a, 0x68E31Du);
+  a ^= a >> 16;
+  return a;
+}
 
 // ---- LDS image of a [rows][64] bf16 tile: 128-byte rows, the 16-byte chunk index XORed with img_swz(row).
 // img_swz = bit-reversed (row>>1)&7: rows 2t, 2t+1 keep their 128-B bank offset from the row parity, the 8 row pairs of
@@ -91,7 +111,7 @@ __device__ __forceinline__ bf16x8 img_tr_frag(const char* img, int r0, int ct, i
 }
 
 // NT = number of 32-row tiles covering L (LP = 32*NT <= 256)
-template <int NT>
+template <int NT, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int LP = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -107,7 +127,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   const bf16_t* vb = a.v + b * a.v_sb + hh * a.v_sh;
 
   img_load(Ks, kb, a.k_sl, a.L, LP, wave, 4, lane);
-  if (!(a.debug & 2)) img_load(Vs, vb, a.v_sl, a.L, LP, wave, 4, lane);
+  img_load(Vs, vb, a.v_sl, a.L, LP, wave, 4, lane);
+  const uint32_t dkey = DROP ? drop_key(a.seed_lo, a.seed_hi, (uint32_t)bh) : 0u;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -140,12 +161,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     };
     float m = -INFINITY;
 #pragma unroll 1
-    for (int jt = 0; jt < NT && !(a.debug & 4); ++jt) {
+    for (int jt = 0; jt < NT; ++jt) {
       const f32x16 x = score_tile(jt);
 #pragma unroll
       for (int e = 0; e < 16; ++e) m = fmaxf(m, x[e]);
     }
-    if (a.debug & 4) m = 30.f;
     m = fmaxf(m, __shfl_xor(m, 32));
 
     // ---- O^T[d][i] = sum_j V^T[d][j] P^T[j][i]: A = V^T fragment, B = the accumulator tile itself
@@ -164,8 +184,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
         x[e] = att_exp2(x[e] - m);
         sum += x[e];
       }
+      if (DROP) {  // the row sum above is the softmax denominator; dropped weights only leave the PV product
 #pragma unroll
-      for (int s = 0; s < 2 && !(a.debug & 1); ++s) {
+        for (int e = 0; e < 16; e += 2) {
+          const uint32_t w = drop_word(dkey, i, (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) >> 1);
+          if ((w & 0xFFFFu) < a.drop_thr) x[e] = 0.f;
+          if ((w >> 16) < a.drop_thr) x[e + 1] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
         bf16x8 pf;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)x[8 * s + jj];
@@ -177,8 +205,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     }
     sum += __shfl_xor(sum, 32);
     // ---- epilogue: o[dt][reg] = O^T[d][i], d = 32dt + (reg&3) + 8(reg>>2) + 4h ; normalise, store 4 d at a time
-    if (i < a.L && !(a.debug & 8)) {
-      const float inv = 1.f / sum;
+    if (i < a.L) {
+      const float inv = (DROP ? a.drop_scale : 1.f) / sum;
       bf16_t* orow = a.out + (((long)b * a.L + i) * a.H + hh) * ATT_DH;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -194,11 +222,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   }
 }
 
-template <int NT>
+template <int NT, bool DROP>
 static int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   constexpr int LP = 32 * NT;
   constexpr int bytes = 2 * LP * 128;
-  auto kern = attn_fwd_kernel<NT>;
+  auto kern = attn_fwd_kernel<NT, DROP>;
   static bool attr_set = false;
   if (bytes > 64 * 1024 && !attr_set) {
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -236,6 +264,8 @@ struct AttnBwdArgs {
   long v_sb, v_sh, v_sl;
   int B, H, L;
   float scale;
+  uint32_t seed_lo, seed_hi, drop_thr;
+  float drop_scale;
 };
 
 // acc[dt][e] = X^T[d][row], d = 32dt + 8(e>>2) + 4h + (e&3), row on the lane: scaled 8-byte stores into [.., 64] rows
@@ -251,7 +281,7 @@ __device__ __forceinline__ void store_t_tile(bf16_t* rowp, const f32x16 (&acc)[2
     }
 }
 
-template <int NT, int NW>
+template <int NT, int NW, bool DROP>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdArgs a) {
   constexpr int LP = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -297,6 +327,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdArgs a) 
   __syncthreads();
 
   const float sl2 = a.scale * 1.4426950408889634f;
+  // with dropout mask M and c = 1/(1-p):  O = c (M.P) V, so dV^T += dO^T (c M.P), dP = c M.(dO V^T), and
+  // delta = rowsum(P.dP) is still rowsum(dO.O)
+  const uint32_t dkey = DROP ? drop_key(a.seed_lo, a.seed_hi, (uint32_t)bh) : 0u;
 
   // ---------------- phase 1: dK, dV of key tile jt
   for (int jt = wave; jt < NT; jt += NW) {
@@ -334,8 +367,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdArgs a) 
         for (int e4 = 0; e4 < 4; ++e4) {
           const int e = 4 * g4 + e4;
           const float p = jvalid ? att_exp2(fmaf(sc[e], sl2, -l2v[e4])) : 0.f;
-          pf[e >> 3][e & 7] = (bf16_t)p;
-          df[e >> 3][e & 7] = (bf16_t)(p * (dp[e] - dlv[e4]));
+          float keep = 1.f;
+          if (DROP) {
+            const uint32_t w = drop_word(dkey, it * 32 + 8 * g4 + 4 * h + e4, j >> 1);
+            keep = ((w >> (16 * (j & 1))) & 0xFFFFu) < a.drop_thr ? 0.f : a.drop_scale;
+          }
+          pf[e >> 3][e & 7] = (bf16_t)(p * keep);
+          df[e >> 3][e & 7] = (bf16_t)(p * (dp[e] * keep - dlv[e4]));
         }
       }
 #pragma unroll
@@ -380,6 +418,14 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdArgs a) 
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(Vs, jt * 32 + r, kk, h), gf[kk], dp, 0, 0, 0);
       }
       bf16x8 df[2];
+      if (DROP) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const uint32_t w = drop_word(dkey, i, (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) >> 1);
+          dp[e] *= (w & 0xFFFFu) < a.drop_thr ? 0.f : a.drop_scale;
+          dp[e + 1] *= (w >> 16) < a.drop_thr ? 0.f : a.drop_scale;
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int j = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -397,11 +443,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdArgs a) 
   }
 }
 
-template <int NT, int NW>
+template <int NT, int NW, bool DROP>
 static int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int LP = 32 * NT;
   constexpr int bytes = 4 * LP * 128 + 2 * LP * 4;
-  auto kern = attn_bwd_kernel<NT, NW>;
+  auto kern = attn_bwd_kernel<NT, NW, DROP>;
   static bool attr_set = false;
   if (bytes > 64 * 1024 && !attr_set) {
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -417,47 +463,56 @@ static int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st) {
 
 using namespace mmk;
 
+namespace {
+// dropout probability -> 16-bit threshold; the scale uses the probability the threshold actually realises
+bool drop_params(float p, uint64_t seed, uint32_t* lo, uint32_t* hi, uint32_t* thr, float* scale) {
+  *lo = (uint32_t)(seed & 0xFFFFFFFFull);
+  *hi = (uint32_t)(seed >> 32);
+  *thr = p > 0.f ? (uint32_t)lrintf(p * 65536.f) : 0u;
+  *scale = 65536.f / (65536.f - (float)*thr);
+  return *thr > 0;
+}
+#define MMK_ATTN_STRIDES_OK(a)                                                                                       \
+  ((a.q_sl % 8 == 0) && (a.k_sl % 8 == 0) && (a.v_sl % 8 == 0) && (a.q_sh % 8 == 0) && (a.k_sh % 8 == 0) &&        \
+   (a.v_sh % 8 == 0) && (a.q_sb % 8 == 0) && (a.k_sb % 8 == 0) && (a.v_sb % 8 == 0))
+}  // namespace
+
 extern "C" int mmk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int L, int dh,
                             const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, float scale,
-                            void* stream) {
+                            float dropout_p, uint64_t seed, void* stream) {
   MMK_REQUIRE(q && k && v && out && lse && q_strides && k_strides && v_strides, "null pointer");
   MMK_REQUIRE(B > 0 && H > 0 && L > 0, "empty problem");
   MMK_REQUIRE(dh == ATT_DH, "attention kernel supports head_dim 64");
   MMK_REQUIRE(L <= 256, "attention kernel supports sequence length <= 256");
+  MMK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
   AttnArgs a;
   a.q = static_cast<const bf16_t*>(q); a.k = static_cast<const bf16_t*>(k); a.v = static_cast<const bf16_t*>(v);
   a.out = static_cast<bf16_t*>(out); a.lse = lse;
   a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sl = q_strides[2];
   a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sl = k_strides[2];
   a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sl = v_strides[2];
-  MMK_REQUIRE((a.q_sl % 8 == 0) && (a.k_sl % 8 == 0) && (a.v_sl % 8 == 0) && (a.q_sh % 8 == 0) && (a.k_sh % 8 == 0) &&
-                  (a.v_sh % 8 == 0) && (a.q_sb % 8 == 0) && (a.k_sb % 8 == 0) && (a.v_sb % 8 == 0),
-              "q/k/v rows must be 16-byte aligned");
+  MMK_REQUIRE(MMK_ATTN_STRIDES_OK(a), "q/k/v rows must be 16-byte aligned");
   a.B = B; a.H = H; a.L = L; a.scale = scale;
-  {
-    static int dbg = getenv("MMK_ATTN_DEBUG") ? atoi(getenv("MMK_ATTN_DEBUG")) : 0;
-    a.debug = dbg;
-  }
+  const bool drop = drop_params(dropout_p, seed, &a.seed_lo, &a.seed_hi, &a.drop_thr, &a.drop_scale);
   hipStream_t st = static_cast<hipStream_t>(stream);
+#define MMK_ATTN_FWD_CASE(NT) \
+  case NT: return drop ? launch_attn_fwd<NT, true>(a, st) : launch_attn_fwd<NT, false>(a, st);
   switch ((L + 31) / 32) {
-    case 1: return launch_attn_fwd<1>(a, st);
-    case 2: return launch_attn_fwd<2>(a, st);
-    case 3: return launch_attn_fwd<3>(a, st);
-    case 4: return launch_attn_fwd<4>(a, st);
-    case 5: return launch_attn_fwd<5>(a, st);
-    case 6: return launch_attn_fwd<6>(a, st);
-    case 7: return launch_attn_fwd<7>(a, st);
-    default: return launch_attn_fwd<8>(a, st);
+    MMK_ATTN_FWD_CASE(1) MMK_ATTN_FWD_CASE(2) MMK_ATTN_FWD_CASE(3) MMK_ATTN_FWD_CASE(4)
+    MMK_ATTN_FWD_CASE(5) MMK_ATTN_FWD_CASE(6) MMK_ATTN_FWD_CASE(7)
+    default: return drop ? launch_attn_fwd<8, true>(a, st) : launch_attn_fwd<8, false>(a, st);
   }
 }
 
 extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
                             void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
-                            const int64_t* k_strides, const int64_t* v_strides, float scale, void* stream) {
+                            const int64_t* k_strides, const int64_t* v_strides, float scale, float dropout_p, uint64_t seed,
+                            void* stream) {
   MMK_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && q_strides && k_strides && v_strides, "null pointer");
   MMK_REQUIRE(B > 0 && H > 0 && L > 0, "empty problem");
   MMK_REQUIRE(dh == ATT_DH, "attention kernel supports head_dim 64");
   MMK_REQUIRE(L <= 256, "attention kernel supports sequence length <= 256");
+  MMK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
   AttnBwdArgs a;
   a.q = static_cast<const bf16_t*>(q); a.k = static_cast<const bf16_t*>(k); a.v = static_cast<const bf16_t*>(v);
   a.o = static_cast<const bf16_t*>(out); a.dout = static_cast<const bf16_t*>(dout); a.lse = lse;
@@ -465,19 +520,15 @@ extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const v
   a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sl = q_strides[2];
   a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sl = k_strides[2];
   a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sl = v_strides[2];
-  MMK_REQUIRE((a.q_sl % 8 == 0) && (a.k_sl % 8 == 0) && (a.v_sl % 8 == 0) && (a.q_sh % 8 == 0) && (a.k_sh % 8 == 0) &&
-                  (a.v_sh % 8 == 0) && (a.q_sb % 8 == 0) && (a.k_sb % 8 == 0) && (a.v_sb % 8 == 0),
-              "q/k/v rows must be 16-byte aligned");
+  MMK_REQUIRE(MMK_ATTN_STRIDES_OK(a), "q/k/v rows must be 16-byte aligned");
   a.B = B; a.H = H; a.L = L; a.scale = scale;
+  const bool drop = drop_params(dropout_p, seed, &a.seed_lo, &a.seed_hi, &a.drop_thr, &a.drop_scale);
   hipStream_t st = static_cast<hipStream_t>(stream);
+#define MMK_ATTN_BWD_CASE(NT, NW) \
+  case NT: return drop ? launch_attn_bwd<NT, NW, true>(a, st) : launch_attn_bwd<NT, NW, false>(a, st);
   switch ((L + 31) / 32) {
-    case 1: return launch_attn_bwd<1, 4>(a, st);
-    case 2: return launch_attn_bwd<2, 4>(a, st);
-    case 3: return launch_attn_bwd<3, 4>(a, st);
-    case 4: return launch_attn_bwd<4, 4>(a, st);
-    case 5: return launch_attn_bwd<5, 8>(a, st);
-    case 6: return launch_attn_bwd<6, 8>(a, st);
-    case 7: return launch_attn_bwd<7, 8>(a, st);
-    default: return launch_attn_bwd<8, 8>(a, st);
+    MMK_ATTN_BWD_CASE(1, 4) MMK_ATTN_BWD_CASE(2, 4) MMK_ATTN_BWD_CASE(3, 4) MMK_ATTN_BWD_CASE(4, 4)
+    MMK_ATTN_BWD_CASE(5, 8) MMK_ATTN_BWD_CASE(6, 8) MMK_ATTN_BWD_CASE(7, 8)
+    default: return drop ? launch_attn_bwd<8, 8, true>(a, st) : launch_attn_bwd<8, 8, false>(a, st);
   }
 }

@@ -387,19 +387,21 @@ def _strides3(t: torch.Tensor):
     return (C.c_int64 * 3)(sb, sh, sl)
 
 
-def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float):
-    """q/k/v: [B, H, L, 64] bf16 views (last dim contiguous) -> (out [B, L, H, 64] contiguous, lse f32 [B, H, L])."""
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0):
+    """q/k/v: [B, H, L, 64] bf16 views (last dim contiguous) -> (out [B, L, H, 64] contiguous, lse f32 [B, H, L]).
+    ``dropout_p`` > 0 drops attention probabilities with the counter-based mask of ``seed`` (see csrc/attention.hip)."""
     require_gpu(q)
     B, H, L, dh = q.shape
     out = torch.empty((B, L, H, dh), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
     qs, ks, vs = _strides3(q), _strides3(k), _strides3(v)
     check(_lib.lib().mmk_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), B, H, L, dh, C.cast(qs, C.c_void_p), C.cast(ks, C.c_void_p),
-                                  C.cast(vs, C.c_void_p), float(scale), stream()))
+                                  C.cast(vs, C.c_void_p), float(scale), float(dropout_p), int(seed), stream()))
     return out, lse
 
 
-def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, lse: torch.Tensor, dout: torch.Tensor, scale: float):
+def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, lse: torch.Tensor, dout: torch.Tensor, scale: float,
+             dropout_p: float = 0.0, seed: int = 0):
     """Backward of ``attn_fwd``: out / dout are [B, L, H, 64] contiguous; returns dq, dk, dv as [B, H, L, 64] VIEWS of
     [B, L, H, 64] buffers (the layout the q/k/v projections' backward consumes without a copy)."""
     require_gpu(q)
@@ -408,5 +410,6 @@ def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
     dq, dk, dv = (torch.empty((B, L, H, dh), dtype=q.dtype, device=q.device) for _ in range(3))
     qs, ks, vs = _strides3(q), _strides3(k), _strides3(v)
     check(_lib.lib().mmk_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(dq), ptr(dk), ptr(dv), B, H, L, dh,
-                                  C.cast(qs, C.c_void_p), C.cast(ks, C.c_void_p), C.cast(vs, C.c_void_p), float(scale), stream()))
+                                  C.cast(qs, C.c_void_p), C.cast(ks, C.c_void_p), C.cast(vs, C.c_void_p), float(scale), float(dropout_p),
+                                  int(seed), stream()))
     return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)

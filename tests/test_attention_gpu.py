@@ -43,6 +43,39 @@ def test_attention_fwd_bwd_vs_torch(B, H, L):
         assert e <= 3e-2 * max(ref_l.abs().max().item(), 1e-3), (name, e, ref_l.abs().max().item())
 
 
+@pytest.mark.parametrize("B,H,L,p", [(2, 3, 77, 0.1), (2, 2, 197, 0.1), (1, 2, 64, 0.5), (3, 1, 33, 0.25)])
+def test_attention_dropout_matches_oracle_mask(B, H, L, p):
+    """The kernel's keep-mask is a pure function of (seed, b, h, i, j); oracle/attention_oracle.py restates it in numpy,
+    so forward and backward with dropout are compared exactly like the p = 0 case."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import attention_oracle as AO
+    from mmlearn_amd.attention import attention
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(17 * L + B)
+    dh, scale, seed = 64, 0.125, 0x1234_5678_9ABC_DEF0 + L
+    q0, k0, v0 = ((torch.randn(B, L, H * dh, generator=g) * 1.5).bfloat16() for _ in range(3))
+    qr, kr, vr = (t.float().view(B, L, H, dh).transpose(1, 2).clone().requires_grad_(True) for t in (q0, k0, v0))
+    out_r = AO.attention(qr, kr, vr, scale, p, seed)
+    w = torch.randn(B, L, H, dh, generator=g)
+    (out_r * w).sum().backward()
+    qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q0, k0, v0))
+    out = attention(*(t.view(B, L, H, dh).transpose(1, 2) for t in (qd, kd, vd)), scale, p, seed)
+    err = (out.float().cpu() - out_r.detach()).abs().max().item()
+    assert err <= 2e-2 * max(1.0, out_r.abs().max().item()), err
+    (out.float() * w.to(dev)).sum().backward()
+    for got, ref, name in ((qd.grad, qr.grad, "dq"), (kd.grad, kr.grad, "dk"), (vd.grad, vr.grad, "dv")):
+        ref_l = ref.transpose(1, 2).reshape(B, L, H * dh)
+        e = (got.float().cpu() - ref_l).abs().max().item()
+        assert e <= 3e-2 * max(ref_l.abs().max().item(), 1e-3), (name, e, ref_l.abs().max().item())
+    # the realised keep rate is what the threshold promises, and a different seed gives a different mask
+    m = AO.keep_mask(seed, B, H, L, p)
+    assert abs(m.mean() - (1 - AO.drop_threshold(p) / 65536)) < 4 * np.sqrt(p * (1 - p) / m.size) + 1e-3
+    out2 = attention(*(t.detach().view(B, L, H, dh).transpose(1, 2) for t in (qd, kd, vd)), scale, p, seed + 1)
+    assert (out2.float() - out.float()).abs().max().item() > 1e-3
+
+
 def test_attention_lse_and_hf_interface():
     from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
 

@@ -167,3 +167,17 @@ def test_alignment_oracle_vs_reference(name):
             ref = c[f"{prefix}_grad_{m}"]
             assert np.abs(res["grads"][m] - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-3), (name, prefix, m)
         assert abs(res["dscale"] - float(c[f"{prefix}_grad_scale"])) <= 2e-5 * max(1.0, abs(res["dscale"]))
+
+
+def test_attention_dropout_mask_statistics():
+    """The counter-based keep-mask restated in oracle/attention_oracle.py: rate, independence along i / j / (b, h)."""
+    from oracle import attention_oracle as AO
+
+    m = AO.keep_mask(987654321, 4, 8, 197, 0.1).astype(np.float64)
+    assert abs(m.mean() - (1 - AO.drop_threshold(0.1) / 65536)) < 2e-3
+    d = m - m.mean()
+    var = d.var()
+    for a, b in ((d[..., :-1], d[..., 1:]), (d[..., :-1, :], d[..., 1:, :]), (d[:, :-1], d[:, 1:]), (d[:-1], d[1:])):
+        assert abs((a * b).mean() / var) < 5e-3
+    assert AO.keep_mask(1, 1, 1, 8, 0.0).all()
+    assert (AO.keep_mask(5, 1, 2, 64, 0.5) != AO.keep_mask(6, 1, 2, 64, 0.5)).mean() > 0.4

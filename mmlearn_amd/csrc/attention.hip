@@ -70,16 +70,29 @@ __device__ __forceinline__ int img_swz(int row) {
   return ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1);
 }
 
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS at the wave-uniform byte address
+// `lds_addr`.  Written as inline asm (what the __builtin_amdgcn_global_load_lds builtin emits) so that the compiler does
+// not track it: with the builtin, every later LDS read that might alias the destination gets a compiler-inserted
+// s_waitcnt vmcnt(0), which would stall the compute of item n on the prefetch of item n+1.  The kernels order these
+// writes themselves (s_waitcnt vmcnt(0) + barrier before the first read of an image); pieces are issued BEFORE any
+// compiler-visible load of the same phase so the compiler's own vmcnt counts stay conservative.
+__device__ __forceinline__ void lds_dma16(const void* src, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
+  return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
+}
+
 // global [L][64] rows (element stride sl) -> image of LP rows; rows >= L repeat row L-1 (finite filler that the
 // callers neutralise).  8 rows = 1 KiB per wave-instruction; the swizzle is applied to the SOURCE chunk.
 __device__ __forceinline__ void img_load(char* img, const bf16_t* base, long sl, int L, int LP, int wave, int nwaves,
                                          int lane) {
+  const uint32_t img_addr = lds_addr_of(img);
   for (int g = wave; g < LP / 8; g += nwaves) {
     const int row = 8 * g + (lane >> 3);
     const int ch = (lane & 7) ^ img_swz(row);
     const bf16_t* src = base + (long)min(row, L - 1) * sl + ch * 8;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(img + g * 1024), 16, 0, 0);
+    lds_dma16(src, __builtin_amdgcn_readfirstlane(img_addr + g * 1024));
   }
 }
 
@@ -110,130 +123,240 @@ __device__ __forceinline__ bf16x8 img_tr_frag(const char* img, int r0, int ct, i
   return f;
 }
 
-// NT = number of 32-row tiles covering L (LP = 32*NT <= 256)
-template <int NT, bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
-  constexpr int LP = 32 * NT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ks = smem;             // image of K
-  char* Vs = smem + LP * 128;  // image of V
-
-  const int bh = blockIdx.x;
-  const int b = bh / a.H, hh = bh % a.H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Per-lane byte offsets into an image that do not depend on the 32-row tile: a tile adds 4096 B, the second k-step of
+// a transposed fragment (rows +16) adds 2048 B, because img_swz only looks at (row >> 1) & 7.  Computing them once
+// keeps the integer address arithmetic out of the MFMA loops (the loops were VALU-issue bound without this).
+struct ImgLane {
+  int row[4];    // img_row_frag(img, 32t + r, kk, h)            = img + 4096 t + row[kk]
+  int tr[2][2];  // img_tr4(img, 32t + 16s + 4h + 8u, ct, lane)  = img + 4096 t + 2048 s + tr[u][ct]
+};
+__device__ __forceinline__ ImgLane img_lane(int lane) {
+  ImgLane o;
   const int r = lane & 31, h = lane >> 5;
-  const bf16_t* qb = a.q + b * a.q_sb + hh * a.q_sh;
-  const bf16_t* kb = a.k + b * a.k_sb + hh * a.k_sh;
-  const bf16_t* vb = a.v + b * a.v_sb + hh * a.v_sh;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) o.row[kk] = r * 128 + (((2 * kk + h) ^ img_swz(r)) << 4);
+  const int li = lane & 15, q = li >> 2, p = li & 3;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int row = 4 * h + 8 * u + q;
+      const int ch = 4 * ct + 2 * ((lane >> 4) & 1) + (p >> 1);
+      o.tr[u][ct] = row * 128 + ((ch ^ img_swz(row)) << 4) + 8 * (p & 1);
+    }
+  return o;
+}
+__device__ __forceinline__ bf16x8 lds_row_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 lds_tr_frag(const char* img, const ImgLane& il, int tile_s_off, int ct) {
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(img + tile_s_off + il.tr[0][ct]));
+  const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(img + tile_s_off + il.tr[1][ct]));
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  s8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, f);
+}
 
-  img_load(Ks, kb, a.k_sl, a.L, LP, wave, 4, lane);
-  img_load(Vs, vb, a.v_sl, a.L, LP, wave, 4, lane);
+constexpr int STAGE_BYTES = 32 * 128;  // one wave's [32 rows][64] bf16 staging tile, 16-B chunk index ^= row & 7
+
+// acc[dt][e] = X^T[d][row], d = 32dt + 8(e>>2) + 4h + (e&3), the row on the lane  ->  rows of a [.., 64] bf16 tensor.
+// Staged through a per-wave LDS tile so that global stores are whole 128-B rows (8 lanes x 16 B): a row-per-lane store
+// touches 32 cache lines per instruction and is issue-bound.
+__device__ __forceinline__ void store_rows_staged(char* stage, bf16_t* dst, long row_stride, int row0, int nrows_valid,
+                                                  const f32x16 (&acc)[2], float mul, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      bf16x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(acc[dt][4 * q4 + e] * mul);
+      *reinterpret_cast<bf16x4*>(stage + r * 128 + (((dt * 4 + q4) ^ (r & 7)) << 4) + 8 * h) = w;
+    }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + (lane >> 3), ch = lane & 7;
+    const bf16x8 val = *reinterpret_cast<const bf16x8*>(stage + row * 128 + ((ch ^ (row & 7)) << 4));
+    if (row0 + row < nrows_valid) *reinterpret_cast<bf16x8*>(dst + (long)(row0 + row) * row_stride + ch * 8) = val;
+  }
+}
+
+// v_max3_f32 as one instruction: fmaxf on MFMA results makes the compiler canonicalise each operand first (v_max x, x)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// One 32-query tile of one (batch, head): queries i = 32t + (lane&31) against all keys of the K / V images.
+// S^T tile jt: acc[reg] = sum_d K[j][d] Q[i][d],  j = 32jt + (reg&3) + 8(reg>>2) + 4h, the query on the LANE, so the
+// row maximum and sum are lane-local.  ONEPASS keeps all NT score tiles in registers (16 NT VGPRs, NT <= 7 at two waves
+// per SIMD); otherwise QK^T is formed twice (pass 1: maximum, pass 2: exponentials + PV).
+template <int NT, bool DROP, bool ONEPASS>
+__device__ __forceinline__ void attn_fwd_tile(const AttnArgs& a, const char* Ks, const char* Vs, char* stage,
+                                              const ImgLane& il, const bf16x8 (&qf)[4], int bh, int t, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int b = bh / a.H, hh = bh % a.H;
+  const int i = t * 32 + r;  // this lane's query row
+  const float sl2 = a.scale * 1.4426950408889634f;  // scale > 0: the row maximum commutes with the scaling
   const uint32_t dkey = DROP ? drop_key(a.seed_lo, a.seed_hi, (uint32_t)bh) : 0u;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const float sl2 = a.scale * 1.4426950408889634f;
-  for (int t = wave; t < NT; t += 4) {
-    const int i = t * 32 + r;            // this lane's query row
-    const int ic = min(i, a.L - 1);
-    // Q fragments straight from global: lane (r, h) needs Q[i][16kk + 8h .. +8]
-    bf16x8 qf[4];
+  auto score_tile = [&](int jt) {  // raw q.k; keys beyond L (last tile only) = -inf
+    f32x16 acc;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qb + (long)ic * a.q_sl + 16 * kk + 8 * h);
-
-    // S^T tile jt: acc[reg] = sum_d K[j][d] Q[i][d],  j = 32jt + (reg&3) + 8(reg>>2) + 4h.  Computed TWICE (pass 1: row
-    // maximum, pass 2: exponentials + PV) instead of keeping NT accumulator tiles alive: 16 instead of 16*NT registers,
-    // which is what lets 2-4 workgroups share a CU and overlap their load and compute phases (the kernel is HBM-bound;
-    // the extra QK^T MFMAs are free).
-    auto score_tile = [&](int jt) {
-      f32x16 acc;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int kk = 0; kk < 4; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(Ks + jt * 4096 + il.row[kk]), qf[kk], acc, 0, 0, 0);
+    if (jt == NT - 1 && a.L < 32 * NT) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(Ks, jt * 32 + r, kk, h), qf[kk], acc, 0, 0, 0);
+      for (int e = 0; e < 16; ++e)
+        if (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= a.L) acc[e] = -INFINITY;
+    }
+    return acc;
+  };
+  float sum = 0.f;
+  f32x16 o[2];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int j = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        acc[e] = (j < a.L) ? acc[e] * sl2 : -INFINITY;
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+  // exponentials of one score tile, then O^T[d][i] += sum_j V^T[d][j] P^T[j][i]: A = V^T fragment (transposed read),
+  // B = the accumulator tile itself: the B fragment of k-step s (s = 0,1) is regs 8s..8s+7, whose element jj is row
+  // 16s + 8(jj>>2) + 4h + (jj&3) of the tile
+  auto pv_tile = [&](int jt, f32x16 x, float nm2) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      x[e] = att_exp2(fmaf(x[e], sl2, nm2));
+      sum += x[e];
+    }
+    if (DROP) {  // the row sum above is the softmax denominator; dropped weights only leave the PV product
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const uint32_t w = drop_word(dkey, i, (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) >> 1);
+        if ((w & 0xFFFFu) < a.drop_thr) x[e] = 0.f;
+        if ((w >> 16) < a.drop_thr) x[e + 1] = 0.f;
       }
-      return acc;
-    };
-    float m = -INFINITY;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 pf;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)x[8 * s + jj];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(Vs, il, jt * 4096 + s * 2048, dt), pf, o[dt], 0, 0, 0);
+    }
+  };
+  float m = -INFINITY;
+  if (ONEPASS) {
+    f32x16 sc[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) sc[jt] = score_tile(jt);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) m = max3(m, sc[jt][e], sc[jt][e + 1]);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const float nm2 = -m * sl2;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) pv_tile(jt, sc[jt], nm2);
+  } else {
 #pragma unroll 1
     for (int jt = 0; jt < NT; ++jt) {
       const f32x16 x = score_tile(jt);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) m = fmaxf(m, x[e]);
+      for (int e = 0; e < 16; e += 2) m = max3(m, x[e], x[e + 1]);
     }
     m = fmaxf(m, __shfl_xor(m, 32));
-
-    // ---- O^T[d][i] = sum_j V^T[d][j] P^T[j][i]: A = V^T fragment, B = the accumulator tile itself
-    // B fragment of k-step s (s = 0,1) of tile jt = regs 8s..8s+7; its element jj is row 16s + 8(jj>>2) + 4h + (jj&3)
-    float sum = 0.f;
-    f32x16 o[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+    const float nm2 = -m * sl2;
 #pragma unroll 1
-    for (int jt = 0; jt < NT; ++jt) {
-      f32x16 x = score_tile(jt);
+    for (int jt = 0; jt < NT; ++jt) pv_tile(jt, score_tile(jt), nm2);
+  }
+  sum += __shfl_xor(sum, 32);
+  // ---- epilogue: o[dt][reg] = O^T[d][i], d = 32dt + (reg&3) + 8(reg>>2) + 4h ; normalise per lane, store whole rows
+  const float inv = (DROP ? a.drop_scale : 1.f) / sum;
+  store_rows_staged(stage, a.out + ((long)b * a.L * a.H + hh) * ATT_DH, (long)a.H * ATT_DH, t * 32, a.L, o, inv, lane);
+  if (i < a.L && h == 0) a.lse[((long)b * a.H + hh) * a.L + i] = (m * sl2 + log2f(sum)) * 0.6931471805599453f;
+}
+
+// Q fragments straight from global: lane (r, h) of the wave owning tile t needs Q[i][16kk + 8h .. +8]
+__device__ __forceinline__ void attn_load_q(const AttnArgs& a, int bh, int t, int lane, bf16x8 (&qf)[4]) {
+  const int b = bh / a.H, hh = bh % a.H;
+  const int ic = min(t * 32 + (lane & 31), a.L - 1);
+  const bf16_t* qrow = a.q + b * a.q_sb + hh * a.q_sh + (long)ic * a.q_sl + 8 * (lane >> 5);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        x[e] = att_exp2(x[e] - m);
-        sum += x[e];
-      }
-      if (DROP) {  // the row sum above is the softmax denominator; dropped weights only leave the PV product
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + 16 * kk);
+}
+
+// s_waitcnt vmcnt(0) as the BUILTIN (expcnt / lgkmcnt fields left at their maxima): unlike an asm statement the
+// compiler's wait-count bookkeeping sees it, so it knows every earlier load has landed and inserts no vmcnt of its own
+// in the compute phase -- vmcnt is in-order, and any such wait would also wait for the prefetch issued after it.
+__device__ __forceinline__ void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+// Persistent workgroups: NT <= NW, wave w owns query tile w of every (batch, head) item the workgroup walks.  The K / V
+// images are double-buffered: the LDS-DMA of item n+1 and its Q fragments are in flight while item n is computed, so
+// the HBM stream never stops behind a compute phase (one barrier per item).
+template <int NT, int NW, bool DROP>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int LP = 32 * NT;
+  constexpr int IMG = LP * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nitems = a.B * a.H;
+  auto issue_kv = [&](int bh, int buf) {
+    const int b = bh / a.H, hh = bh % a.H;
+    img_load(smem + (2 * buf) * IMG, a.k + b * a.k_sb + hh * a.k_sh, a.k_sl, a.L, LP, wave, NW, lane);
+    img_load(smem + (2 * buf + 1) * IMG, a.v + b * a.v_sb + hh * a.v_sh, a.v_sl, a.L, LP, wave, NW, lane);
+  };
+  char* stage = smem + 4 * IMG + wave * STAGE_BYTES;
+  const ImgLane il = img_lane(lane);
+  int item = blockIdx.x;
+  bf16x8 qn[4];  // Q fragments of the item whose images are in flight
+  if (item < nitems) {
+    if (wave < NT) attn_load_q(a, item, wave, lane, qn);
+    asm volatile("" ::: "memory");
+    issue_kv(item, 0);
+  }
+  for (int n = 0; item < nitems; item += gridDim.x, ++n) {
+    wait_vmem_all();  // this wave's DMA pieces and Q fragments of `item` have landed
+    __syncthreads();  // images of `item` complete; every wave is done with the buffers of the previous item
+    bf16x8 qf[4];
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const uint32_t w = drop_word(dkey, i, (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) >> 1);
-          if ((w & 0xFFFFu) < a.drop_thr) x[e] = 0.f;
-          if ((w >> 16) < a.drop_thr) x[e + 1] = 0.f;
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 pf;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)x[8 * s + jj];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(Vs, jt * 32 + 16 * s + 4 * h, dt, lane), pf, o[dt],
-                                                          0, 0, 0);
-      }
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = qn[kk];
+    const int next = item + gridDim.x;
+    if (next < nitems) {
+      // prefetch of the next item: compiler-visible Q loads FIRST, then the LDS-DMA pieces it does not track
+      if (wave < NT) attn_load_q(a, next, wave, lane, qn);
+      asm volatile("" ::: "memory");  // keeps the Q loads from being sunk to their first use
+      issue_kv(next, (n + 1) & 1);
     }
-    sum += __shfl_xor(sum, 32);
-    // ---- epilogue: o[dt][reg] = O^T[d][i], d = 32dt + (reg&3) + 8(reg>>2) + 4h ; normalise, store 4 d at a time
-    if (i < a.L) {
-      const float inv = (DROP ? a.drop_scale : 1.f) / sum;
-      bf16_t* orow = a.out + (((long)b * a.L + i) * a.H + hh) * ATT_DH;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          bf16x4 w;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(o[dt][4 * q4 + e] * inv);
-          *reinterpret_cast<bf16x4*>(orow + dt * 32 + 8 * q4 + 4 * h) = w;
-        }
-      if (h == 0) a.lse[((long)b * a.H + hh) * a.L + i] = (m + log2f(sum)) * 0.6931471805599453f;
-    }
+    if (wave < NT)
+      attn_fwd_tile<NT, DROP, (DROP ? NT <= 6 : NT <= 7)>(a, smem + (2 * (n & 1)) * IMG, smem + (2 * (n & 1) + 1) * IMG, stage, il, qf, item, wave, lane);
   }
 }
 
 template <int NT, bool DROP>
 static int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   constexpr int LP = 32 * NT;
-  constexpr int bytes = 2 * LP * 128;
-  auto kern = attn_fwd_kernel<NT, DROP>;
-  static bool attr_set = false;
-  if (bytes > 64 * 1024 && !attr_set) {
-    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    attr_set = true;
+  constexpr int NW = NT <= 4 ? 4 : 8;
+  constexpr int bytes = 4 * LP * 128 + NW * STAGE_BYTES;
+  auto kern = attn_fwd_kernel<NT, NW, DROP>;
+  static int wgs_per_cu = 0, cus = 0;
+  if (!wgs_per_cu) {
+    if (bytes > 64 * 1024)
+      MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    int dev = 0;
+    MMK_HIP(hipGetDevice(&dev));
+    MMK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int occ = 0;
+    MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * NW, bytes));
+    wgs_per_cu = std::max(1, occ);
   }
+  const int grid = std::min(a.B * a.H, cus * wgs_per_cu);
   ProfEvents pe(MMK_K_ATTN_FWD);
-  hipExtLaunchKernelGGL(kern, dim3(a.B * a.H), dim3(256), bytes, st, pe.start, pe.stop, 0, a);
+  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), bytes, st, pe.start, pe.stop, 0, a);
   MMK_LAUNCH_CHECK();
   return 0;
 }
@@ -485,6 +608,7 @@ extern "C" int mmk_attn_fwd(const void* q, const void* k, const void* v, void* o
   MMK_REQUIRE(dh == ATT_DH, "attention kernel supports head_dim 64");
   MMK_REQUIRE(L <= 256, "attention kernel supports sequence length <= 256");
   MMK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
+  MMK_REQUIRE(scale > 0.f, "scale must be positive");
   AttnArgs a;
   a.q = static_cast<const bf16_t*>(q); a.k = static_cast<const bf16_t*>(k); a.v = static_cast<const bf16_t*>(v);
   a.out = static_cast<bf16_t*>(out); a.lse = lse;

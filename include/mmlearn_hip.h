@@ -227,10 +227,11 @@ int mmk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* 
                  const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, float scale,
                  float dropout_p, uint64_t seed, void* stream);
 
-/* Backward of mmk_attn_fwd: out / dout / dq / dk / dv are [B, L, H, 64] contiguous, lse is the forward's [B, H, L].
+/* Backward of mmk_attn_fwd: out / dout / dq / dk / dv are [B, L, H, 64] contiguous, lse is the forward's [B, H, L],
+ * delta_ws an f32 workspace of B * H * 512 elements (per (batch, head): 256 scaled-LSE values and 256 rowsum(dout . out)).
  * Replaces autograd through the same reference expressions (softmax(QK^T)V backward). */
 int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
-                 void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
+                 float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
                  const int64_t* k_strides, const int64_t* v_strides, float scale, float dropout_p, uint64_t seed,
                  void* stream);
 

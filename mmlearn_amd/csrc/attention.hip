@@ -42,6 +42,13 @@ struct AttnArgs {
 
 __device__ __forceinline__ float att_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// A copy of a per-lane value the optimiser cannot see through: address arithmetic built on it is redone where it is used
+// instead of being hoisted out of the persistent item loop, where every hoisted value pins a VGPR for the whole kernel.
+__device__ __forceinline__ int opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
 // ---- attention dropout: a counter-based mask that forward and backward regenerate instead of storing.
 // One 32-bit word per (query i, key pair j>>1) of a (batch, head) problem; the low / high 16 bits decide keys 2jp and
 // 2jp+1.  Three multiply-xorshift rounds built on the full-rate 24-bit multiply (v_mul_u32_u24; a 32-bit v_mul_lo is
@@ -76,23 +83,39 @@ __device__ __forceinline__ int img_swz(int row) {
 // s_waitcnt vmcnt(0), which would stall the compute of item n on the prefetch of item n+1.  The kernels order these
 // writes themselves (s_waitcnt vmcnt(0) + barrier before the first read of an image); pieces are issued BEFORE any
 // compiler-visible load of the same phase so the compiler's own vmcnt counts stay conservative.
-__device__ __forceinline__ void lds_dma16(const void* src, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory");
+__device__ __forceinline__ void lds_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+  // scalar 64-bit base + 32-bit per-lane byte offset: one VGPR of addressing per image instead of a pointer per piece
+  const uint64_t pb = reinterpret_cast<uint64_t>(sbase);
+  const uint64_t ps = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pb >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb);
+  sbase = reinterpret_cast<const void*>(ps);
+  lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const char* p) {
   return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)p);
 }
 
 // global [L][64] rows (element stride sl) -> image of LP rows; rows >= L repeat row L-1 (finite filler that the
-// callers neutralise).  8 rows = 1 KiB per wave-instruction; the swizzle is applied to the SOURCE chunk.
+// callers neutralise).  8 rows = 1 KiB per wave-instruction; the swizzle is applied to the SOURCE chunk.  `base`, `sl`,
+// `L` must be wave-uniform.  Piece g of a wave advances the scalar base by 8 * nwaves rows; the per-lane offset (row
+// 8 wave + lane/8, swizzled chunk) is the same for all of them because img_swz is periodic in 16 rows.
 __device__ __forceinline__ void img_load(char* img, const bf16_t* base, long sl, int L, int LP, int wave, int nwaves,
                                          int lane) {
   const uint32_t img_addr = lds_addr_of(img);
-  for (int g = wave; g < LP / 8; g += nwaves) {
-    const int row = 8 * g + (lane >> 3);
-    const int ch = (lane & 7) ^ img_swz(row);
-    const bf16_t* src = base + (long)min(row, L - 1) * sl + ch * 8;
-    lds_dma16(src, __builtin_amdgcn_readfirstlane(img_addr + g * 1024));
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int row0 = 8 * wave_s + (lane >> 3);
+  const int ch = (lane & 7) ^ img_swz(row0);
+  const uint32_t voff = (uint32_t)(row0 * (int)sl + ch * 8) * 2u;
+  for (int g = wave_s; g < LP / 8; g += nwaves) {
+    const bf16_t* sbase = base + (long)(8 * (g - wave_s)) * sl;
+    if (8 * g + 7 < L) {
+      lds_dma16(sbase, voff, img_addr + g * 1024);
+    } else {  // piece reaching past the last row: clamp per lane
+      const int row = 8 * g + (lane >> 3);
+      const uint32_t vo = (uint32_t)((min(row, L - 1) - 8 * (g - wave_s)) * (int)sl + ch * 8) * 2u;
+      lds_dma16(sbase, vo, img_addr + g * 1024);
+    }
   }
 }
 
@@ -162,24 +185,33 @@ constexpr int STAGE_BYTES = 32 * 128;  // one wave's [32 rows][64] bf16 staging 
 
 // acc[dt][e] = X^T[d][row], d = 32dt + 8(e>>2) + 4h + (e&3), the row on the lane  ->  rows of a [.., 64] bf16 tensor.
 // Staged through a per-wave LDS tile so that global stores are whole 128-B rows (8 lanes x 16 B): a row-per-lane store
-// touches 32 cache lines per instruction and is issue-bound.
+// touches 32 cache lines per instruction and is issue-bound.  ROWS = 32 stages the tile at once (4 KiB per wave),
+// ROWS = 16 in two halves (2 KiB per wave, for the configurations whose images leave no more LDS).
+template <int ROWS = 32>
 __device__ __forceinline__ void store_rows_staged(char* stage, bf16_t* dst, long row_stride, int row0, int nrows_valid,
                                                   const f32x16 (&acc)[2], float mul, int lane) {
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int half = 0; half < 32 / ROWS; ++half) {
+    const int rs = r - half * ROWS;  // row inside the staged slab
+    if (ROWS == 32 || (rs >= 0 && rs < ROWS)) {
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      bf16x4 w;
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(acc[dt][4 * q4 + e] * mul);
-      *reinterpret_cast<bf16x4*>(stage + r * 128 + (((dt * 4 + q4) ^ (r & 7)) << 4) + 8 * h) = w;
+        for (int q4 = 0; q4 < 4; ++q4) {
+          bf16x4 w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(acc[dt][4 * q4 + e] * mul);
+          *reinterpret_cast<bf16x4*>(stage + rs * 128 + (((dt * 4 + q4) ^ (rs & 7)) << 4) + 8 * h) = w;
+        }
     }
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int row = it * 8 + (lane >> 3), ch = lane & 7;
-    const bf16x8 val = *reinterpret_cast<const bf16x8*>(stage + row * 128 + ((ch ^ (row & 7)) << 4));
-    if (row0 + row < nrows_valid) *reinterpret_cast<bf16x8*>(dst + (long)(row0 + row) * row_stride + ch * 8) = val;
+    for (int it = 0; it < ROWS / 8; ++it) {
+      const int row = it * 8 + (lane >> 3), ch = lane & 7;
+      const bf16x8 val = *reinterpret_cast<const bf16x8*>(stage + row * 128 + ((ch ^ (row & 7)) << 4));
+      const int grow = row0 + half * ROWS + row;
+      if (grow < nrows_valid) *reinterpret_cast<bf16x8*>(dst + (long)grow * row_stride + ch * 8) = val;
+    }
   }
 }
 
@@ -379,6 +411,7 @@ struct AttnBwdArgs {
   const bf16_t* o;     // [B, L, H, 64] contiguous
   const bf16_t* dout;  // [B, L, H, 64] contiguous
   const float* lse;    // [B, H, L] (natural log)
+  float* delta;        // [B * H][2][256] workspace: lse2 and delta rows, filled by attn_delta_kernel
   bf16_t* dq;          // [B, L, H, 64] contiguous
   bf16_t* dk;
   bf16_t* dv;
@@ -391,193 +424,269 @@ struct AttnBwdArgs {
   float drop_scale;
 };
 
-// acc[dt][e] = X^T[d][row], d = 32dt + 8(e>>2) + 4h + (e&3), row on the lane: scaled 8-byte stores into [.., 64] rows
-__device__ __forceinline__ void store_t_tile(bf16_t* rowp, const f32x16 (&acc)[2], float mul, int h) {
-#pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      bf16x4 w;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(acc[dt][4 * q4 + e] * mul);
-      *reinterpret_cast<bf16x4*>(rowp + dt * 32 + 8 * q4 + 4 * h) = w;
-    }
-}
-
-template <int NT, int NW, bool DROP>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdArgs a) {
-  constexpr int LP = 32 * NT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Qs = smem;
-  char* Ks = Qs + LP * 128;
-  char* Vs = Ks + LP * 128;
-  char* Gs = Vs + LP * 128;  // dO
-  float* lse2s = reinterpret_cast<float*>(Gs + LP * 128);
-  float* dls = lse2s + LP;
-
-  const int bh = blockIdx.x;
-  const int b = bh / a.H, hh = bh % a.H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const long osl = (long)a.H * ATT_DH;
-  const long obase = ((long)b * a.L * a.H + hh) * ATT_DH;
-  const bf16_t* ob = a.o + obase;
-  const bf16_t* gb = a.dout + obase;
-
-  img_load(Qs, a.q + b * a.q_sb + hh * a.q_sh, a.q_sl, a.L, LP, wave, NW, lane);
-  img_load(Gs, gb, osl, a.L, LP, wave, NW, lane);
-  img_load(Ks, a.k + b * a.k_sb + hh * a.k_sh, a.k_sl, a.L, LP, wave, NW, lane);
-  img_load(Vs, a.v + b * a.v_sb + hh * a.v_sh, a.v_sl, a.L, LP, wave, NW, lane);
-  // delta and the log2-domain LSE per query row (8 lanes per row); padded rows get lse2 = +inf, i.e. P = 0
-  for (int c = tid; c < LP * 8; c += 64 * NW) {
-    const int row = c >> 3, ch = c & 7;
+// Row constants of the backward, one 2-KiB record per (batch, head):  ws[bh][0][l] = lse[bh][l] * log2(e) (+inf for
+// l >= L, which makes P = 0 on padded rows), ws[bh][1][l] = delta = sum_d dO[b, l, h, d] * O[b, l, h, d] (0 for l >= L).
+// 256 floats per row so that the main kernel fetches a record with two 1-KiB LDS-DMA pieces whatever L is.
+constexpr int ROWC = 256;
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ g,
+                                                         const float* __restrict__ lse, float* __restrict__ ws, int B,
+                                                         int H, int L) {
+  const long nrows = (long)B * L * H;
+  for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nrows * 8; c += (long)gridDim.x * 256) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(o + c * 8);  // 8 lanes per 128-byte row, fully coalesced
+    const bf16x8 y = *reinterpret_cast<const bf16x8*>(g + c * 8);
     float part = 0.f;
-    if (row < a.L) {
-      const bf16x8 x = *reinterpret_cast<const bf16x8*>(ob + row * osl + ch * 8);
-      const bf16x8 y = *reinterpret_cast<const bf16x8*>(gb + row * osl + ch * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) part += (float)x[e] * (float)y[e];
-    }
+    for (int e = 0; e < 8; ++e) part += (float)x[e] * (float)y[e];
     part += __shfl_xor(part, 1);
     part += __shfl_xor(part, 2);
     part += __shfl_xor(part, 4);
-    if (ch == 0) {
-      dls[row] = part;
-      lse2s[row] = row < a.L ? a.lse[((long)b * a.H + hh) * a.L + row] * 1.4426950408889634f : INFINITY;
+    if ((c & 7) == 0) {
+      const long row = c >> 3;  // (b * L + l) * H + h
+      const int hh = (int)(row % H);
+      const long bl = row / H;
+      const int l = (int)(bl % L);
+      const long b = bl / L;
+      ws[((b * H + hh) * 2 + 1) * ROWC + l] = part;
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  const long nbh = (long)B * H;
+  for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nbh * ROWC; c += (long)gridDim.x * 256) {
+    const long bh = c / ROWC;
+    const int l = (int)(c % ROWC);
+    ws[(bh * 2) * ROWC + l] = l < L ? lse[bh * L + l] * 1.4426950408889634f : INFINITY;
+    if (l >= L) ws[(bh * 2 + 1) * ROWC + l] = 0.f;
+  }
+}
 
+// Persistent workgroups, NT <= NW: wave w owns key tile w in phase 1 and query tile w in phase 2 of every (batch, head)
+// item its workgroup walks.  Four image buffers (Q, dO, K, V) and no idle HBM phase:
+//   barrier A  Q, dO images of item n and its delta / lse2 rows are in LDS; K, V buffers are free
+//              -> issue the LDS-DMA of K, V (n);  PHASE 1 (n) on the Q / dO images with K_j, V_j fragments that were
+//                 prefetched into registers;  pick up this wave's Q_i, dO_i fragments for phase 2
+//   barrier B  K, V images of item n landed; Q, dO buffers are free
+//              -> prefetch item n+1: K_j, V_j fragments into registers, LDS-DMA of Q, dO (n+1) and of its lse2 /
+//                 delta record into the other row-constant buffer;  PHASE 2 (n) on the K / V images
+// The lse2 / delta records (delta_i = sum_d dO_id O_id) come from attn_delta_kernel, one streaming pass before this one.
+// Compiler-visible global loads are always issued BEFORE the untracked LDS-DMA pieces of the same window and are
+// consumed only after the next barrier's s_waitcnt vmcnt(0), so no compiler-inserted vmcnt lands inside a phase.
+template <int NT, int NW, bool DROP>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(const AttnBwdArgs a) {
+  constexpr int LP = 32 * NT;
+  constexpr int IMG = LP * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* Gs = Qs + IMG;  // dO
+  char* Ks = Gs + IMG;
+  char* Vs = Ks + IMG;
+  constexpr int SROWS = NT <= 7 ? 32 : 16;  // staging slab rows per wave (LDS budget at NT = 8)
+  float* rowc = reinterpret_cast<float*>(Vs + IMG);  // [2 buffers][lse2 | delta][ROWC]
+  char* stage = reinterpret_cast<char*>(rowc + 4 * ROWC) + (threadIdx.x >> 6) * (SROWS * 128);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const ImgLane il = img_lane(lane);
+  const long osl = (long)a.H * ATT_DH;
   const float sl2 = a.scale * 1.4426950408889634f;
-  // with dropout mask M and c = 1/(1-p):  O = c (M.P) V, so dV^T += dO^T (c M.P), dP = c M.(dO V^T), and
-  // delta = rowsum(P.dP) is still rowsum(dO.O)
-  const uint32_t dkey = DROP ? drop_key(a.seed_lo, a.seed_hi, (uint32_t)bh) : 0u;
+  const int nitems = a.B * a.H;
+  const bool active = wave < NT;  // wave-uniform: this wave owns tile `wave`
 
-  // ---------------- phase 1: dK, dV of key tile jt
-  for (int jt = wave; jt < NT; jt += NW) {
-    const int j = jt * 32 + r;
-    const bool jvalid = j < a.L;
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      kf[kk] = img_row_frag(Ks, j, kk, h);
-      vf[kk] = img_row_frag(Vs, j, kk, h);
-    }
-    f32x16 dkt[2], dvt[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) dkt[dt][e] = dvt[dt][e] = 0.f;
-#pragma unroll 1
-    for (int it = 0; it < NT; ++it) {
-      f32x16 sc, dp;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sc[e] = dp[e] = 0.f;
+  bf16x8 kf[4], vf[4];        // K_j, V_j fragments of the item entering phase 1
+
+  auto obase_of = [&](int bh) { return ((long)(bh / a.H) * a.L * a.H + (bh % a.H)) * ATT_DH; };
+  // compiler-visible prefetch loads of item bh (K_j, V_j fragments)
+  // (scalar base + 32-bit per-lane byte offset: no 64-bit per-lane pointers to keep alive across the item loop)
+  auto load_regs = [&](int bh) {
+    const int b = bh / a.H, hh = bh % a.H;
+    if (active) {
+      const int lo = opaque(lane);
+      const int jc = min(wave * 32 + (lo & 31), a.L - 1);
+      const uint32_t koff = (uint32_t)(jc * (int)a.k_sl + 8 * (lo >> 5)) * 2u;
+      const uint32_t voff = (uint32_t)(jc * (int)a.v_sl + 8 * (lo >> 5)) * 2u;
+      const char* kbase = reinterpret_cast<const char*>(a.k + b * a.k_sb + hh * a.k_sh);
+      const char* vbase = reinterpret_cast<const char*>(a.v + b * a.v_sb + hh * a.v_sh);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(Qs, it * 32 + r, kk, h), kf[kk], sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(Gs, it * 32 + r, kk, h), vf[kk], dp, 0, 0, 0);
+        kf[kk] = *reinterpret_cast<const bf16x8*>(kbase + koff + 32 * kk);
+        vf[kk] = *reinterpret_cast<const bf16x8*>(vbase + voff + 32 * kk);
       }
-      bf16x8 pf[2], df[2];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const float4 l2 = *reinterpret_cast<const float4*>(lse2s + it * 32 + 8 * g4 + 4 * h);
-        const float4 dl = *reinterpret_cast<const float4*>(dls + it * 32 + 8 * g4 + 4 * h);
-        const float l2v[4] = {l2.x, l2.y, l2.z, l2.w};
-        const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-          const int e = 4 * g4 + e4;
-          const float p = jvalid ? att_exp2(fmaf(sc[e], sl2, -l2v[e4])) : 0.f;
-          float keep = 1.f;
-          if (DROP) {
-            const uint32_t w = drop_word(dkey, it * 32 + 8 * g4 + 4 * h + e4, j >> 1);
-            keep = ((w >> (16 * (j & 1))) & 0xFFFFu) < a.drop_thr ? 0.f : a.drop_scale;
-          }
-          pf[e >> 3][e & 7] = (bf16_t)(p * keep);
-          df[e >> 3][e & 7] = (bf16_t)(p * (dp[e] * keep - dlv[e4]));
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(Gs, it * 32 + 16 * s + 4 * h, dt, lane), pf[s],
-                                                            dvt[dt], 0, 0, 0);
-          dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(Qs, it * 32 + 16 * s + 4 * h, dt, lane), df[s],
-                                                            dkt[dt], 0, 0, 0);
-        }
     }
-    if (jvalid) {
-      store_t_tile(a.dk + obase + j * osl, dkt, a.scale, h);
-      store_t_tile(a.dv + obase + j * osl, dvt, 1.f, h);
-    }
+    asm volatile("" ::: "memory");  // keep the loads here (not sunk to their first use)
+  };
+  auto issue_qg = [&](int bh, int buf) {  // + the item's row-constant record (two pieces, waves 0 and 1)
+    const int b = bh / a.H, hh = bh % a.H;
+    const int lo = opaque(lane);
+    img_load(Qs, a.q + b * a.q_sb + hh * a.q_sh, a.q_sl, a.L, LP, wave, NW, lo);
+    img_load(Gs, a.dout + obase_of(bh), osl, a.L, LP, wave, NW, lo);
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    if (wave_s < 2)
+      lds_dma16(a.delta + ((long)bh * 2 + wave_s) * ROWC, (uint32_t)lo * 16u,
+                lds_addr_of(reinterpret_cast<const char*>(rowc + (buf * 2 + wave_s) * ROWC)));
+  };
+  auto issue_kv = [&](int bh) {
+    const int b = bh / a.H, hh = bh % a.H;
+    const int lo = opaque(lane);
+    img_load(Ks, a.k + b * a.k_sb + hh * a.k_sh, a.k_sl, a.L, LP, wave, NW, lo);
+    img_load(Vs, a.v + b * a.v_sb + hh * a.v_sh, a.v_sl, a.L, LP, wave, NW, lo);
+  };
+
+  int item = blockIdx.x;
+  if (item < nitems) {
+    load_regs(item);
+    issue_qg(item, 0);
+    wait_vmem_all();
   }
-
-  // ---------------- phase 2: dQ of query tile it
-  for (int it = wave; it < NT; it += NW) {
-    const int i = it * 32 + r;
+  // The s_waitcnt vmcnt(0) for a window's DMA sits at the END of the following MFMA loop, before that phase's output
+  // stores: the pieces had the whole phase to land, and the stores stay in flight across the barrier.
+  for (int n = 0; item < nitems; item += gridDim.x, ++n) {
+    const float* lse2s = rowc + (n & 1) * 2 * ROWC;
+    const float* dls = lse2s + ROWC;
+    const long obase = obase_of(item);
+    const uint32_t dkey = DROP ? drop_key(a.seed_lo, a.seed_hi, (uint32_t)item) : 0u;
+    __syncthreads();  // ---- barrier A
+    issue_kv(item);
     bf16x8 qf[4], gf[4];
+    f32x16 acc1[2], acc2[2];  // phase 1: dK^T, dV^T;  phase 2: dQ^T (acc1)
+    if (active) {
+      // ---------------- phase 1: dK, dV of key tile `wave` (the key on the lane)
+      const int j = wave * 32 + r;
+      const bool jvalid = j < a.L;
+      f32x16 (&dkt)[2] = acc1;
+      f32x16 (&dvt)[2] = acc2;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      qf[kk] = img_row_frag(Qs, i, kk, h);
-      gf[kk] = img_row_frag(Gs, i, kk, h);
-    }
-    const float l2 = lse2s[i], dl = dls[i];
-    f32x16 dqt[2];
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) dqt[dt][e] = 0.f;
+        for (int e = 0; e < 16; ++e) dkt[dt][e] = dvt[dt][e] = 0.f;
 #pragma unroll 1
-    for (int jt = 0; jt < NT; ++jt) {
-      f32x16 sc, dp;
+      for (int it = 0; it < NT; ++it) {
+        f32x16 sc, dp;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sc[e] = dp[e] = 0.f;
+        for (int e = 0; e < 16; ++e) sc[e] = dp[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(Qs + it * 4096 + il.row[kk]), kf[kk], sc, 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(Gs + it * 4096 + il.row[kk]), vf[kk], dp, 0, 0, 0);
+        bf16x8 pf[2], df[2];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float4 l2 = *reinterpret_cast<const float4*>(lse2s + it * 32 + 8 * g4 + 4 * h);
+          const float4 dl = *reinterpret_cast<const float4*>(dls + it * 32 + 8 * g4 + 4 * h);
+          const float l2v[4] = {l2.x, l2.y, l2.z, l2.w};
+          const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const int e = 4 * g4 + e4;
+            const float p = jvalid ? att_exp2(fmaf(sc[e], sl2, -l2v[e4])) : 0.f;
+            float keep = 1.f;
+            if (DROP) {
+              const uint32_t w = drop_word(dkey, it * 32 + 8 * g4 + 4 * h + e4, j >> 1);
+              keep = ((w >> (16 * (j & 1))) & 0xFFFFu) < a.drop_thr ? 0.f : a.drop_scale;
+            }
+            pf[e >> 3][e & 7] = (bf16_t)(DROP ? p * keep : p);
+            df[e >> 3][e & 7] = (bf16_t)(p * ((DROP ? dp[e] * keep : dp[e]) - dlv[e4]));
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(Gs, il, it * 4096 + s * 2048, dt), pf[s], dvt[dt], 0, 0, 0);
+            dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(Qs, il, it * 4096 + s * 2048, dt), df[s], dkt[dt], 0, 0, 0);
+          }
+      }
+    }
+    wait_vmem_all();  // K, V pieces of this item (issued before phase 1)
+    if (active) {
+      store_rows_staged<SROWS>(stage, a.dk + obase, osl, wave * 32, a.L, acc1, a.scale, opaque(lane));
+      store_rows_staged<SROWS>(stage, a.dv + obase, osl, wave * 32, a.L, acc2, 1.f, opaque(lane));
+      // this wave's query-side fragments for phase 2, before the Q / dO buffers are handed to the next item
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(Ks, jt * 32 + r, kk, h), qf[kk], sc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_row_frag(Vs, jt * 32 + r, kk, h), gf[kk], dp, 0, 0, 0);
+        qf[kk] = lds_row_frag(Qs + wave * 4096 + il.row[kk]);
+        gf[kk] = lds_row_frag(Gs + wave * 4096 + il.row[kk]);
       }
-      bf16x8 df[2];
-      if (DROP) {
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const uint32_t w = drop_word(dkey, i, (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) >> 1);
-          dp[e] *= (w & 0xFFFFu) < a.drop_thr ? 0.f : a.drop_scale;
-          dp[e + 1] *= (w >> 16) < a.drop_thr ? 0.f : a.drop_scale;
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int j = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float p = (j < a.L) ? att_exp2(fmaf(sc[e], sl2, -l2)) : 0.f;
-        df[e >> 3][e & 7] = (bf16_t)(p * (dp[e] - dl));
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(img_tr_frag(Ks, jt * 32 + 16 * s + 4 * h, dt, lane), df[s],
-                                                            dqt[dt], 0, 0, 0);
     }
-    if (i < a.L) store_t_tile(a.dq + obase + i * osl, dqt, a.scale, h);
+    __syncthreads();  // ---- barrier B
+    const int next = item + gridDim.x;
+    if (next < nitems) {
+      load_regs(next);
+      issue_qg(next, (n + 1) & 1);
+    }
+    if (active) {
+      // ---------------- phase 2: dQ of query tile `wave` (the query on the lane)
+      const int i = wave * 32 + r;
+      const float l2 = lse2s[i], dl = dls[i];
+      f32x16 (&dqt)[2] = acc1;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dqt[dt][e] = 0.f;
+#pragma unroll 1
+      for (int jt = 0; jt < NT; ++jt) {
+        f32x16 sc, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[e] = dp[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(Ks + jt * 4096 + il.row[kk]), qf[kk], sc, 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(Vs + jt * 4096 + il.row[kk]), gf[kk], dp, 0, 0, 0);
+        if (DROP) {
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) {
+            const uint32_t w = drop_word(dkey, i, (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) >> 1);
+            dp[e] *= (w & 0xFFFFu) < a.drop_thr ? 0.f : a.drop_scale;
+            dp[e + 1] *= (w >> 16) < a.drop_thr ? 0.f : a.drop_scale;
+          }
+        }
+        bf16x8 df[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) df[e >> 3][e & 7] = (bf16_t)(att_exp2(fmaf(sc[e], sl2, -l2)) * (dp[e] - dl));
+        if (jt == NT - 1 && a.L < LP) {  // keys beyond L (finite filler rows): dS = 0
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= a.L) df[e >> 3][e & 7] = (bf16_t)0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(Ks, il, jt * 4096 + s * 2048, dt), df[s], dqt[dt], 0, 0, 0);
+      }
+    }
+    wait_vmem_all();  // Q, dO pieces and the register prefetch of the next item
+    if (active) store_rows_staged<SROWS>(stage, a.dq + obase, osl, wave * 32, a.L, acc1, a.scale, opaque(lane));
   }
 }
 
 template <int NT, int NW, bool DROP>
 static int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int LP = 32 * NT;
-  constexpr int bytes = 4 * LP * 128 + 2 * LP * 4;
+  constexpr int bytes = 4 * LP * 128 + 4 * ROWC * 4 + NW * (NT <= 7 ? 32 : 16) * 128;
+  static_assert(bytes <= 160 * 1024, "LDS budget");
   auto kern = attn_bwd_kernel<NT, NW, DROP>;
-  static bool attr_set = false;
-  if (bytes > 64 * 1024 && !attr_set) {
-    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    attr_set = true;
+  static int wgs_per_cu = 0, cus = 0;
+  if (!wgs_per_cu) {
+    if (bytes > 64 * 1024)
+      MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    int dev = 0;
+    MMK_HIP(hipGetDevice(&dev));
+    MMK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int occ = 0;
+    MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * NW, bytes));
+    wgs_per_cu = std::max(1, occ);
+  }
+  const int grid = std::min(a.B * a.H, cus * wgs_per_cu);
+  {
+    const long chunks = (long)a.B * a.L * a.H * 8;
+    const int dgrid = (int)std::min<long>((chunks + 255) / 256, (long)cus * 16);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, st, a.o, a.dout, a.lse, a.delta, a.B, a.H, a.L);
   }
   ProfEvents pe(MMK_K_ATTN_BWD);
-  hipExtLaunchKernelGGL(kern, dim3(a.B * a.H), dim3(64 * NW), bytes, st, pe.start, pe.stop, 0, a);
+  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), bytes, st, pe.start, pe.stop, 0, a);
   MMK_LAUNCH_CHECK();
   return 0;
 }
@@ -629,17 +738,18 @@ extern "C" int mmk_attn_fwd(const void* q, const void* k, const void* v, void* o
 }
 
 extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
-                            void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
+                            float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
                             const int64_t* k_strides, const int64_t* v_strides, float scale, float dropout_p, uint64_t seed,
                             void* stream) {
-  MMK_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv && q_strides && k_strides && v_strides, "null pointer");
+  MMK_REQUIRE(q && k && v && out && dout && lse && delta_ws && dq && dk && dv && q_strides && k_strides && v_strides,
+              "null pointer");
   MMK_REQUIRE(B > 0 && H > 0 && L > 0, "empty problem");
   MMK_REQUIRE(dh == ATT_DH, "attention kernel supports head_dim 64");
   MMK_REQUIRE(L <= 256, "attention kernel supports sequence length <= 256");
   MMK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
   AttnBwdArgs a;
   a.q = static_cast<const bf16_t*>(q); a.k = static_cast<const bf16_t*>(k); a.v = static_cast<const bf16_t*>(v);
-  a.o = static_cast<const bf16_t*>(out); a.dout = static_cast<const bf16_t*>(dout); a.lse = lse;
+  a.o = static_cast<const bf16_t*>(out); a.dout = static_cast<const bf16_t*>(dout); a.lse = lse; a.delta = delta_ws;
   a.dq = static_cast<bf16_t*>(dq); a.dk = static_cast<bf16_t*>(dk); a.dv = static_cast<bf16_t*>(dv);
   a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sl = q_strides[2];
   a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sl = k_strides[2];

@@ -408,8 +408,9 @@ def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
     B, H, L, dh = q.shape
     assert out.is_contiguous() and dout.is_contiguous() and out.shape == (B, L, H, dh) == dout.shape
     dq, dk, dv = (torch.empty((B, L, H, dh), dtype=q.dtype, device=q.device) for _ in range(3))
+    delta = torch.empty((B * H, 2, 256), dtype=torch.float32, device=q.device)  # lse2 / delta records (csrc/attention.hip)
     qs, ks, vs = _strides3(q), _strides3(k), _strides3(v)
-    check(_lib.lib().mmk_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(dq), ptr(dk), ptr(dv), B, H, L, dh,
+    check(_lib.lib().mmk_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), B, H, L, dh,
                                   C.cast(qs, C.c_void_p), C.cast(ks, C.c_void_p), C.cast(vs, C.c_void_p), float(scale), float(dropout_p),
                                   int(seed), stream()))
     return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)

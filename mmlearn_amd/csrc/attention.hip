@@ -12,6 +12,7 @@
 //   HBM traffic = Q, K, V read once + O written once (the roofline that bounds it); LSE is kept for the backward.
 #include <hip/hip_ext.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -662,6 +663,207 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(cons
   }
 }
 
+// ---- five-product backward for NT < NW (a spare wave exists; L = 197 -> 7 key waves + 1, L = 77 -> 3 + 1)
+// Waves 0..NT-1 each own 32 KEYS for the whole item and sweep the query tiles in lockstep: S = Q Kᵀ and dP = dO Vᵀ
+// with the key on the lane, P and dS = P∘(dP - δ) feed dVᵀ += dOᵀ P and dKᵀ += Qᵀ dS as B operands (as phase 1
+// above).  dQ needs the sum over ALL keys, i.e. over the key waves: every key wave also drops its dS tile, transposed,
+// into a [key][query] LDS image (4 ds_write_b64 per lane), and after the step's barrier wave NT alone forms
+// dQᵀ[it] = Kᵀ dSᵀ over the 32·NT keys (both operands by transposed reads: K image, dS image) while the key waves are
+// already on the next query tile (two dS buffers).  Five MFMA products per tile pair instead of seven and no second
+// set of exponentials; the dQ wave's 2·NT·2 MFMAs per step balance a key wave's 16 MFMAs + softmax arithmetic.
+template <int NT, int NW, bool DROP>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(const AttnBwdArgs a) {
+  static_assert(NT < NW, "needs a spare wave for dQ");
+  constexpr int LP = 32 * NT;
+  constexpr int IMG = LP * 128;
+  constexpr int DSB = LP * 64;  // one dS image: [LP keys][32 queries] bf16, 8-byte slot index ^= (key>>1)&7
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* Gs = Qs + IMG;  // dO
+  char* Ks = Gs + IMG;
+  char* DS = Ks + IMG;                                      // 2 buffers
+  float* rowc = reinterpret_cast<float*>(DS + 2 * DSB);     // [lse2 | delta][ROWC]
+  char* stage = reinterpret_cast<char*>(rowc + 2 * ROWC) + (threadIdx.x >> 6) * STAGE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const ImgLane il = img_lane(lane);
+  const long osl = (long)a.H * ATT_DH;
+  const float sl2 = a.scale * 1.4426950408889634f;
+  const int nitems = a.B * a.H;
+  const bool keyw = wave < NT;   // wave-uniform roles
+  const bool dqw = wave == NT;
+  const float* lse2s = rowc;
+  const float* dls = rowc + ROWC;
+
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / a.H, hh = item % a.H;
+    const long obase = ((long)b * a.L * a.H + hh) * ATT_DH;
+    const uint32_t dkey = DROP ? drop_key(a.seed_lo, a.seed_hi, (uint32_t)item) : 0u;
+    // ---- load: V_j fragments (compiler-visible, first), then the Q, dO, K images and the row-constant record
+    bf16x8 kf[4], vf[4];
+    if (keyw) {
+      const int lo = opaque(lane);
+      const uint32_t voff = (uint32_t)(min(wave * 32 + (lo & 31), a.L - 1) * (int)a.v_sl + 8 * (lo >> 5)) * 2u;
+      const char* vbase = reinterpret_cast<const char*>(a.v + b * a.v_sb + hh * a.v_sh);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) vf[kk] = *reinterpret_cast<const bf16x8*>(vbase + voff + 32 * kk);
+    }
+    asm volatile("" ::: "memory");
+    {
+      const int lo = opaque(lane);
+      img_load(Qs, a.q + b * a.q_sb + hh * a.q_sh, a.q_sl, a.L, LP, wave, NW, lo);
+      img_load(Gs, a.dout + obase, osl, a.L, LP, wave, NW, lo);
+      img_load(Ks, a.k + b * a.k_sb + hh * a.k_sh, a.k_sl, a.L, LP, wave, NW, lo);
+      const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+      if (wave_s < 2)
+        lds_dma16(a.delta + ((long)item * 2 + wave_s) * ROWC, (uint32_t)lo * 16u,
+                  lds_addr_of(reinterpret_cast<const char*>(rowc + wave_s * ROWC)));
+    }
+    wait_vmem_all();
+    __syncthreads();
+
+    f32x16 acc1[2], acc2[2];  // key waves: dKᵀ, dVᵀ;  dQ wave: dQᵀ of one query tile (acc1)
+    const int j = wave * 32 + r;  // key waves: this lane's key
+    const bool jvalid = j < a.L;
+    if (keyw) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) kf[kk] = lds_row_frag(Ks + wave * 4096 + il.row[kk]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[dt][e] = acc2[dt][e] = 0.f;
+    }
+    // per-lane offsets of the dQ wave's transposed reads (natural k order: element jj <-> key 16ks + 8h + jj)
+    int ktr[2][2], dtr[2];
+    {
+      const int li = lane & 15, q = li >> 2, p = li & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int row = 8 * h + 4 * u + q;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ktr[u][mt] = row * 128 + (((4 * mt + 2 * g1 + (p >> 1)) ^ img_swz(row)) << 4) + 8 * (p & 1);
+        dtr[u] = row * 64 + (((4 * g1 + p) ^ ((row >> 1) & 7)) << 3);
+      }
+    }
+
+#pragma unroll 1
+    for (int it = 0; it <= NT; ++it) {
+      if (keyw && it < NT) {
+        // ---------------- pair (query tile it, key tile wave), the key on the lane
+        f32x16 sc, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[e] = dp[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(Qs + it * 4096 + il.row[kk]), kf[kk], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(Gs + it * 4096 + il.row[kk]), vf[kk], dp, 0, 0, 0);
+        }
+        bf16x8 pf[2], df[2];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float4 l2 = *reinterpret_cast<const float4*>(lse2s + it * 32 + 8 * g4 + 4 * h);
+          const float4 dl = *reinterpret_cast<const float4*>(dls + it * 32 + 8 * g4 + 4 * h);
+          const float l2v[4] = {l2.x, l2.y, l2.z, l2.w};
+          const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const int e = 4 * g4 + e4;
+            const float p = jvalid ? att_exp2(fmaf(sc[e], sl2, -l2v[e4])) : 0.f;
+            float keep = 1.f;
+            if (DROP) {
+              const uint32_t w = drop_word(dkey, it * 32 + 8 * g4 + 4 * h + e4, j >> 1);
+              keep = ((w >> (16 * (j & 1))) & 0xFFFFu) < a.drop_thr ? 0.f : a.drop_scale;
+            }
+            pf[e >> 3][e & 7] = (bf16_t)(DROP ? p * keep : p);
+            df[e >> 3][e & 7] = (bf16_t)(p * ((DROP ? dp[e] * keep : dp[e]) - dlv[e4]));
+          }
+        }
+        // dS tile -> [key][query] image of this step: registers 4g..4g+3 = queries 8g + 4h .. +3 of key j
+        {
+          char* dsrow = DS + (it & 1) * DSB + j * 64;
+          const int sw = (j >> 1) & 7;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            bf16x4 w4;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) w4[e4] = df[g4 >> 1][4 * (g4 & 1) + e4];
+            *reinterpret_cast<bf16x4*>(dsrow + (((2 * g4 + h) ^ sw) << 3)) = w4;
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            acc2[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(Gs, il, it * 4096 + s * 2048, dt), pf[s], acc2[dt], 0, 0, 0);
+            acc1[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(Qs, il, it * 4096 + s * 2048, dt), df[s], acc1[dt], 0, 0, 0);
+          }
+      }
+      if (dqw && it > 0) {
+        // ---------------- dQᵀ of query tile it-1 = Kᵀ dSᵀ over all keys
+        const char* dsb = DS + ((it - 1) & 1) * DSB;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc1[dt][e] = 0.f;
+        typedef short s4 __attribute__((ext_vector_type(4)));
+        typedef short s8 __attribute__((ext_vector_type(8)));
+        auto tr8 = [&](const char* p0, const char* p1) {
+          const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p0));
+          const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p1));
+          s8 f;
+          f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+          f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+          return __builtin_bit_cast(bf16x8, f);
+        };
+#pragma unroll
+        for (int ks = 0; ks < 2 * NT; ++ks) {
+          const bf16x8 bfr = tr8(dsb + ks * 1024 + dtr[0], dsb + ks * 1024 + dtr[1]);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Ks + ks * 2048 + ktr[0][mt], Ks + ks * 2048 + ktr[1][mt]), bfr,
+                                                               acc1[mt], 0, 0, 0);
+        }
+        store_rows_staged(stage, a.dq + obase, osl, (it - 1) * 32, a.L, acc1, a.scale, opaque(lane));
+      }
+      __syncthreads();
+    }
+    if (keyw) {
+      store_rows_staged(stage, a.dk + obase, osl, wave * 32, a.L, acc1, a.scale, opaque(lane));
+      store_rows_staged(stage, a.dv + obase, osl, wave * 32, a.L, acc2, 1.f, opaque(lane));
+    }
+  }
+}
+
+template <int NT, int NW, bool DROP>
+static int launch_attn_bwd5(const AttnBwdArgs& a, hipStream_t st) {
+  constexpr int LP = 32 * NT;
+  constexpr int bytes = 3 * LP * 128 + 2 * LP * 64 + 2 * ROWC * 4 + NW * STAGE_BYTES;
+  static_assert(bytes <= 160 * 1024, "LDS budget");
+  auto kern = attn_bwd5_kernel<NT, NW, DROP>;
+  static int wgs_per_cu = 0, cus = 0;
+  if (!wgs_per_cu) {
+    if (bytes > 64 * 1024)
+      MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    int dev = 0;
+    MMK_HIP(hipGetDevice(&dev));
+    MMK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int occ = 0;
+    MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * NW, bytes));
+    wgs_per_cu = std::max(1, occ);
+  }
+  const int grid = std::min(a.B * a.H, cus * wgs_per_cu);
+  {
+    const long chunks = (long)a.B * a.L * a.H * 8;
+    const int dgrid = (int)std::min<long>((chunks + 255) / 256, (long)cus * 16);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, st, a.o, a.dout, a.lse, a.delta, a.B, a.H, a.L);
+  }
+  ProfEvents pe(MMK_K_ATTN_BWD);
+  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), bytes, st, pe.start, pe.stop, 0, a);
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int NT, int NW, bool DROP>
 static int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int LP = 32 * NT;
@@ -758,11 +960,16 @@ extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const v
   a.B = B; a.H = H; a.L = L; a.scale = scale;
   const bool drop = drop_params(dropout_p, seed, &a.seed_lo, &a.seed_hi, &a.drop_thr, &a.drop_scale);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  static const bool seven = getenv("MMK_ATTN_BWD7") != nullptr;  // force the seven-product kernel (A/B runs)
 #define MMK_ATTN_BWD_CASE(NT, NW) \
   case NT: return drop ? launch_attn_bwd<NT, NW, true>(a, st) : launch_attn_bwd<NT, NW, false>(a, st);
+#define MMK_ATTN_BWD5_CASE(NT, NW)                                                                                   \
+  case NT:                                                                                                           \
+    if (seven) return drop ? launch_attn_bwd<NT, NW, true>(a, st) : launch_attn_bwd<NT, NW, false>(a, st);           \
+    return drop ? launch_attn_bwd5<NT, NW, true>(a, st) : launch_attn_bwd5<NT, NW, false>(a, st);
   switch ((L + 31) / 32) {
-    MMK_ATTN_BWD_CASE(1, 4) MMK_ATTN_BWD_CASE(2, 4) MMK_ATTN_BWD_CASE(3, 4) MMK_ATTN_BWD_CASE(4, 4)
-    MMK_ATTN_BWD_CASE(5, 8) MMK_ATTN_BWD_CASE(6, 8) MMK_ATTN_BWD_CASE(7, 8)
+    MMK_ATTN_BWD5_CASE(1, 4) MMK_ATTN_BWD5_CASE(2, 4) MMK_ATTN_BWD5_CASE(3, 4) MMK_ATTN_BWD_CASE(4, 4)
+    MMK_ATTN_BWD5_CASE(5, 8) MMK_ATTN_BWD5_CASE(6, 8) MMK_ATTN_BWD5_CASE(7, 8)
     default: return drop ? launch_attn_bwd<8, 8, true>(a, st) : launch_attn_bwd<8, 8, false>(a, st);
   }
 }

@@ -227,13 +227,15 @@ int mmk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* 
                  const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, float scale,
                  float dropout_p, uint64_t seed, void* stream);
 
-/* Backward of mmk_attn_fwd: out / dout / dq / dk / dv are [B, L, H, 64] contiguous, lse is the forward's [B, H, L],
+/* Backward of mmk_attn_fwd: out / dout are [B, L, H, 64] contiguous, lse is the forward's [B, H, L]; dq / dk / dv are
+ * [B, L, H, 64] views with element strides grad_strides = {batch, row} (heads 64 apart), so the three gradients can be
+ * written straight into one packed [B, L, 3, H, 64] buffer for a fused QKV projection;
  * delta_ws an f32 workspace of B * H * 512 elements (per (batch, head): 256 scaled-LSE values and 256 rowsum(dout . out)).
  * Replaces autograd through the same reference expressions (softmax(QK^T)V backward). */
 int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
                  float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
-                 const int64_t* k_strides, const int64_t* v_strides, float scale, float dropout_p, uint64_t seed,
-                 void* stream);
+                 const int64_t* k_strides, const int64_t* v_strides, const int64_t* grad_strides, float scale,
+                 float dropout_p, uint64_t seed, void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,36 @@ class _Attention(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
+class _AttentionPacked(torch.autograd.Function):
+    """Same kernels on a packed ``[B, L, 3, H, 64]`` QKV tensor (the output of ONE fused projection); the backward writes
+    dq / dk / dv straight into one packed gradient, so autograd sees a single tensor in and out."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale, dropout_p, seed):
+        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))   # [B, H, L, 64] views, row stride 3*H*64
+        out, lse = K.attn_fwd(q, k, v, scale, dropout_p, seed)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.scale, ctx.dropout_p, ctx.seed = scale, dropout_p, seed
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+        return K.attn_bwd(q, k, v, out, lse, dout.contiguous(), ctx.scale, ctx.dropout_p, ctx.seed, packed=True), None, None, None
+
+
+def attention_qkvpacked(qkv: torch.Tensor, scale: Optional[float] = None, dropout_p: float = 0.0, seed: Optional[int] = None) -> torch.Tensor:
+    """``qkv``: ``[B, L, 3, H, 64]`` bf16 contiguous (``Linear(E, 3E)(x).view(B, L, 3, H, 64)``) -> ``[B, L, H, 64]``."""
+    K.require_gpu(qkv)
+    if not (qkv.dim() == 5 and qkv.shape[2] == 3 and qkv.shape[-1] == 64 and qkv.shape[1] <= 256 and qkv.dtype == torch.bfloat16
+            and qkv.is_contiguous() and 0.0 <= dropout_p < 1.0):
+        raise ValueError("mmlearn_amd.attention_qkvpacked: need a contiguous bf16 [B, L<=256, 3, H, 64] tensor")
+    if dropout_p > 0.0 and seed is None:
+        seed = draw_seed()
+    return _AttentionPacked.apply(qkv, float(scale if scale is not None else 0.125), float(dropout_p), int(seed or 0))
+
+
 def draw_seed() -> int:
     """A 63-bit seed from torch's default CPU generator (no device sync; reproducible under ``torch.manual_seed``)."""
     return int(torch.empty((), dtype=torch.int64).random_().item())

@@ -413,9 +413,10 @@ struct AttnBwdArgs {
   const bf16_t* dout;  // [B, L, H, 64] contiguous
   const float* lse;    // [B, H, L] (natural log)
   float* delta;        // [B * H][2][256] workspace: lse2 and delta rows, filled by attn_delta_kernel
-  bf16_t* dq;          // [B, L, H, 64] contiguous
-  bf16_t* dk;
-  bf16_t* dv;
+  bf16_t* dq;          // [B, L, H, 64] views: element strides g_sb (batch), g_sl (row); heads 64 apart.  A packed
+  bf16_t* dk;          // [B, L, 3, H, 64] gradient buffer for a fused QKV projection is g_sl = 3 H 64 with the three
+  bf16_t* dv;          // pointers H 64 elements apart
+  long g_sb, g_sl;
   long q_sb, q_sh, q_sl;
   long k_sb, k_sh, k_sl;
   long v_sb, v_sh, v_sl;
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(cons
   for (int n = 0; item < nitems; item += gridDim.x, ++n) {
     const float* lse2s = rowc + (n & 1) * 2 * ROWC;
     const float* dls = lse2s + ROWC;
-    const long obase = obase_of(item);
+    const long gbase = (long)(item / a.H) * a.g_sb + (long)(item % a.H) * ATT_DH;
     const uint32_t dkey = DROP ? drop_key(a.seed_lo, a.seed_hi, (uint32_t)item) : 0u;
     __syncthreads();  // ---- barrier A
     issue_kv(item);
@@ -600,8 +601,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(cons
     }
     wait_vmem_all();  // K, V pieces of this item (issued before phase 1)
     if (active) {
-      store_rows_staged<SROWS>(stage, a.dk + obase, osl, wave * 32, a.L, acc1, a.scale, opaque(lane));
-      store_rows_staged<SROWS>(stage, a.dv + obase, osl, wave * 32, a.L, acc2, 1.f, opaque(lane));
+      store_rows_staged<SROWS>(stage, a.dk + gbase, a.g_sl, wave * 32, a.L, acc1, a.scale, opaque(lane));
+      store_rows_staged<SROWS>(stage, a.dv + gbase, a.g_sl, wave * 32, a.L, acc2, 1.f, opaque(lane));
       // this wave's query-side fragments for phase 2, before the Q / dO buffers are handed to the next item
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(cons
       }
     }
     wait_vmem_all();  // Q, dO pieces and the register prefetch of the next item
-    if (active) store_rows_staged<SROWS>(stage, a.dq + obase, osl, wave * 32, a.L, acc1, a.scale, opaque(lane));
+    if (active) store_rows_staged<SROWS>(stage, a.dq + gbase, a.g_sl, wave * 32, a.L, acc1, a.scale, opaque(lane));
   }
 }
 
@@ -699,6 +700,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int b = item / a.H, hh = item % a.H;
     const long obase = ((long)b * a.L * a.H + hh) * ATT_DH;
+    const long gbase = (long)b * a.g_sb + (long)hh * ATT_DH;
     const uint32_t dkey = DROP ? drop_key(a.seed_lo, a.seed_hi, (uint32_t)item) : 0u;
     // ---- load: V_j fragments (compiler-visible, first), then the Q, dO, K images and the row-constant record
     bf16x8 kf[4], vf[4];
@@ -824,13 +826,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
             acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Ks + ks * 2048 + ktr[0][mt], Ks + ks * 2048 + ktr[1][mt]), bfr,
                                                                acc1[mt], 0, 0, 0);
         }
-        store_rows_staged(stage, a.dq + obase, osl, (it - 1) * 32, a.L, acc1, a.scale, opaque(lane));
+        store_rows_staged(stage, a.dq + gbase, a.g_sl, (it - 1) * 32, a.L, acc1, a.scale, opaque(lane));
       }
       __syncthreads();
     }
     if (keyw) {
-      store_rows_staged(stage, a.dk + obase, osl, wave * 32, a.L, acc1, a.scale, opaque(lane));
-      store_rows_staged(stage, a.dv + obase, osl, wave * 32, a.L, acc2, 1.f, opaque(lane));
+      store_rows_staged(stage, a.dk + gbase, a.g_sl, wave * 32, a.L, acc1, a.scale, opaque(lane));
+      store_rows_staged(stage, a.dv + gbase, a.g_sl, wave * 32, a.L, acc2, 1.f, opaque(lane));
     }
   }
 }
@@ -941,9 +943,10 @@ extern "C" int mmk_attn_fwd(const void* q, const void* k, const void* v, void* o
 
 extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
                             float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
-                            const int64_t* k_strides, const int64_t* v_strides, float scale, float dropout_p, uint64_t seed,
-                            void* stream) {
-  MMK_REQUIRE(q && k && v && out && dout && lse && delta_ws && dq && dk && dv && q_strides && k_strides && v_strides,
+                            const int64_t* k_strides, const int64_t* v_strides, const int64_t* grad_strides, float scale,
+                            float dropout_p, uint64_t seed, void* stream) {
+  MMK_REQUIRE(q && k && v && out && dout && lse && delta_ws && dq && dk && dv && q_strides && k_strides && v_strides &&
+                  grad_strides,
               "null pointer");
   MMK_REQUIRE(B > 0 && H > 0 && L > 0, "empty problem");
   MMK_REQUIRE(dh == ATT_DH, "attention kernel supports head_dim 64");
@@ -953,6 +956,8 @@ extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const v
   a.q = static_cast<const bf16_t*>(q); a.k = static_cast<const bf16_t*>(k); a.v = static_cast<const bf16_t*>(v);
   a.o = static_cast<const bf16_t*>(out); a.dout = static_cast<const bf16_t*>(dout); a.lse = lse; a.delta = delta_ws;
   a.dq = static_cast<bf16_t*>(dq); a.dk = static_cast<bf16_t*>(dk); a.dv = static_cast<bf16_t*>(dv);
+  a.g_sb = grad_strides[0]; a.g_sl = grad_strides[1];
+  MMK_REQUIRE(a.g_sb % 8 == 0 && a.g_sl % 8 == 0 && a.g_sl >= (long)H * ATT_DH, "gradient rows must be 16-byte aligned");
   a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sl = q_strides[2];
   a.k_sb = k_strides[0]; a.k_sh = k_strides[1]; a.k_sl = k_strides[2];
   a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sl = v_strides[2];

@@ -111,3 +111,57 @@ def test_attention_lse_and_hf_interface():
     gmax = max(v.abs().max().item() for v in g0.values())
     for n in g0:
         assert (g0[n] - g1[n]).abs().max() <= 6e-2 * max(g0[n].abs().max().item(), 1e-2 * gmax), n
+
+
+@pytest.mark.parametrize("B,H,L,p", [(2, 4, 197, 0.0), (3, 2, 77, 0.1), (1, 3, 50, 0.0)])
+def test_attention_qkvpacked_matches_unpacked(B, H, L, p):
+    """The packed entry (one [B, L, 3, H, 64] tensor in, one packed gradient out) is the same computation."""
+    from mmlearn_amd.attention import attention, attention_qkvpacked
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5 * L + H)
+    qkv0 = (torch.randn(B, L, 3, H, 64, generator=g) * 1.5).bfloat16().to(dev)
+    w = torch.randn(B, L, H, 64, generator=g).to(dev)
+    a = qkv0.clone().requires_grad_(True)
+    out_a = attention_qkvpacked(a, 0.125, p, 99)
+    (out_a.float() * w).sum().backward()
+    b = qkv0.clone().requires_grad_(True)
+    q, k, v = (b[:, :, i].transpose(1, 2) for i in range(3))
+    out_b = attention(q, k, v, 0.125, p, 99)
+    (out_b.float() * w).sum().backward()
+    assert torch.equal(out_a, out_b)
+    assert torch.equal(a.grad, b.grad)
+
+
+def test_fused_qkv_modules_match_stock_hf_models():
+    """fuse_qkv_attention keeps parameters / state_dict and reproduces the stock CLIP and BERT encoders (dropout off)."""
+    from transformers import BertConfig, BertModel, CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    from mmlearn_amd.fused import fuse_qkv_attention
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    cfg = CLIPVisionConfig(patch_size=16, image_size=224, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                           num_attention_heads=2, projection_dim=64)
+    bcfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                      hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cases = [(CLIPVisionModelWithProjection(cfg).to(dev), {"pixel_values": torch.rand(3, 3, 224, 224, device=dev)}, "image_embeds"),
+             (BertModel(bcfg, add_pooling_layer=False).to(dev), {"input_ids": torch.randint(0, 30522, (4, 77), device=dev)}, "last_hidden_state")]
+    for model, inputs, field in cases:
+        keys = list(model.state_dict().keys())
+        outs = []
+        for fused in (False, True):
+            if fused:
+                assert fuse_qkv_attention(model) == 2
+                assert list(model.state_dict().keys()) == keys
+            model.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                e = getattr(model(**inputs), field)
+            e.float().square().mean().backward()
+            outs.append((e.float().detach(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+        (e0, g0), (e1, g1) = outs
+        assert (e0 - e1).abs().max() <= 3e-2 * e0.abs().max()
+        assert g0.keys() == g1.keys()
+        gmax = max(v.abs().max().item() for v in g0.values())
+        for n in g0:
+            assert (g0[n] - g1[n]).abs().max() <= 6e-2 * max(g0[n].abs().max().item(), 1e-2 * gmax), n

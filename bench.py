@@ -111,8 +111,9 @@ def build_task(loss, small: bool, fused: bool = False):
 
         # CLIP is pre-LN: these LayerNorms feed autocast Linears only, so they may emit bf16 directly;
         # BERT is post-LN (the LN output is the residual stream) and keeps f32 outputs.
-        accelerate_encoder(rgb, low_precision_ln=("layer_norm1", "layer_norm2", "post_layernorm"), fuse_qkv=not small)
-        accelerate_encoder(text, fuse_qkv=not small)
+        add_ln = os.environ.get("MMK_BENCH_NO_ADD_LN") is None   # A/B switch for the fused residual add + LayerNorm
+        accelerate_encoder(rgb, low_precision_ln=("layer_norm1", "layer_norm2", "post_layernorm"), fuse_qkv=not small, fuse_add_ln=add_ln)
+        accelerate_encoder(text, fuse_qkv=not small, fuse_add_ln=add_ln)
     return ContrastivePretraining(
         encoders={"rgb": rgb, "text": text},
         loss=loss,
@@ -272,7 +273,7 @@ def main():
                                    f"per-GPU batch {args.batch}, {'local' if world == 1 else 'global-batch (all-gather)'} negatives"
                                    + (" [DEBUG small encoders]" if args.small else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": "mmlearn_amd.ContrastiveLoss (HIP)",
-                       "encoder_ops": "torch" if args.no_fused_encoder_ops else "HIP LayerNorm + quick-GELU + fused-QKV attention for ViT and BERT (mmlearn_amd.fused / .attention)",
+                       "encoder_ops": "torch" if args.no_fused_encoder_ops else "HIP LayerNorm (+ fused residual add / dropout) + quick-GELU + fused-QKV attention for ViT and BERT (mmlearn_amd.fused / .attention)",
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline,
         }

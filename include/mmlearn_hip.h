@@ -212,6 +212,19 @@ int mmk_layernorm_fwd(const void* x, const float* w, const float* b, void* y, fl
                       float eps, int dtype, void* stream);
 int mmk_layernorm_bwd(const void* x, const void* dy, const float* w, const float* mean, const float* rstd, void* dx, float* part,
                       float* part2, float* dw, float* db, int64_t rows, int d, int dtype, void* stream);
+/* Residual add (+ hidden-state dropout) + LayerNorm in one pass:  s = r + dropout(x),  y = LN(s).  Replaces
+ * "hidden = residual + sublayer_out" followed by the next nn.LayerNorm in the encoders' transformer blocks (HF
+ * CLIPEncoderLayer: layer_norm2(residual + attn); BertSelfOutput / BertOutput: LayerNorm(dropout(dense(h)) + input)).
+ * x: [rows, d] in dtype&15, r / s: f32, y in dtype>>4.  s may be NULL only if the caller never needs the sum (it is
+ * what the backward re-normalises, so training callers pass it).  Dropout: the counter-based mask of (seed, row, col). */
+int mmk_add_layernorm_fwd(const void* x, const float* r, const float* w, const float* b, float* s, void* y, float* mean,
+                          float* rstd, int64_t rows, int d, float eps, int dtype, float dropout_p, uint64_t seed, void* stream);
+/* Backward: ds = ds_in + LNbwd(dy) (ds_in nullable);  dr = ds (f32);  dx = dropout_mask(ds) in dtype&15;  dy in dtype>>4;
+ * dw/db (nullable pair) with the workspaces of mmk_layernorm_bwd. */
+int mmk_add_layernorm_bwd(const float* s, const void* dy, const float* ds_in, const float* w, const float* mean, const float* rstd,
+                          float* dr, void* dx, float* part, float* part2, float* dw, float* db, int64_t rows, int d, int dtype,
+                          float dropout_p, uint64_t seed, void* stream);
+
 /* HF QuickGELUActivation  x * sigmoid(1.702 x)  (CLIP MLP), forward and backward, n elements (multiple of 4) */
 int mmk_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
 int mmk_quick_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);

@@ -50,25 +50,6 @@ __device__ __forceinline__ int opaque(int x) {
   return x;
 }
 
-// ---- attention dropout: a counter-based mask that forward and backward regenerate instead of storing.
-// One 32-bit word per (query i, key pair j>>1) of a (batch, head) problem; the low / high 16 bits decide keys 2jp and
-// 2jp+1.  Three multiply-xorshift rounds built on the full-rate 24-bit multiply (v_mul_u32_u24; a 32-bit v_mul_lo is
-// quarter rate).  oracle/attention_oracle.py restates it in numpy for the tests.
-__device__ __forceinline__ uint32_t drop_key(uint32_t seed_lo, uint32_t seed_hi, uint32_t bh) {
-  uint32_t h = seed_lo ^ (bh * 0x9E3779B1u);
-  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-  return h ^ seed_hi;
-}
-__device__ __forceinline__ uint32_t drop_word(uint32_t key, int i, int jp) {
-  uint32_t a = __umul24((uint32_t)(i * 128 + jp), 0x9E3779u) + key;
-  a ^= a >> 16;
-  a = __umul24(a, 0xB5297Au) + 0x1B873593u;
-  a ^= a >> 15;
-  a = __umul24(a, 0x68E31Du);
-  a ^= a >> 16;
-  return a;
-}
-
 // ---- LDS image of a [rows][64] bf16 tile: 128-byte rows, the 16-byte chunk index XORed with img_swz(row).
 // img_swz = bit-reversed (row>>1)&7: rows 2t, 2t+1 keep their 128-B bank offset from the row parity, the 8 row pairs of
 // a ds_read_b128 lane group land in 8 different chunks (row reads conflict-free), and rows i, i+2 of an aligned 4-row
@@ -900,14 +881,6 @@ static int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st) {
 using namespace mmk;
 
 namespace {
-// dropout probability -> 16-bit threshold; the scale uses the probability the threshold actually realises
-bool drop_params(float p, uint64_t seed, uint32_t* lo, uint32_t* hi, uint32_t* thr, float* scale) {
-  *lo = (uint32_t)(seed & 0xFFFFFFFFull);
-  *hi = (uint32_t)(seed >> 32);
-  *thr = p > 0.f ? (uint32_t)lrintf(p * 65536.f) : 0u;
-  *scale = 65536.f / (65536.f - (float)*thr);
-  return *thr > 0;
-}
 #define MMK_ATTN_STRIDES_OK(a)                                                                                       \
   ((a.q_sl % 8 == 0) && (a.k_sl % 8 == 0) && (a.v_sl % 8 == 0) && (a.q_sh % 8 == 0) && (a.k_sh % 8 == 0) &&        \
    (a.v_sh % 8 == 0) && (a.q_sb % 8 == 0) && (a.k_sb % 8 == 0) && (a.v_sb % 8 == 0))

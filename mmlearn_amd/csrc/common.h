@@ -1,6 +1,7 @@
 // Shared helpers for libmmlearn_hip.so (gfx950 only: wave64, MFMA, 160 KiB LDS).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -130,6 +131,36 @@ struct Vec4<f16_t> {
     *reinterpret_cast<h4*>(p) = o;
   }
 };
+
+// ---- counter-based dropout masks that forward and backward regenerate instead of storing (attention probabilities,
+// hidden-state dropout fused into add + LayerNorm).  One 32-bit word per (row i, column pair j>>1) of a keyed problem
+// (attention: key = (seed, batch*head), i = query, j = key; hidden dropout: key = (seed, row), i = 0, j = column); the
+// low / high 16 bits decide columns 2jp and 2jp+1.  Three multiply-xorshift rounds built on the full-rate 24-bit multiply (v_mul_u32_u24; a 32-bit v_mul_lo is
+// quarter rate).  oracle/attention_oracle.py restates it in numpy for the tests.
+__device__ __forceinline__ uint32_t drop_key(uint32_t seed_lo, uint32_t seed_hi, uint32_t bh) {
+  uint32_t h = seed_lo ^ (bh * 0x9E3779B1u);
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h ^ seed_hi;
+}
+__device__ __forceinline__ uint32_t drop_word(uint32_t key, int i, int jp) {
+  uint32_t a = __umul24((uint32_t)(i * 128 + jp), 0x9E3779u) + key;
+  a ^= a >> 16;
+  a = __umul24(a, 0xB5297Au) + 0x1B873593u;
+  a ^= a >> 15;
+  a = __umul24(a, 0x68E31Du);
+  a ^= a >> 16;
+  return a;
+}
+
+
+// dropout probability -> 16-bit threshold; the scale uses the probability the threshold actually realises
+static inline bool drop_params(float p, uint64_t seed, uint32_t* lo, uint32_t* hi, uint32_t* thr, float* scale) {
+  *lo = (uint32_t)(seed & 0xFFFFFFFFull);
+  *hi = (uint32_t)(seed >> 32);
+  *thr = p > 0.f ? (uint32_t)lrintf(p * 65536.f) : 0u;
+  *scale = 65536.f / (65536.f - (float)*thr);
+  return *thr > 0;
+}
 
 static inline size_t dtype_size(int dt) { return dt == MMK_F32 ? 4 : 2; }
 

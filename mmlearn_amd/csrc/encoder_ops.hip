@@ -140,6 +140,159 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const X* __restrict_
     part[(size_t)blockIdx.x * 2 * d + c] = lds[c] + lds[2 * d + c] + lds[4 * d + c] + lds[6 * d + c];
 }
 
+// ------------------------------------------------------------------ residual add (+ dropout) + LayerNorm, fused
+// s = r + dropout(x);  y = LN(s).   The transformer blocks' "hidden = residual + sublayer(...)" followed by the next
+// LayerNorm (HF CLIPEncoderLayer: residual + attn -> layer_norm2; BertSelfOutput / BertOutput: LayerNorm(dropout(dense)
+// + input)).  One pass instead of add kernel + LayerNorm kernel (+ dropout kernel): reads x and r, writes s (only when
+// the caller needs the sum, i.e. pre-LN blocks) and y.  Dropout uses the counter-based mask of common.h keyed by
+// (seed, row): the backward regenerates it.
+template <typename XT, typename Y, int VEC, bool DROP>
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ r,
+                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                float* __restrict__ s_out, Y* __restrict__ y,
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                long rows, int d, float eps, uint32_t seed_lo, uint32_t seed_hi,
+                                                                uint32_t drop_thr, float drop_scale) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const uint32_t key = DROP ? drop_key(seed_lo, seed_hi, (uint32_t)row) : 0u;
+  float4 v[VEC];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int c = (lane + 64 * k) * 4;
+    if (c < d) {
+      float4 xv = Vec4<XT>::load(x + row * d + c);
+      if (DROP) {
+        const uint32_t w0 = drop_word(key, 0, c >> 1), w1 = drop_word(key, 0, (c >> 1) + 1);
+        xv.x = (w0 & 0xFFFFu) < drop_thr ? 0.f : xv.x * drop_scale;
+        xv.y = (w0 >> 16) < drop_thr ? 0.f : xv.y * drop_scale;
+        xv.z = (w1 & 0xFFFFu) < drop_thr ? 0.f : xv.z * drop_scale;
+        xv.w = (w1 >> 16) < drop_thr ? 0.f : xv.w * drop_scale;
+      }
+      const float4 rv = *reinterpret_cast<const float4*>(r + row * d + c);
+      v[k] = make_float4(xv.x + rv.x, xv.y + rv.y, xv.z + rv.z, xv.w + rv.w);
+      if (s_out) *reinterpret_cast<float4*>(s_out + row * d + c) = v[k];
+      sum += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
+  }
+  const float mean = wave_sum(sum) / d;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int c = (lane + 64 * k) * 4;
+    if (c < d) {
+      const float a0 = v[k].x - mean, a1 = v[k].y - mean, a2 = v[k].z - mean, a3 = v[k].w - mean;
+      ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / d + eps);
+  if (lane == 0) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int c = (lane + 64 * k) * 4;
+    if (c < d) {
+      float4 g = make_float4(1.f, 1.f, 1.f, 1.f), o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (w) g = *reinterpret_cast<const float4*>(w + c);
+      if (b) o = *reinterpret_cast<const float4*>(b + c);
+      float4 q;
+      q.x = (v[k].x - mean) * rstd * g.x + o.x;
+      q.y = (v[k].y - mean) * rstd * g.y + o.y;
+      q.z = (v[k].z - mean) * rstd * g.z + o.z;
+      q.w = (v[k].w - mean) * rstd * g.w + o.w;
+      Vec4<Y>::store(y + row * d + c, q);
+    }
+  }
+}
+
+// Backward of the fused op from the saved sum s:  ds = ds_in + LNbwd(dy)  (ds_in = gradient reaching s through the
+// residual stream, absent in post-LN blocks);  dr = ds (f32),  dx = dropout_mask(ds) cast to the sublayer output's dtype.
+// Replaces LayerNorm backward + the gradient-accumulation add + the f32 -> bf16 cast of the sublayer gradient.
+template <typename G, typename XT, int VEC, bool DROP>
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __restrict__ sv, const G* __restrict__ dy,
+                                                                const float* __restrict__ ds_in, const float* __restrict__ w,
+                                                                const float* __restrict__ mean_in,
+                                                                const float* __restrict__ rstd_in, float* __restrict__ dr,
+                                                                XT* __restrict__ dx, float* __restrict__ part, long rows, int d,
+                                                                uint32_t seed_lo, uint32_t seed_hi, uint32_t drop_thr,
+                                                                float drop_scale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][2][d]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4 dg[VEC], db[VEC], wv[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    dg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = (lane + 64 * k) * 4;
+    wv[k] = (w && c < d) ? *reinterpret_cast<const float4*>(w + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+  }
+  const long row0 = ((long)blockIdx.x * 4 + wave) * LN_ROWS_PER_WAVE;
+  for (int q = 0; q < LN_ROWS_PER_WAVE; ++q) {
+    const long row = row0 + q;
+    if (row >= rows) break;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float4 xh[VEC], gy[VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int c = (lane + 64 * k) * 4;
+      if (c < d) {
+        const float4 xv = *reinterpret_cast<const float4*>(sv + row * d + c);
+        const float4 g = Vec4<G>::load(dy + row * d + c);
+        xh[k] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        gy[k] = make_float4(g.x * wv[k].x, g.y * wv[k].y, g.z * wv[k].z, g.w * wv[k].w);
+        s1 += gy[k].x + gy[k].y + gy[k].z + gy[k].w;
+        s2 += gy[k].x * xh[k].x + gy[k].y * xh[k].y + gy[k].z * xh[k].z + gy[k].w * xh[k].w;
+        dg[k].x += g.x * xh[k].x; dg[k].y += g.y * xh[k].y; dg[k].z += g.z * xh[k].z; dg[k].w += g.w * xh[k].w;
+        db[k].x += g.x; db[k].y += g.y; db[k].z += g.z; db[k].w += g.w;
+      }
+    }
+    const float m1 = wave_sum(s1) / d, m2 = wave_sum(s2) / d;
+    const uint32_t key = DROP ? drop_key(seed_lo, seed_hi, (uint32_t)row) : 0u;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int c = (lane + 64 * k) * 4;
+      if (c < d) {
+        float4 t;
+        t.x = rstd * (gy[k].x - m1 - xh[k].x * m2);
+        t.y = rstd * (gy[k].y - m1 - xh[k].y * m2);
+        t.z = rstd * (gy[k].z - m1 - xh[k].z * m2);
+        t.w = rstd * (gy[k].w - m1 - xh[k].w * m2);
+        if (ds_in) {
+          const float4 u = *reinterpret_cast<const float4*>(ds_in + row * d + c);
+          t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        *reinterpret_cast<float4*>(dr + row * d + c) = t;
+        if (DROP) {
+          const uint32_t w0 = drop_word(key, 0, c >> 1), w1 = drop_word(key, 0, (c >> 1) + 1);
+          t.x = (w0 & 0xFFFFu) < drop_thr ? 0.f : t.x * drop_scale;
+          t.y = (w0 >> 16) < drop_thr ? 0.f : t.y * drop_scale;
+          t.z = (w1 & 0xFFFFu) < drop_thr ? 0.f : t.z * drop_scale;
+          t.w = (w1 >> 16) < drop_thr ? 0.f : t.w * drop_scale;
+        }
+        Vec4<XT>::store(dx + row * d + c, t);
+      }
+    }
+  }
+  if (part == nullptr) return;
+  float* mine = lds + (size_t)wave * 2 * d;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    const int c = (lane + 64 * k) * 4;
+    if (c < d) {
+      *reinterpret_cast<float4*>(mine + c) = dg[k];
+      *reinterpret_cast<float4*>(mine + d + c) = db[k];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * d; c += 256)
+    part[(size_t)blockIdx.x * 2 * d + c] = lds[c] + lds[2 * d + c] + lds[4 * d + c] + lds[6 * d + c];
+}
+
 // dgamma/dbeta = column sums of the block partials: grid over column chunks x row slices, then atomics-free 2nd stage
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int n_rows, int n_cols,
                                                      float* __restrict__ out, int rows_per_block) {
@@ -244,6 +397,86 @@ int mmk_layernorm_bwd(const void* x, const void* dy, const float* w, const float
     MMK_HIP(hipMemcpyAsync(dw, part, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
     MMK_HIP(hipMemcpyAsync(db, part + d, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
   }
+  return 0;
+}
+
+// second-stage reduction of the per-block [2][d] partials shared by the LayerNorm backwards
+static int ln_reduce_partials(float* part, float* part2, float* dw, float* db, int n_blocks, int d, hipStream_t st) {
+  const int slices = std::min(64, n_blocks);
+  const int rpb = (n_blocks + slices - 1) / slices;
+  hipLaunchKernelGGL(colsum_kernel, dim3((2 * d + 255) / 256, slices), dim3(256), 0, st, part, n_blocks, 2 * d, part2, rpb);
+  hipLaunchKernelGGL(colsum_kernel, dim3((2 * d + 255) / 256, 1), dim3(256), 0, st, part2, slices, 2 * d, part, slices);
+  MMK_LAUNCH_CHECK();
+  MMK_HIP(hipMemcpyAsync(dw, part, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
+  MMK_HIP(hipMemcpyAsync(db, part + d, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+#define MMK_ADDLN_FWD(VEC, DROP)                                                                                        \
+  hipLaunchKernelGGL((add_layernorm_fwd_kernel<XT, Y, VEC, DROP>), grid, dim3(256), 0, st, static_cast<const XT*>(x), r, w, \
+                     b, s, static_cast<Y*>(y), mean, rstd, (long)rows, d, eps, lo, hi, thr, scale)
+#define MMK_ADDLN_BWD(VEC, DROP)                                                                                       \
+  hipLaunchKernelGGL((add_layernorm_bwd_kernel<G, XT, VEC, DROP>), dim3(n_blocks), dim3(256), lds, st, s,              \
+                     static_cast<const G*>(dy), ds_in, w, mean, rstd, dr, static_cast<XT*>(dx), dw ? part : nullptr,   \
+                     (long)rows, d, lo, hi, thr, scale)
+
+int mmk_add_layernorm_fwd(const void* x, const float* r, const float* w, const float* b, float* s, void* y, float* mean,
+                          float* rstd, int64_t rows, int d, float eps, int dtype, float dropout_p, uint64_t seed, void* stream) {
+  // dtype packs (x dtype) | (y dtype << 4); r and s are f32
+  MMK_REQUIRE(x && r && y && mean && rstd && rows >= 0 && d > 0, "bad arguments");
+  MMK_REQUIRE(d % 4 == 0 && d <= 64 * 4 * LN_MAX_VEC, "add_layernorm: d must be a multiple of 4 and <= 2048");
+  MMK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
+  if (rows == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  uint32_t lo, hi, thr;
+  float scale;
+  const bool drop = drop_params(dropout_p, seed, &lo, &hi, &thr, &scale);
+  ProfScope ps(MMK_K_LAYERNORM_FWD, st);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  int rc = MMK_DISPATCH_DTYPE(dtype & 15, XT, [&]() -> int {
+    return MMK_DISPATCH_DTYPE((dtype >> 4) & 15, Y, [&]() -> int {
+      if (d <= 1024) {
+        if (drop) MMK_ADDLN_FWD(4, true); else MMK_ADDLN_FWD(4, false);
+      } else {
+        if (drop) MMK_ADDLN_FWD(8, true); else MMK_ADDLN_FWD(8, false);
+      }
+      return 0;
+    });
+  });
+  if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+int mmk_add_layernorm_bwd(const float* s, const void* dy, const float* ds_in, const float* w, const float* mean, const float* rstd,
+                          float* dr, void* dx, float* part, float* part2, float* dw, float* db, int64_t rows, int d, int dtype,
+                          float dropout_p, uint64_t seed, void* stream) {
+  // dtype packs (dx dtype) | (dy dtype << 4).  part: float[n_blocks, 2, d]; part2: float[64, 2, d] (second stage)
+  MMK_REQUIRE(s && dy && mean && rstd && dr && dx && rows >= 0 && d > 0, "bad arguments");
+  MMK_REQUIRE(d % 4 == 0 && d <= 64 * 4 * LN_MAX_VEC, "add_layernorm: d must be a multiple of 4 and <= 2048");
+  MMK_REQUIRE((dw == nullptr && db == nullptr) || (part && part2 && dw && db), "dgamma/dbeta need both outputs and the workspaces");
+  MMK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
+  if (rows == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  uint32_t lo, hi, thr;
+  float scale;
+  const bool drop = drop_params(dropout_p, seed, &lo, &hi, &thr, &scale);
+  ProfScope ps(MMK_K_LAYERNORM_BWD, st);
+  const int n_blocks = mmk_layernorm_part_blocks(rows);
+  const size_t lds = dw ? 8 * d * sizeof(float) : 0;
+  int rc = MMK_DISPATCH_DTYPE(dtype & 15, XT, [&]() -> int {
+    return MMK_DISPATCH_DTYPE((dtype >> 4) & 15, G, [&]() -> int {
+      if (d <= 1024) {
+        if (drop) MMK_ADDLN_BWD(4, true); else MMK_ADDLN_BWD(4, false);
+      } else {
+        if (drop) MMK_ADDLN_BWD(8, true); else MMK_ADDLN_BWD(8, false);
+      }
+      return 0;
+    });
+  });
+  if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  if (dw) return ln_reduce_partials(part, part2, dw, db, n_blocks, d, st);
   return 0;
 }
 

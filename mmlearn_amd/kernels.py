@@ -368,6 +368,42 @@ def layernorm_bwd(x2: torch.Tensor, dy2: torch.Tensor, w: Optional[torch.Tensor]
     return dx, dw, db
 
 
+def add_layernorm_fwd(x2: torch.Tensor, r2: torch.Tensor, w: Optional[torch.Tensor], b: Optional[torch.Tensor], eps: float,
+                      out_dtype: torch.dtype, dropout_p: float = 0.0, seed: int = 0):
+    """s = r2 + dropout(x2), y = LN(s): x2 [rows, d] (bf16 / f32), r2 f32 -> (s f32, y of out_dtype, mean, rstd)."""
+    require_gpu(x2)
+    rows, d = x2.shape
+    assert r2.shape == x2.shape and r2.dtype == torch.float32 and r2.is_contiguous() and x2.is_contiguous()
+    s = torch.empty((rows, d), dtype=torch.float32, device=x2.device)
+    y = torch.empty((rows, d), dtype=out_dtype, device=x2.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    dt = dtype_tag(x2.dtype) | (dtype_tag(out_dtype) << 4)
+    check(_lib.lib().mmk_add_layernorm_fwd(ptr(x2), ptr(r2), ptr(w), ptr(b), ptr(s), ptr(y), ptr(mean), ptr(rstd), rows, d, float(eps), dt,
+                                           float(dropout_p), int(seed), stream()))
+    return s, y, mean, rstd
+
+
+def add_layernorm_bwd(s2: torch.Tensor, dy2: torch.Tensor, ds_in: Optional[torch.Tensor], w: Optional[torch.Tensor], mean: torch.Tensor,
+                      rstd: torch.Tensor, x_dtype: torch.dtype, need_wb: bool, dropout_p: float = 0.0, seed: int = 0):
+    """-> (dr f32 = ds_in + LNbwd(dy), dx = dropout_mask(dr) in x_dtype, dgamma, dbeta)."""
+    rows, d = s2.shape
+    dev = s2.device
+    dr = torch.empty((rows, d), dtype=torch.float32, device=dev)
+    dx = torch.empty((rows, d), dtype=x_dtype, device=dev)
+    part = part2 = dw = db = None
+    if need_wb:
+        nb = _lib.lib().mmk_layernorm_part_blocks(rows)
+        part = torch.empty((max(nb, 1), 2, d), dtype=torch.float32, device=dev)
+        part2 = torch.empty((64, 2, d), dtype=torch.float32, device=dev)
+        dw = torch.empty(d, dtype=torch.float32, device=dev)
+        db = torch.empty(d, dtype=torch.float32, device=dev)
+    dt = dtype_tag(x_dtype) | (dtype_tag(dy2.dtype) << 4)
+    check(_lib.lib().mmk_add_layernorm_bwd(ptr(s2), ptr(dy2), ptr(ds_in), ptr(w), ptr(mean), ptr(rstd), ptr(dr), ptr(dx), ptr(part), ptr(part2),
+                                           ptr(dw), ptr(db), rows, d, dt, float(dropout_p), int(seed), stream()))
+    return dr, dx, dw, db
+
+
 def quick_gelu_fwd(x: torch.Tensor) -> torch.Tensor:
     require_gpu(x)
     y = torch.empty_like(x)

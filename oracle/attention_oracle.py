@@ -70,3 +70,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, d
         keep = torch.from_numpy(keep_mask(seed, B, H, L, dropout_p)).to(p.device)
         p = p * keep.to(dtype) * (65536.0 / (65536.0 - thr))
     return (p @ v.to(dtype)).transpose(1, 2)
+
+
+def hidden_keep_mask(seed: int, rows: int, d: int, p: float) -> np.ndarray:
+    """bool [rows, d]: the keep-mask of the dropout fused into add + LayerNorm (csrc/encoder_ops.hip): key = (seed, row),
+    one word per column pair."""
+    thr = np.uint64(drop_threshold(p))
+    jp = np.arange((d + 1) // 2)
+    out = np.empty((rows, 2 * ((d + 1) // 2)), dtype=bool)
+    keys = drop_key(seed, np.arange(rows))
+    for r in range(rows):
+        w = drop_word(keys[r], 0, jp)
+        out[r, 0::2] = (w & np.uint64(0xFFFF)) >= thr
+        out[r, 1::2] = (w >> np.uint64(16)) >= thr
+    return out[:, :d]

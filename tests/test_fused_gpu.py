@@ -103,7 +103,7 @@ def test_accelerate_encoder_matches_stock_hf_models():
     clip_f, bert_f = copy.deepcopy(clip), copy.deepcopy(bert)
     n1 = fused.accelerate_encoder(clip_f, ("layer_norm1", "layer_norm2", "post_layernorm"))
     n2 = fused.accelerate_encoder(bert_f)
-    assert n1 == {"layernorm": 6, "quick_gelu": 2, "fused_qkv": 0} and n2["layernorm"] == 5
+    assert n1 == {"layernorm": 6, "quick_gelu": 2, "fused_qkv": 0, "fused_add_ln": 0} and n2["layernorm"] == 5
     px = torch.rand(6, 3, 64, 64, device=dev)
     tok = torch.randint(0, 30522, (6, 16), device=dev)
     for autocast, tol in ((False, 2e-4), (True, 3e-2)):
@@ -124,3 +124,83 @@ def test_accelerate_encoder_matches_stock_hf_models():
             gmax = max(v.abs().max().item() for v in ref.values())
             for n in ref:  # parameters with (numerically) zero gradient, e.g. key biases, are compared on the global scale
                 assert (ref[n] - got[n]).abs().max() <= 3 * tol * max(ref[n].abs().max().item(), 1e-2 * gmax), (autocast, n)
+
+
+@pytest.mark.parametrize("rows,d,xdt,p,lowp", [(300, 768, torch.bfloat16, 0.0, True), (77, 768, torch.bfloat16, 0.1, False),
+                                               (129, 1280, torch.float32, 0.25, False), (5, 64, torch.bfloat16, 0.0, False)])
+def test_add_layer_norm_vs_torch(rows, d, xdt, p, lowp):
+    """s = r + dropout(x), y = LN(s) and its backward (incl. a gradient arriving on s) vs plain torch f32, with the
+    dropout mask restated by oracle/attention_oracle.py."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import attention_oracle as AO
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(rows + d)
+    x0 = torch.randn(rows, d, generator=g).to(xdt)
+    r0 = torch.randn(rows, d, generator=g)
+    ln_ref = torch.nn.LayerNorm(d)
+    with torch.no_grad():
+        ln_ref.weight.copy_(torch.rand(d, generator=g) + 0.5)
+        ln_ref.bias.copy_(torch.randn(d, generator=g) * 0.1)
+    seed = 424242 + rows
+    ws, wy = torch.randn(rows, d, generator=g), torch.randn(rows, d, generator=g)
+    # reference (f32 math on the same inputs)
+    xr, rr = x0.float().clone().requires_grad_(True), r0.clone().requires_grad_(True)
+    keep = torch.from_numpy(AO.hidden_keep_mask(seed, rows, d, p)).float() if p > 0 else torch.ones(rows, d)
+    scale = 65536.0 / (65536.0 - AO.drop_threshold(p)) if p > 0 else 1.0
+    s_ref = rr + xr * keep * scale
+    y_ref = ln_ref(s_ref)
+    ((s_ref * ws).sum() + (y_ref * wy).sum()).backward()
+    # HIP
+    ln = fused.LayerNorm.from_torch(torch.nn.LayerNorm(d).to(dev), lowp)
+    with torch.no_grad():
+        ln.weight.copy_(ln_ref.weight.to(dev)); ln.bias.copy_(ln_ref.bias.to(dev))
+    xd, rd = x0.detach().to(dev).requires_grad_(True), r0.detach().to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=lowp):
+        s, y = fused.add_layer_norm(xd, rd, ln, p, seed)
+    assert s.dtype == torch.float32 and y.dtype == (torch.bfloat16 if lowp else torch.float32)
+    ((s * ws.to(dev)).sum() + (y.float() * wy.to(dev)).sum()).backward()
+    tol = 2e-2 if (lowp or xdt != torch.float32) else 2e-4
+    def close(a, b, name):
+        e = (a.float().cpu() - b).abs().max().item()
+        assert e <= tol * max(1.0, b.abs().max().item()), (name, e)
+    close(s, s_ref.detach(), "s"); close(y, y_ref.detach(), "y")
+    close(xd.grad, xr.grad, "dx"); close(rd.grad, rr.grad, "dr")
+    close(ln.weight.grad, ln_ref.weight.grad, "dgamma"); close(ln.bias.grad, ln_ref.bias.grad, "dbeta")
+
+
+def test_fuse_add_layer_norm_matches_stock_hf_models():
+    from transformers import BertConfig, BertModel, CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    cfg = CLIPVisionConfig(patch_size=16, image_size=64, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                           num_attention_heads=2, projection_dim=64)
+    bcfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                      hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cases = [(CLIPVisionModelWithProjection(cfg).to(dev), {"pixel_values": torch.rand(3, 3, 64, 64, device=dev)}, "image_embeds", 2, True),
+             (BertModel(bcfg, add_pooling_layer=False).to(dev), {"input_ids": torch.randint(0, 30522, (4, 16), device=dev)}, "last_hidden_state", 4, False)]
+    for model, inputs, field, n_expected, lowp in cases:
+        keys = list(model.state_dict().keys())
+        outs = []
+        for patched in (False, True):
+            if patched:
+                n = fused.accelerate_encoder(model, ("layer_norm1", "layer_norm2", "post_layernorm") if lowp else (), fuse_add_ln=True)
+                assert n["fused_add_ln"] == n_expected and list(model.state_dict().keys()) == keys
+            model.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = model(**inputs, output_hidden_states=True)
+            e = getattr(out, field)
+            e.float().square().mean().backward()
+            outs.append((e.float().detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                         [h.float().detach() for h in out.hidden_states]))
+        (e0, g0, h0), (e1, g1, h1) = outs
+        assert (e0 - e1).abs().max() <= 3e-2 * e0.abs().max()
+        assert len(h0) == len(h1) and all((a - b).abs().max() <= 3e-2 * a.abs().max() for a, b in zip(h0, h1))
+        gmax = max(v.abs().max().item() for v in g0.values())
+        for k in g0:
+            assert (g0[k] - g1[k]).abs().max() <= 6e-2 * max(g0[k].abs().max().item(), 1e-2 * gmax), k

@@ -216,14 +216,26 @@ int mmk_layernorm_bwd(const void* x, const void* dy, const float* w, const float
  * "hidden = residual + sublayer_out" followed by the next nn.LayerNorm in the encoders' transformer blocks (HF
  * CLIPEncoderLayer: layer_norm2(residual + attn); BertSelfOutput / BertOutput: LayerNorm(dropout(dense(h)) + input)).
  * x: [rows, d] in dtype&15, r / s: f32, y in dtype>>4.  s may be NULL only if the caller never needs the sum (it is
- * what the backward re-normalises, so training callers pass it).  Dropout: the counter-based mask of (seed, row, col). */
-int mmk_add_layernorm_fwd(const void* x, const float* r, const float* w, const float* b, float* s, void* y, float* mean,
-                          float* rstd, int64_t rows, int d, float eps, int dtype, float dropout_p, uint64_t seed, void* stream);
+ * what the backward re-normalises, so training callers pass it).  Dropout: the counter-based mask of (seed, row, col).
+ * xbias (nullable, f32[d]): the bias of the Linear that produced x, when that Linear was run without it -- it is added
+ * before the dropout, and its gradient (column sums of dx) comes out of the backward as dxbias instead of a separate
+ * dY.sum(0) pass. */
+int mmk_add_layernorm_fwd(const void* x, const float* xbias, const float* r, const float* w, const float* b, float* s, void* y,
+                          float* mean, float* rstd, int64_t rows, int d, float eps, int dtype, float dropout_p, uint64_t seed,
+                          void* stream);
 /* Backward: ds = ds_in + LNbwd(dy) (ds_in nullable);  dr = ds (f32);  dx = dropout_mask(ds) in dtype&15;  dy in dtype>>4;
- * dw/db (nullable pair) with the workspaces of mmk_layernorm_bwd. */
+ * dw/db (nullable pair) with the workspaces of mmk_layernorm_bwd (3 slabs per block instead of 2 when dxbias is given). */
 int mmk_add_layernorm_bwd(const float* s, const void* dy, const float* ds_in, const float* w, const float* mean, const float* rstd,
-                          float* dr, void* dx, float* part, float* part2, float* dw, float* db, int64_t rows, int d, int dtype,
-                          float dropout_p, uint64_t seed, void* stream);
+                          float* dr, void* dx, float* part, float* part2, float* dw, float* db, float* dxbias, int64_t rows, int d,
+                          int dtype, float dropout_p, uint64_t seed, void* stream);
+
+/* y = act(x + bias) for a Linear run without its bias (fc1 of the encoders' MLPs: HF CLIPMLP fc1 + quick_gelu,
+ * BertIntermediate dense + erf GELU); act 0 = x*sigmoid(1.702x), 1 = erf GELU.  The backward writes
+ * dx = act'(x + bias) * dy and dbias = column sums of dx (part: f32[mmk_bias_act_part_blocks(rows), d], part2: f32[64, d]). */
+int mmk_bias_act_part_blocks(long rows);
+int mmk_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, int d, int act, int dtype, void* stream);
+int mmk_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx, float* part, float* part2, float* dbias, int64_t rows,
+                     int d, int act, int dtype, void* stream);
 
 /* HF QuickGELUActivation  x * sigmoid(1.702 x)  (CLIP MLP), forward and backward, n elements (multiple of 4) */
 int mmk_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);

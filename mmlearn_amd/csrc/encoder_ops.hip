@@ -147,8 +147,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const X* __restrict_
 // the caller needs the sum, i.e. pre-LN blocks) and y.  Dropout uses the counter-based mask of common.h keyed by
 // (seed, row): the backward regenerates it.
 template <typename XT, typename Y, int VEC, bool DROP>
-__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ r,
-                                                                const float* __restrict__ w, const float* __restrict__ b,
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const XT* __restrict__ x, const float* __restrict__ xb,
+                                                                const float* __restrict__ r, const float* __restrict__ w,
+                                                                const float* __restrict__ b,
                                                                 float* __restrict__ s_out, Y* __restrict__ y,
                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                                 long rows, int d, float eps, uint32_t seed_lo, uint32_t seed_hi,
@@ -164,6 +165,10 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const XT* __rest
     const int c = (lane + 64 * k) * 4;
     if (c < d) {
       float4 xv = Vec4<XT>::load(x + row * d + c);
+      if (xb) {  // the producing Linear's bias, deferred into this kernel (its gradient comes out of the backward)
+        const float4 bb = *reinterpret_cast<const float4*>(xb + c);
+        xv.x += bb.x; xv.y += bb.y; xv.z += bb.z; xv.w += bb.w;
+      }
       if (DROP) {
         const uint32_t w0 = drop_word(key, 0, c >> 1), w1 = drop_word(key, 0, (c >> 1) + 1);
         xv.x = (w0 & 0xFFFFu) < drop_thr ? 0.f : xv.x * drop_scale;
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const XT* __rest
 // Backward of the fused op from the saved sum s:  ds = ds_in + LNbwd(dy)  (ds_in = gradient reaching s through the
 // residual stream, absent in post-LN blocks);  dr = ds (f32),  dx = dropout_mask(ds) cast to the sublayer output's dtype.
 // Replaces LayerNorm backward + the gradient-accumulation add + the f32 -> bf16 cast of the sublayer gradient.
-template <typename G, typename XT, int VEC, bool DROP>
+template <typename G, typename XT, int VEC, bool DROP, bool XBIAS>
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __restrict__ sv, const G* __restrict__ dy,
                                                                 const float* __restrict__ ds_in, const float* __restrict__ w,
                                                                 const float* __restrict__ mean_in,
@@ -220,13 +225,15 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
                                                                 XT* __restrict__ dx, float* __restrict__ part, long rows, int d,
                                                                 uint32_t seed_lo, uint32_t seed_hi, uint32_t drop_thr,
                                                                 float drop_scale) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][2][d]
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves][NP][d], NP = 2 (+1 with XBIAS)
+  constexpr int NP = XBIAS ? 3 : 2;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float4 dg[VEC], db[VEC], wv[VEC];
+  float4 dg[VEC], db[VEC], wv[VEC], dxb[XBIAS ? VEC : 1];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
     dg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     db[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (XBIAS) dxb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int c = (lane + 64 * k) * 4;
     wv[k] = (w && c < d) ? *reinterpret_cast<const float4*>(w + c) : make_float4(1.f, 1.f, 1.f, 1.f);
   }
@@ -275,22 +282,80 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
           t.w = (w1 >> 16) < drop_thr ? 0.f : t.w * drop_scale;
         }
         Vec4<XT>::store(dx + row * d + c, t);
+        if (XBIAS) {  // d(bias of the producing Linear) = column sums of dx
+          dxb[k].x += (float)(XT)t.x; dxb[k].y += (float)(XT)t.y; dxb[k].z += (float)(XT)t.z; dxb[k].w += (float)(XT)t.w;
+        }
       }
     }
   }
   if (part == nullptr) return;
-  float* mine = lds + (size_t)wave * 2 * d;
+  float* mine = lds + (size_t)wave * NP * d;
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
     const int c = (lane + 64 * k) * 4;
     if (c < d) {
       *reinterpret_cast<float4*>(mine + c) = dg[k];
       *reinterpret_cast<float4*>(mine + d + c) = db[k];
+      if (XBIAS) *reinterpret_cast<float4*>(mine + 2 * d + c) = dxb[k];
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * d; c += 256)
-    part[(size_t)blockIdx.x * 2 * d + c] = lds[c] + lds[2 * d + c] + lds[4 * d + c] + lds[6 * d + c];
+  for (int c = threadIdx.x; c < NP * d; c += 256)
+    part[(size_t)blockIdx.x * NP * d + c] = lds[c] + lds[NP * d + c] + lds[2 * NP * d + c] + lds[3 * NP * d + c];
+}
+
+// ------------------------------------------------------------------ bias + activation, fused (fc1 of the MLPs)
+// y = act(x + b) with the producing Linear run WITHOUT its bias: forward is one pass; the backward recomputes x + b,
+// writes dx = act'(x + b) * dy and accumulates per-block column sums of dx, which ARE the bias gradient -- the separate
+// dY.sum(0) pass of the Linear's backward disappears.  ACT 0: x * sigmoid(1.702 x) (HF quick_gelu), 1: erf GELU.
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float z) {
+  if (ACT == 0) return z / (1.f + __expf(-1.702f * z));
+  return 0.5f * z * (1.f + erff(z * 0.70710678118654752f));
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad(float z, float g) {
+  if (ACT == 0) {
+    const float sg = 1.f / (1.f + __expf(-1.702f * z));
+    return g * sg * (1.f + 1.702f * z * (1.f - sg));
+  }
+  return g * (0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z));
+}
+constexpr int BA_ROWS = 32;  // rows per block of the backward (one [d] partial per block)
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bias_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ b, T* __restrict__ y,
+                                                           long rows, int d) {
+  const int d4 = d / 4;
+  const long n4 = rows * d4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % d4) * 4;
+    float4 v = Vec4<T>::load(x + i * 4);
+    const float4 bb = *reinterpret_cast<const float4*>(b + c);
+    v.x = act_fwd<ACT>(v.x + bb.x); v.y = act_fwd<ACT>(v.y + bb.y); v.z = act_fwd<ACT>(v.z + bb.z); v.w = act_fwd<ACT>(v.w + bb.w);
+    Vec4<T>::store(y + i * 4, v);
+  }
+}
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__ x, const float* __restrict__ b,
+                                                           const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ part,
+                                                           long rows, int d) {
+  const int d4 = d / 4;
+  const long r0 = (long)blockIdx.x * BA_ROWS, r1 = min(rows, r0 + BA_ROWS);
+  for (int cv = threadIdx.x; cv < d4; cv += 256) {  // this thread's column vectors (d4 <= 4 * 256 in practice)
+    const int c = cv * 4;
+    const float4 bb = *reinterpret_cast<const float4*>(b + c);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (long row = r0; row < r1; ++row) {
+      const float4 v = Vec4<T>::load(x + row * d + c), g = Vec4<T>::load(dy + row * d + c);
+      const float4 t = make_float4(act_grad<ACT>(v.x + bb.x, g.x), act_grad<ACT>(v.y + bb.y, g.y), act_grad<ACT>(v.z + bb.z, g.z),
+                                   act_grad<ACT>(v.w + bb.w, g.w));
+      Vec4<T>::store(dx + row * d + c, t);
+      // the sums are taken over the ROUNDED dx values the weight-gradient GEMM will see
+      acc.x += (float)(T)t.x; acc.y += (float)(T)t.y; acc.z += (float)(T)t.z; acc.w += (float)(T)t.w;
+    }
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * d + c) = acc;
+  }
 }
 
 // dgamma/dbeta = column sums of the block partials: grid over column chunks x row slices, then atomics-free 2nd stage
@@ -400,28 +465,17 @@ int mmk_layernorm_bwd(const void* x, const void* dy, const float* w, const float
   return 0;
 }
 
-// second-stage reduction of the per-block [2][d] partials shared by the LayerNorm backwards
-static int ln_reduce_partials(float* part, float* part2, float* dw, float* db, int n_blocks, int d, hipStream_t st) {
-  const int slices = std::min(64, n_blocks);
-  const int rpb = (n_blocks + slices - 1) / slices;
-  hipLaunchKernelGGL(colsum_kernel, dim3((2 * d + 255) / 256, slices), dim3(256), 0, st, part, n_blocks, 2 * d, part2, rpb);
-  hipLaunchKernelGGL(colsum_kernel, dim3((2 * d + 255) / 256, 1), dim3(256), 0, st, part2, slices, 2 * d, part, slices);
-  MMK_LAUNCH_CHECK();
-  MMK_HIP(hipMemcpyAsync(dw, part, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
-  MMK_HIP(hipMemcpyAsync(db, part + d, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
-  return 0;
-}
-
 #define MMK_ADDLN_FWD(VEC, DROP)                                                                                        \
-  hipLaunchKernelGGL((add_layernorm_fwd_kernel<XT, Y, VEC, DROP>), grid, dim3(256), 0, st, static_cast<const XT*>(x), r, w, \
-                     b, s, static_cast<Y*>(y), mean, rstd, (long)rows, d, eps, lo, hi, thr, scale)
-#define MMK_ADDLN_BWD(VEC, DROP)                                                                                       \
-  hipLaunchKernelGGL((add_layernorm_bwd_kernel<G, XT, VEC, DROP>), dim3(n_blocks), dim3(256), lds, st, s,              \
+  hipLaunchKernelGGL((add_layernorm_fwd_kernel<XT, Y, VEC, DROP>), grid, dim3(256), 0, st, static_cast<const XT*>(x), xbias, r, \
+                     w, b, s, static_cast<Y*>(y), mean, rstd, (long)rows, d, eps, lo, hi, thr, scale)
+#define MMK_ADDLN_BWD(VEC, DROP, XB)                                                                                   \
+  hipLaunchKernelGGL((add_layernorm_bwd_kernel<G, XT, VEC, DROP, XB>), dim3(n_blocks), dim3(256), lds, st, s,          \
                      static_cast<const G*>(dy), ds_in, w, mean, rstd, dr, static_cast<XT*>(dx), dw ? part : nullptr,   \
                      (long)rows, d, lo, hi, thr, scale)
 
-int mmk_add_layernorm_fwd(const void* x, const float* r, const float* w, const float* b, float* s, void* y, float* mean,
-                          float* rstd, int64_t rows, int d, float eps, int dtype, float dropout_p, uint64_t seed, void* stream) {
+int mmk_add_layernorm_fwd(const void* x, const float* xbias, const float* r, const float* w, const float* b, float* s, void* y,
+                          float* mean, float* rstd, int64_t rows, int d, float eps, int dtype, float dropout_p, uint64_t seed,
+                          void* stream) {
   // dtype packs (x dtype) | (y dtype << 4); r and s are f32
   MMK_REQUIRE(x && r && y && mean && rstd && rows >= 0 && d > 0, "bad arguments");
   MMK_REQUIRE(d % 4 == 0 && d <= 64 * 4 * LN_MAX_VEC, "add_layernorm: d must be a multiple of 4 and <= 2048");
@@ -449,10 +503,12 @@ int mmk_add_layernorm_fwd(const void* x, const float* r, const float* w, const f
 }
 
 int mmk_add_layernorm_bwd(const float* s, const void* dy, const float* ds_in, const float* w, const float* mean, const float* rstd,
-                          float* dr, void* dx, float* part, float* part2, float* dw, float* db, int64_t rows, int d, int dtype,
-                          float dropout_p, uint64_t seed, void* stream) {
-  // dtype packs (dx dtype) | (dy dtype << 4).  part: float[n_blocks, 2, d]; part2: float[64, 2, d] (second stage)
+                          float* dr, void* dx, float* part, float* part2, float* dw, float* db, float* dxbias, int64_t rows, int d,
+                          int dtype, float dropout_p, uint64_t seed, void* stream) {
+  // dtype packs (dx dtype) | (dy dtype << 4).  part: float[n_blocks, NP, d]; part2: float[64, NP, d] (second stage),
+  // NP = 3 when dxbias (the column sums of dx = gradient of the deferred Linear bias) is requested, else 2
   MMK_REQUIRE(s && dy && mean && rstd && dr && dx && rows >= 0 && d > 0, "bad arguments");
+  MMK_REQUIRE(dxbias == nullptr || dw != nullptr, "dxbias is produced together with dgamma/dbeta");
   MMK_REQUIRE(d % 4 == 0 && d <= 64 * 4 * LN_MAX_VEC, "add_layernorm: d must be a multiple of 4 and <= 2048");
   MMK_REQUIRE((dw == nullptr && db == nullptr) || (part && part2 && dw && db), "dgamma/dbeta need both outputs and the workspaces");
   MMK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
@@ -463,20 +519,85 @@ int mmk_add_layernorm_bwd(const float* s, const void* dy, const float* ds_in, co
   const bool drop = drop_params(dropout_p, seed, &lo, &hi, &thr, &scale);
   ProfScope ps(MMK_K_LAYERNORM_BWD, st);
   const int n_blocks = mmk_layernorm_part_blocks(rows);
-  const size_t lds = dw ? 8 * d * sizeof(float) : 0;
+  const int np = dxbias ? 3 : 2;
+  const size_t lds = dw ? 4 * np * d * sizeof(float) : 0;
   int rc = MMK_DISPATCH_DTYPE(dtype & 15, XT, [&]() -> int {
     return MMK_DISPATCH_DTYPE((dtype >> 4) & 15, G, [&]() -> int {
       if (d <= 1024) {
-        if (drop) MMK_ADDLN_BWD(4, true); else MMK_ADDLN_BWD(4, false);
+        if (dxbias) { if (drop) MMK_ADDLN_BWD(4, true, true); else MMK_ADDLN_BWD(4, false, true); }
+        else { if (drop) MMK_ADDLN_BWD(4, true, false); else MMK_ADDLN_BWD(4, false, false); }
       } else {
-        if (drop) MMK_ADDLN_BWD(8, true); else MMK_ADDLN_BWD(8, false);
+        if (dxbias) { if (drop) MMK_ADDLN_BWD(8, true, true); else MMK_ADDLN_BWD(8, false, true); }
+        else { if (drop) MMK_ADDLN_BWD(8, true, false); else MMK_ADDLN_BWD(8, false, false); }
       }
       return 0;
     });
   });
   if (rc) return rc;
   MMK_LAUNCH_CHECK();
-  if (dw) return ln_reduce_partials(part, part2, dw, db, n_blocks, d, st);
+  if (dw) {
+    const int slices = std::min(64, n_blocks);
+    const int rpb = (n_blocks + slices - 1) / slices;
+    hipLaunchKernelGGL(colsum_kernel, dim3((np * d + 255) / 256, slices), dim3(256), 0, st, part, n_blocks, np * d, part2, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3((np * d + 255) / 256, 1), dim3(256), 0, st, part2, slices, np * d, part, slices);
+    MMK_LAUNCH_CHECK();
+    MMK_HIP(hipMemcpyAsync(dw, part, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
+    MMK_HIP(hipMemcpyAsync(db, part + d, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
+    if (dxbias) MMK_HIP(hipMemcpyAsync(dxbias, part + 2 * d, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
+  }
+  return 0;
+}
+
+int mmk_bias_act_part_blocks(long rows) { return (int)((rows + BA_ROWS - 1) / BA_ROWS); }
+
+int mmk_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, int d, int act, int dtype, void* stream) {
+  MMK_REQUIRE(x && bias && y && rows >= 0 && d > 0 && d % 4 == 0, "bias_act: d must be a multiple of 4");
+  MMK_REQUIRE(act == 0 || act == 1, "bias_act: act must be 0 (quick_gelu) or 1 (gelu)");
+  if (rows == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope ps(MMK_K_ACT, st);
+  const long n4 = rows * (d / 4);
+  const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 256 * 16);
+  int rc = MMK_DISPATCH_DTYPE(dtype, T, [&]() -> int {
+    if (act == 0)
+      hipLaunchKernelGGL((bias_act_fwd_kernel<T, 0>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(x), bias, static_cast<T*>(y), (long)rows, d);
+    else
+      hipLaunchKernelGGL((bias_act_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(x), bias, static_cast<T*>(y), (long)rows, d);
+    return 0;
+  });
+  if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+int mmk_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx, float* part, float* part2, float* dbias, int64_t rows,
+                     int d, int act, int dtype, void* stream) {
+  // part: float[mmk_bias_act_part_blocks(rows), d]; part2: float[64, d]
+  MMK_REQUIRE(x && bias && dy && dx && part && part2 && dbias && rows >= 0 && d > 0 && d % 4 == 0, "bad arguments");
+  MMK_REQUIRE(act == 0 || act == 1, "bias_act: act must be 0 (quick_gelu) or 1 (gelu)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (rows == 0) {
+    MMK_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * d, st));
+    return 0;
+  }
+  ProfScope ps(MMK_K_ACT, st);
+  const int n_blocks = mmk_bias_act_part_blocks(rows);
+  int rc = MMK_DISPATCH_DTYPE(dtype, T, [&]() -> int {
+    if (act == 0)
+      hipLaunchKernelGGL((bias_act_bwd_kernel<T, 0>), dim3(n_blocks), dim3(256), 0, st, static_cast<const T*>(x), bias,
+                         static_cast<const T*>(dy), static_cast<T*>(dx), part, (long)rows, d);
+    else
+      hipLaunchKernelGGL((bias_act_bwd_kernel<T, 1>), dim3(n_blocks), dim3(256), 0, st, static_cast<const T*>(x), bias,
+                         static_cast<const T*>(dy), static_cast<T*>(dx), part, (long)rows, d);
+    return 0;
+  });
+  if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  const int slices = std::min(64, n_blocks);
+  const int rpb = (n_blocks + slices - 1) / slices;
+  hipLaunchKernelGGL(colsum_kernel, dim3((d + 255) / 256, slices), dim3(256), 0, st, part, n_blocks, d, part2, rpb);
+  hipLaunchKernelGGL(colsum_kernel, dim3((d + 255) / 256, 1), dim3(256), 0, st, part2, slices, d, dbias, slices);
+  MMK_LAUNCH_CHECK();
   return 0;
 }
 

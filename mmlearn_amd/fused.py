@@ -95,42 +95,46 @@ class LayerNorm(nn.LayerNorm):
 
 
 class _AddLayerNormFn(torch.autograd.Function):
-    """(s, y) = (r + dropout(x), LN(r + dropout(x))) in one kernel each way (csrc/encoder_ops.hip)."""
+    """(s, y) = (r + dropout(x + xbias), LN(s)) in one kernel each way (csrc/encoder_ops.hip)."""
 
     @staticmethod
-    def forward(ctx, x, r, weight, bias, eps, out_dtype, dropout_p, seed):
+    def forward(ctx, x, r, weight, bias, xbias, eps, out_dtype, dropout_p, seed):
         d = x.shape[-1]
         x2 = x.contiguous().view(-1, d)
         r2 = r.contiguous().view(-1, d)
         w32 = None if weight is None else weight.detach().float().contiguous()
         b32 = None if bias is None else bias.detach().float().contiguous()
-        s, y, mean, rstd = K.add_layernorm_fwd(x2, r2, w32, b32, eps, out_dtype, dropout_p, seed)
+        xb32 = None if xbias is None else xbias.detach().float().contiguous()
+        s, y, mean, rstd = K.add_layernorm_fwd(x2, r2, w32, b32, eps, out_dtype, dropout_p, seed, xb32)
         ctx.save_for_backward(s, w32, mean, rstd)
         ctx.shape, ctx.x_dtype, ctx.dropout_p, ctx.seed = x.shape, x.dtype, dropout_p, seed
         ctx.wb = (weight is not None and weight.requires_grad, bias is not None and bias.requires_grad,
                   None if weight is None else weight.dtype, None if bias is None else bias.dtype)
-        s_out = s.view(x.shape)
-        return s_out, y.view(x.shape)
+        ctx.xb = (xbias is not None and xbias.requires_grad, None if xbias is None else xbias.dtype)
+        return s.view(x.shape), y.view(x.shape)
 
     @staticmethod
     def backward(ctx, gs, gy):
         s, w32, mean, rstd = ctx.saved_tensors
         d = s.shape[-1]
         need_w, need_b, wdt, bdt = ctx.wb
+        need_xb, xbdt = ctx.xb
         if gy is None:
             gy = torch.zeros(ctx.shape, dtype=torch.float32, device=s.device)
         ds_in = None if gs is None else gs.contiguous().view(-1, d).float()
-        dr, dx, dw, db = K.add_layernorm_bwd(s, gy.contiguous().view(-1, d), ds_in, w32, mean, rstd, ctx.x_dtype, need_w or need_b,
-                                             ctx.dropout_p, ctx.seed)
+        dr, dx, dw, db, dxb = K.add_layernorm_bwd(s, gy.contiguous().view(-1, d), ds_in, w32, mean, rstd, ctx.x_dtype, need_w or need_b,
+                                                  ctx.dropout_p, ctx.seed, need_xb)
         return (dx.view(ctx.shape), dr.view(ctx.shape), dw.to(wdt) if need_w else None, db.to(bdt) if need_b else None,
-                None, None, None, None)
+                dxb.to(xbdt) if need_xb else None, None, None, None, None)
 
 
 def add_layer_norm(x: torch.Tensor, residual: torch.Tensor, ln: nn.LayerNorm, dropout_p: float = 0.0, seed: Optional[int] = None,
-                   low_precision_out: Optional[bool] = None):
-    """``s = residual + dropout(x)``, ``y = ln(s)`` fused; returns ``(s, y)``.  ``x`` is the sublayer output (autocast
-    dtype or f32), ``residual`` the f32 stream.  ``y`` is f32 like ``F.layer_norm`` under autocast unless
-    ``low_precision_out`` (default: the module's own ``low_precision_out`` flag) asks for the autocast dtype."""
+                   low_precision_out: Optional[bool] = None, xbias: Optional[torch.Tensor] = None):
+    """``s = residual + dropout(x + xbias)``, ``y = ln(s)`` fused; returns ``(s, y)``.  ``x`` is the sublayer output
+    (autocast dtype or f32), ``residual`` the f32 stream.  ``y`` is f32 like ``F.layer_norm`` under autocast unless
+    ``low_precision_out`` (default: the module's own ``low_precision_out`` flag) asks for the autocast dtype.
+    ``xbias``: bias of the Linear that produced ``x`` when it was run bias-free (``linear_nobias``); its gradient is
+    then a by-product of this op's backward instead of a separate pass over the Linear's output gradient."""
     K.require_gpu(x)
     if residual.dtype != torch.float32:
         residual = residual.float()
@@ -143,7 +147,7 @@ def add_layer_norm(x: torch.Tensor, residual: torch.Tensor, ln: nn.LayerNorm, dr
         from .attention import draw_seed
 
         seed = draw_seed()
-    return _AddLayerNormFn.apply(x, residual, ln.weight, ln.bias, ln.eps, out_dtype, float(dropout_p), int(seed or 0))
+    return _AddLayerNormFn.apply(x, residual, ln.weight, ln.bias, xbias, ln.eps, out_dtype, float(dropout_p), int(seed or 0))
 
 
 def _ln_fusable(ln, x: torch.Tensor) -> bool:
@@ -151,38 +155,122 @@ def _ln_fusable(ln, x: torch.Tensor) -> bool:
             and x.shape[-1] % 4 == 0 and x.shape[-1] <= 2048 and x.dtype in (torch.float32, torch.bfloat16, torch.float16))
 
 
+class _BiasActFn(torch.autograd.Function):
+    """``act(x + bias)`` for a bias-free Linear output; the backward also yields the bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, bias, act):
+        d = x.shape[-1]
+        x2 = x.contiguous().view(-1, d)
+        b32 = bias.detach().float().contiguous()
+        ctx.save_for_backward(x2, b32)
+        ctx.act, ctx.shape, ctx.bdt = act, x.shape, bias.dtype
+        return K.bias_act_fwd(x2, b32, act).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, b32 = ctx.saved_tensors
+        dx, db = K.bias_act_bwd(x2, b32, dy.contiguous().view(x2.shape), ctx.act)
+        return dx.view(ctx.shape), db.to(ctx.bdt), None
+
+
+def bias_act(x: torch.Tensor, bias: torch.Tensor, act: str) -> torch.Tensor:
+    """``quick_gelu(x + bias)`` / ``gelu(x + bias)`` (erf form) in one kernel; ``x`` = ``linear_nobias(...)``."""
+    K.require_gpu(x)
+    return _BiasActFn.apply(x, bias, {"quick_gelu": K.ACT_QUICK_GELU, "gelu": K.ACT_GELU}[act])
+
+
+def linear_nobias(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """``x @ W^T`` of an ``nn.Linear`` whose bias is added by the consumer kernel (``add_layer_norm`` / ``bias_act``)."""
+    return F.linear(x, lin.weight, None)
+
+
+def _act_name(fn) -> Optional[str]:
+    name = type(fn).__name__
+    if name in ("QuickGELUActivation", "QuickGELU"):
+        return "quick_gelu"
+    if name == "GELUActivation" and getattr(fn, "act", None) is F.gelu:
+        return "gelu"
+    return None
+
+
+def _bias_deferrable(lin: nn.Linear, x: torch.Tensor) -> bool:
+    return (lin.bias is not None and x.is_cuda and lin.out_features % 4 == 0
+            and (torch.is_autocast_enabled() or lin.weight.dtype == x.dtype))
+
+
+def _clip_mlp_nobias(mlp, x2: torch.Tensor):
+    """HF ``CLIPMLP`` as fc1 (bias-free GEMM) -> bias + activation kernel -> fc2 (bias-free GEMM); returns the bias-free
+    output and fc2's bias for the consumer, or ``(mlp(x2), None)`` when that form does not apply."""
+    act = _act_name(mlp.activation_fn)
+    if act is None or not (_bias_deferrable(mlp.fc1, x2) and _bias_deferrable(mlp.fc2, x2)):
+        return mlp(x2), None
+    h = linear_nobias(mlp.fc1, x2)
+    if h.dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        return mlp(x2), None
+    return linear_nobias(mlp.fc2, bias_act(h, mlp.fc1.bias, act)), mlp.fc2.bias
+
+
 def _clip_layer_forward(self, hidden_states, attention_mask=None, **kwargs):
     """Replaces HF ``CLIPEncoderLayer.forward``.  ``residual + attn`` runs inside ``layer_norm2``'s kernel, and
     ``residual + mlp`` inside the NEXT layer's ``layer_norm1`` kernel: this layer still returns the sum (the hidden state
-    HF records), with the already-normalised tensor attached to it for the next layer to pick up."""
+    HF records), with the already-normalised tensor attached to it for the next layer to pick up.  The biases of
+    ``out_proj`` / ``fc1`` / ``fc2`` are applied by the consuming kernels (their gradients fall out of those kernels'
+    backward passes instead of three ``dY.sum(0)`` reductions)."""
     residual = hidden_states
     x = getattr(hidden_states, "_mmk_prenormed", None)
     if x is None:
         x = self.layer_norm1(hidden_states)
-    a, _ = self.self_attn(hidden_states=x, attention_mask=attention_mask, **kwargs)
+    attn = self.self_attn
+    defer = hasattr(attn, "_mmk_stock_forward") and _ln_fusable(self.layer_norm2, x) and _bias_deferrable(attn.out_proj, x)
+    if defer:
+        attn._mmk_defer_out_bias = True
+    try:
+        a, _ = attn(hidden_states=x, attention_mask=attention_mask, **kwargs)
+        deferred = defer and getattr(attn, "_mmk_out_bias_deferred", False)
+    finally:
+        if defer:
+            attn._mmk_defer_out_bias = False
+            attn._mmk_out_bias_deferred = False
     if _ln_fusable(self.layer_norm2, a):
-        h, x2 = add_layer_norm(a, residual, self.layer_norm2)
+        h, x2 = add_layer_norm(a, residual, self.layer_norm2, xbias=attn.out_proj.bias if deferred else None)
     else:
         h = residual + a
         x2 = self.layer_norm2(h)
-    m = self.mlp(x2)
     nxt = getattr(self, "_mmk_next_ln", None)
-    if nxt is not None and _ln_fusable(nxt, m):
-        out, y = add_layer_norm(m, h, nxt)
+    if nxt is not None and _ln_fusable(nxt, x2):
+        m, mb = _clip_mlp_nobias(self.mlp, x2)
+        out, y = add_layer_norm(m, h, nxt, xbias=mb)
         out._mmk_prenormed = y
         return out
-    return h + m
+    return h + self.mlp(x2)
 
 
 def _bert_output_forward(self, hidden_states, input_tensor):
-    """Replaces HF ``BertSelfOutput.forward`` / ``BertOutput.forward``: dropout + residual add + LayerNorm in one kernel."""
-    h = self.dense(hidden_states)
-    if _ln_fusable(self.LayerNorm, h):
-        return add_layer_norm(h, input_tensor, self.LayerNorm, self.dropout.p if self.training else 0.0)[1]
+    """Replaces HF ``BertSelfOutput.forward`` / ``BertOutput.forward``: dense bias + dropout + residual add + LayerNorm in
+    one kernel (the dense GEMM runs bias-free; the bias gradient comes out of the fused backward)."""
+    if _bias_deferrable(self.dense, hidden_states):
+        h = linear_nobias(self.dense, hidden_states)
+        if _ln_fusable(self.LayerNorm, h):
+            return add_layer_norm(h, input_tensor, self.LayerNorm, self.dropout.p if self.training else 0.0, xbias=self.dense.bias)[1]
+        h = h + self.dense.bias
+    else:
+        h = self.dense(hidden_states)
+        if _ln_fusable(self.LayerNorm, h):
+            return add_layer_norm(h, input_tensor, self.LayerNorm, self.dropout.p if self.training else 0.0)[1]
     return self.LayerNorm(self.dropout(h) + input_tensor)
 
 
-_ADD_LN_FORWARDS = {"CLIPEncoderLayer": _clip_layer_forward, "BertSelfOutput": _bert_output_forward, "BertOutput": _bert_output_forward}
+def _bert_intermediate_forward(self, hidden_states):
+    """Replaces HF ``BertIntermediate.forward``: bias-free dense GEMM + one bias + GELU kernel."""
+    act = _act_name(self.intermediate_act_fn)
+    if act is not None and _bias_deferrable(self.dense, hidden_states):
+        return bias_act(linear_nobias(self.dense, hidden_states), self.dense.bias, act)
+    return self.intermediate_act_fn(self.dense(hidden_states))
+
+
+_ADD_LN_FORWARDS = {"CLIPEncoderLayer": _clip_layer_forward, "BertSelfOutput": _bert_output_forward, "BertOutput": _bert_output_forward,
+                    "BertIntermediate": _bert_intermediate_forward}
 
 
 def fuse_add_layer_norm(module: nn.Module) -> int:
@@ -250,6 +338,9 @@ def _clip_attention_forward(self, hidden_states, attention_mask=None, **kwargs):
     if attention_mask is None and getattr(self, "head_dim", 0) == 64:
         ctx = _fused_qkv(self, hidden_states, ("q_proj", "k_proj", "v_proj"), self.scale, self.dropout if self.training else 0.0)
         if ctx is not None:
+            if getattr(self, "_mmk_defer_out_bias", False):   # the enclosing patched layer adds out_proj.bias itself
+                self._mmk_out_bias_deferred = True
+                return linear_nobias(self.out_proj, ctx), None
             return self.out_proj(ctx), None
     return self._mmk_stock_forward(hidden_states, attention_mask, **kwargs)
 

@@ -369,8 +369,9 @@ def layernorm_bwd(x2: torch.Tensor, dy2: torch.Tensor, w: Optional[torch.Tensor]
 
 
 def add_layernorm_fwd(x2: torch.Tensor, r2: torch.Tensor, w: Optional[torch.Tensor], b: Optional[torch.Tensor], eps: float,
-                      out_dtype: torch.dtype, dropout_p: float = 0.0, seed: int = 0):
-    """s = r2 + dropout(x2), y = LN(s): x2 [rows, d] (bf16 / f32), r2 f32 -> (s f32, y of out_dtype, mean, rstd)."""
+                      out_dtype: torch.dtype, dropout_p: float = 0.0, seed: int = 0, xbias: Optional[torch.Tensor] = None):
+    """s = r2 + dropout(x2 + xbias), y = LN(s): x2 [rows, d] (bf16 / f32), r2 f32, xbias f32[d] or None
+    -> (s f32, y of out_dtype, mean, rstd)."""
     require_gpu(x2)
     rows, d = x2.shape
     assert r2.shape == x2.shape and r2.dtype == torch.float32 and r2.is_contiguous() and x2.is_contiguous()
@@ -379,29 +380,57 @@ def add_layernorm_fwd(x2: torch.Tensor, r2: torch.Tensor, w: Optional[torch.Tens
     mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
     dt = dtype_tag(x2.dtype) | (dtype_tag(out_dtype) << 4)
-    check(_lib.lib().mmk_add_layernorm_fwd(ptr(x2), ptr(r2), ptr(w), ptr(b), ptr(s), ptr(y), ptr(mean), ptr(rstd), rows, d, float(eps), dt,
-                                           float(dropout_p), int(seed), stream()))
+    check(_lib.lib().mmk_add_layernorm_fwd(ptr(x2), ptr(xbias), ptr(r2), ptr(w), ptr(b), ptr(s), ptr(y), ptr(mean), ptr(rstd), rows, d,
+                                           float(eps), dt, float(dropout_p), int(seed), stream()))
     return s, y, mean, rstd
 
 
 def add_layernorm_bwd(s2: torch.Tensor, dy2: torch.Tensor, ds_in: Optional[torch.Tensor], w: Optional[torch.Tensor], mean: torch.Tensor,
-                      rstd: torch.Tensor, x_dtype: torch.dtype, need_wb: bool, dropout_p: float = 0.0, seed: int = 0):
-    """-> (dr f32 = ds_in + LNbwd(dy), dx = dropout_mask(dr) in x_dtype, dgamma, dbeta)."""
+                      rstd: torch.Tensor, x_dtype: torch.dtype, need_wb: bool, dropout_p: float = 0.0, seed: int = 0, need_xbias: bool = False):
+    """-> (dr f32 = ds_in + LNbwd(dy), dx = dropout_mask(dr) in x_dtype, dgamma, dbeta, dxbias = colsum(dx) or None)."""
     rows, d = s2.shape
     dev = s2.device
     dr = torch.empty((rows, d), dtype=torch.float32, device=dev)
     dx = torch.empty((rows, d), dtype=x_dtype, device=dev)
-    part = part2 = dw = db = None
-    if need_wb:
+    part = part2 = dw = db = dxb = None
+    if need_wb or need_xbias:
+        npart = 3 if need_xbias else 2
         nb = _lib.lib().mmk_layernorm_part_blocks(rows)
-        part = torch.empty((max(nb, 1), 2, d), dtype=torch.float32, device=dev)
-        part2 = torch.empty((64, 2, d), dtype=torch.float32, device=dev)
+        part = torch.empty((max(nb, 1), npart, d), dtype=torch.float32, device=dev)
+        part2 = torch.empty((64, npart, d), dtype=torch.float32, device=dev)
         dw = torch.empty(d, dtype=torch.float32, device=dev)
         db = torch.empty(d, dtype=torch.float32, device=dev)
+        dxb = torch.empty(d, dtype=torch.float32, device=dev) if need_xbias else None
     dt = dtype_tag(x_dtype) | (dtype_tag(dy2.dtype) << 4)
     check(_lib.lib().mmk_add_layernorm_bwd(ptr(s2), ptr(dy2), ptr(ds_in), ptr(w), ptr(mean), ptr(rstd), ptr(dr), ptr(dx), ptr(part), ptr(part2),
-                                           ptr(dw), ptr(db), rows, d, dt, float(dropout_p), int(seed), stream()))
-    return dr, dx, dw, db
+                                           ptr(dw), ptr(db), ptr(dxb), rows, d, dt, float(dropout_p), int(seed), stream()))
+    return dr, dx, dw, db, dxb
+
+
+ACT_QUICK_GELU, ACT_GELU = 0, 1
+
+
+def bias_act_fwd(x2: torch.Tensor, bias: torch.Tensor, act: int) -> torch.Tensor:
+    """y = act(x2 + bias): x2 [rows, d] (the bias-free Linear output), bias f32[d]."""
+    require_gpu(x2)
+    rows, d = x2.shape
+    y = torch.empty_like(x2)
+    check(_lib.lib().mmk_bias_act_fwd(ptr(x2), ptr(bias), ptr(y), rows, d, int(act), dtype_tag(x2.dtype), stream()))
+    return y
+
+
+def bias_act_bwd(x2: torch.Tensor, bias: torch.Tensor, dy2: torch.Tensor, act: int):
+    """-> (dx = act'(x2 + bias) * dy2, dbias f32[d] = column sums of dx)."""
+    rows, d = x2.shape
+    dev = x2.device
+    dx = torch.empty_like(x2)
+    nb = _lib.lib().mmk_bias_act_part_blocks(rows)
+    part = torch.empty((max(nb, 1), d), dtype=torch.float32, device=dev)
+    part2 = torch.empty((64, d), dtype=torch.float32, device=dev)
+    dbias = torch.empty(d, dtype=torch.float32, device=dev)
+    check(_lib.lib().mmk_bias_act_bwd(ptr(x2), ptr(bias), ptr(dy2), ptr(dx), ptr(part), ptr(part2), ptr(dbias), rows, d, int(act),
+                                      dtype_tag(x2.dtype), stream()))
+    return dx, dbias
 
 
 def quick_gelu_fwd(x: torch.Tensor) -> torch.Tensor:

@@ -183,7 +183,7 @@ def test_fuse_add_layer_norm_matches_stock_hf_models():
     bcfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                       hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     cases = [(CLIPVisionModelWithProjection(cfg).to(dev), {"pixel_values": torch.rand(3, 3, 64, 64, device=dev)}, "image_embeds", 2, True),
-             (BertModel(bcfg, add_pooling_layer=False).to(dev), {"input_ids": torch.randint(0, 30522, (4, 16), device=dev)}, "last_hidden_state", 4, False)]
+             (BertModel(bcfg, add_pooling_layer=False).to(dev), {"input_ids": torch.randint(0, 30522, (4, 16), device=dev)}, "last_hidden_state", 6, False)]
     for model, inputs, field, n_expected, lowp in cases:
         keys = list(model.state_dict().keys())
         outs = []
@@ -204,3 +204,29 @@ def test_fuse_add_layer_norm_matches_stock_hf_models():
         gmax = max(v.abs().max().item() for v in g0.values())
         for k in g0:
             assert (g0[k] - g1[k]).abs().max() <= 6e-2 * max(g0[k].abs().max().item(), 1e-2 * gmax), k
+
+
+@pytest.mark.parametrize("rows,d,dt,act", [(200, 3072, torch.bfloat16, "quick_gelu"), (77, 512, torch.bfloat16, "gelu"),
+                                            (33, 256, torch.float32, "gelu"), (65, 128, torch.float32, "quick_gelu")])
+def test_bias_act_vs_torch(rows, d, dt, act):
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(rows * 7 + d)
+    x0 = (torch.randn(rows, d, generator=g) * 2).to(dt)
+    b0 = torch.randn(d, generator=g)
+    w = torch.randn(rows, d, generator=g)
+    xr, br = x0.float().clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    z = xr + br
+    y_ref = z * torch.sigmoid(1.702 * z) if act == "quick_gelu" else F.gelu(z)
+    (y_ref * w).sum().backward()
+    xd, bd = x0.detach().to(dev).requires_grad_(True), b0.detach().to(dev).requires_grad_(True)
+    y = fused.bias_act(xd, bd, act)
+    assert y.dtype == dt
+    (y.float() * w.to(dev)).sum().backward()
+    tol = 2e-2 if dt != torch.float32 else 1e-4
+    for a, b, name in ((y, y_ref.detach(), "y"), (xd.grad, xr.grad, "dx")):
+        e = (a.float().cpu() - b).abs().max().item()
+        assert e <= tol * max(1.0, b.abs().max().item()), (name, e)
+    e = (bd.grad.cpu() - br.grad).abs().max().item()
+    assert e <= (5e-2 if dt != torch.float32 else 1e-3) * max(1.0, br.grad.abs().max().item()), ("dbias", e)

@@ -47,7 +47,7 @@ enum {
   MMK_K_SIM_GRAD, MMK_K_GRAD_GEMM, MMK_K_GRAD_FINALIZE, MMK_K_L2NORM, MMK_K_IJEPA_LOSS_FWD,
   MMK_K_IJEPA_LOSS_BWD, MMK_K_GATHER_ROWS, MMK_K_SCATTER_ROWS, MMK_K_PRED_ASSEMBLE, MMK_K_PRED_ASSEMBLE_BWD,
   MMK_K_EMA, MMK_K_MASK_INDEX, MMK_K_LAYERNORM_FWD, MMK_K_LAYERNORM_BWD, MMK_K_ACT, MMK_K_ATTN_FWD,
-  MMK_K_ATTN_BWD, MMK_K_COUNT
+  MMK_K_ATTN_BWD, MMK_K_WGRAD, MMK_K_COUNT
 };
 int mmk_profile_enable(int on);          /* on=1 start recording (clears), on=0 stop */
 /* resolve recorded events (synchronises on them); fills count[k] and total_ms[k] for k < MMK_K_COUNT */
@@ -236,6 +236,14 @@ int mmk_bias_act_part_blocks(long rows);
 int mmk_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, int d, int act, int dtype, void* stream);
 int mmk_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx, float* part, float* part2, float* dbias, int64_t rows,
                      int d, int act, int dtype, void* stream);
+
+/* Weight gradient of a Linear, dW[N, K] = dY^T x for dY [M, N], x [M, K] (bf16, row strides ldy / ldx in elements):
+ * replaces the dY.t() @ x GEMM of autograd's linear backward where its output is too small to fill the chip
+ * (attention output projections: 768 x 768 over M = 201,728).  Split over M, partial tiles in `ws`
+ * (mmk_wgrad_plan gives the element count), summed into dw (out_dtype, row stride ldw). */
+int mmk_wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* ws_floats_out);
+int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx, int64_t ldw,
+              int out_dtype, void* stream);
 
 /* HF QuickGELUActivation  x * sigmoid(1.702 x)  (CLIP MLP), forward and backward, n elements (multiple of 4) */
 int mmk_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);

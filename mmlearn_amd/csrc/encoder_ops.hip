@@ -369,6 +369,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ p
   out[(size_t)blockIdx.y * n_cols + c] = s;
 }
 
+// second stage: column sums of the `n_rows` slice rows of a [n_rows][np * d] buffer, slab p written straight to outs[p]
+struct ColsumOuts {
+  float* p[3];
+};
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int n_rows, int d, int np, ColsumOuts outs) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= np * d) return;
+  float s = 0.f;
+  for (int r = 0; r < n_rows; ++r) s += part[(size_t)r * np * d + c];
+  outs.p[c / d][c % d] = s;
+}
+
 // ------------------------------------------------------------------ quick-GELU (x * sigmoid(1.702 x))
 template <typename T>
 __global__ __launch_bounds__(256) void quick_gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n4) {
@@ -457,10 +469,9 @@ int mmk_layernorm_bwd(const void* x, const void* dy, const float* w, const float
     const int slices = std::min(64, n_blocks);
     const int rpb = (n_blocks + slices - 1) / slices;
     hipLaunchKernelGGL(colsum_kernel, dim3((2 * d + 255) / 256, slices), dim3(256), 0, st, part, n_blocks, 2 * d, part2, rpb);
-    hipLaunchKernelGGL(colsum_kernel, dim3((2 * d + 255) / 256, 1), dim3(256), 0, st, part2, slices, 2 * d, part, slices);
+    ColsumOuts outs = {{dw, db, nullptr}};
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, st, part2, slices, d, 2, outs);
     MMK_LAUNCH_CHECK();
-    MMK_HIP(hipMemcpyAsync(dw, part, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
-    MMK_HIP(hipMemcpyAsync(db, part + d, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
   }
   return 0;
 }
@@ -539,11 +550,9 @@ int mmk_add_layernorm_bwd(const float* s, const void* dy, const float* ds_in, co
     const int slices = std::min(64, n_blocks);
     const int rpb = (n_blocks + slices - 1) / slices;
     hipLaunchKernelGGL(colsum_kernel, dim3((np * d + 255) / 256, slices), dim3(256), 0, st, part, n_blocks, np * d, part2, rpb);
-    hipLaunchKernelGGL(colsum_kernel, dim3((np * d + 255) / 256, 1), dim3(256), 0, st, part2, slices, np * d, part, slices);
+    ColsumOuts outs = {{dw, db, dxbias}};
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((np * d + 255) / 256), dim3(256), 0, st, part2, slices, d, np, outs);
     MMK_LAUNCH_CHECK();
-    MMK_HIP(hipMemcpyAsync(dw, part, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
-    MMK_HIP(hipMemcpyAsync(db, part + d, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
-    if (dxbias) MMK_HIP(hipMemcpyAsync(dxbias, part + 2 * d, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
   }
   return 0;
 }

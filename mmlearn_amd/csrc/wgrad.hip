@@ -1,0 +1,236 @@
+// weight-gradient GEMM of the encoders' Linear layers,  dW[N, K] = dY^T x  with  dY [M, N], x [M, K]
+// row-major and the contraction over the M = batch * tokens rows (201,728 for ViT-B/16 at B = 1024).  For the
+// attention output projections the result is only 768 x 768: nine 256 x 256 tiles cannot fill 256 CUs, and the
+// library's answer to that (hipBLASLt, any operand layout, also after TunableOp) runs at 300-380 TFLOP/s -- 0.7 ms for a
+// GEMM whose operands stream from HBM in 0.12 ms.  This kernel splits M across the chip instead:
+//   * work unit = (M split, 256 x 256 output tile); all tiles of a split are placed on ONE XCD and walk the rows in
+//     step, so each dY / x row block comes from HBM once and serves the split's other tiles from that XCD's L2;
+//   * both operands have the contraction along their ROWS, so neither can be read as an MFMA fragment directly: the
+//     [64 rows][256 columns] stages are filled by LDS-DMA (global_load_lds_dwordx4, swizzled on the source chunk) and
+//     read with the hardware transpose read ds_read_b64_tr_b16 -- no transposed copy of dY or x ever exists;
+//   * 8 waves as 4 x 2, 64 x 128 per wave = 8 accumulator tiles of v_mfma_f32_32x32x16_bf16, two LDS stages (128 KiB);
+//   * f32 partial tiles go to a workspace, a second kernel sums the splits (deterministic, no atomics) and writes dW in
+//     the parameter's dtype.
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace mmk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int WG_TILE = 256;   // output tile edge
+constexpr int WG_BM = 64;      // contraction rows per LDS stage
+constexpr int WG_STAGE = WG_BM * WG_TILE * 2;  // bytes of one operand stage (32 KiB)
+
+struct WgradArgs {
+  const bf16_t* dy;  // [M, N], row stride ldy
+  const bf16_t* x;   // [M, K], row stride ldx
+  float* ws;         // [splits][N_pad][K_pad] partial tiles (N_pad, K_pad = multiples of 256)
+  long ldy, ldx;
+  int M, N, K;
+  int splits, tiles_n, tiles_k, rows_per_split;
+};
+
+__device__ __forceinline__ void wg_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+  const uint64_t pb = reinterpret_cast<uint64_t>(sbase);
+  const uint64_t ps = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pb >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb);
+  lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(reinterpret_cast<const void*>(ps)), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ int wg_opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// LDS stage image: 64 rows x 512 B, 16-byte chunk index (0..31) ^= (row & 3) << 2: the four rows of a transposed-read
+// block land in four different 64-byte groups of a 256-byte bank window (conflict-free ds_read_b64_tr_b16).
+// Fill: piece p (0..31) = rows 2p, 2p+1; lane l writes chunk position l & 31 of row 2p + (l >> 5).
+__device__ __forceinline__ void wg_fill(char* stage, const bf16_t* base, long ld, int col0, int ncols, long row0, long row_end, int wave,
+                                        int lane) {
+  const uint32_t saddr = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)stage);
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = wave_s * 4 + i;
+    const int rr = 2 * p + (lane >> 5);
+    const int ch = (lane & 31) ^ ((rr & 3) << 2);
+    // rows past the split's end and columns past the operand's width read a valid address (row / column clamped); the
+    // main loop zeroes the fragments of out-of-range rows, out-of-range columns only reach workspace padding
+    const long srow = min(row0 + 2 * p, row_end - 1);                  // wave-uniform part of the address
+    const int drow = (int)(min(row0 + rr, row_end - 1) - srow);        // 0 or 1
+    const int col = min(col0 + ch * 8, ncols - 8);
+    wg_dma16(base + srow * ld, (uint32_t)(drow * (int)ld + col) * 2u, saddr + p * 1024);
+  }
+}
+
+template <typename OUT>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, OUT* __restrict__ dw, long ldw, int N, int K,
+                                                           int n_pad, int k_pad, int splits) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int k4 = K / 4;
+  if (idx >= (long)N * k4) return;
+  const int n = (int)(idx / k4), k = (int)(idx % k4) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < splits; ++s) {
+    const float4 v = *reinterpret_cast<const float4*>(ws + ((size_t)s * n_pad + n) * k_pad + k);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  Vec4<OUT>::store(dw + (long)n * ldw + k, acc);
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware unit map: block b runs on XCD b % 8; XCD x owns splits x, x + 8, ...; consecutive slots of an XCD are the
+  // tiles of one split
+  const int T = a.tiles_n * a.tiles_k;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int split = (slot / T) * 8 + xcd, tile = slot % T;
+  if (split >= a.splits) return;
+  const int tn = tile / a.tiles_k, tk = tile % a.tiles_k;
+  const long row0 = (long)split * a.rows_per_split;
+  const long row_end = min((long)a.M, row0 + a.rows_per_split);
+  const int nstages = (int)((row_end - row0 + WG_BM - 1) / WG_BM);
+
+  const int wm = wave >> 1, wn = wave & 1;  // wave grid 4 x 2: output rows 64 wm.., output columns 128 wn..
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // per-lane transposed-read offsets inside a stage (natural k order: element jj <-> stage row 16 ks + 8h + jj)
+  const int li = lane & 15, q = li >> 2, p = li & 3, g1 = (lane >> 4) & 1, h = lane >> 5;
+  // element (row, 16-B chunk c) of a stage sits at chunk position c ^ ((row & 3) << 2); for the 32-column tile t the
+  // block's chunks are 4t + 2 g1 + (p >> 1), and row & 3 == q, so the swizzle turns into the tile index t ^ q
+  int troff[2], xa[2], xb[4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) troff[u] = (8 * h + 4 * u + q) * 512 + ((2 * g1 + (p >> 1)) << 4) + 8 * (p & 1);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) xa[i] = (((wm * 2 + i) ^ q) << 6);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xb[j] = (((wn * 4 + j) ^ q) << 6);
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  auto tr8 = [&](const char* base) {
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base + troff[0]));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base + troff[1]));
+    s8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, f);
+  };
+
+  auto issue = [&](int st) {
+    char* sa = smem + (st & 1) * 2 * WG_STAGE;
+    const int lo = wg_opaque(lane);
+    wg_fill(sa, a.dy, a.ldy, tn * WG_TILE, a.N, row0 + (long)st * WG_BM, row_end, wave, lo);
+    wg_fill(sa + WG_STAGE, a.x, a.ldx, tk * WG_TILE, a.K, row0 + (long)st * WG_BM, row_end, wave, lo);
+  };
+  issue(0);
+  for (int st = 0; st < nstages; ++st) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of stage st
+    __syncthreads();                     // stage st complete; every wave is done with the other buffer
+    if (st + 1 < nstages) issue(st + 1);
+    char* sa = smem + (st & 1) * 2 * WG_STAGE;
+    char* sb = sa + WG_STAGE;
+    // rows of the last stage beyond the split: their filler (a repeated valid row) must not be accumulated
+    const int valid = (int)min((long)WG_BM, row_end - (row0 + (long)st * WG_BM));
+    const int ksteps = (valid + 15) / 16;
+#pragma unroll 1
+    for (int ks = 0; ks < ksteps; ++ks) {
+      bf16x8 af[2], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = tr8(sa + ks * 8192 + xa[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = tr8(sb + ks * 8192 + xb[j]);
+      if (valid < WG_BM && (ks + 1) * 16 > valid) {  // partial k-step: zero the elements of rows >= valid
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+          if (ks * 16 + 8 * h + jj >= valid) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i][jj] = (bf16_t)0.f;
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // ---- partial tile -> workspace: acc[i][j][e] = C[n = 64 wm + 32 i + (e&3) + 8(e>>2) + 4h][k = 128 wn + 32 j + (lane&31)]
+  const int n_pad = a.tiles_n * WG_TILE, k_pad = a.tiles_k * WG_TILE;
+  float* wsb = a.ws + ((size_t)split * n_pad + (size_t)tn * WG_TILE) * k_pad + (size_t)tk * WG_TILE;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        wsb[(size_t)n * k_pad + 128 * wn + 32 * j + (lane & 31)] = acc[i][j][e];
+      }
+}
+
+}  // namespace mmk
+
+using namespace mmk;
+
+extern "C" {
+
+// plan: number of M splits and workspace floats for a [N, K] weight gradient over M rows
+int mmk_wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* ws_floats_out) {
+  MMK_REQUIRE(M > 0 && N > 0 && K > 0 && splits_out && ws_floats_out, "bad arguments");
+  const int tn = cdiv(N, WG_TILE), tk = cdiv(K, WG_TILE);
+  int splits = std::max(1, 256 / (tn * tk));
+  splits = (int)std::min<int64_t>(splits, std::max<int64_t>(1, M / 512));
+  *splits_out = splits;
+  *ws_floats_out = (int64_t)splits * tn * WG_TILE * tk * WG_TILE;
+  return 0;
+}
+
+int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx, int64_t ldw,
+              int out_dtype, void* stream) {
+  MMK_REQUIRE(dy && x && dw && ws && M > 0 && N > 0 && K > 0, "bad arguments");
+  MMK_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldw % 4 == 0, "wgrad: N, K and the row strides must be multiples of 8");
+  WgradArgs a;
+  a.dy = static_cast<const bf16_t*>(dy); a.x = static_cast<const bf16_t*>(x); a.ws = ws;
+  a.ldy = ldy; a.ldx = ldx; a.M = (int)M; a.N = N; a.K = K;
+  a.tiles_n = cdiv(N, WG_TILE); a.tiles_k = cdiv(K, WG_TILE);
+  int64_t wsf;
+  mmk_wgrad_plan(M, N, K, &a.splits, &wsf);
+  a.rows_per_split = round_up((int)cdiv((int)M, a.splits), WG_BM);
+  a.splits = cdiv((int)M, a.rows_per_split);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int T = a.tiles_n * a.tiles_k;
+  const int grid = 8 * cdiv(a.splits, 8) * T;
+  static bool attr = false;
+  const int bytes = 4 * WG_STAGE;
+  if (!attr) {
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr = true;
+  }
+  {
+    ProfEvents pe(MMK_K_WGRAD);
+    hipExtLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(512), bytes, st, pe.start, pe.stop, 0, a);
+  }
+  MMK_LAUNCH_CHECK();
+  const long n4 = (long)N * (K / 4);
+  const int n_pad = a.tiles_n * WG_TILE, k_pad = a.tiles_k * WG_TILE;
+  int rc = MMK_DISPATCH_DTYPE(out_dtype, OUT, [&]() -> int {
+    hipLaunchKernelGGL((wgrad_reduce_kernel<OUT>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, ws, static_cast<OUT*>(dw), (long)ldw,
+                       N, K, n_pad, k_pad, a.splits);
+    return 0;
+  });
+  if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+}

@@ -180,8 +180,45 @@ def bias_act(x: torch.Tensor, bias: torch.Tensor, act: str) -> torch.Tensor:
     return _BiasActFn.apply(x, bias, {"quick_gelu": K.ACT_QUICK_GELU, "gelu": K.ACT_GELU}[act])
 
 
+class _LinearSmallOutFn(torch.autograd.Function):
+    """Bias-free ``x @ W^T`` in bf16 whose weight gradient ``dY^T x`` runs on ``csrc/wgrad.hip`` (split over the rows,
+    f32 sums, written straight in the parameter's dtype) -- for weights so small that the library GEMM cannot fill the
+    chip with output tiles (768 x 768 attention output projections: 0.75 -> 0.46 ms at M = 201,728)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        k = x.shape[-1]
+        x2 = x.reshape(-1, k).to(torch.bfloat16)
+        w16 = w.detach().to(torch.bfloat16)
+        ctx.save_for_backward(x2, w16)
+        ctx.x_shape, ctx.x_dtype, ctx.w_dtype = x.shape, x.dtype, w.dtype
+        with torch.autocast("cuda", enabled=False):
+            y = x2 @ w16.t()
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w16 = ctx.saved_tensors
+        dy2 = dy.reshape(-1, w16.shape[0]).to(torch.bfloat16).contiguous()
+        dx = dw = None
+        with torch.autocast("cuda", enabled=False):
+            if ctx.needs_input_grad[0]:
+                dx = (dy2 @ w16).view(ctx.x_shape).to(ctx.x_dtype)
+            if ctx.needs_input_grad[1]:
+                dw = K.wgrad(dy2, x2, ctx.w_dtype if ctx.w_dtype in (torch.float32, torch.bfloat16) else torch.float32).to(ctx.w_dtype)
+        return dx, dw
+
+
+def _small_out_linear(lin: nn.Linear, x: torch.Tensor) -> bool:
+    rows = x.numel() // max(x.shape[-1], 1)
+    return (x.is_cuda and lin.out_features * lin.in_features <= 1024 * 1024 and lin.out_features % 8 == 0 and lin.in_features % 8 == 0
+            and rows >= 16384 and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)))
+
+
 def linear_nobias(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     """``x @ W^T`` of an ``nn.Linear`` whose bias is added by the consumer kernel (``add_layer_norm`` / ``bias_act``)."""
+    if _small_out_linear(lin, x) and torch.is_grad_enabled() and lin.weight.requires_grad:
+        return _LinearSmallOutFn.apply(x, lin.weight)
     return F.linear(x, lin.weight, None)
 
 

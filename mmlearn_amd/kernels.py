@@ -407,6 +407,20 @@ def add_layernorm_bwd(s2: torch.Tensor, dy2: torch.Tensor, ds_in: Optional[torch
     return dr, dx, dw, db, dxb
 
 
+def wgrad(dy2: torch.Tensor, x2: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """dW [N, K] = dy2^T @ x2 for bf16 dy2 [M, N], x2 [M, K] (rows contiguous), summed in f32, returned in out_dtype."""
+    require_gpu(dy2)
+    assert dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and dy2.stride(1) == 1 and x2.stride(1) == 1 and dy2.shape[0] == x2.shape[0]
+    M, N = dy2.shape
+    K_ = x2.shape[1]
+    splits, wsf = C.c_int(0), C.c_int64(0)
+    check(_lib.lib().mmk_wgrad_plan(M, N, K_, C.cast(C.pointer(splits), C.c_void_p), C.cast(C.pointer(wsf), C.c_void_p)))
+    ws = torch.empty(wsf.value, dtype=torch.float32, device=dy2.device)
+    dw = torch.empty((N, K_), dtype=out_dtype, device=dy2.device)
+    check(_lib.lib().mmk_wgrad(ptr(dy2), ptr(x2), ptr(dw), ptr(ws), M, N, K_, dy2.stride(0), x2.stride(0), dw.stride(0), dtype_tag(out_dtype), stream()))
+    return dw
+
+
 ACT_QUICK_GELU, ACT_GELU = 0, 1
 
 

@@ -1,0 +1,64 @@
+"""GPU parity of the split-M weight-gradient GEMM (csrc/wgrad.hip) against a plain PyTorch f32 reference."""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 768, 768), (1000, 256, 512), (77 * 13, 768, 3072), (64, 8, 8), (5000, 2304, 768),
+                                   (130, 520, 264)])
+def test_wgrad_vs_torch(M, N, K):
+    from mmlearn_amd import kernels as Kn
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, N, generator=g).bfloat16()
+    x = torch.randn(M, K, generator=g).bfloat16()
+    ref = dy.float().t() @ x.float()
+    for out_dtype in (torch.float32, torch.bfloat16):
+        dw = Kn.wgrad(dy.to(dev), x.to(dev), out_dtype)
+        assert dw.shape == (N, K) and dw.dtype == out_dtype
+        err = (dw.float().cpu() - ref).abs().max().item()
+        tol = (2e-3 if out_dtype == torch.float32 else 1e-2) * max(1.0, ref.abs().max().item())
+        assert err <= tol, (out_dtype, err, ref.abs().max().item())
+
+
+def test_wgrad_strided_operands():
+    """Operands that are column slices of wider buffers (row stride != width), as the packed QKV gradient is."""
+    from mmlearn_amd import kernels as Kn
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    big_dy = torch.randn(3000, 3 * 256, generator=g).bfloat16().to(dev)
+    big_x = torch.randn(3000, 512 + 64, generator=g).bfloat16().to(dev)
+    dy, x = big_dy[:, 256:512], big_x[:, 64:]
+    ref = dy.float().t() @ x.float()
+    dw = Kn.wgrad(dy, x)
+    assert (dw - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+def test_small_out_linear_function_matches_f_linear():
+    """The autograd wrapper used for the attention output projections (bias-free Linear, HIP weight gradient)."""
+    import torch.nn.functional as F
+
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(256, 128).to(dev)
+    x0 = torch.randn(40, 500, 256, device=dev)
+    w = torch.randn(40, 500, 128, device=dev)
+    outs = []
+    for custom in (False, True):
+        lin.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert fused._small_out_linear(lin, x)
+            y = fused.linear_nobias(lin, x) if custom else F.linear(x, lin.weight, None)
+        assert y.dtype == torch.bfloat16
+        (y.float() * w).sum().backward()
+        outs.append((y.float().detach(), x.grad.clone(), lin.weight.grad.clone()))
+    for a, b, name in zip(outs[0], outs[1], ("y", "dx", "dw")):
+        assert a.dtype == b.dtype
+        assert (a - b).abs().max() <= 2e-2 * a.abs().max(), name

@@ -1,0 +1,22 @@
+"""Weight-gradient GEMM: csrc/wgrad.hip vs hipBLASLt (dY.t() @ x) at the encoder shapes."""
+import json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmlearn_amd import kernels as K
+dev = torch.device("cuda", 0)
+def t(fn, it=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(it): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / it * 1e6
+for M in (1024 * 197, 1024 * 77):
+    for N, K_ in ((768, 768), (768, 3072), (3072, 768), (2304, 768)):
+        dy = torch.randn(M, N, device=dev).bfloat16()
+        x = torch.randn(M, K_, device=dev).bfloat16()
+        res = {"M": M, "N": N, "K": K_, "GF": round(2 * M * N * K_ / 1e9)}
+        res["hipblaslt_us"] = round(t(lambda: dy.t() @ x), 1)
+        res["wgrad_us"] = round(t(lambda: K.wgrad(dy, x)), 1)
+        res["wgrad_TFs"] = round(2 * M * N * K_ / res["wgrad_us"] / 1e6, 1)
+        ref = dy.t() @ x
+        res["max_rel_err"] = float(((K.wgrad(dy, x) - ref.float()).abs().max() / ref.float().abs().max()).item())
+        print(json.dumps(res))

@@ -8,7 +8,8 @@
 //   * both operands have the contraction along their ROWS, so neither can be read as an MFMA fragment directly: the
 //     [64 rows][256 columns] stages are filled by LDS-DMA (global_load_lds_dwordx4, swizzled on the source chunk) and
 //     read with the hardware transpose read ds_read_b64_tr_b16 -- no transposed copy of dY or x ever exists;
-//   * 8 waves as 4 x 2, 64 x 128 per wave = 8 accumulator tiles of v_mfma_f32_32x32x16_bf16, two LDS stages (128 KiB);
+//   * 16 waves as 4 x 4, 64 x 64 per wave = 4 accumulator tiles of v_mfma_f32_32x32x16_bf16 (four waves per SIMD hide
+//     the LDS latency without software pipelining), two LDS stages (128 KiB);
 //   * f32 partial tiles go to a workspace, a second kernel sums the splits (deterministic, no atomics) and writes dW in
 //     the parameter's dtype.
 #include <hip/hip_ext.h>
@@ -55,8 +56,8 @@ __device__ __forceinline__ void wg_fill(char* stage, const bf16_t* base, long ld
   const uint32_t saddr = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)stage);
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = wave_s * 4 + i;
+  for (int i = 0; i < 2; ++i) {
+    const int p = wave_s * 2 + i;
     const int rr = 2 * p + (lane >> 5);
     const int ch = (lane & 31) ^ ((rr & 3) << 2);
     // rows past the split's end and columns past the operand's width read a valid address (row / column clamped); the
@@ -83,26 +84,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   Vec4<OUT>::store(dw + (long)n * ldw + k, acc);
 }
 
-__global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware unit map: block b runs on XCD b % 8; XCD x owns splits x, x + 8, ...; consecutive slots of an XCD are the
   // tiles of one split
   const int T = a.tiles_n * a.tiles_k;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int split = (slot / T) * 8 + xcd, tile = slot % T;
+  int split, tile;
+  if (T <= 32) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    split = (slot / T) * 8 + xcd;
+    tile = slot % T;
+  } else {  // more tiles than one XCD has CUs: plain order
+    split = blockIdx.x / T;
+    tile = blockIdx.x % T;
+  }
   if (split >= a.splits) return;
   const int tn = tile / a.tiles_k, tk = tile % a.tiles_k;
   const long row0 = (long)split * a.rows_per_split;
   const long row_end = min((long)a.M, row0 + a.rows_per_split);
   const int nstages = (int)((row_end - row0 + WG_BM - 1) / WG_BM);
 
-  const int wm = wave >> 1, wn = wave & 1;  // wave grid 4 x 2: output rows 64 wm.., output columns 128 wn..
-  f32x16 acc[2][4];
+  const int wm = wave >> 2, wn = wave & 3;  // wave grid 4 x 4: output rows 64 wm.., output columns 64 wn..
+  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -110,18 +118,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
   const int li = lane & 15, q = li >> 2, p = li & 3, g1 = (lane >> 4) & 1, h = lane >> 5;
   // element (row, 16-B chunk c) of a stage sits at chunk position c ^ ((row & 3) << 2); for the 32-column tile t the
   // block's chunks are 4t + 2 g1 + (p >> 1), and row & 3 == q, so the swizzle turns into the tile index t ^ q
-  int troff[2], xa[2], xb[4];
+  int troff[2], xa[2], xb[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) troff[u] = (8 * h + 4 * u + q) * 512 + ((2 * g1 + (p >> 1)) << 4) + 8 * (p & 1);
 #pragma unroll
   for (int i = 0; i < 2; ++i) xa[i] = (((wm * 2 + i) ^ q) << 6);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) xb[j] = (((wn * 4 + j) ^ q) << 6);
+  for (int j = 0; j < 2; ++j) xb[j] = (((wn * 2 + j) ^ q) << 6);
   typedef short s4 __attribute__((ext_vector_type(4)));
   typedef short s8 __attribute__((ext_vector_type(8)));
   auto tr8 = [&](const char* base) {
-    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base + troff[0]));
-    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base + troff[1]));
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base + (troff[1] - troff[0])));
     s8 f;
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
@@ -139,19 +147,21 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of stage st
     __syncthreads();                     // stage st complete; every wave is done with the other buffer
     if (st + 1 < nstages) issue(st + 1);
-    char* sa = smem + (st & 1) * 2 * WG_STAGE;
+    // per-stage base through an opaque value: the 12 per-lane fragment addresses are rebuilt here once per stage instead of
+    // being hoisted for both buffers out of the loop (LDS offsets >= 64 KiB do not fit an instruction immediate, the
+    // hoisted copies spilled)
+    char* sa = smem + wg_opaque((st & 1) * 2 * WG_STAGE) + troff[0];
     char* sb = sa + WG_STAGE;
-    // rows of the last stage beyond the split: their filler (a repeated valid row) must not be accumulated
     const int valid = (int)min((long)WG_BM, row_end - (row0 + (long)st * WG_BM));
     const int ksteps = (valid + 15) / 16;
 #pragma unroll 1
     for (int ks = 0; ks < ksteps; ++ks) {
-      bf16x8 af[2], bfr[4];
+      bf16x8 af[2], bfr[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) af[i] = tr8(sa + ks * 8192 + xa[i]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = tr8(sb + ks * 8192 + xb[j]);
-      if (valid < WG_BM && (ks + 1) * 16 > valid) {  // partial k-step: zero the elements of rows >= valid
+      for (int j = 0; j < 2; ++j) bfr[j] = tr8(sb + ks * 8192 + xb[j]);
+      if ((ks + 1) * 16 > valid) {  // last stage of the last split: rows >= valid hold filler (a repeated valid row)
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj)
           if (ks * 16 + 8 * h + jj >= valid) {
@@ -162,20 +172,20 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   }
-  // ---- partial tile -> workspace: acc[i][j][e] = C[n = 64 wm + 32 i + (e&3) + 8(e>>2) + 4h][k = 128 wn + 32 j + (lane&31)]
+  // ---- partial tile -> workspace: acc[i][j][e] = C[n = 64 wm + 32 i + (e&3) + 8(e>>2) + 4h][k = 64 wn + 32 j + (lane&31)]
   const int n_pad = a.tiles_n * WG_TILE, k_pad = a.tiles_k * WG_TILE;
   float* wsb = a.ws + ((size_t)split * n_pad + (size_t)tn * WG_TILE) * k_pad + (size_t)tk * WG_TILE;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int n = 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        wsb[(size_t)n * k_pad + 128 * wn + 32 * j + (lane & 31)] = acc[i][j][e];
+        wsb[(size_t)n * k_pad + 64 * wn + 32 * j + (lane & 31)] = acc[i][j][e];
       }
 }
 
@@ -188,8 +198,9 @@ extern "C" {
 // plan: number of M splits and workspace floats for a [N, K] weight gradient over M rows
 int mmk_wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* ws_floats_out) {
   MMK_REQUIRE(M > 0 && N > 0 && K > 0 && splits_out && ws_floats_out, "bad arguments");
-  const int tn = cdiv(N, WG_TILE), tk = cdiv(K, WG_TILE);
-  int splits = std::max(1, 256 / (tn * tk));
+  const int tn = cdiv(N, WG_TILE), tk = cdiv(K, WG_TILE), T = tn * tk;
+  // one workgroup per CU and a single round: with T <= 32 tiles every XCD (32 CUs) hosts floor(32 / T) whole splits
+  int splits = T <= 32 ? 8 * (32 / T) : std::max(1, 256 / T);
   splits = (int)std::min<int64_t>(splits, std::max<int64_t>(1, M / 512));
   *splits_out = splits;
   *ws_floats_out = (int64_t)splits * tn * WG_TILE * tk * WG_TILE;
@@ -210,7 +221,7 @@ int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int
   a.splits = cdiv((int)M, a.rows_per_split);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int T = a.tiles_n * a.tiles_k;
-  const int grid = 8 * cdiv(a.splits, 8) * T;
+  const int grid = T <= 32 ? 8 * cdiv(a.splits, 8) * T : a.splits * T;
   static bool attr = false;
   const int bytes = 4 * WG_STAGE;
   if (!attr) {
@@ -219,7 +230,7 @@ int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int
   }
   {
     ProfEvents pe(MMK_K_WGRAD);
-    hipExtLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(512), bytes, st, pe.start, pe.stop, 0, a);
+    hipExtLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
   }
   MMK_LAUNCH_CHECK();
   const long n4 = (long)N * (K / 4);

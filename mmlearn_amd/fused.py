@@ -180,46 +180,57 @@ def bias_act(x: torch.Tensor, bias: torch.Tensor, act: str) -> torch.Tensor:
     return _BiasActFn.apply(x, bias, {"quick_gelu": K.ACT_QUICK_GELU, "gelu": K.ACT_GELU}[act])
 
 
-class _LinearSmallOutFn(torch.autograd.Function):
-    """Bias-free ``x @ W^T`` in bf16 whose weight gradient ``dY^T x`` runs on ``csrc/wgrad.hip`` (split over the rows,
-    f32 sums, written straight in the parameter's dtype) -- for weights so small that the library GEMM cannot fill the
-    chip with output tiles (768 x 768 attention output projections: 0.75 -> 0.46 ms at M = 201,728)."""
+class _LinearWgradFn(torch.autograd.Function):
+    """``x @ W^T (+ b)`` in bf16 whose weight gradient ``dY^T x`` runs on ``csrc/wgrad.hip`` (split over the rows, f32 sums,
+    written straight in the parameter's dtype).  At the encoder shapes (M = batch x tokens = 201,728 / 78,848 rows) that
+    GEMM is where the library is weakest -- 0.75 -> 0.30 ms for the 768 x 768 projections, 1.1-1.4 -> 0.75-0.97 ms for
+    the 2304- and 3072-wide ones -- because an output of a few hundred tiles with a contraction of 10^5 rows needs the
+    split over M and the shared-L2 placement more than it needs a big tile."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, b):
         k = x.shape[-1]
         x2 = x.reshape(-1, k).to(torch.bfloat16)
         w16 = w.detach().to(torch.bfloat16)
         ctx.save_for_backward(x2, w16)
         ctx.x_shape, ctx.x_dtype, ctx.w_dtype = x.shape, x.dtype, w.dtype
+        ctx.b_dtype = None if b is None else b.dtype
         with torch.autocast("cuda", enabled=False):
-            y = x2 @ w16.t()
+            y = x2 @ w16.t() if b is None else torch.addmm(b.detach().to(torch.bfloat16), x2, w16.t())
         return y.view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, w16 = ctx.saved_tensors
         dy2 = dy.reshape(-1, w16.shape[0]).to(torch.bfloat16).contiguous()
-        dx = dw = None
+        dx = dw = db = None
         with torch.autocast("cuda", enabled=False):
             if ctx.needs_input_grad[0]:
                 dx = (dy2 @ w16).view(ctx.x_shape).to(ctx.x_dtype)
             if ctx.needs_input_grad[1]:
                 dw = K.wgrad(dy2, x2, ctx.w_dtype if ctx.w_dtype in (torch.float32, torch.bfloat16) else torch.float32).to(ctx.w_dtype)
-        return dx, dw
+            if ctx.b_dtype is not None and ctx.needs_input_grad[2]:
+                db = dy2.sum(0, dtype=torch.float32).to(ctx.b_dtype)
+        return dx, dw, db
 
 
-def _small_out_linear(lin: nn.Linear, x: torch.Tensor) -> bool:
+def _wgrad_linear_ok(weight: torch.Tensor, x: torch.Tensor) -> bool:
     rows = x.numel() // max(x.shape[-1], 1)
-    return (x.is_cuda and lin.out_features * lin.in_features <= 1024 * 1024 and lin.out_features % 8 == 0 and lin.in_features % 8 == 0
-            and rows >= 16384 and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)))
+    return (x.is_cuda and weight.dim() == 2 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0 and rows >= 16384
+            and torch.is_grad_enabled() and weight.requires_grad
+            and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)))
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.linear`` with the HIP weight-gradient kernel in its backward where that applies (bf16, >= 16k rows)."""
+    if _wgrad_linear_ok(weight, x):
+        return _LinearWgradFn.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
 
 
 def linear_nobias(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     """``x @ W^T`` of an ``nn.Linear`` whose bias is added by the consumer kernel (``add_layer_norm`` / ``bias_act``)."""
-    if _small_out_linear(lin, x) and torch.is_grad_enabled() and lin.weight.requires_grad:
-        return _LinearSmallOutFn.apply(x, lin.weight)
-    return F.linear(x, lin.weight, None)
+    return linear(x, lin.weight, None)
 
 
 def _act_name(fn) -> Optional[str]:
@@ -363,7 +374,7 @@ def _fused_qkv(self, hidden_states: torch.Tensor, names, scale: float, dropout_p
         return None
     w = torch.cat([q.weight, k.weight, v.weight], 0)
     b = None if q.bias is None else torch.cat([q.bias, k.bias, v.bias], 0)
-    qkv = F.linear(hidden_states, w, b)                      # [B, L, 3E] in the autocast dtype
+    qkv = linear(hidden_states, w, b)                        # [B, L, 3E] in the autocast dtype
     if qkv.dtype != torch.bfloat16:
         return None
     out = attention_qkvpacked(qkv.view(B, L, 3, E // 64, 64), scale, dropout_p)

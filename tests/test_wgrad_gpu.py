@@ -38,7 +38,7 @@ def test_wgrad_strided_operands():
     assert (dw - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
 
 
-def test_small_out_linear_function_matches_f_linear():
+def test_wgrad_linear_function_matches_f_linear():
     """The autograd wrapper used for the attention output projections (bias-free Linear, HIP weight gradient)."""
     import torch.nn.functional as F
 
@@ -54,11 +54,11 @@ def test_small_out_linear_function_matches_f_linear():
         lin.zero_grad(set_to_none=True)
         x = x0.clone().requires_grad_(True)
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            assert fused._small_out_linear(lin, x)
-            y = fused.linear_nobias(lin, x) if custom else F.linear(x, lin.weight, None)
+            assert fused._wgrad_linear_ok(lin.weight, x)
+            y = fused.linear(x, lin.weight, lin.bias) if custom else F.linear(x, lin.weight, lin.bias)
         assert y.dtype == torch.bfloat16
         (y.float() * w).sum().backward()
-        outs.append((y.float().detach(), x.grad.clone(), lin.weight.grad.clone()))
-    for a, b, name in zip(outs[0], outs[1], ("y", "dx", "dw")):
+        outs.append((y.float().detach(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()))
+    for a, b, name in zip(outs[0], outs[1], ("y", "dx", "dw", "db")):
         assert a.dtype == b.dtype
         assert (a - b).abs().max() <= 2e-2 * a.abs().max(), name

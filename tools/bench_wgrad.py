@@ -3,6 +3,7 @@ import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmlearn_amd import kernels as K
+from mmlearn_amd import _lib
 dev = torch.device("cuda", 0)
 def t(fn, it=10):
     for _ in range(3): fn()
@@ -16,6 +17,11 @@ for M in (1024 * 197, 1024 * 77):
         res = {"M": M, "N": N, "K": K_, "GF": round(2 * M * N * K_ / 1e9)}
         res["hipblaslt_us"] = round(t(lambda: dy.t() @ x), 1)
         res["wgrad_us"] = round(t(lambda: K.wgrad(dy, x)), 1)
+        _lib.profile_enable(True); _lib.profile_read()
+        for _ in range(5): K.wgrad(dy, x)
+        torch.cuda.synchronize()
+        pr = _lib.profile_read(); _lib.profile_enable(False)
+        res["wgrad_main_kernel_us"] = round(pr["wgrad"][1] / pr["wgrad"][0] * 1e3, 1)
         res["wgrad_TFs"] = round(2 * M * N * K_ / res["wgrad_us"] / 1e6, 1)
         ref = dy.t() @ x
         res["max_rel_err"] = float(((K.wgrad(dy, x) - ref.float()).abs().max() / ref.float().abs().max()).item())

@@ -273,7 +273,7 @@ def main():
                                    f"per-GPU batch {args.batch}, {'local' if world == 1 else 'global-batch (all-gather)'} negatives"
                                    + (" [DEBUG small encoders]" if args.small else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": "mmlearn_amd.ContrastiveLoss (HIP)",
-                       "encoder_ops": "torch" if args.no_fused_encoder_ops else "HIP LayerNorm (+ fused residual add / dropout) + quick-GELU + fused-QKV attention for ViT and BERT (mmlearn_amd.fused / .attention)",
+                       "encoder_ops": "torch" if args.no_fused_encoder_ops else "HIP LayerNorm (+ fused residual add / dropout / deferred biases), bias+activation, fused-QKV attention, weight-gradient GEMM (mmlearn_amd.fused / .attention)",
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline,
         }

@@ -291,7 +291,8 @@ def _clip_layer_forward(self, hidden_states, attention_mask=None, **kwargs):
         out, y = add_layer_norm(m, h, nxt, xbias=mb)
         out._mmk_prenormed = y
         return out
-    return h + self.mlp(x2)
+    m, mb = _clip_mlp_nobias(self.mlp, x2)   # last layer: no next LayerNorm to fuse the add into
+    return h + m if mb is None else h + (m + mb)
 
 
 def _bert_output_forward(self, hidden_states, input_tensor):

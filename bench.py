@@ -105,15 +105,15 @@ def build_task(loss, small: bool, fused: bool = False):
     from mmlearn_amd.tasks.contrastive_pretraining import ContrastivePretraining
 
     torch.manual_seed(0)
-    rgb, text = VisionEncoder(small, hip_attention=fused and not small), TextEncoder(small, hip_attention=fused and not small)
+    rgb, text = VisionEncoder(small, hip_attention=fused), TextEncoder(small, hip_attention=fused)
     if fused:  # HIP LayerNorm / quick-GELU inside the encoders (same parameters, same math)
         from mmlearn_amd.fused import accelerate_encoder
 
         # CLIP is pre-LN: these LayerNorms feed autocast Linears only, so they may emit bf16 directly;
         # BERT is post-LN (the LN output is the residual stream) and keeps f32 outputs.
         add_ln = os.environ.get("MMK_BENCH_NO_ADD_LN") is None   # A/B switch for the fused residual add + LayerNorm
-        accelerate_encoder(rgb, low_precision_ln=("layer_norm1", "layer_norm2", "post_layernorm"), fuse_qkv=not small, fuse_add_ln=add_ln)
-        accelerate_encoder(text, fuse_qkv=not small, fuse_add_ln=add_ln)
+        accelerate_encoder(rgb, low_precision_ln=("layer_norm1", "layer_norm2", "post_layernorm"), fuse_qkv=True, fuse_add_ln=add_ln)
+        accelerate_encoder(text, fuse_qkv=True, fuse_add_ln=add_ln)
     return ContrastivePretraining(
         encoders={"rgb": rgb, "text": text},
         loss=loss,

@@ -1,0 +1,76 @@
+"""GPU: the bench's training step under DistributedDataParallel with every encoder-side fusion switched on.
+
+Two worker processes share cuda:0 and talk over gloo (RCCL refuses two ranks on one device; the loss's device
+collectives are staged through the host as in test_dist_gpu).  Checks that the patched HF encoders, the custom autograd
+functions (fused QKV attention, add + LayerNorm, bias + activation, HIP weight gradient) and the row-sharded loss run
+under DDP, give finite losses, and leave identical (all-reduced) gradients on both ranks.
+"""
+
+import os
+import sys
+import traceback
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        for p in (ROOT, os.path.join(ROOT, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from test_dist_gpu import _stage_collectives_through_host
+
+        _stage_collectives_through_host()
+        import bench
+        from mmlearn_amd import ContrastiveLoss
+
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(0)  # same initial weights on both ranks
+        task = bench.build_task(ContrastiveLoss(static_shapes=True), small=True, fused=True).to(dev)
+        stepper = torch.nn.parallel.DistributedDataParallel(bench._Step(task), device_ids=[0])
+        opt = task.configure_optimizers()
+        batch = bench.synthetic_batch(1024, rank, dev)   # 1024 x 17 tokens >= 16k rows: the wgrad path is live
+        losses = []
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = stepper(batch)
+            loss.backward()
+            gsum = torch.stack([p.grad.float().abs().sum() for p in task.parameters() if p.grad is not None]).sum()
+            opt.step()
+            losses.append((float(loss.detach().float().item()), float(gsum.item())))
+        q.put((rank, losses, None))
+    except Exception:  # pragma: no cover
+        q.put((rank, None, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_ddp_step_with_fused_encoders():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    res.sort(key=lambda r: r[0])
+    for rank, losses, err in res:
+        assert err is None, f"rank {rank}:\n{err}"
+    (l0, g0), (l1, g1) = res[0][1][0], res[1][1][0]
+    assert all(map(lambda v: v == v and abs(v) < 1e6, (l0, l1, g0, g1)))
+    assert abs(g0 - g1) <= 1e-3 * max(g0, 1e-6)          # DDP left the same averaged gradients on both ranks
+    assert res[0][1][1][0] == res[0][1][1][0]            # second step finite

@@ -245,6 +245,11 @@ int mmk_wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* ws_floats_
 int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx, int64_t ldw,
               int out_dtype, void* stream);
 
+/* im2col of a Conv2d whose stride equals its kernel (ViT patch embedding; HF CLIPVisionEmbeddings.patch_embedding,
+ * mmlearn/modules/layers/embedding.py PatchEmbed): out[(b, py, px)][(c, i, j)] = in[b][c][py P + i][px P + j] as bf16,
+ * so that the convolution runs as one GEMM against weight.view(E, C P P).  in: [B, C, H, W] of `dtype`, contiguous. */
+int mmk_patchify(const void* in, void* out, int B, int C, int H, int W, int P, int dtype, void* stream);
+
 /* HF QuickGELUActivation  x * sigmoid(1.702 x)  (CLIP MLP), forward and backward, n elements (multiple of 4) */
 int mmk_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
 int mmk_quick_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);

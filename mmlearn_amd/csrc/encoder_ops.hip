@@ -407,6 +407,26 @@ __global__ __launch_bounds__(256) void quick_gelu_bwd_kernel(const T* __restrict
   }
 }
 
+// ------------------------------------------------------------------ patchify (non-overlapping conv as a GEMM)
+// out[(b, py, px)][(c, i, j)] = in[b][c][py P + i][px P + j], cast to bf16: the im2col of a Conv2d whose stride equals its
+// kernel (ViT patch embedding) is a pure permutation, so the convolution becomes one [B gh gw, C P P] x [C P P, E] GEMM
+// (MIOpen's implicit-GEMM solvers + layout transposes took 5.7 ms per step for it, forward + weight gradient).
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ in, bf16_t* __restrict__ out, int B, int C, int H, int W,
+                                                       int P) {
+  const int gh = H / P, gw = W / P, cpp4 = C * P * P / 4, p4 = P / 4;
+  const long n4 = (long)B * gh * gw * cpp4;
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n4; o += (long)gridDim.x * 256) {
+    const int col4 = (int)(o % cpp4);
+    const long row = o / cpp4;
+    const int j4 = col4 % p4, i = (col4 / p4) % P, c = col4 / (p4 * P);
+    const int px = (int)(row % gw), py = (int)((row / gw) % gh);
+    const long b = row / ((long)gw * gh);
+    const float4 v = Vec4<T>::load(in + ((b * C + c) * H + (long)py * P + i) * W + (long)px * P + j4 * 4);
+    Vec4<bf16_t>::store(out + o * 4, v);
+  }
+}
+
 }  // namespace mmk
 
 using namespace mmk;
@@ -636,6 +656,21 @@ int mmk_quick_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int d
   int rc = MMK_DISPATCH_DTYPE(dtype, T, [&]() -> int {
     hipLaunchKernelGGL((quick_gelu_bwd_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(x), static_cast<const T*>(dy),
                        static_cast<T*>(dx), n4);
+    return 0;
+  });
+  if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+int mmk_patchify(const void* in, void* out, int B, int C, int H, int W, int P, int dtype, void* stream) {
+  MMK_REQUIRE(in && out && B > 0 && C > 0 && H > 0 && W > 0 && P > 0, "bad arguments");
+  MMK_REQUIRE(P % 4 == 0 && H % P == 0 && W % P == 0, "patchify: patch size must be a multiple of 4 and divide H and W");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long n4 = (long)B * (H / P) * (W / P) * (C * P * P / 4);
+  const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 256 * 32);
+  int rc = MMK_DISPATCH_DTYPE(dtype, T, [&]() -> int {
+    hipLaunchKernelGGL((patchify_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(in), static_cast<bf16_t*>(out), B, C, H, W, P);
     return 0;
   });
   if (rc) return rc;

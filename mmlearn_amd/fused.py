@@ -16,6 +16,8 @@ HBM-bound modules that dominate the non-GEMM time of the encoder step under bf16
 * :func:`fuse_add_layer_norm` -- the blocks' ``residual + sublayer(...)`` (+ BERT's hidden-state dropout) runs inside
   the following LayerNorm's kernel, forward and backward (the backward also absorbs the gradient-accumulation add and
   the f32 -> bf16 cast of the sublayer gradient).
+* :func:`patch_conv_as_gemm` -- a ``Conv2d`` whose stride equals its kernel (ViT patch embedding) runs as HIP im2col +
+  one GEMM (with the HIP weight gradient) instead of MIOpen's implicit GEMM and its layout transposes.
 * :func:`accelerate_encoder` swaps those modules in place inside any encoder (HF CLIP / BERT, mmlearn's own ViT).
 
 There is no CPU path: CPU tensors raise.
@@ -420,6 +422,33 @@ def fuse_qkv_attention(module: nn.Module) -> int:
     return n
 
 
+def _patch_conv_forward(self, x):
+    """Replaces the forward of an ``nn.Conv2d`` whose stride equals its kernel (ViT patch embedding): HIP im2col
+    (a permutation + cast) and one GEMM; the result is returned as a ``[B, E, gh, gw]`` view of the ``[B, gh gw, E]``
+    GEMM output, so the usual ``.flatten(2).transpose(1, 2)`` that follows is free."""
+    P = self.kernel_size[0]
+    bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)
+    if (x.dim() == 4 and x.is_cuda and bf16 and not x.requires_grad and P % 4 == 0 and x.shape[2] % P == 0 and x.shape[3] % P == 0
+            and x.dtype in (torch.float32, torch.bfloat16, torch.float16)):
+        B, _, H, W = x.shape
+        y = linear(K.patchify(x, P), self.weight.view(self.out_channels, -1), self.bias)
+        return y.view(B, H // P, W // P, self.out_channels).permute(0, 3, 1, 2)
+    return self._mmk_stock_forward(x)
+
+
+def patch_conv_as_gemm(module: nn.Module) -> int:
+    """Patch every ``nn.Conv2d`` with ``stride == kernel_size`` (square, no padding / dilation / groups) inside ``module``."""
+    n = 0
+    for m in module.modules():
+        if (type(m) is nn.Conv2d and m.kernel_size == m.stride and m.kernel_size[0] == m.kernel_size[1] and m.kernel_size[0] > 1
+                and m.padding == (0, 0) and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros"
+                and not hasattr(m, "_mmk_stock_forward")):
+            m._mmk_stock_forward = m.forward
+            m.forward = types.MethodType(_patch_conv_forward, m)
+            n += 1
+    return n
+
+
 def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), fuse_qkv: bool = False, fuse_add_ln: bool = False) -> dict:
     """Swap ``nn.LayerNorm`` -> :class:`LayerNorm` and quick-GELU activations -> :class:`QuickGELU` inside ``module`` (in place);
     with ``fuse_qkv`` also patch the attention modules (:func:`fuse_qkv_attention`), with ``fuse_add_ln`` the residual
@@ -443,4 +472,5 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
                 swapped["quick_gelu"] += 1
     if fuse_add_ln:  # after the LayerNorm swap, so the patched forwards see the modules' low_precision_out flags
         swapped["fused_add_ln"] = fuse_add_layer_norm(module)
+        swapped["patch_conv"] = patch_conv_as_gemm(module)
     return swapped

@@ -421,6 +421,16 @@ def wgrad(dy2: torch.Tensor, x2: torch.Tensor, out_dtype: torch.dtype = torch.fl
     return dw
 
 
+def patchify(x: torch.Tensor, patch: int) -> torch.Tensor:
+    """[B, C, H, W] (f32 / bf16 / f16, contiguous) -> bf16 [B * H/P * W/P, C * P * P]: im2col of a stride == kernel conv."""
+    require_gpu(x)
+    B, Cc, H, W = x.shape
+    x = x.contiguous()
+    out = torch.empty((B * (H // patch) * (W // patch), Cc * patch * patch), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mmk_patchify(ptr(x), ptr(out), B, Cc, H, W, int(patch), dtype_tag(x.dtype), stream()))
+    return out
+
+
 ACT_QUICK_GELU, ACT_GELU = 0, 1
 
 

@@ -230,3 +230,31 @@ def test_bias_act_vs_torch(rows, d, dt, act):
         assert e <= tol * max(1.0, b.abs().max().item()), (name, e)
     e = (bd.grad.cpu() - br.grad).abs().max().item()
     assert e <= (5e-2 if dt != torch.float32 else 1e-3) * max(1.0, br.grad.abs().max().item()), ("dbias", e)
+
+
+@pytest.mark.parametrize("B,C,H,W,P,E,bias", [(3, 3, 224, 224, 16, 768, False), (2, 3, 64, 96, 16, 64, True), (5, 4, 32, 32, 8, 40, True)])
+def test_patch_conv_as_gemm_matches_conv2d(B, C, H, W, P, E, bias):
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(B + P)
+    conv = torch.nn.Conv2d(C, E, kernel_size=P, stride=P, bias=bias).to(dev)
+    x = torch.rand(B, C, H, W, device=dev)
+    w = torch.randn(B, E, H // P, W // P, device=dev)
+    outs = []
+    for patched in (False, True):
+        if patched:
+            assert fused.patch_conv_as_gemm(conv) == 1
+        conv.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = conv(x)
+        assert y.shape == (B, E, H // P, W // P) and y.dtype == torch.bfloat16
+        t = y.flatten(2).transpose(1, 2)
+        assert t.shape == (B, (H // P) * (W // P), E)
+        (y.float() * w).sum().backward()
+        outs.append((y.float().detach(), conv.weight.grad.clone(), None if not bias else conv.bias.grad.clone()))
+    (y0, gw0, gb0), (y1, gw1, gb1) = outs
+    assert (y0 - y1).abs().max() <= 2e-2 * max(1.0, y0.abs().max().item())
+    assert (gw0 - gw1).abs().max() <= 2e-2 * max(1.0, gw0.abs().max().item())
+    if bias:
+        assert (gb0 - gb1).abs().max() <= 2e-2 * max(1.0, gb0.abs().max().item())

@@ -256,6 +256,19 @@ def main():
                         "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2),
                         "launches": cnt, "dominant_by_time": dom,
                         "loss_path_kernel_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in prof.items()}}
+        # the dominant hand-written kernel of the whole step (SURVEY 8(f1) widening): the weight-gradient GEMM.  Algorithmic
+        # FLOPs = 2 M N K summed over the encoder Linears it serves, time from the same HIP-stamped events.
+        roofline_widened = None
+        if "wgrad" in prof and not args.small and not args.no_fused_encoder_ops:
+            m_v, m_t, e = args.batch * 197, args.batch * 77, 768
+            per_step = (12 * 2.0 * m_v * e * (3 * e + e + 4 * e + 4 * e) + 2.0 * args.batch * 196 * e * e
+                        + 12 * 2.0 * m_t * e * (3 * e + e + 4 * e + 4 * e))
+            cnt, ms = prof["wgrad"]
+            achieved = per_step * args.steps / (ms * 1e-3) / 1e12
+            roofline_widened = {"bound": "mfma", "kernel": "wgrad", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                                "avg_launch_us": round(ms / cnt * 1e3, 1), "launches": cnt,
+                                "share_of_step_time": round(ms / 1e3 / dt, 3)}
         out = {
             "metric": "image-text pairs/s (whole node), ViT-B/16+BERT-base contrastive step",
             "value": round(args.batch * world * args.steps / dt, 2),
@@ -276,6 +289,7 @@ def main():
                        "encoder_ops": "torch" if args.no_fused_encoder_ops else "HIP LayerNorm (+ fused residual add / dropout / deferred biases), bias+activation, fused-QKV attention, weight-gradient GEMM (mmlearn_amd.fused / .attention)",
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline,
+            "roofline_widened": roofline_widened,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

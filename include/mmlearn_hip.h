@@ -219,15 +219,16 @@ int mmk_layernorm_bwd(const void* x, const void* dy, const float* w, const float
  * what the backward re-normalises, so training callers pass it).  Dropout: the counter-based mask of (seed, row, col).
  * xbias (nullable, f32[d]): the bias of the Linear that produced x, when that Linear was run without it -- it is added
  * before the dropout, and its gradient (column sums of dx) comes out of the backward as dxbias instead of a separate
- * dY.sum(0) pass. */
+ * dY.sum(0) pass.  y_twin (nullable): a bf16 copy of y for the GEMM that consumes it in post-LN blocks (BERT), where y
+ * is also the f32 residual stream; the gradient reaching the twin comes back through dy_twin and is summed in-kernel. */
 int mmk_add_layernorm_fwd(const void* x, const float* xbias, const float* r, const float* w, const float* b, float* s, void* y,
-                          float* mean, float* rstd, int64_t rows, int d, float eps, int dtype, float dropout_p, uint64_t seed,
-                          void* stream);
+                          void* y_twin, float* mean, float* rstd, int64_t rows, int d, float eps, int dtype, float dropout_p,
+                          uint64_t seed, void* stream);
 /* Backward: ds = ds_in + LNbwd(dy) (ds_in nullable);  dr = ds (f32);  dx = dropout_mask(ds) in dtype&15;  dy in dtype>>4;
  * dw/db (nullable pair) with the workspaces of mmk_layernorm_bwd (3 slabs per block instead of 2 when dxbias is given). */
-int mmk_add_layernorm_bwd(const float* s, const void* dy, const float* ds_in, const float* w, const float* mean, const float* rstd,
-                          float* dr, void* dx, float* part, float* part2, float* dw, float* db, float* dxbias, int64_t rows, int d,
-                          int dtype, float dropout_p, uint64_t seed, void* stream);
+int mmk_add_layernorm_bwd(const float* s, const void* dy, const void* dy_twin, const float* ds_in, const float* w, const float* mean,
+                          const float* rstd, float* dr, void* dx, float* part, float* part2, float* dw, float* db, float* dxbias,
+                          int64_t rows, int d, int dtype, float dropout_p, uint64_t seed, void* stream);
 
 /* y = act(x + bias) for a Linear run without its bias (fc1 of the encoders' MLPs: HF CLIPMLP fc1 + quick_gelu,
  * BertIntermediate dense + erf GELU); act 0 = x*sigmoid(1.702x), 1 = erf GELU.  The backward writes

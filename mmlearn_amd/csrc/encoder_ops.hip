@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const XT* __rest
                                                                 const float* __restrict__ r, const float* __restrict__ w,
                                                                 const float* __restrict__ b,
                                                                 float* __restrict__ s_out, Y* __restrict__ y,
-                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                bf16_t* __restrict__ y_twin, float* __restrict__ mean_out,
+                                                                float* __restrict__ rstd_out,
                                                                 long rows, int d, float eps, uint32_t seed_lo, uint32_t seed_hi,
                                                                 uint32_t drop_thr, float drop_scale) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const XT* __rest
       q.z = (v[k].z - mean) * rstd * g.z + o.z;
       q.w = (v[k].w - mean) * rstd * g.w + o.w;
       Vec4<Y>::store(y + row * d + c, q);
+      if (y_twin) Vec4<bf16_t>::store(y_twin + row * d + c, q);  // bf16 copy for the consumer GEMM (post-LN forks)
     }
   }
 }
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const XT* __rest
 // Replaces LayerNorm backward + the gradient-accumulation add + the f32 -> bf16 cast of the sublayer gradient.
 template <typename G, typename XT, int VEC, bool DROP, bool XBIAS>
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __restrict__ sv, const G* __restrict__ dy,
+                                                                const bf16_t* __restrict__ dy_twin,
                                                                 const float* __restrict__ ds_in, const float* __restrict__ w,
                                                                 const float* __restrict__ mean_in,
                                                                 const float* __restrict__ rstd_in, float* __restrict__ dr,
@@ -249,7 +252,11 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
       const int c = (lane + 64 * k) * 4;
       if (c < d) {
         const float4 xv = *reinterpret_cast<const float4*>(sv + row * d + c);
-        const float4 g = Vec4<G>::load(dy + row * d + c);
+        float4 g = dy ? Vec4<G>::load(dy + row * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dy_twin) {  // gradient that reached the bf16 twin of y (the consumer GEMM's dX): summed here, not by autograd
+          const float4 g2 = Vec4<bf16_t>::load(dy_twin + row * d + c);
+          g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+        }
         xh[k] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
         gy[k] = make_float4(g.x * wv[k].x, g.y * wv[k].y, g.z * wv[k].z, g.w * wv[k].w);
         s1 += gy[k].x + gy[k].y + gy[k].z + gy[k].w;
@@ -498,15 +505,16 @@ int mmk_layernorm_bwd(const void* x, const void* dy, const float* w, const float
 
 #define MMK_ADDLN_FWD(VEC, DROP)                                                                                        \
   hipLaunchKernelGGL((add_layernorm_fwd_kernel<XT, Y, VEC, DROP>), grid, dim3(256), 0, st, static_cast<const XT*>(x), xbias, r, \
-                     w, b, s, static_cast<Y*>(y), mean, rstd, (long)rows, d, eps, lo, hi, thr, scale)
+                     w, b, s, static_cast<Y*>(y), static_cast<bf16_t*>(y_twin), mean, rstd, (long)rows, d, eps, lo, hi, thr, scale)
 #define MMK_ADDLN_BWD(VEC, DROP, XB)                                                                                   \
   hipLaunchKernelGGL((add_layernorm_bwd_kernel<G, XT, VEC, DROP, XB>), dim3(n_blocks), dim3(256), lds, st, s,          \
-                     static_cast<const G*>(dy), ds_in, w, mean, rstd, dr, static_cast<XT*>(dx), dw ? part : nullptr,   \
+                     static_cast<const G*>(dy), static_cast<const bf16_t*>(dy_twin), ds_in, w, mean, rstd, dr,           \
+                     static_cast<XT*>(dx), dw ? part : nullptr,                                                         \
                      (long)rows, d, lo, hi, thr, scale)
 
 int mmk_add_layernorm_fwd(const void* x, const float* xbias, const float* r, const float* w, const float* b, float* s, void* y,
-                          float* mean, float* rstd, int64_t rows, int d, float eps, int dtype, float dropout_p, uint64_t seed,
-                          void* stream) {
+                          void* y_twin, float* mean, float* rstd, int64_t rows, int d, float eps, int dtype, float dropout_p,
+                          uint64_t seed, void* stream) {
   // dtype packs (x dtype) | (y dtype << 4); r and s are f32
   MMK_REQUIRE(x && r && y && mean && rstd && rows >= 0 && d > 0, "bad arguments");
   MMK_REQUIRE(d % 4 == 0 && d <= 64 * 4 * LN_MAX_VEC, "add_layernorm: d must be a multiple of 4 and <= 2048");
@@ -533,12 +541,12 @@ int mmk_add_layernorm_fwd(const void* x, const float* xbias, const float* r, con
   return 0;
 }
 
-int mmk_add_layernorm_bwd(const float* s, const void* dy, const float* ds_in, const float* w, const float* mean, const float* rstd,
-                          float* dr, void* dx, float* part, float* part2, float* dw, float* db, float* dxbias, int64_t rows, int d,
-                          int dtype, float dropout_p, uint64_t seed, void* stream) {
+int mmk_add_layernorm_bwd(const float* s, const void* dy, const void* dy_twin, const float* ds_in, const float* w, const float* mean,
+                          const float* rstd, float* dr, void* dx, float* part, float* part2, float* dw, float* db, float* dxbias,
+                          int64_t rows, int d, int dtype, float dropout_p, uint64_t seed, void* stream) {
   // dtype packs (dx dtype) | (dy dtype << 4).  part: float[n_blocks, NP, d]; part2: float[64, NP, d] (second stage),
   // NP = 3 when dxbias (the column sums of dx = gradient of the deferred Linear bias) is requested, else 2
-  MMK_REQUIRE(s && dy && mean && rstd && dr && dx && rows >= 0 && d > 0, "bad arguments");
+  MMK_REQUIRE(s && (dy || dy_twin) && mean && rstd && dr && dx && rows >= 0 && d > 0, "bad arguments");
   MMK_REQUIRE(dxbias == nullptr || dw != nullptr, "dxbias is produced together with dgamma/dbeta");
   MMK_REQUIRE(d % 4 == 0 && d <= 64 * 4 * LN_MAX_VEC, "add_layernorm: d must be a multiple of 4 and <= 2048");
   MMK_REQUIRE((dw == nullptr && db == nullptr) || (part && part2 && dw && db), "dgamma/dbeta need both outputs and the workspaces");

@@ -97,46 +97,52 @@ class LayerNorm(nn.LayerNorm):
 
 
 class _AddLayerNormFn(torch.autograd.Function):
-    """(s, y) = (r + dropout(x + xbias), LN(s)) in one kernel each way (csrc/encoder_ops.hip)."""
+    """(s, y[, y16]) = (r + dropout(x + xbias), LN(s)[, bf16 copy of y]) in one kernel each way (csrc/encoder_ops.hip)."""
 
     @staticmethod
-    def forward(ctx, x, r, weight, bias, xbias, eps, out_dtype, dropout_p, seed):
+    def forward(ctx, x, r, weight, bias, xbias, eps, out_dtype, dropout_p, seed, twin):
         d = x.shape[-1]
         x2 = x.contiguous().view(-1, d)
         r2 = r.contiguous().view(-1, d)
         w32 = None if weight is None else weight.detach().float().contiguous()
         b32 = None if bias is None else bias.detach().float().contiguous()
         xb32 = None if xbias is None else xbias.detach().float().contiguous()
-        s, y, mean, rstd = K.add_layernorm_fwd(x2, r2, w32, b32, eps, out_dtype, dropout_p, seed, xb32)
+        s, y, mean, rstd, y16 = K.add_layernorm_fwd(x2, r2, w32, b32, eps, out_dtype, dropout_p, seed, xb32, twin)
         ctx.save_for_backward(s, w32, mean, rstd)
         ctx.shape, ctx.x_dtype, ctx.dropout_p, ctx.seed = x.shape, x.dtype, dropout_p, seed
         ctx.wb = (weight is not None and weight.requires_grad, bias is not None and bias.requires_grad,
                   None if weight is None else weight.dtype, None if bias is None else bias.dtype)
         ctx.xb = (xbias is not None and xbias.requires_grad, None if xbias is None else xbias.dtype)
+        if twin:
+            return s.view(x.shape), y.view(x.shape), y16.view(x.shape)
         return s.view(x.shape), y.view(x.shape)
 
     @staticmethod
-    def backward(ctx, gs, gy):
+    def backward(ctx, gs, gy, gy16=None):
         s, w32, mean, rstd = ctx.saved_tensors
         d = s.shape[-1]
         need_w, need_b, wdt, bdt = ctx.wb
         need_xb, xbdt = ctx.xb
-        if gy is None:
+        if gy is None and gy16 is None:
             gy = torch.zeros(ctx.shape, dtype=torch.float32, device=s.device)
         ds_in = None if gs is None else gs.contiguous().view(-1, d).float()
-        dr, dx, dw, db, dxb = K.add_layernorm_bwd(s, gy.contiguous().view(-1, d), ds_in, w32, mean, rstd, ctx.x_dtype, need_w or need_b,
-                                                  ctx.dropout_p, ctx.seed, need_xb)
+        dr, dx, dw, db, dxb = K.add_layernorm_bwd(s, None if gy is None else gy.contiguous().view(-1, d), ds_in, w32, mean, rstd, ctx.x_dtype,
+                                                  need_w or need_b, ctx.dropout_p, ctx.seed, need_xb,
+                                                  None if gy16 is None else gy16.contiguous().view(-1, d).to(torch.bfloat16))
         return (dx.view(ctx.shape), dr.view(ctx.shape), dw.to(wdt) if need_w else None, db.to(bdt) if need_b else None,
-                dxb.to(xbdt) if need_xb else None, None, None, None, None)
+                dxb.to(xbdt) if need_xb else None, None, None, None, None, None)
 
 
 def add_layer_norm(x: torch.Tensor, residual: torch.Tensor, ln: nn.LayerNorm, dropout_p: float = 0.0, seed: Optional[int] = None,
-                   low_precision_out: Optional[bool] = None, xbias: Optional[torch.Tensor] = None):
+                   low_precision_out: Optional[bool] = None, xbias: Optional[torch.Tensor] = None, twin: bool = False):
     """``s = residual + dropout(x + xbias)``, ``y = ln(s)`` fused; returns ``(s, y)``.  ``x`` is the sublayer output
     (autocast dtype or f32), ``residual`` the f32 stream.  ``y`` is f32 like ``F.layer_norm`` under autocast unless
     ``low_precision_out`` (default: the module's own ``low_precision_out`` flag) asks for the autocast dtype.
     ``xbias``: bias of the Linear that produced ``x`` when it was run bias-free (``linear_nobias``); its gradient is
-    then a by-product of this op's backward instead of a separate pass over the Linear's output gradient."""
+    then a by-product of this op's backward instead of a separate pass over the Linear's output gradient.
+    ``twin`` (f32 ``y`` only): also emit a bf16 copy of ``y`` and attach it as ``y._mmk_bf16`` -- in post-LN blocks ``y`` is
+    both the f32 residual stream and the input of the next GEMM; ``fused.linear`` picks the copy up instead of casting,
+    and the two gradients meeting at this fork are summed inside the backward kernel (no cast, no add kernel)."""
     K.require_gpu(x)
     if residual.dtype != torch.float32:
         residual = residual.float()
@@ -149,7 +155,11 @@ def add_layer_norm(x: torch.Tensor, residual: torch.Tensor, ln: nn.LayerNorm, dr
         from .attention import draw_seed
 
         seed = draw_seed()
-    return _AddLayerNormFn.apply(x, residual, ln.weight, ln.bias, xbias, ln.eps, out_dtype, float(dropout_p), int(seed or 0))
+    twin = bool(twin and out_dtype == torch.float32 and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)
+    outs = _AddLayerNormFn.apply(x, residual, ln.weight, ln.bias, xbias, ln.eps, out_dtype, float(dropout_p), int(seed or 0), twin)
+    if twin:
+        outs[1]._mmk_bf16 = outs[2]
+    return outs[0], outs[1]
 
 
 def _ln_fusable(ln, x: torch.Tensor) -> bool:
@@ -225,6 +235,9 @@ def _wgrad_linear_ok(weight: torch.Tensor, x: torch.Tensor) -> bool:
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``F.linear`` with the HIP weight-gradient kernel in its backward where that applies (bf16, >= 16k rows)."""
+    x16 = getattr(x, "_mmk_bf16", None)   # bf16 twin attached by add_layer_norm(twin=True)
+    if x16 is not None and x16.shape == x.shape and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+        x = x16
     if _wgrad_linear_ok(weight, x):
         return _LinearWgradFn.apply(x, weight, bias)
     return F.linear(x, weight, bias)
@@ -303,7 +316,8 @@ def _bert_output_forward(self, hidden_states, input_tensor):
     if _bias_deferrable(self.dense, hidden_states):
         h = linear_nobias(self.dense, hidden_states)
         if _ln_fusable(self.LayerNorm, h):
-            return add_layer_norm(h, input_tensor, self.LayerNorm, self.dropout.p if self.training else 0.0, xbias=self.dense.bias)[1]
+            return add_layer_norm(h, input_tensor, self.LayerNorm, self.dropout.p if self.training else 0.0, xbias=self.dense.bias,
+                                  twin=True)[1]
         h = h + self.dense.bias
     else:
         h = self.dense(hidden_states)

@@ -369,9 +369,10 @@ def layernorm_bwd(x2: torch.Tensor, dy2: torch.Tensor, w: Optional[torch.Tensor]
 
 
 def add_layernorm_fwd(x2: torch.Tensor, r2: torch.Tensor, w: Optional[torch.Tensor], b: Optional[torch.Tensor], eps: float,
-                      out_dtype: torch.dtype, dropout_p: float = 0.0, seed: int = 0, xbias: Optional[torch.Tensor] = None):
+                      out_dtype: torch.dtype, dropout_p: float = 0.0, seed: int = 0, xbias: Optional[torch.Tensor] = None,
+                      twin: bool = False):
     """s = r2 + dropout(x2 + xbias), y = LN(s): x2 [rows, d] (bf16 / f32), r2 f32, xbias f32[d] or None
-    -> (s f32, y of out_dtype, mean, rstd)."""
+    -> (s f32, y of out_dtype, mean, rstd, y_twin = bf16 copy of y or None)."""
     require_gpu(x2)
     rows, d = x2.shape
     assert r2.shape == x2.shape and r2.dtype == torch.float32 and r2.is_contiguous() and x2.is_contiguous()
@@ -379,15 +380,17 @@ def add_layernorm_fwd(x2: torch.Tensor, r2: torch.Tensor, w: Optional[torch.Tens
     y = torch.empty((rows, d), dtype=out_dtype, device=x2.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    y16 = torch.empty((rows, d), dtype=torch.bfloat16, device=x2.device) if twin else None
     dt = dtype_tag(x2.dtype) | (dtype_tag(out_dtype) << 4)
-    check(_lib.lib().mmk_add_layernorm_fwd(ptr(x2), ptr(xbias), ptr(r2), ptr(w), ptr(b), ptr(s), ptr(y), ptr(mean), ptr(rstd), rows, d,
+    check(_lib.lib().mmk_add_layernorm_fwd(ptr(x2), ptr(xbias), ptr(r2), ptr(w), ptr(b), ptr(s), ptr(y), ptr(y16), ptr(mean), ptr(rstd), rows, d,
                                            float(eps), dt, float(dropout_p), int(seed), stream()))
-    return s, y, mean, rstd
+    return s, y, mean, rstd, y16
 
 
-def add_layernorm_bwd(s2: torch.Tensor, dy2: torch.Tensor, ds_in: Optional[torch.Tensor], w: Optional[torch.Tensor], mean: torch.Tensor,
-                      rstd: torch.Tensor, x_dtype: torch.dtype, need_wb: bool, dropout_p: float = 0.0, seed: int = 0, need_xbias: bool = False):
-    """-> (dr f32 = ds_in + LNbwd(dy), dx = dropout_mask(dr) in x_dtype, dgamma, dbeta, dxbias = colsum(dx) or None)."""
+def add_layernorm_bwd(s2: torch.Tensor, dy2: Optional[torch.Tensor], ds_in: Optional[torch.Tensor], w: Optional[torch.Tensor], mean: torch.Tensor,
+                      rstd: torch.Tensor, x_dtype: torch.dtype, need_wb: bool, dropout_p: float = 0.0, seed: int = 0, need_xbias: bool = False,
+                      dy_twin: Optional[torch.Tensor] = None):
+    """-> (dr f32 = ds_in + LNbwd(dy + dy_twin), dx = dropout_mask(dr) in x_dtype, dgamma, dbeta, dxbias = colsum(dx) or None)."""
     rows, d = s2.shape
     dev = s2.device
     dr = torch.empty((rows, d), dtype=torch.float32, device=dev)
@@ -401,9 +404,9 @@ def add_layernorm_bwd(s2: torch.Tensor, dy2: torch.Tensor, ds_in: Optional[torch
         dw = torch.empty(d, dtype=torch.float32, device=dev)
         db = torch.empty(d, dtype=torch.float32, device=dev)
         dxb = torch.empty(d, dtype=torch.float32, device=dev) if need_xbias else None
-    dt = dtype_tag(x_dtype) | (dtype_tag(dy2.dtype) << 4)
-    check(_lib.lib().mmk_add_layernorm_bwd(ptr(s2), ptr(dy2), ptr(ds_in), ptr(w), ptr(mean), ptr(rstd), ptr(dr), ptr(dx), ptr(part), ptr(part2),
-                                           ptr(dw), ptr(db), ptr(dxb), rows, d, dt, float(dropout_p), int(seed), stream()))
+    dt = dtype_tag(x_dtype) | (dtype_tag(torch.float32 if dy2 is None else dy2.dtype) << 4)
+    check(_lib.lib().mmk_add_layernorm_bwd(ptr(s2), ptr(dy2), ptr(dy_twin), ptr(ds_in), ptr(w), ptr(mean), ptr(rstd), ptr(dr), ptr(dx), ptr(part),
+                                           ptr(part2), ptr(dw), ptr(db), ptr(dxb), rows, d, dt, float(dropout_p), int(seed), stream()))
     return dr, dx, dw, db, dxb
 
 

@@ -258,3 +258,33 @@ def test_patch_conv_as_gemm_matches_conv2d(B, C, H, W, P, E, bias):
     assert (gw0 - gw1).abs().max() <= 2e-2 * max(1.0, gw0.abs().max().item())
     if bias:
         assert (gb0 - gb1).abs().max() <= 2e-2 * max(1.0, gb0.abs().max().item())
+
+
+def test_add_layer_norm_twin_output_and_gradient():
+    """twin=True: y (f32) carries a bf16 copy for the consumer GEMM; gradients reaching y and the copy are summed in-kernel."""
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    rows, d = 333, 768
+    ln = fused.LayerNorm.from_torch(torch.nn.LayerNorm(d).to(dev), False)
+    x0 = torch.randn(rows, d, device=dev).bfloat16()
+    r0 = torch.randn(rows, d, device=dev)
+    w1, w2 = torch.randn(rows, d, device=dev), torch.randn(rows, d, device=dev)
+    grads = []
+    for twin in (False, True):
+        ln.zero_grad(set_to_none=True)
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            _, y = fused.add_layer_norm(x, r, ln, twin=twin)
+        y16 = getattr(y, "_mmk_bf16", None)
+        assert (y16 is not None) == twin and y.dtype == torch.float32
+        if twin:
+            assert y16.dtype == torch.bfloat16 and torch.equal(y16, y.to(torch.bfloat16))
+            loss = (y * w1).sum() + (y16.float() * w2).sum()
+        else:
+            loss = (y * w1).sum() + (y.to(torch.bfloat16).float() * w2).sum()
+        loss.backward()
+        grads.append((x.grad.float().clone(), r.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone()))
+    for a, b, name in zip(grads[0], grads[1], ("dx", "dr", "dgamma", "dbeta")):
+        assert (a - b).abs().max() <= 2e-2 * max(1.0, a.abs().max().item()), name

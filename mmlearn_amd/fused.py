@@ -35,6 +35,10 @@ from torch import nn
 from . import kernels as K
 
 
+def _autocast_bf16() -> bool:
+    return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, eps, out_dtype):
@@ -150,12 +154,12 @@ def add_layer_norm(x: torch.Tensor, residual: torch.Tensor, ln: nn.LayerNorm, dr
         low_precision_out = bool(getattr(ln, "low_precision_out", False))
     out_dtype = torch.float32
     if low_precision_out and torch.is_autocast_enabled():
-        out_dtype = torch.get_autocast_gpu_dtype()
+        out_dtype = torch.get_autocast_dtype("cuda")
     if dropout_p > 0.0 and seed is None:
         from .attention import draw_seed
 
         seed = draw_seed()
-    twin = bool(twin and out_dtype == torch.float32 and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)
+    twin = bool(twin and out_dtype == torch.float32 and _autocast_bf16())
     outs = _AddLayerNormFn.apply(x, residual, ln.weight, ln.bias, xbias, ln.eps, out_dtype, float(dropout_p), int(seed or 0), twin)
     if twin:
         outs[1]._mmk_bf16 = outs[2]
@@ -230,13 +234,13 @@ def _wgrad_linear_ok(weight: torch.Tensor, x: torch.Tensor) -> bool:
     rows = x.numel() // max(x.shape[-1], 1)
     return (x.is_cuda and weight.dim() == 2 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0 and rows >= 16384
             and torch.is_grad_enabled() and weight.requires_grad
-            and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)))
+            and (x.dtype == torch.bfloat16 or _autocast_bf16()))
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``F.linear`` with the HIP weight-gradient kernel in its backward where that applies (bf16, >= 16k rows)."""
     x16 = getattr(x, "_mmk_bf16", None)   # bf16 twin attached by add_layer_norm(twin=True)
-    if x16 is not None and x16.shape == x.shape and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16:
+    if x16 is not None and x16.shape == x.shape and _autocast_bf16():
         x = x16
     if _wgrad_linear_ok(weight, x):
         return _LinearWgradFn.apply(x, weight, bias)
@@ -387,7 +391,7 @@ def _fused_qkv(self, hidden_states: torch.Tensor, names, scale: float, dropout_p
     B, L, E = hidden_states.shape
     if E % 64 or L > 256 or q.weight.shape != (E, E) or not (0.0 <= dropout_p < 1.0):
         return None
-    if not (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) and q.weight.dtype != torch.bfloat16:
+    if not _autocast_bf16() and q.weight.dtype != torch.bfloat16:
         return None
     w = torch.cat([q.weight, k.weight, v.weight], 0)
     b = None if q.bias is None else torch.cat([q.bias, k.bias, v.bias], 0)
@@ -441,7 +445,7 @@ def _patch_conv_forward(self, x):
     (a permutation + cast) and one GEMM; the result is returned as a ``[B, E, gh, gw]`` view of the ``[B, gh gw, E]``
     GEMM output, so the usual ``.flatten(2).transpose(1, 2)`` that follows is free."""
     P = self.kernel_size[0]
-    bf16 = x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)
+    bf16 = x.dtype == torch.bfloat16 or _autocast_bf16()
     if (x.dim() == 4 and x.is_cuda and bf16 and not x.requires_grad and P % 4 == 0 and x.shape[2] % P == 0 and x.shape[3] % P == 0
             and x.dtype in (torch.float32, torch.bfloat16, torch.float16)):
         B, _, H, W = x.shape

@@ -9,7 +9,14 @@
 //             straight from global memory), so max / sum over the keys are lane-local; the exponentiated accumulators
 //             are then used directly as the B operand of O^T = V^T P^T (accumulator-as-operand, k order permuted
 //             accordingly), with V^T fragments delivered by the hardware transpose read.
-//   HBM traffic = Q, K, V read once + O written once (the roofline that bounds it); LSE is kept for the backward.
+//             Persistent workgroups walk the (batch, head) items with the K / V images double-buffered.
+//   backward: a streaming pass writes per-item records (lse * log2 e, delta = rowsum(dO . O)); the main kernel recomputes P
+//             from Q, K and the LSE.  Two forms: a seven-product two-phase kernel with four resident images (no cross-wave
+//             sums; any tile count), and -- whenever the tile count leaves a wave spare (L = 197, 77) -- a five-product
+//             kernel in which the key waves hand their dS tile, transposed through LDS, to a dedicated dQ wave.
+//             Dropout (BERT) is a counter-based mask regenerated from (seed, batch * head, query, key) in both passes.
+//   HBM traffic = Q, K, V read once + O written once (forward), Q, K, V, dO, O in + dQ, dK, dV out (backward): both
+//   are HBM-bound by bytes; DESIGN.md 5.2 has the measured distances to that bound.
 #include <hip/hip_ext.h>
 #include <math.h>
 #include <stdlib.h>
@@ -101,39 +108,18 @@ __device__ __forceinline__ void img_load(char* img, const bf16_t* base, long sl,
   }
 }
 
-// MFMA operand with k along the 64 columns: lane (r, h) takes row `row`, elements 16kk + 8h .. +7
-__device__ __forceinline__ bf16x8 img_row_frag(const char* img, int row, int kk, int h) {
-  return *reinterpret_cast<const bf16x8*>(img + row * 128 + (((2 * kk + h) ^ img_swz(row)) << 4));
-}
-
-// MFMA operand with k along the ROWS (transposed use of the same image): for the 32x32x16 A operand X^T[c][k] with
-// c = 32ct + (lane&31) and the accumulator-as-operand k order, the lane needs column c of rows r0 .. r0+3 and
-// r0+8 .. r0+11, r0 = 16s + 4h (+ tile base).  ds_read_b64_tr_b16: lane 4q+p of each 16-lane group supplies the address
-// of row q, columns 4p..4p+3 of the group's 4 x 16 block and receives column (lane&15) of the 4 rows.
-__device__ __forceinline__ bf16x4 img_tr4(const char* img, int r0, int ct, int lane) {
-  const int li = lane & 15, q = li >> 2, p = li & 3;
-  const int row = r0 + q;
-  const int ch = 4 * ct + 2 * ((lane >> 4) & 1) + (p >> 1);
-  const char* addr = img + row * 128 + ((ch ^ img_swz(row)) << 4) + 8 * (p & 1);
-  typedef short s4 __attribute__((ext_vector_type(4)));
-  const s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(addr));
-  return __builtin_bit_cast(bf16x4, v);
-}
-__device__ __forceinline__ bf16x8 img_tr_frag(const char* img, int r0, int ct, int lane) {
-  const bf16x4 lo = img_tr4(img, r0, ct, lane);
-  const bf16x4 hi = img_tr4(img, r0 + 8, ct, lane);
-  bf16x8 f;
-  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-  return f;
-}
-
+// MFMA operands out of an image.  k along the 64 COLUMNS: lane (r, h) takes row `row`, elements 16kk + 8h .. +7, one
+// ds_read_b128 at  row * 128 + (((2 kk + h) ^ img_swz(row)) << 4).  k along the ROWS (transposed use of the same image):
+// for the 32x32x16 A operand X^T[c][k] with c = 32 ct + (lane & 31) and the accumulator-as-operand k order, the lane
+// needs column c of rows r0 .. r0+3 and r0+8 .. r0+11 (r0 = 16 s + 4 h + tile base): two ds_read_b64_tr_b16, for which
+// lane 4q + p of each 16-lane group supplies the address of row r0 + q, columns 4p .. 4p+3 of the group's 4 x 16 block
+// (chunk 4 ct + 2 (lane>>4 & 1) + (p >> 1), byte 8 (p & 1)) and receives column (lane & 15) of the four rows.
 // Per-lane byte offsets into an image that do not depend on the 32-row tile: a tile adds 4096 B, the second k-step of
 // a transposed fragment (rows +16) adds 2048 B, because img_swz only looks at (row >> 1) & 7.  Computing them once
 // keeps the integer address arithmetic out of the MFMA loops (the loops were VALU-issue bound without this).
 struct ImgLane {
-  int row[4];    // img_row_frag(img, 32t + r, kk, h)            = img + 4096 t + row[kk]
-  int tr[2][2];  // img_tr4(img, 32t + 16s + 4h + 8u, ct, lane)  = img + 4096 t + 2048 s + tr[u][ct]
+  int row[4];    // row fragment kk of row 32t + (lane & 31)             = img + 4096 t + row[kk]
+  int tr[2][2];  // transposed half u of k-step s, column tile ct        = img + 4096 t + 2048 s + tr[u][ct]
 };
 __device__ __forceinline__ ImgLane img_lane(int lane) {
   ImgLane o;

@@ -338,23 +338,103 @@ def _bert_intermediate_forward(self, hidden_states):
     return self.intermediate_act_fn(self.dense(hidden_states))
 
 
+def _is_preln_block(m: nn.Module) -> bool:
+    """Duck type of the timm-style pre-LN block mmlearn's own ViT / I-JEPA predictor are built from
+    (mmlearn/modules/layers/transformer_block.py: ``norm1, attn(qkv, proj, attn_drop, proj_drop, num_heads, scale),
+    drop_path, norm2, mlp``)."""
+    a = getattr(m, "attn", None)
+    return (all(hasattr(m, k) for k in ("norm1", "norm2", "mlp", "drop_path")) and a is not None
+            and isinstance(getattr(a, "qkv", None), nn.Linear) and isinstance(getattr(a, "proj", None), nn.Linear)
+            and all(hasattr(a, k) for k in ("num_heads", "scale", "attn_drop", "proj_drop")))
+
+
+def _drop_p(mod, training: bool) -> Optional[float]:
+    """Dropout probability of an ``nn.Dropout`` / ``nn.Identity`` (None: something this path does not understand)."""
+    if isinstance(mod, nn.Identity):
+        return 0.0
+    if isinstance(mod, nn.Dropout):
+        return float(mod.p) if training else 0.0
+    return None
+
+
+def _seq_mlp_nobias(mlp, x2: torch.Tensor, training: bool):
+    """``Sequential(Linear, act, Dropout, Linear, Dropout)`` (mmlearn/modules/layers/mlp.py with one hidden layer) as
+    fc1 (bias-free GEMM) -> bias + activation kernel -> fc2 (bias-free GEMM).  Returns (output without fc2's bias, that
+    bias, dropout p after fc2) or None when the container is not of that form / has an active inner dropout."""
+    if not isinstance(mlp, nn.Sequential) or len(mlp) != 5:
+        return None
+    fc1, act, d1, fc2, d2 = mlp
+    name = "gelu" if (type(act) is nn.GELU and getattr(act, "approximate", "none") == "none") else _act_name(act)
+    p1, p2 = _drop_p(d1, training), _drop_p(d2, training)
+    if not (isinstance(fc1, nn.Linear) and isinstance(fc2, nn.Linear) and name is not None and p1 == 0.0 and p2 is not None
+            and _bias_deferrable(fc1, x2) and _bias_deferrable(fc2, x2)):
+        return None
+    return linear_nobias(fc2, bias_act(linear_nobias(fc1, x2), fc1.bias, name)), fc2.bias, p2
+
+
+def _preln_block_forward(self, x, return_attention: bool = False):
+    """Replaces the forward of a timm-style pre-LN block (mmlearn/modules/layers/transformer_block.py:125-133): fused QKV
+    attention on the packed projection, ``x + proj_drop(proj(.))`` inside ``norm2``'s kernel, bias + activation kernel in
+    the MLP and ``x + mlp(.)`` inside the next block's ``norm1`` kernel.  Stochastic depth, attention-map requests, head
+    sizes other than 64, sequences over 256 tokens and non-bf16 runs take the stock forward."""
+    from .attention import attention_qkvpacked
+
+    attn = self.attn
+    p_attn, p_proj = _drop_p(attn.attn_drop, self.training), _drop_p(attn.proj_drop, self.training)
+    ok = (not return_attention and isinstance(self.drop_path, nn.Identity) and p_attn is not None and p_proj is not None
+          and x.dim() == 3 and x.is_cuda and _autocast_bf16() and x.shape[1] <= 256 and x.shape[2] == 64 * attn.num_heads
+          and attn.qkv.out_features == 3 * x.shape[2] and _ln_fusable(self.norm2, x) and _bias_deferrable(attn.proj, x))
+    if not ok:
+        if hasattr(x, "_mmk_prenormed"):
+            del x._mmk_prenormed
+        return self._mmk_stock_layer_forward(x, return_attention)
+    B, L, E = x.shape
+    xn = getattr(x, "_mmk_prenormed", None)
+    if xn is None:
+        xn = self.norm1(x)
+    qkv = linear(xn, attn.qkv.weight, attn.qkv.bias)
+    if qkv.dtype != torch.bfloat16:
+        return self._mmk_stock_layer_forward(x, return_attention)
+    ctx = attention_qkvpacked(qkv.view(B, L, 3, attn.num_heads, 64), float(attn.scale), p_attn)
+    y = linear_nobias(attn.proj, ctx.reshape(B, L, E))
+    h, x2 = add_layer_norm(y, x, self.norm2, p_proj, xbias=attn.proj.bias)
+    fused = _seq_mlp_nobias(self.mlp, x2, self.training)
+    nxt = getattr(self, "_mmk_next_ln", None)
+    if fused is not None and nxt is not None and _ln_fusable(nxt, x2):
+        m, mb, p2 = fused
+        out, yn = add_layer_norm(m, h, nxt, p2, xbias=mb)
+        out._mmk_prenormed = yn
+        return out
+    if fused is not None and fused[2] == 0.0:
+        return h + (fused[0] + fused[1])
+    return h + self.mlp(x2)
+
+
 _ADD_LN_FORWARDS = {"CLIPEncoderLayer": _clip_layer_forward, "BertSelfOutput": _bert_output_forward, "BertOutput": _bert_output_forward,
                     "BertIntermediate": _bert_intermediate_forward}
 
 
 def fuse_add_layer_norm(module: nn.Module) -> int:
-    """Patch HF ``CLIPEncoderLayer`` / ``BertSelfOutput`` / ``BertOutput`` inside ``module`` (in place, parameters and
-    state_dict untouched) so that each residual add (+ hidden dropout) runs inside the following LayerNorm's kernel."""
+    """Patch HF ``CLIPEncoderLayer`` / ``BertSelfOutput`` / ``BertOutput`` / ``BertIntermediate`` and timm-style pre-LN
+    blocks (mmlearn's own ViT and I-JEPA predictor: recognised by their attributes, see ``_is_preln_block``) inside
+    ``module`` -- in place, parameters and state_dict untouched -- so that each residual add (+ hidden dropout) runs
+    inside the following LayerNorm's kernel and the Linear biases are applied by the consuming kernels."""
     n = 0
     for m in module.modules():
         fwd = _ADD_LN_FORWARDS.get(type(m).__name__)
+        if fwd is None and _is_preln_block(m):
+            fwd = _preln_block_forward
         if fwd is not None and not hasattr(m, "_mmk_stock_layer_forward"):
             m._mmk_stock_layer_forward = m.forward
             m.forward = types.MethodType(fwd, m)
             n += 1
-        if isinstance(m, nn.ModuleList) and len(m) > 1 and all(type(c).__name__ == "CLIPEncoderLayer" for c in m):
-            for cur, nxt in zip(list(m)[:-1], list(m)[1:]):   # consecutive pre-LN layers: see _clip_layer_forward
-                object.__setattr__(cur, "_mmk_next_ln", nxt.layer_norm1)
+        if isinstance(m, nn.ModuleList) and len(m) > 1:   # consecutive pre-LN layers: see _clip_layer_forward
+            if all(type(c).__name__ == "CLIPEncoderLayer" for c in m):
+                for cur, nxt in zip(list(m)[:-1], list(m)[1:]):
+                    object.__setattr__(cur, "_mmk_next_ln", nxt.layer_norm1)
+            elif all(_is_preln_block(c) for c in m):
+                for cur, nxt in zip(list(m)[:-1], list(m)[1:]):
+                    object.__setattr__(cur, "_mmk_next_ln", nxt.norm1)
     return n
 
 

@@ -289,3 +289,72 @@ def test_add_layer_norm_twin_output_and_gradient():
         grads.append((x.grad.float().clone(), r.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone()))
     for a, b, name in zip(grads[0], grads[1], ("dx", "dr", "dgamma", "dbeta")):
         assert (a - b).abs().max() <= 2e-2 * max(1.0, a.abs().max().item()), name
+
+
+class _TimmStyleAttention(torch.nn.Module):
+    """Attribute-compatible stand-in for the pre-LN attention of mmlearn's own ViT (qkv / proj Linears, explicit softmax)."""
+
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads, self.scale = heads, (dim // heads) ** -0.5
+        self.qkv = torch.nn.Linear(dim, 3 * dim, bias=True)
+        self.attn_drop = torch.nn.Dropout(0.0)
+        self.proj = torch.nn.Linear(dim, dim)
+        self.proj_drop = torch.nn.Dropout(0.0)
+
+    def forward(self, x):
+        b, n, c = x.shape
+        q, k, v = self.qkv(x).reshape(b, n, 3, self.num_heads, c // self.num_heads).permute(2, 0, 3, 1, 4)
+        a = self.attn_drop(((q @ k.transpose(-2, -1)) * self.scale).softmax(dim=-1))
+        return self.proj_drop(self.proj((a @ v).transpose(1, 2).reshape(b, n, c))), a
+
+
+class _TimmStyleBlock(torch.nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.norm1, self.norm2 = torch.nn.LayerNorm(dim), torch.nn.LayerNorm(dim)
+        self.attn = _TimmStyleAttention(dim, heads)
+        self.drop_path = torch.nn.Identity()
+        self.mlp = torch.nn.Sequential(torch.nn.Linear(dim, 4 * dim), torch.nn.GELU(), torch.nn.Dropout(0.0), torch.nn.Linear(4 * dim, dim),
+                                       torch.nn.Dropout(0.0))
+
+    def forward(self, x, return_attention=False):
+        y, attn = self.attn(self.norm1(x))
+        if return_attention:
+            return attn
+        x = x + self.drop_path(y)
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+def test_preln_block_fusion_matches_stock_blocks():
+    """fuse_add_layer_norm recognises timm-style pre-LN blocks (mmlearn's own ViT / I-JEPA predictor) by their attributes."""
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(4)
+    blocks = torch.nn.ModuleList([_TimmStyleBlock(128, 2) for _ in range(3)]).to(dev)
+    x0 = torch.randn(6, 50, 128, device=dev)
+    keys = list(blocks.state_dict().keys())
+
+    def run():
+        blocks.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            h = x
+            for b in blocks:
+                h = b(h)
+        h.float().square().mean().backward()
+        return h.float().detach(), x.grad.clone(), {k: p.grad.clone() for k, p in blocks.named_parameters()}
+
+    ref = run()
+    n = fused.accelerate_encoder(blocks, low_precision_ln=("norm1", "norm2"), fuse_add_ln=True)
+    assert n["fused_add_ln"] == 3 and n["layernorm"] == 6 and list(blocks.state_dict().keys()) == keys
+    got = run()
+    assert (ref[0] - got[0]).abs().max() <= 3e-2 * ref[0].abs().max()
+    assert (ref[1] - got[1]).abs().max() <= 6e-2 * ref[1].abs().max()
+    gmax = max(v.abs().max().item() for v in ref[2].values())
+    for k in ref[2]:
+        assert (ref[2][k] - got[2][k]).abs().max() <= 6e-2 * max(ref[2][k].abs().max().item(), 1e-2 * gmax), k
+    with torch.autocast("cuda", dtype=torch.bfloat16):   # attention-map request: stock path, same result type
+        a = blocks[0](x0, return_attention=True)
+    assert a.shape == (6, 2, 50, 50)

@@ -14,4 +14,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 torch.cuda.synchronize(); e0.record()
 for _ in range(10): K.attn_bwd(q, k, v, o, lse, do, 0.125, p, 7)
 e1.record(); torch.cuda.synchronize()
-print(json.dumps({"L": L, "p": p, "stagger": os.environ.get("MMK_ATTN_STAGGER", "0"), "bwd_us": round(e0.elapsed_time(e1) * 100, 1)}))
+print(json.dumps({"L": L, "p": p, "seven_product": os.environ.get("MMK_ATTN_BWD7") is not None, "bwd_us": round(e0.elapsed_time(e1) * 100, 1)}))

@@ -117,6 +117,7 @@ class _AddLayerNormFn(torch.autograd.Function):
         ctx.wb = (weight is not None and weight.requires_grad, bias is not None and bias.requires_grad,
                   None if weight is None else weight.dtype, None if bias is None else bias.dtype)
         ctx.xb = (xbias is not None and xbias.requires_grad, None if xbias is None else xbias.dtype)
+        ctx.set_materialize_grads(False)  # an unused output (s in post-LN blocks) must arrive as None, not as a zeros tensor
         if twin:
             return s.view(x.shape), y.view(x.shape), y16.view(x.shape)
         return s.view(x.shape), y.view(x.shape)

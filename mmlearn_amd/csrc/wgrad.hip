@@ -90,17 +90,37 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
   // XCD-aware unit map: block b runs on XCD b % 8; XCD x owns splits x, x + 8, ...; consecutive slots of an XCD are the
   // tiles of one split
   const int T = a.tiles_n * a.tiles_k;
-  int split, tile;
+  int split, tn, tk;
   if (T <= 32) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     split = (slot / T) * 8 + xcd;
-    tile = slot % T;
-  } else {  // more tiles than one XCD has CUs: plain order
-    split = blockIdx.x / T;
-    tile = blockIdx.x % T;
+    const int tile = slot % T;
+    tn = tile / a.tiles_k;
+    tk = tile % a.tiles_k;
+  } else {
+    // more tiles than one XCD has CUs: consecutive positions of an XCD walk the tiles in blocks of (all tiles of the
+    // short dimension) x (4 of the long one), so a block's 12-16 workgroups share each dY / x slab 3-4 ways in L2
+    const int per_xcd = (a.splits * T + 7) >> 3;
+    const int pos = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    split = pos / T;
+    const int q = pos % T;
+    const bool n_short = a.tiles_n <= a.tiles_k;
+    const int ts = n_short ? a.tiles_n : a.tiles_k, tl = n_short ? a.tiles_k : a.tiles_n;  // short / long tile counts
+    const int full = tl / 4, bsz = ts * 4;
+    int s_idx, l_idx;
+    if (q < full * bsz) {
+      const int inner = q % bsz;
+      s_idx = inner / 4;
+      l_idx = (q / bsz) * 4 + inner % 4;
+    } else {
+      const int rem = tl - full * 4, inner = q - full * bsz;
+      s_idx = inner / rem;
+      l_idx = full * 4 + inner % rem;
+    }
+    tn = n_short ? s_idx : l_idx;
+    tk = n_short ? l_idx : s_idx;
   }
   if (split >= a.splits) return;
-  const int tn = tile / a.tiles_k, tk = tile % a.tiles_k;
   const long row0 = (long)split * a.rows_per_split;
   const long row_end = min((long)a.M, row0 + a.rows_per_split);
   const int nstages = (int)((row_end - row0 + WG_BM - 1) / WG_BM);
@@ -221,7 +241,7 @@ int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int
   a.splits = cdiv((int)M, a.rows_per_split);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int T = a.tiles_n * a.tiles_k;
-  const int grid = T <= 32 ? 8 * cdiv(a.splits, 8) * T : a.splits * T;
+  const int grid = T <= 32 ? 8 * cdiv(a.splits, 8) * T : 8 * cdiv(a.splits * T, 8);
   static bool attr = false;
   const int bytes = 4 * WG_STAGE;
   if (!attr) {

@@ -162,6 +162,36 @@ static inline bool drop_params(float p, uint64_t seed, uint32_t* lo, uint32_t* h
   return *thr > 0;
 }
 
+// 8 consecutive elements as two float4 (one 16-byte access for the 2-byte types; pointer 8-element aligned)
+template <typename T>
+struct Vec8 {
+  static __device__ __forceinline__ void load(const T* p, float4& a, float4& b) {
+    a = Vec4<T>::load(p);
+    b = Vec4<T>::load(p + 4);
+  }
+  static __device__ __forceinline__ void store(T* p, float4 a, float4 b) {
+    Vec4<T>::store(p, a);
+    Vec4<T>::store(p + 4, b);
+  }
+};
+template <>
+struct Vec8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float4& a, float4& b) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    a = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                    __uint_as_float(u.y & 0xffff0000u));
+    b = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                    __uint_as_float(u.w & 0xffff0000u));
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, float4 a, float4 b) {
+    typedef bf16_t bf8 __attribute__((ext_vector_type(8)));
+    bf8 o;
+    o[0] = (bf16_t)a.x; o[1] = (bf16_t)a.y; o[2] = (bf16_t)a.z; o[3] = (bf16_t)a.w;
+    o[4] = (bf16_t)b.x; o[5] = (bf16_t)b.y; o[6] = (bf16_t)b.z; o[7] = (bf16_t)b.w;
+    *reinterpret_cast<bf8*>(p) = o;
+  }
+};
+
 static inline size_t dtype_size(int dt) { return dt == MMK_F32 ? 4 : 2; }
 
 // dispatch a generic lambda on a user dtype tag

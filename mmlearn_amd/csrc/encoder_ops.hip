@@ -329,39 +329,48 @@ __device__ __forceinline__ float act_grad(float z, float g) {
   return g * (0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z));
 }
 constexpr int BA_ROWS = 32;  // rows per block of the backward (one [d] partial per block)
+// 8 elements (16 bytes of bf16) per thread and access: d % 8 == 0
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bias_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ b, T* __restrict__ y,
                                                            long rows, int d) {
-  const int d4 = d / 4;
-  const long n4 = rows * d4;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % d4) * 4;
-    float4 v = Vec4<T>::load(x + i * 4);
-    const float4 bb = *reinterpret_cast<const float4*>(b + c);
-    v.x = act_fwd<ACT>(v.x + bb.x); v.y = act_fwd<ACT>(v.y + bb.y); v.z = act_fwd<ACT>(v.z + bb.z); v.w = act_fwd<ACT>(v.w + bb.w);
-    Vec4<T>::store(y + i * 4, v);
+  const int d8 = d / 8;
+  const long n8 = rows * d8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % d8) * 8;
+    float4 v0, v1;
+    Vec8<T>::load(x + i * 8, v0, v1);
+    const float4 b0 = *reinterpret_cast<const float4*>(b + c), b1 = *reinterpret_cast<const float4*>(b + c + 4);
+    v0.x = act_fwd<ACT>(v0.x + b0.x); v0.y = act_fwd<ACT>(v0.y + b0.y); v0.z = act_fwd<ACT>(v0.z + b0.z); v0.w = act_fwd<ACT>(v0.w + b0.w);
+    v1.x = act_fwd<ACT>(v1.x + b1.x); v1.y = act_fwd<ACT>(v1.y + b1.y); v1.z = act_fwd<ACT>(v1.z + b1.z); v1.w = act_fwd<ACT>(v1.w + b1.w);
+    Vec8<T>::store(y + i * 8, v0, v1);
   }
 }
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const T* __restrict__ x, const float* __restrict__ b,
                                                            const T* __restrict__ dy, T* __restrict__ dx, float* __restrict__ part,
                                                            long rows, int d) {
-  const int d4 = d / 4;
+  const int d8 = d / 8;
   const long r0 = (long)blockIdx.x * BA_ROWS, r1 = min(rows, r0 + BA_ROWS);
-  for (int cv = threadIdx.x; cv < d4; cv += 256) {  // this thread's column vectors (d4 <= 4 * 256 in practice)
-    const int c = cv * 4;
-    const float4 bb = *reinterpret_cast<const float4*>(b + c);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int cv = threadIdx.x; cv < d8; cv += 256) {  // this thread's column vectors
+    const int c = cv * 8;
+    const float4 b0 = *reinterpret_cast<const float4*>(b + c), b1 = *reinterpret_cast<const float4*>(b + c + 4);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
 #pragma unroll 4
     for (long row = r0; row < r1; ++row) {
-      const float4 v = Vec4<T>::load(x + row * d + c), g = Vec4<T>::load(dy + row * d + c);
-      const float4 t = make_float4(act_grad<ACT>(v.x + bb.x, g.x), act_grad<ACT>(v.y + bb.y, g.y), act_grad<ACT>(v.z + bb.z, g.z),
-                                   act_grad<ACT>(v.w + bb.w, g.w));
-      Vec4<T>::store(dx + row * d + c, t);
+      float4 v0, v1, g0, g1;
+      Vec8<T>::load(x + row * d + c, v0, v1);
+      Vec8<T>::load(dy + row * d + c, g0, g1);
+      const float4 t0 = make_float4(act_grad<ACT>(v0.x + b0.x, g0.x), act_grad<ACT>(v0.y + b0.y, g0.y), act_grad<ACT>(v0.z + b0.z, g0.z),
+                                    act_grad<ACT>(v0.w + b0.w, g0.w));
+      const float4 t1 = make_float4(act_grad<ACT>(v1.x + b1.x, g1.x), act_grad<ACT>(v1.y + b1.y, g1.y), act_grad<ACT>(v1.z + b1.z, g1.z),
+                                    act_grad<ACT>(v1.w + b1.w, g1.w));
+      Vec8<T>::store(dx + row * d + c, t0, t1);
       // the sums are taken over the ROUNDED dx values the weight-gradient GEMM will see
-      acc.x += (float)(T)t.x; acc.y += (float)(T)t.y; acc.z += (float)(T)t.z; acc.w += (float)(T)t.w;
+      a0.x += (float)(T)t0.x; a0.y += (float)(T)t0.y; a0.z += (float)(T)t0.z; a0.w += (float)(T)t0.w;
+      a1.x += (float)(T)t1.x; a1.y += (float)(T)t1.y; a1.z += (float)(T)t1.z; a1.w += (float)(T)t1.w;
     }
-    *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * d + c) = acc;
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * d + c) = a0;
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * d + c + 4) = a1;
   }
 }
 
@@ -588,13 +597,13 @@ int mmk_add_layernorm_bwd(const float* s, const void* dy, const void* dy_twin, c
 int mmk_bias_act_part_blocks(long rows) { return (int)((rows + BA_ROWS - 1) / BA_ROWS); }
 
 int mmk_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, int d, int act, int dtype, void* stream) {
-  MMK_REQUIRE(x && bias && y && rows >= 0 && d > 0 && d % 4 == 0, "bias_act: d must be a multiple of 4");
+  MMK_REQUIRE(x && bias && y && rows >= 0 && d > 0 && d % 8 == 0, "bias_act: d must be a multiple of 8");
   MMK_REQUIRE(act == 0 || act == 1, "bias_act: act must be 0 (quick_gelu) or 1 (gelu)");
   if (rows == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(MMK_K_ACT, st);
-  const long n4 = rows * (d / 4);
-  const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 256 * 16);
+  const long n8 = rows * (d / 8);
+  const unsigned grid = (unsigned)std::min<long>((n8 + 255) / 256, 256 * 16);
   int rc = MMK_DISPATCH_DTYPE(dtype, T, [&]() -> int {
     if (act == 0)
       hipLaunchKernelGGL((bias_act_fwd_kernel<T, 0>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(x), bias, static_cast<T*>(y), (long)rows, d);
@@ -610,7 +619,7 @@ int mmk_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, in
 int mmk_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx, float* part, float* part2, float* dbias, int64_t rows,
                      int d, int act, int dtype, void* stream) {
   // part: float[mmk_bias_act_part_blocks(rows), d]; part2: float[64, d]
-  MMK_REQUIRE(x && bias && dy && dx && part && part2 && dbias && rows >= 0 && d > 0 && d % 4 == 0, "bad arguments");
+  MMK_REQUIRE(x && bias && dy && dx && part && part2 && dbias && rows >= 0 && d > 0 && d % 8 == 0, "bias_act: d must be a multiple of 8");
   MMK_REQUIRE(act == 0 || act == 1, "bias_act: act must be 0 (quick_gelu) or 1 (gelu)");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (rows == 0) {

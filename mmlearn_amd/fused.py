@@ -263,7 +263,7 @@ def _act_name(fn) -> Optional[str]:
 
 
 def _bias_deferrable(lin: nn.Linear, x: torch.Tensor) -> bool:
-    return (lin.bias is not None and x.is_cuda and lin.out_features % 4 == 0
+    return (lin.bias is not None and x.is_cuda and lin.out_features % 8 == 0
             and (torch.is_autocast_enabled() or lin.weight.dtype == x.dtype))
 
 

@@ -251,6 +251,11 @@ int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int
  * so that the convolution runs as one GEMM against weight.view(E, C P P).  in: [B, C, H, W] of `dtype`, contiguous. */
 int mmk_patchify(const void* in, void* out, int B, int C, int H, int W, int P, int dtype, void* stream);
 
+/* Backward of nn.Embedding (HF BertEmbeddings word / token-type tables): dw[ids[r], :] += dout[r, :], f32 dw zeroed by
+ * the caller; runs of equal ids are summed in registers before one hardware float atomic per element (summation order is
+ * not fixed: results can differ in the last bits between runs, as with ATen's atomic paths). */
+int mmk_embedding_bwd(const void* dout, const int64_t* ids, float* dw, int64_t rows, int d, int64_t vocab, int dtype, void* stream);
+
 /* HF QuickGELUActivation  x * sigmoid(1.702 x)  (CLIP MLP), forward and backward, n elements (multiple of 4) */
 int mmk_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
 int mmk_quick_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);

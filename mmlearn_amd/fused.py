@@ -548,6 +548,41 @@ def patch_conv_as_gemm(module: nn.Module) -> int:
     return n
 
 
+class _EmbeddingFn(torch.autograd.Function):
+    """``F.embedding`` whose weight gradient is the run-summing atomic scatter of ``csrc/encoder_ops.hip``."""
+
+    @staticmethod
+    def forward(ctx, ids, weight):
+        ctx.save_for_backward(ids)
+        ctx.vocab, ctx.w_dtype = weight.shape[0], weight.dtype
+        return F.embedding(ids, weight)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        dw = K.embedding_bwd(dout.reshape(-1, dout.shape[-1]), ids.reshape(-1), ctx.vocab)
+        return None, dw.to(ctx.w_dtype)
+
+
+def _embedding_forward(self, ids):
+    if (ids.is_cuda and ids.dtype == torch.int64 and self.weight.requires_grad and torch.is_grad_enabled() and ids.numel() >= 4096
+            and self.weight.dtype in (torch.float32, torch.bfloat16) and self.embedding_dim % 4 == 0):
+        return _EmbeddingFn.apply(ids, self.weight)
+    return self._mmk_stock_forward(ids)
+
+
+def patch_embedding_backward(module: nn.Module) -> int:
+    """Give plain ``nn.Embedding`` tables (no padding_idx / max_norm / sparse / scale_grad_by_freq) the HIP backward."""
+    n = 0
+    for m in module.modules():
+        if (type(m) is nn.Embedding and m.padding_idx is None and m.max_norm is None and not m.sparse and not m.scale_grad_by_freq
+                and not hasattr(m, "_mmk_stock_forward")):
+            m._mmk_stock_forward = m.forward
+            m.forward = types.MethodType(_embedding_forward, m)
+            n += 1
+    return n
+
+
 def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), fuse_qkv: bool = False, fuse_add_ln: bool = False) -> dict:
     """Swap ``nn.LayerNorm`` -> :class:`LayerNorm` and quick-GELU activations -> :class:`QuickGELU` inside ``module`` (in place);
     with ``fuse_qkv`` also patch the attention modules (:func:`fuse_qkv_attention`), with ``fuse_add_ln`` the residual
@@ -572,4 +607,5 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
     if fuse_add_ln:  # after the LayerNorm swap, so the patched forwards see the modules' low_precision_out flags
         swapped["fused_add_ln"] = fuse_add_layer_norm(module)
         swapped["patch_conv"] = patch_conv_as_gemm(module)
+        swapped["embedding"] = patch_embedding_backward(module)
     return swapped

@@ -434,6 +434,17 @@ def patchify(x: torch.Tensor, patch: int) -> torch.Tensor:
     return out
 
 
+def embedding_bwd(dout2: torch.Tensor, ids: torch.Tensor, vocab: int) -> torch.Tensor:
+    """dW f32 [vocab, d] with dW[ids[r]] += dout2[r] (dout2 [rows, d] f32 / bf16, ids int64 [rows])."""
+    require_gpu(dout2)
+    rows, d = dout2.shape
+    dout2, ids = dout2.contiguous(), ids.contiguous().view(-1)
+    assert ids.dtype == torch.int64 and ids.numel() == rows
+    dw = torch.zeros((vocab, d), dtype=torch.float32, device=dout2.device)
+    check(_lib.lib().mmk_embedding_bwd(ptr(dout2), ptr(ids), ptr(dw), rows, d, int(vocab), dtype_tag(dout2.dtype), stream()))
+    return dw
+
+
 ACT_QUICK_GELU, ACT_GELU = 0, 1
 
 

@@ -358,3 +358,30 @@ def test_preln_block_fusion_matches_stock_blocks():
     with torch.autocast("cuda", dtype=torch.bfloat16):   # attention-map request: stock path, same result type
         a = blocks[0](x0, return_attention=True)
     assert a.shape == (6, 2, 50, 50)
+
+
+@pytest.mark.parametrize("ids_kind", ["random", "constant", "runs"])
+def test_embedding_backward_matches_torch(ids_kind):
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(5)
+    vocab, d, B, L = 1000, 768, 64, 77
+    emb = torch.nn.Embedding(vocab, d).to(dev)
+    if ids_kind == "random":
+        ids = torch.randint(0, vocab, (B, L), device=dev)
+    elif ids_kind == "constant":
+        ids = torch.zeros((B, L), dtype=torch.long, device=dev)
+    else:
+        ids = torch.randint(0, vocab, (B, 1), device=dev).expand(B, L).contiguous()
+    w = torch.randn(B, L, d, device=dev)
+    grads = []
+    for patched in (False, True):
+        if patched:
+            assert fused.patch_embedding_backward(emb) == 1
+        emb.zero_grad(set_to_none=True)
+        out = emb(ids)
+        (out * w).sum().backward()
+        grads.append((out.detach().clone(), emb.weight.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0])
+    assert (grads[0][1] - grads[1][1]).abs().max() <= 1e-3 * max(1.0, grads[0][1].abs().max().item())

@@ -2,8 +2,9 @@
 
 Only the hot path lives here: the ContrastiveLoss boundary, the
 ContrastivePretraining / IJEPA task surface around it and the HIP kernels (``csrc/``) behind a
-C ABI (``include/mmlearn_hip.h``).  Importing the package does not load the HIP library;
-the first op does, and fails loudly if it is missing.
+C ABI (``include/mmlearn_hip.h``).  ``mmlearn_amd.fused`` / ``mmlearn_amd.attention`` hold the opt-in
+encoder-side kernels of the first widening (section 8(f1)): ``fused.accelerate_encoder(module, ...)``.
+Importing the package does not load the HIP library; the first op does, and fails loudly if it is missing.
 """
 
 from .losses import ContrastiveLoss, LossPairSpec, find_matching_indices  # noqa: F401

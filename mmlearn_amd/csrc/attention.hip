@@ -33,6 +33,17 @@ typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ATT_DH = 64;  // head dimension (one 128-byte row of bf16)
 
+// Workgroups per resident slot of the persistent kernels.  1 = every workgroup lives for the whole launch, which is the
+// fastest when the GPU is ours alone; but a workgroup that starts late (CUs held by a concurrent kernel -- RCCL's
+// all-reduce under DDP) then finishes a whole share late.  With a factor of 4 a share is a quarter of that, at the price
+// of three more exposed prologues per slot (+2 % measured alone).  MMK_ATTN_GRID_FACTOR selects it; the default stays 1:
+// DDP's bucketed all-reduce is active for a few per cent of the backward at 8 GPUs, less than the factor would cost.
+static int att_grid_factor() {
+  const char* e = getenv("MMK_ATTN_GRID_FACTOR");
+  const int f = e ? atoi(e) : 1;
+  return f < 1 ? 1 : (f > 64 ? 64 : f);
+}
+
 struct AttnArgs {
   const bf16_t* q;
   const bf16_t* k;
@@ -354,7 +365,7 @@ static int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
     MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * NW, bytes));
     wgs_per_cu = std::max(1, occ);
   }
-  const int grid = std::min(a.B * a.H, cus * wgs_per_cu);
+  const int grid = std::min(a.B * a.H, cus * wgs_per_cu * att_grid_factor());
   ProfEvents pe(MMK_K_ATTN_FWD);
   hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), bytes, st, pe.start, pe.stop, 0, a);
   MMK_LAUNCH_CHECK();
@@ -821,7 +832,7 @@ static int launch_attn_bwd5(const AttnBwdArgs& a, hipStream_t st) {
     MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * NW, bytes));
     wgs_per_cu = std::max(1, occ);
   }
-  const int grid = std::min(a.B * a.H, cus * wgs_per_cu);
+  const int grid = std::min(a.B * a.H, cus * wgs_per_cu * att_grid_factor());
   {
     const long chunks = (long)a.B * a.L * a.H * 8;
     const int dgrid = (int)std::min<long>((chunks + 255) / 256, (long)cus * 16);
@@ -850,7 +861,7 @@ static int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st) {
     MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * NW, bytes));
     wgs_per_cu = std::max(1, occ);
   }
-  const int grid = std::min(a.B * a.H, cus * wgs_per_cu);
+  const int grid = std::min(a.B * a.H, cus * wgs_per_cu * att_grid_factor());
   {
     const long chunks = (long)a.B * a.L * a.H * 8;
     const int dgrid = (int)std::min<long>((chunks + 255) / 256, (long)cus * 16);

@@ -13,6 +13,7 @@
 //   * f32 partial tiles go to a workspace, a second kernel sums the splits (deterministic, no atomics) and writes dW in
 //     the parameter's dtype.
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -219,8 +220,12 @@ extern "C" {
 int mmk_wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* ws_floats_out) {
   MMK_REQUIRE(M > 0 && N > 0 && K > 0 && splits_out && ws_floats_out, "bad arguments");
   const int tn = cdiv(N, WG_TILE), tk = cdiv(K, WG_TILE), T = tn * tk;
-  // one workgroup per CU and a single round: with T <= 32 tiles every XCD (32 CUs) hosts floor(32 / T) whole splits
-  int splits = T <= 32 ? 8 * (32 / T) : std::max(1, 256 / T);
+  // one workgroup per CU and a single round: with T <= 32 tiles every XCD (32 CUs) hosts floor(32 / T) whole splits.
+  // MMK_WGRAD_RESERVE_CUS (per XCD, default 0) leaves CUs to a concurrent kernel such as RCCL's all-reduce -- a launch
+  // that no longer fits one round takes two -- at +8 % for the 36-tile shapes when the GPU is not shared.
+  static const int reserve = getenv("MMK_WGRAD_RESERVE_CUS") ? std::min(16, std::max(0, atoi(getenv("MMK_WGRAD_RESERVE_CUS")))) : 0;
+  const int per_xcd = 32 - reserve;
+  int splits = T <= per_xcd ? 8 * (per_xcd / T) : std::max(1, 8 * per_xcd / T);
   splits = (int)std::min<int64_t>(splits, std::max<int64_t>(1, M / 512));
   *splits_out = splits;
   *ws_floats_out = (int64_t)splits * tn * WG_TILE * tk * WG_TILE;

@@ -573,7 +573,9 @@ int mmk_add_layernorm_fwd(const void* x, const float* xbias, const float* r, con
   const dim3 grid((unsigned)((rows + 3) / 4));
   int rc = MMK_DISPATCH_DTYPE(dtype & 15, XT, [&]() -> int {
     return MMK_DISPATCH_DTYPE((dtype >> 4) & 15, Y, [&]() -> int {
-      if (d <= 1024) {
+      if (d <= 768) {  // ViT-B / BERT-base width: three float4 per lane, a quarter fewer registers than VEC = 4
+        if (drop) MMK_ADDLN_FWD(3, true); else MMK_ADDLN_FWD(3, false);
+      } else if (d <= 1024) {
         if (drop) MMK_ADDLN_FWD(4, true); else MMK_ADDLN_FWD(4, false);
       } else {
         if (drop) MMK_ADDLN_FWD(8, true); else MMK_ADDLN_FWD(8, false);
@@ -607,7 +609,10 @@ int mmk_add_layernorm_bwd(const float* s, const void* dy, const void* dy_twin, c
   const size_t lds = dw ? 4 * np * d * sizeof(float) : 0;
   int rc = MMK_DISPATCH_DTYPE(dtype & 15, XT, [&]() -> int {
     return MMK_DISPATCH_DTYPE((dtype >> 4) & 15, G, [&]() -> int {
-      if (d <= 1024) {
+      if (d <= 768) {
+        if (dxbias) { if (drop) MMK_ADDLN_BWD(3, true, true); else MMK_ADDLN_BWD(3, false, true); }
+        else { if (drop) MMK_ADDLN_BWD(3, true, false); else MMK_ADDLN_BWD(3, false, false); }
+      } else if (d <= 1024) {
         if (dxbias) { if (drop) MMK_ADDLN_BWD(4, true, true); else MMK_ADDLN_BWD(4, false, true); }
         else { if (drop) MMK_ADDLN_BWD(4, true, false); else MMK_ADDLN_BWD(4, false, false); }
       } else {

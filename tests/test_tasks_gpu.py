@@ -191,3 +191,38 @@ def test_contrastive_with_ijepa_auxiliary():
     assert torch.isfinite(loss) and "train/ijepa_loss" in task.logged
     task.on_before_zero_grad(None)
     assert task.auxiliary_tasks["ijepa"].target_encoder.num_updates == 1
+
+
+def test_fused_encoder_training_trajectory_matches_stock():
+    """End-to-end regression for the whole encoder-side stack: 10 SGD steps of the bench's task (small encoders, dropout
+    off) with every fusion on follow the stock-module run -- same losses within bf16 noise, same weight updates."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mmlearn_amd import ContrastiveLoss
+
+    dev = torch.device("cuda", 0)
+    curves, deltas = [], []
+    for fused in (False, True):
+        task = bench.build_task(ContrastiveLoss(static_shapes=True), small=True, fused=fused).to(dev)
+        task.eval()  # dropout off (BERT's default 0.1 would make the two runs draw different masks); grads still flow
+        init = torch.cat([p.detach().float().flatten() for p in task.parameters()])
+        opt = torch.optim.SGD(task.parameters(), lr=0.5)   # plain SGD: the weight change is the sum of the gradients
+        batch = bench.synthetic_batch(1024, 0, dev)
+        losses = []
+        for _ in range(10):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = task.training_step(batch, 0)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach().float().item()))
+        curves.append(losses)
+        deltas.append(torch.cat([p.detach().float().flatten() for p in task.parameters()]) - init)
+    a, b = curves
+    for x, y in zip(a, b):
+        assert abs(x - y) <= 2e-2 * max(1.0, abs(x)), (a, b)
+    da, db = deltas
+    assert da.norm() > 0
+    cos = torch.dot(da, db) / (da.norm() * db.norm())
+    assert cos >= 0.98 and abs(da.norm() / db.norm() - 1) <= 0.05, (cos.item(), (da.norm() / db.norm()).item())

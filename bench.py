@@ -101,6 +101,15 @@ def synthetic_batch(b: int, rank: int, device):
     }
 
 
+def _adamw(fused: bool):
+    """AdamW(lr=1e-4, weight_decay=0.1): torch's, or the same update as one HIP launch per group (mmlearn_amd.optim)."""
+    if fused and os.environ.get("MMK_BENCH_TORCH_ADAMW") is None:
+        from mmlearn_amd.optim import AdamW
+
+        return partial(AdamW, lr=1e-4, weight_decay=0.1)
+    return partial(torch.optim.AdamW, lr=1e-4, weight_decay=0.1)
+
+
 def build_task(loss, small: bool, fused: bool = False):
     from mmlearn_amd.tasks.contrastive_pretraining import ContrastivePretraining
 
@@ -117,7 +126,7 @@ def build_task(loss, small: bool, fused: bool = False):
     return ContrastivePretraining(
         encoders={"rgb": rgb, "text": text},
         loss=loss,
-        optimizer=partial(torch.optim.AdamW, lr=1e-4, weight_decay=0.1),
+        optimizer=_adamw(fused),
         compute_validation_loss=False,
         compute_test_loss=False,
     )

@@ -202,6 +202,25 @@ typedef struct {
 int mmk_ema_update(const mmk_ema_entry* table, int n_tensors, int64_t max_numel, float decay, int mode,
                    void* stream);
 
+/* Multi-tensor AdamW step for one parameter group (torch.optim.AdamW semantics: decoupled weight decay, bias
+ * correction, eps added to sqrt(v)/sqrt(bc2); amsgrad / maximize off).  f32 parameters and moments; gradients f32 or
+ * bf16 (grad_dtypes[k] = MMK_*), their pointers re-supplied every step.  `chunks` is the flat work list: one entry per
+ * mmk_adamw_chunk_elems() elements of a tensor.  All four tables live in device memory. */
+typedef struct {
+  void* param;
+  void* exp_avg;
+  void* exp_avg_sq;
+  int64_t numel;
+} mmk_adamw_tensor;
+typedef struct {
+  int32_t tensor;
+  int32_t pad;
+  int64_t offset;
+} mmk_adamw_chunk;
+int mmk_adamw_chunk_elems(void);
+int mmk_adamw_update(const mmk_adamw_tensor* tensors, const void* const* grads, const int32_t* grad_dtypes, const mmk_adamw_chunk* chunks,
+                     int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
+
 /* ------------------------------------------------------------------ encoder-side row ops
  * torch.nn.LayerNorm inside the encoders the tasks drive (mmlearn/modules/encoders/{clip,text,vision}.py):
  * F.layer_norm forward / backward with f32 statistics.  x: [rows, d]; w, b: f32[d] or NULL; mean/rstd: f32[rows].

@@ -405,6 +405,53 @@ __global__ __launch_bounds__(256) void ema_kernel(const mmk_ema_entry* __restric
   }
 }
 
+// ------------------------------------------------------------------ multi-tensor AdamW (one launch per parameter group)
+// torch.optim.AdamW's single-tensor update (torch/optim/adamw.py -> _single_tensor_adam with decoupled weight decay),
+// f32 parameters / moments, gradient f32 or bf16:
+//   p *= 1 - lr * wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+// The foreach implementation is ~7 passes of 15-25 launches over the parameters (3.7 ms for 172 M parameters); this is one
+// pass: every block takes one 4096-element chunk from a flat (tensor, offset) work list built once on the host.
+__global__ __launch_bounds__(256) void adamw_kernel(const mmk_adamw_tensor* __restrict__ tensors, const void* const* __restrict__ grads,
+                                                    const int32_t* __restrict__ grad_dtypes, const mmk_adamw_chunk* __restrict__ chunks,
+                                                    float lr, float b1, float b2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2) {
+  const mmk_adamw_chunk ck = chunks[blockIdx.x];
+  const mmk_adamw_tensor t = tensors[ck.tensor];
+  const void* g = grads[ck.tensor];
+  const int gdt = grad_dtypes[ck.tensor];
+  const long base = ck.offset;
+  const long end = min(t.numel, base + EMA_CHUNK);
+  float* p = static_cast<float*>(t.param);
+  float* m = static_cast<float*>(t.exp_avg);
+  float* v = static_cast<float*>(t.exp_avg_sq);
+  const float decay = 1.f - lr * wd, step = lr * inv_bc1, c1 = 1.f - b1, c2 = 1.f - b2;
+  auto upd = [&](float& pv, float& mv, float& vv, float gv) {
+    pv *= decay;
+    mv = b1 * mv + c1 * gv;
+    vv = b2 * vv + c2 * gv * gv;
+    pv -= step * mv / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+  };
+  if (base + EMA_CHUNK <= t.numel && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+                                       reinterpret_cast<uintptr_t>(g)) & 15) == 0 && (base & 3) == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long i = base + (threadIdx.x + 256 * u) * 4;
+      float4 pv = *reinterpret_cast<float4*>(p + i), mv = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+      const float4 gv = gdt == MMK_F32 ? *reinterpret_cast<const float4*>(static_cast<const float*>(g) + i)
+                                       : Vec4<bf16_t>::load(static_cast<const bf16_t*>(g) + i);
+      upd(pv.x, mv.x, vv.x, gv.x); upd(pv.y, mv.y, vv.y, gv.y); upd(pv.z, mv.z, vv.z, gv.z); upd(pv.w, mv.w, vv.w, gv.w);
+      *reinterpret_cast<float4*>(p + i) = pv;
+      *reinterpret_cast<float4*>(m + i) = mv;
+      *reinterpret_cast<float4*>(v + i) = vv;
+    }
+    return;
+  }
+  for (long i = base + threadIdx.x; i < end; i += 256) {
+    float pv = p[i], mv = m[i], vv = v[i];
+    upd(pv, mv, vv, load_tag(g, i, gdt));
+    p[i] = pv; m[i] = mv; v[i] = vv;
+  }
+}
+
 }  // namespace mmk
 
 using namespace mmk;
@@ -616,6 +663,19 @@ int mmk_ema_update(const mmk_ema_entry* table, int n_tensors, int64_t max_numel,
   ProfScope ps(MMK_K_EMA, st);
   const long chunks = (max_numel + EMA_CHUNK - 1) / EMA_CHUNK;
   hipLaunchKernelGGL(ema_kernel, dim3((unsigned)chunks, n_tensors), dim3(256), 0, st, table, decay, mode);
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+int mmk_adamw_chunk_elems(void) { return EMA_CHUNK; }
+
+int mmk_adamw_update(const mmk_adamw_tensor* tensors, const void* const* grads, const int32_t* grad_dtypes, const mmk_adamw_chunk* chunks,
+                     int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream) {
+  MMK_REQUIRE(tensors && grads && grad_dtypes && chunks && n_chunks > 0 && step > 0, "bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)n_chunks), dim3(256), 0, st, tensors, grads, grad_dtypes, chunks, lr, beta1, beta2, eps,
+                     weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
   MMK_LAUNCH_CHECK();
   return 0;
 }

@@ -1,0 +1,96 @@
+"""``AdamW`` with the update as ONE multi-tensor HIP launch per parameter group (``csrc/ijepa.hip::adamw_kernel``).
+
+Same algorithm and hyper-parameters as ``torch.optim.AdamW`` (decoupled weight decay, bias correction, ``amsgrad`` /
+``maximize`` off) for f32 parameters on the GPU; the foreach implementation makes ~7 passes of 15-25 launches over the
+parameters (3.7 ms for the 172 M parameters of ViT-B/16 + BERT-base), this one reads and writes every tensor once.
+Use it wherever an mmlearn task takes ``optimizer=partial(torch.optim.AdamW, ...)``:
+``optimizer=partial(mmlearn_amd.optim.AdamW, lr=..., weight_decay=...)``.  ``state_dict`` keeps torch's layout
+(``step``, ``exp_avg``, ``exp_avg_sq`` per parameter).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, List
+
+import torch
+
+from . import _lib
+from .kernels import check, dtype_tag, require_gpu, stream
+
+
+class _Tensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("numel", C.c_int64)]
+
+
+class _Chunk(C.Structure):
+    _fields_ = [("tensor", C.c_int32), ("pad", C.c_int32), ("offset", C.c_int64)]
+
+
+def _to_device(raw: bytes, device) -> torch.Tensor:
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tables: Dict[int, Any] = {}
+
+    def _table(self, gi: int, plist: List[torch.Tensor]):
+        """Static device tables of one group (rebuilt when the set of parameters with gradients changes)."""
+        key = tuple(p.data_ptr() for p in plist)
+        tab = self._tables.get(gi)
+        if tab is not None and tab["key"] == key:
+            return tab
+        chunk = _lib.lib().mmk_adamw_chunk_elems()
+        tens = (_Tensor * len(plist))()
+        chunks = []
+        for k, p in enumerate(plist):
+            st = self.state[p]
+            tens[k].param, tens[k].exp_avg, tens[k].exp_avg_sq, tens[k].numel = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+            chunks.extend((k, off) for off in range(0, p.numel(), chunk))
+        carr = (_Chunk * len(chunks))()
+        for i, (k, off) in enumerate(chunks):
+            carr[i].tensor, carr[i].offset = k, off
+        dev = plist[0].device
+        tab = {"key": key, "tensors": _to_device(bytes(tens), dev), "chunks": _to_device(bytes(carr), dev), "n_chunks": len(chunks)}
+        self._tables[gi] = tab
+        return tab
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None]
+            if not plist:
+                continue
+            for p in plist:
+                require_gpu(p)
+                if p.dtype != torch.float32 or not p.is_contiguous() or p.grad.is_sparse:
+                    raise RuntimeError("mmlearn_amd.optim.AdamW supports dense contiguous f32 parameters")
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.zeros((), dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            tab = self._table(gi, plist)
+            steps = {int(self.state[p]["step"].item()) for p in plist}
+            if len(steps) != 1:
+                raise RuntimeError("mmlearn_amd.optim.AdamW needs all parameters of a group at the same step")
+            step = steps.pop() + 1
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in plist]
+            dev = plist[0].device
+            gptr = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64).to(dev, non_blocking=True)
+            gdt = torch.tensor([dtype_tag(g.dtype) for g in grads], dtype=torch.int32).to(dev, non_blocking=True)
+            b1, b2 = group["betas"]
+            check(_lib.lib().mmk_adamw_update(tab["tensors"].data_ptr(), gptr.data_ptr(), gdt.data_ptr(), tab["chunks"].data_ptr(), tab["n_chunks"],
+                                              float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), step,
+                                              stream()))
+            for p in plist:
+                self.state[p]["step"] += 1
+        return loss

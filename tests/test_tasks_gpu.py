@@ -226,3 +226,29 @@ def test_fused_encoder_training_trajectory_matches_stock():
     assert da.norm() > 0
     cos = torch.dot(da, db) / (da.norm() * db.norm())
     assert cos >= 0.98 and abs(da.norm() / db.norm() - 1) <= 0.05, (cos.item(), (da.norm() / db.norm()).item())
+
+
+def test_hip_adamw_matches_torch_adamw():
+    from mmlearn_amd.optim import AdamW
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    shapes = [(300, 768), (768,), (5000, 64), (7,), (4096 * 3 + 5,)]
+    ref_p = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in shapes]
+    hip_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    kw = dict(lr=3e-3, betas=(0.9, 0.98), eps=1e-6)
+    ref = torch.optim.AdamW([{"params": ref_p[:3], "weight_decay": 0.1}, {"params": ref_p[3:], "weight_decay": 0.0}], **kw)
+    hip = AdamW([{"params": hip_p[:3], "weight_decay": 0.1}, {"params": hip_p[3:], "weight_decay": 0.0}], **kw)
+    for it in range(5):
+        for a, b in zip(ref_p, hip_p):
+            g = torch.randn_like(a)
+            a.grad = g.clone()
+            b.grad = g.to(torch.bfloat16).float() if it == 2 else g.clone()   # any f32 gradient values
+            if it == 2:
+                a.grad = b.grad.clone()
+        ref.step()
+        hip.step()
+        for a, b in zip(ref_p, hip_p):
+            assert (a - b).abs().max() <= 2e-6 * max(1.0, a.abs().max().item()), it
+    sd = hip.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}

@@ -7,12 +7,15 @@ Workload (BASELINE.json configs[1] per GPU; configs[2] at N = 8): CLIP ViT-B/16 
 (HF ``CLIPVisionModelWithProjection`` from config, projection 512) + BERT-base text encoder (HF
 ``BertModel`` from config + Linear(768, 512)), random-init weights, synthetic batches
 (``rand(B,3,224,224)`` pixels, ``randint(0, 30522, (B,77))`` tokens, fully paired ids), bf16 autocast,
-per-GPU batch 1024, AdamW.  One step = encoders forward -> HIP L2-normalise -> HIP contrastive loss
-(global-batch negatives via the packed all-gather when N > 1) -> backward -> optimizer step.
+per-GPU batch 1024, AdamW(lr 1e-4, weight decay 0.1).  One step = encoders forward -> HIP L2-normalise -> HIP
+contrastive loss (global-batch negatives via the packed all-gather when N > 1) -> backward -> optimizer step.  The
+encoders are the stock HF modules with the kernels of SURVEY 8(f1) swapped in underneath (``mmlearn_amd.fused``:
+same parameters, same math; ``--no-fused-encoder-ops`` runs them untouched, 421 ms vs ~215 ms per step).
 
 The JSON line carries, besides the driver contract:
   roofline     -- the dominant MFMA kernel of the loss path, timed with HIP events on its launch stream
                   inside the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s);
+  roofline_widened -- the same for the dominant hand-written kernel of the whole step (the weight-gradient GEMM);
   cpu_baseline -- the same step (same model, torch eager ops, oracle/eager_torch loss = the reference's op
                   sequence) on the host cores for a bounded sample (rank 0, N = 1 only).
 """

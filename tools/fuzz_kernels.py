@@ -1,0 +1,38 @@
+"""Randomised shape sweep of the attention and weight-gradient kernels against torch references (run by hand on the GPU)."""
+import os, sys, random
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmlearn_amd import kernels as K
+from mmlearn_amd.attention import attention_qkvpacked
+
+dev = torch.device("cuda", 0)
+rng = random.Random(int(os.environ.get("SEED", 0)))
+bad = 0
+for it in range(int(os.environ.get("N", 60))):
+    B, H, L = rng.randint(1, 6), rng.randint(1, 5), rng.randint(1, 256)
+    p = rng.choice([0.0, 0.0, 0.1])
+    qkv = (torch.randn(B, L, 3, H, 64, device=dev) * 1.2).bfloat16().requires_grad_(True)
+    out = attention_qkvpacked(qkv, 0.125, p, 1234 + it)
+    w = torch.randn_like(out, dtype=torch.float32)
+    (out.float() * w).sum().backward()
+    if p == 0.0:
+        q, k, v = (qkv.detach()[:, :, i].transpose(1, 2).float().requires_grad_(True) for i in range(3))
+        ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2)
+        (ref * w).sum().backward()
+        gref = torch.stack([t.grad.transpose(1, 2) for t in (q, k, v)], 2)
+        e1 = (out.float() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+        e2 = (qkv.grad.float() - gref).abs().max().item() / max(1e-3, gref.abs().max().item())
+        if e1 > 2e-2 or e2 > 4e-2 or not torch.isfinite(qkv.grad.float()).all():
+            bad += 1; print("ATTN MISMATCH", B, H, L, e1, e2)
+    elif not (torch.isfinite(out.float()).all() and torch.isfinite(qkv.grad.float()).all()):
+        bad += 1; print("ATTN NONFINITE", B, H, L, p)
+for it in range(int(os.environ.get("N", 60))):
+    M, N, Kk = rng.randint(1, 9000), 8 * rng.randint(1, 120), 8 * rng.randint(1, 120)
+    dy = torch.randn(M, N, device=dev).bfloat16(); x = torch.randn(M, Kk, device=dev).bfloat16()
+    ref = dy.float().t() @ x.float()
+    got = K.wgrad(dy, x)
+    e = (got - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    if e > 3e-3:
+        bad += 1; print("WGRAD MISMATCH", M, N, Kk, e)
+torch.cuda.synchronize()
+print("fuzz done, mismatches:", bad)

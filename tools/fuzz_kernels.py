@@ -36,3 +36,41 @@ for it in range(int(os.environ.get("N", 60))):
         bad += 1; print("WGRAD MISMATCH", M, N, Kk, e)
 torch.cuda.synchronize()
 print("fuzz done, mismatches:", bad)
+
+# ---- row kernels: add + LayerNorm (+ deferred bias, dropout off) and bias + activation
+from mmlearn_amd import fused
+import torch.nn.functional as F
+bad2 = 0
+for it in range(int(os.environ.get("N", 60)) // 2):
+    rows, d = rng.randint(1, 700), 8 * rng.randint(1, 256)
+    ln = fused.LayerNorm.from_torch(torch.nn.LayerNorm(d).to(dev), False)
+    x = torch.randn(rows, d, device=dev).bfloat16().requires_grad_(True)
+    r = torch.randn(rows, d, device=dev).requires_grad_(True)
+    xb = torch.randn(d, device=dev).requires_grad_(True)
+    s, y = fused.add_layer_norm(x, r, ln, xbias=xb)
+    ws, wy = torch.randn_like(s), torch.randn_like(y)
+    ((s * ws).sum() + (y * wy).sum()).backward()
+    x2, r2, xb2 = x.detach().float().requires_grad_(True), r.detach().clone().requires_grad_(True), xb.detach().clone().requires_grad_(True)
+    s_ref = r2 + x2 + xb2
+    y_ref = F.layer_norm(s_ref, (d,), ln.weight.detach(), ln.bias.detach(), ln.eps)
+    ((s_ref * ws).sum() + (y_ref * wy).sum()).backward()
+    errs = [(s - s_ref).abs().max().item(), (y - y_ref).abs().max().item(), (x.grad.float() - x2.grad).abs().max().item() / max(1.0, x2.grad.abs().max().item()),
+            (r.grad - r2.grad).abs().max().item() / max(1.0, r2.grad.abs().max().item()), (xb.grad - xb2.grad).abs().max().item() / max(1.0, xb2.grad.abs().max().item())]
+    if max(errs[:2]) > 1e-3 or max(errs[2:]) > 2e-2:
+        bad2 += 1; print("ADDLN MISMATCH", rows, d, errs)
+    act = rng.choice(["quick_gelu", "gelu"])
+    z = torch.randn(rows, d, device=dev).bfloat16().requires_grad_(True)
+    bb = torch.randn(d, device=dev).requires_grad_(True)
+    a = fused.bias_act(z, bb, act)
+    wa = torch.randn_like(a, dtype=torch.float32)
+    (a.float() * wa).sum().backward()
+    z2, b2 = z.detach().float().requires_grad_(True), bb.detach().clone().requires_grad_(True)
+    t = z2 + b2
+    a_ref = t * torch.sigmoid(1.702 * t) if act == "quick_gelu" else F.gelu(t)
+    (a_ref * wa).sum().backward()
+    e = [(a.float() - a_ref).abs().max().item() / max(1.0, a_ref.abs().max().item()), (z.grad.float() - z2.grad).abs().max().item() / max(1.0, z2.grad.abs().max().item()),
+         (bb.grad - b2.grad).abs().max().item() / max(1.0, b2.grad.abs().max().item())]
+    if max(e[:2]) > 2e-2 or e[2] > 5e-2:
+        bad2 += 1; print("BIASACT MISMATCH", rows, d, act, e)
+torch.cuda.synchronize()
+print("row-kernel fuzz done, mismatches:", bad2)

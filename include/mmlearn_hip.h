@@ -47,7 +47,7 @@ enum {
   MMK_K_SIM_GRAD, MMK_K_GRAD_GEMM, MMK_K_GRAD_FINALIZE, MMK_K_L2NORM, MMK_K_IJEPA_LOSS_FWD,
   MMK_K_IJEPA_LOSS_BWD, MMK_K_GATHER_ROWS, MMK_K_SCATTER_ROWS, MMK_K_PRED_ASSEMBLE, MMK_K_PRED_ASSEMBLE_BWD,
   MMK_K_EMA, MMK_K_MASK_INDEX, MMK_K_LAYERNORM_FWD, MMK_K_LAYERNORM_BWD, MMK_K_ACT, MMK_K_ATTN_FWD,
-  MMK_K_ATTN_BWD, MMK_K_WGRAD, MMK_K_COUNT
+  MMK_K_ATTN_BWD, MMK_K_WGRAD, MMK_K_RECALL, MMK_K_COUNT
 };
 int mmk_profile_enable(int on);          /* on=1 start recording (clears), on=0 stop */
 /* resolve recorded events (synchronises on them); fills count[k] and total_ms[k] for k < MMK_K_COUNT */
@@ -220,6 +220,14 @@ typedef struct {
 int mmk_adamw_chunk_elems(void);
 int mmk_adamw_update(const mmk_adamw_tensor* tensors, const void* const* grads, const int32_t* grad_dtypes, const mmk_adamw_chunk* chunks,
                      int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
+
+/* ------------------------------------------------------------------ eval-side retrieval metric
+ * RetrievalRecallAtK._process_batch + _recall_at_k (mmlearn/modules/metrics/retrieval_recall.py:239-289): for every
+ * query row of x (f32 [n, d], L2-normalised) the number of rows of y (f32 [m, d]) whose score x_i . y_j beats the
+ * score of the query's positive pos[i]; ties go to the lower database index.  recall@k of the row = (rank < k).
+ * tpos_ws: f32[n] workspace; rank: int32[n] out. */
+int mmk_recall_ranks(const float* x, const float* y, const int64_t* pos, float* tpos_ws, int32_t* rank, int n, int m, int d,
+                     void* stream);
 
 /* ------------------------------------------------------------------ encoder-side row ops
  * torch.nn.LayerNorm inside the encoders the tasks drive (mmlearn/modules/encoders/{clip,text,vision}.py):

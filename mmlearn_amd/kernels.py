@@ -445,6 +445,20 @@ def embedding_bwd(dout2: torch.Tensor, ids: torch.Tensor, vocab: int) -> torch.T
     return dw
 
 
+def recall_ranks(xn: torch.Tensor, yn: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    """xn [n, d], yn [m, d] f32 L2-normalised, pos int64[n] -> int32[n]: database rows ranked before each query's positive."""
+    require_gpu(xn)
+    assert xn.dtype == torch.float32 and yn.dtype == torch.float32 and pos.dtype == torch.int64
+    xn, yn, pos = xn.contiguous(), yn.contiguous(), pos.contiguous()
+    n, d = xn.shape
+    m = yn.shape[0]
+    assert yn.shape[1] == d and pos.numel() == n
+    tpos = torch.empty(n, dtype=torch.float32, device=xn.device)
+    rank = torch.empty(n, dtype=torch.int32, device=xn.device)
+    check(_lib.lib().mmk_recall_ranks(ptr(xn), ptr(yn), ptr(pos), ptr(tpos), ptr(rank), n, m, d, stream()))
+    return rank
+
+
 ACT_QUICK_GELU, ACT_GELU = 0, 1
 
 

@@ -7,7 +7,8 @@ Run in the build container only (needs /root/reference):
 Writes small ``.npz`` fixtures (inputs + the reference's outputs).  The
 fixtures are data; no reference source is stored.  Fixture ids follow
 SURVEY.md §8(c): G1 clip-2mod, G2 clip-Nmod, G3 clip-dist, G4 match,
-G5 task-step, G6 ijepa-ops, G7 masks, G8 ema.
+G5 task-step, G6 ijepa-ops, G7 masks, G8 ema; G9 alignment loss, G10 retrieval recall@k (the
+SURVEY 8(f3) widening).
 """
 
 from __future__ import annotations
@@ -430,6 +431,49 @@ def gen_align(R):
     return cases
 
 
+def gen_recall(R):
+    """G10: RetrievalRecallAtK (modules/metrics/retrieval_recall.py) -- update() in batches, compute() on CPU."""
+    import mmlearn.modules.metrics.retrieval_recall as rr
+
+    cases = {}
+    gen = torch.Generator().manual_seed(1234)
+    for name, (n, d, bs, ks, mode) in {
+        "paired_64": (64, 32, 16, (1, 5, 10), "paired"),
+        "shuffled_96": (96, 48, 32, (1, 3, 10), "shuffled"),
+        "noisy_128": (128, 64, 64, (1, 5, 20), "noisy"),
+        "single_batch_40": (40, 16, 40, (1, 2, 7), "noisy"),
+    }.items():
+        base = torch.randn(n, d, generator=gen)
+        if mode == "paired":
+            x, y = base + 0.3 * torch.randn(n, d, generator=gen), base.clone()
+        elif mode == "shuffled":
+            x, y = base + 0.5 * torch.randn(n, d, generator=gen), base.clone()
+        else:
+            x, y = base + 1.5 * torch.randn(n, d, generator=gen), base + 0.2 * torch.randn(n, d, generator=gen)
+        x, y = 3.0 * x, 0.5 * y  # unnormalised inputs: compute() normalises
+        rec = {"in_x": _np(x), "in_y": _np(y), "in_batch": np.array(bs)}
+        # within every batch the positives are a permutation of the batch's y rows (the metric offsets them by the count so far)
+        idx_batches = []
+        for s0 in range(0, n, bs):
+            b = min(bs, n - s0)
+            idx_batches.append(torch.randperm(b, generator=gen) if mode == "shuffled" else torch.arange(b))
+        rec["in_indexes"] = _np(torch.cat(idx_batches))
+        for k in ks:
+            for agg in ("mean", "min"):
+                m = rr.RetrievalRecallAtK(top_k=k, reduction="none", aggregation=agg)
+                for bi, s0 in enumerate(range(0, n, bs)):
+                    b = min(bs, n - s0)
+                    yb = y[s0:s0 + b]
+                    if mode == "shuffled":   # row i of the batch matches y row idx[i] of the same batch
+                        m.update(x[s0:s0 + b], yb, idx_batches[bi])
+                    else:
+                        m.update(x[s0:s0 + b], yb, idx_batches[bi])
+                rec[f"out_recall_k{k}_{agg}"] = _np(m.compute())
+        cases[name] = rec
+        print("  recall", name, {k: float(v) for k, v in rec.items() if k.startswith("out_")})
+    return cases
+
+
 def _save(name, cases):
     flat = {}
     for c, rec in cases.items():
@@ -442,7 +486,7 @@ def _save(name, cases):
 
 def main():
     R = ref_shim.load()
-    which = sys.argv[1:] or ["clip", "match", "task", "ijepa", "masks", "ema", "dist", "align"]
+    which = sys.argv[1:] or ["clip", "match", "task", "ijepa", "masks", "ema", "dist", "align", "recall"]
     if "clip" in which:
         _save("g1_g2_clip", gen_clip(R))
     if "match" in which:
@@ -459,6 +503,8 @@ def main():
         _save("g3_clip_dist", gen_dist())
     if "align" in which:
         _save("g9_align", gen_align(R))
+    if "recall" in which:
+        _save("g10_recall", gen_recall(R))
 
 
 if __name__ == "__main__":

@@ -130,11 +130,16 @@ def install() -> None:
 
     # ---- torchmetrics ------------------------------------------------------
     class Metric(nn.Module):
+        """Stand-in for torchmetrics.Metric: just enough state handling for the reference's metrics to run on one process
+        (add_state keeps a copy of the default as an attribute; no sync, no reset bookkeeping)."""
+
         def __init__(self, *a, **k):
             super().__init__()
+            self.process_group = None
+            self.distributed_available_fn = lambda: False
 
-        def add_state(self, *a, **k):
-            pass
+        def add_state(self, name, default, dist_reduce_fx=None, persistent=False):
+            setattr(self, name, [] if isinstance(default, list) else default.clone())
 
     class _Dummy(Metric):
         pass
@@ -160,7 +165,19 @@ def install() -> None:
     _mod("torchmetrics.utilities.data", dim_zero_cat=lambda x: torch.cat(list(x), 0))
     _mod("torchmetrics.utilities.distributed", gather_all_tensors=lambda x, *a, **k: [x])
     _mod("torchmetrics.retrieval")
-    _mod("torchmetrics.retrieval.base", _retrieval_aggregate=lambda *a, **k: None)
+    def _retrieval_aggregate(values, aggregation="mean", dim=None):
+        # torchmetrics 1.6.2 retrieval/base.py (not vendored): mean / median / min / max over the values, or a callable
+        if aggregation == "mean":
+            return values.mean() if dim is None else values.mean(dim=dim)
+        if aggregation == "median":
+            return values.median() if dim is None else values.median(dim=dim).values
+        if aggregation == "min":
+            return values.min() if dim is None else values.min(dim=dim).values
+        if aggregation == "max":
+            return values.max() if dim is None else values.max(dim=dim).values
+        return aggregation(values, dim=dim)
+
+    _mod("torchmetrics.retrieval.base", _retrieval_aggregate=_retrieval_aggregate)
 
     # ---- timm --------------------------------------------------------------
     def global_pool_nlc(x, pool_type="", num_prefix_tokens=1, reduce_include_prefix=False):

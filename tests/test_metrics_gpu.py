@@ -1,0 +1,70 @@
+"""GPU parity of the eval-side retrieval metric: mmlearn_amd.metrics.RetrievalRecallAtK vs the golden
+vectors produced by the reference's RetrievalRecallAtK and vs the numpy oracle."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_recall_matches_reference_golden():
+    from mmlearn_amd.metrics import RetrievalRecallAtK
+
+    dev = torch.device("cuda", 0)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g10_recall.npz"))
+    for c in sorted({k.split("/")[0] for k in g.files}):
+        x, y, idx, bs = (torch.from_numpy(g[c + "/in_x"]).to(dev), torch.from_numpy(g[c + "/in_y"]).to(dev),
+                         torch.from_numpy(g[c + "/in_indexes"]).to(dev), int(g[c + "/in_batch"]))
+        for f in [f for f in g.files if f.startswith(c + "/out_")]:
+            _, k, agg = f.split("/")[1].split("_")[1:]
+            m = RetrievalRecallAtK(top_k=int(k[1:]), reduction="none", aggregation=agg)
+            for s in range(0, len(x), bs):
+                m.update(x[s:s + bs], y[s:s + bs], idx[s:s + bs])
+            assert abs(float(m.compute()) - float(g[f])) < 1e-6, f
+
+
+@pytest.mark.parametrize("n,m_extra,d", [(1000, 0, 512), (777, 300, 96), (65, 1, 4), (3, 0, 130)])
+def test_recall_ranks_match_oracle(n, m_extra, d):
+    """Ranks (an integer per query) against the oracle, with duplicated database rows so the tie rule is exercised."""
+    from mmlearn_amd import kernels as K
+    from mmlearn_amd.ops import l2_normalize
+    from oracle import metrics_oracle as mo
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(n + d)
+    base = torch.randn(n + m_extra, d, generator=g)
+    x = base[:n] + 0.8 * torch.randn(n, d, generator=g)
+    y = base.clone()
+    if n > 10:   # duplicates: rows 5 and 7 of the database equal the positives of queries 1 and 2 (rows 1, 2)
+        y[5], y[7] = y[1], y[2]
+    idx = torch.randperm(n + m_extra, generator=g)[:n] if m_extra else torch.arange(n)
+    ref = mo.ranks(x.numpy(), y.numpy(), idx.numpy())
+    xn, yn = l2_normalize(x.to(dev)), l2_normalize(y.to(dev))
+    got = K.recall_ranks(xn, yn, idx.to(dev)).cpu().numpy()
+    # f32 scores vs the oracle's f64: a rank may differ only where two scores agree to ~1e-7
+    bad = np.nonzero(got != ref)[0]
+    assert len(bad) <= max(1, n // 500), (len(bad), got[bad][:5], ref[bad][:5])
+    if n > 10:
+        assert got[1] == ref[1] and got[2] == ref[2]       # the exact duplicates tie bit-exactly in both passes
+
+
+def test_recall_metric_argument_errors():
+    from mmlearn_amd.metrics import RetrievalRecallAtK
+
+    with pytest.raises(ValueError):
+        RetrievalRecallAtK(top_k=0)
+    with pytest.raises(ValueError):
+        RetrievalRecallAtK(top_k=1, reduction="max")
+    with pytest.raises(ValueError):
+        RetrievalRecallAtK(top_k=1, aggregation="sum")
+    m = RetrievalRecallAtK(top_k=1, reduction="none")
+    with pytest.raises(ValueError):
+        m.update(torch.zeros(2, 4), torch.zeros(2, 4), None)
+    with pytest.raises(NotImplementedError):
+        m(1)

@@ -181,3 +181,28 @@ def test_attention_dropout_mask_statistics():
         assert abs((a * b).mean() / var) < 5e-3
     assert AO.keep_mask(1, 1, 1, 8, 0.0).all()
     assert (AO.keep_mask(5, 1, 2, 64, 0.5) != AO.keep_mask(6, 1, 2, 64, 0.5)).mean() > 0.4
+
+
+def test_retrieval_recall_oracle_matches_reference_golden():
+    """G10: oracle/metrics_oracle.py against RetrievalRecallAtK.compute() of the reference (all cases, k, aggregations)."""
+    import os
+
+    from oracle import metrics_oracle as mo
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_recall.npz"))
+    cases = sorted({k.split("/")[0] for k in g.files})
+    assert len(cases) == 4
+    for c in cases:
+        x, y, idx, bs = g[c + "/in_x"], g[c + "/in_y"], g[c + "/in_indexes"], int(g[c + "/in_batch"])
+        n = len(x)
+        X, Y, I = mo.concat_batches([x[s:s + bs] for s in range(0, n, bs)], [y[s:s + bs] for s in range(0, n, bs)],
+                                    [idx[s:s + bs] for s in range(0, n, bs)])
+        outs = [f for f in g.files if f.startswith(c + "/out_")]
+        assert outs
+        for f in outs:
+            _, k, agg = f.split("/")[1].split("_")[1:]
+            assert abs(mo.recall_at_k(X, Y, I, int(k[1:]), agg) - float(g[f])) < 1e-6, f
+    # tie rule: a duplicate of the positive with a LOWER index outranks it, one with a higher index does not
+    x = np.eye(4, dtype=np.float32)
+    y = np.stack([x[1], x[0], x[0], x[3]]).astype(np.float32)     # query 0's positive is y row 2, duplicated at row 1
+    assert mo.ranks(x[:1], y, np.array([2])).tolist() == [1] and mo.ranks(x[:1], y, np.array([1])).tolist() == [0]

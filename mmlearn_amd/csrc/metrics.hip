@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const float* __restric
   // staging: thread t moves 16 floats of row t/2 per operand and chunk (two threads per row, 4 float4 each)
   const int lrow = tid >> 1, lseg = (tid & 1) * 16;
   const bool vec = (D & 3) == 0;
-  for (int k0 = 0; k0 < D; k0 += RK_KC) {
+  float4 ra[4], rb[4];
+  auto fetch = [&](int k0) {  // the next chunk travels in registers while the MFMAs of the current one run
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int k = k0 + lseg + 4 * v;
@@ -65,12 +66,21 @@ __global__ __launch_bounds__(256) void recall_rank_kernel(const float* __restric
         a = make_float4(av[0], av[1], av[2], av[3]);
         b = make_float4(bv[0], bv[1], bv[2], bv[3]);
       }
+      ra[v] = a;
+      rb[v] = b;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < D; k0 += RK_KC) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
       float* xd = &xs[lrow][lseg + 4 * v];
       float* yd = &ys[lrow][lseg + 4 * v];
-      xd[0] = a.x; xd[1] = a.y; xd[2] = a.z; xd[3] = a.w;
-      yd[0] = b.x; yd[1] = b.y; yd[2] = b.z; yd[3] = b.w;
+      xd[0] = ra[v].x; xd[1] = ra[v].y; xd[2] = ra[v].z; xd[3] = ra[v].w;
+      yd[0] = rb[v].x; yd[1] = rb[v].y; yd[2] = rb[v].z; yd[3] = rb[v].w;
     }
     __syncthreads();
+    if (k0 + RK_KC < D) fetch(k0 + RK_KC);
 #pragma unroll
     for (int kk = 0; kk < RK_KC / 2; ++kk) {  // lane (r, h): A[row r][k = 2kk + h], B[k = 2kk + h][col r]
       float af[2], bf[2];

@@ -96,3 +96,67 @@ class RetrievalRecallAtK(torch.nn.Module):
 
     def forward(self, *args: Any, **kwargs: Any) -> Any:
         raise NotImplementedError("RetrievalRecallAtK metric does not support forward method")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Zero-shot classification (mmlearn/tasks/zero_shot_classification.py:160-219): same similarity + top-k pattern, the
+# database being the class prototypes and the positive the target class.
+
+
+def class_prototypes(prompt_embeddings: torch.Tensor, num_templates: int) -> torch.Tensor:
+    """``[C * T, D]`` prompt embeddings (class-major, as the reference builds them, :150-154) -> ``[C, D]`` prototypes:
+    normalise, mean over the ``T`` templates, normalise again (:164-168)."""
+    if prompt_embeddings.dim() != 2 or prompt_embeddings.shape[0] % num_templates:
+        raise ValueError("prompt_embeddings must be [num_classes * num_templates, D]")
+    K.require_gpu(prompt_embeddings)
+    e = l2_normalize(prompt_embeddings.detach().float())
+    return l2_normalize(e.view(-1, num_templates, e.shape[-1]).mean(dim=1))
+
+
+def zero_shot_logits(query_embeddings: torch.Tensor, class_embeddings: torch.Tensor) -> torch.Tensor:
+    """The logits ``evaluation_step`` hands to its metrics (:201-214): ``100 * q_n @ C^T``, or for two classes the
+    difference of the softmax columns."""
+    K.require_gpu(query_embeddings)
+    s = l2_normalize(query_embeddings.detach().float()) @ class_embeddings.float().T
+    if class_embeddings.shape[0] == 2:
+        p = s.softmax(dim=-1)
+        return p[:, 1] - p[:, 0]
+    return 100.0 * s
+
+
+class ZeroShotTopKAccuracy(torch.nn.Module):
+    """Micro top-k accuracy of the multiclass zero-shot head for several ``k`` at once (the reference builds one
+    torchmetrics ``Accuracy(task="multiclass", top_k=k, average="micro")`` per ``k``, :240-252, each re-running
+    ``topk`` on the ``[B, C]`` logits).  ``update`` asks the counting kernel for the rank of the target class of every
+    query and keeps only a histogram of ranks below ``max(top_k)``; the logits are never materialised.  Ties: the lower
+    class index wins."""
+
+    def __init__(self, top_k=(1,)) -> None:
+        super().__init__()
+        self.top_k = tuple(int(k) for k in top_k)
+        if not self.top_k or min(self.top_k) < 1:
+            raise ValueError("`top_k` needs positive integers")
+        self.reset()
+
+    def reset(self) -> None:
+        self.hist: Optional[torch.Tensor] = None   # int64 [max_k + 1]; the last bin holds every rank >= max_k
+        self.total = 0
+
+    def update(self, query_embeddings: torch.Tensor, class_embeddings: torch.Tensor, targets: torch.Tensor) -> None:
+        if targets.numel() != query_embeddings.shape[0]:
+            raise ValueError("`targets` needs one class index per query")
+        if not query_embeddings.shape[0]:
+            return
+        K.require_gpu(query_embeddings)
+        r = K.recall_ranks(l2_normalize(query_embeddings.detach().float()), class_embeddings.float().contiguous(),
+                           targets.to(torch.int64))
+        kmax = max(self.top_k)
+        h = torch.bincount(r.clamp(max=kmax).long(), minlength=kmax + 1)
+        self.hist = h if self.hist is None else self.hist + h
+        self.total += query_embeddings.shape[0]
+
+    def compute(self) -> dict:
+        if self.hist is None:
+            raise RuntimeError("no samples: call update() first")
+        c = self.hist.cumsum(0).double() / self.total
+        return {k: c[k - 1].float() for k in self.top_k}

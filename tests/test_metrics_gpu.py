@@ -68,3 +68,32 @@ def test_recall_metric_argument_errors():
         m.update(torch.zeros(2, 4), torch.zeros(2, 4), None)
     with pytest.raises(NotImplementedError):
         m(1)
+
+
+def test_zero_shot_prototypes_logits_and_accuracy():
+    """zero_shot_classification.py:160-219 restated with torch ops on the same device vs the rank-kernel path."""
+    from mmlearn_amd.metrics import ZeroShotTopKAccuracy, class_prototypes, zero_shot_logits
+    g = torch.Generator().manual_seed(7)
+    C, T, D, B = 37, 5, 96, 301
+    prompts = torch.randn(C * T, D, generator=g).cuda()
+    e = prompts / prompts.norm(p=2, dim=-1, keepdim=True)
+    e = e.reshape(C, T, -1).mean(dim=1)
+    ref_proto = e / e.norm(p=2, dim=-1, keepdim=True)
+    proto = class_prototypes(prompts, T)
+    assert torch.allclose(proto, ref_proto, atol=1e-6)
+    targets = torch.randint(0, C, (B,), generator=g).cuda()
+    q = (ref_proto[targets] * 0.6 + 0.25 * torch.randn(B, D, generator=g).cuda())
+    qn = q / q.norm(p=2, dim=-1, keepdim=True)
+    ref_logits = 100.0 * qn @ ref_proto.T
+    assert torch.allclose(zero_shot_logits(q, proto), ref_logits, atol=2e-4)
+    two = zero_shot_logits(q, proto[:2])
+    sm = (qn @ ref_proto[:2].T).softmax(dim=-1)
+    assert torch.allclose(two, sm[:, 1] - sm[:, 0], atol=1e-6)
+    m = ZeroShotTopKAccuracy(top_k=(1, 3, 5))
+    for s in range(0, B, 128):   # batches, as evaluation_step sees them
+        m.update(q[s:s + 128], proto, targets[s:s + 128])
+    got = m.compute()
+    for k in (1, 3, 5):
+        want = (torch.topk(ref_logits, k, dim=1)[1] == targets[:, None]).any(dim=1).float().mean()
+        assert abs(float(got[k]) - float(want)) < 1e-6, (k, float(got[k]), float(want))
+    assert 0.2 < float(got[1]) < 1.0   # the case is neither trivial nor saturated

@@ -97,11 +97,14 @@ class _Step(nn.Module):
 def synthetic_batch(b: int, rank: int, device):
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     ids = torch.stack([torch.zeros(b, dtype=torch.long), torch.arange(rank * b, (rank + 1) * b)], 1)
-    return {
+    batch = {
         "rgb": torch.rand(b, 3, 224, 224, generator=g).to(device),
         "text": torch.randint(0, 30522, (b, 77), generator=g).to(device),
         "example_ids": {"rgb": ids.to(device), "text": ids.to(device)},
     }
+    if os.environ.get("MMK_BENCH_PAIRED_HINT"):  # A/B: what mmlearn_amd.wire.DefaultDataCollator adds (default: the matcher runs)
+        batch["fully_paired"] = True
+    return batch
 
 
 def _adamw(fused: bool):

@@ -12,6 +12,8 @@ Differences from the reference, all inside the hot path:
 
 from __future__ import annotations
 
+import inspect
+
 import itertools
 import math
 from dataclasses import dataclass
@@ -252,7 +254,14 @@ class ContrastivePretraining(TrainingTask):
     def _compute_loss(self, batch: dict[str, Any], batch_idx: int, outputs: dict[str, torch.Tensor]) -> Optional[torch.Tensor]:
         if self.loss_fn is None:
             return None
-        contrastive_loss = self.loss_fn(outputs, batch["example_ids"], self.log_logit_scale.exp(), self.modality_loss_pairs)
+        # wire-format hint of mmlearn_amd.wire.DefaultDataCollator; only a loss that declares the kwarg sees it
+        hint = {}
+        if batch.get("fully_paired") is True:
+            if getattr(self, "_loss_takes_hint", None) is None:
+                self._loss_takes_hint = "fully_paired" in inspect.signature(self.loss_fn.forward).parameters
+            if self._loss_takes_hint:
+                hint = {"fully_paired": True}
+        contrastive_loss = self.loss_fn(outputs, batch["example_ids"], self.log_logit_scale.exp(), self.modality_loss_pairs, **hint)
 
         aux_losses: list[torch.Tensor] = []
         for task_name, spec in self.aux_task_specs.items():

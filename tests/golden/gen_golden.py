@@ -474,6 +474,15 @@ def gen_recall(R):
     return cases
 
 
+# ------------------------------------------------------------------------ G11
+def gen_wire(R):
+    """Example / CombinedDataset / DefaultDataCollator outputs of the reference for tests/golden/wire_scenario.py."""
+    from mmlearn.datasets.core import CombinedDataset, DefaultDataCollator, Example
+
+    import wire_scenario
+    return {"scenario": wire_scenario.run(Example, CombinedDataset, DefaultDataCollator)}
+
+
 def _save(name, cases):
     flat = {}
     for c, rec in cases.items():
@@ -486,7 +495,7 @@ def _save(name, cases):
 
 def main():
     R = ref_shim.load()
-    which = sys.argv[1:] or ["clip", "match", "task", "ijepa", "masks", "ema", "dist", "align", "recall"]
+    which = sys.argv[1:] or ["clip", "match", "task", "ijepa", "masks", "ema", "dist", "align", "recall", "wire"]
     if "clip" in which:
         _save("g1_g2_clip", gen_clip(R))
     if "match" in which:
@@ -505,6 +514,8 @@ def main():
         _save("g9_align", gen_align(R))
     if "recall" in which:
         _save("g10_recall", gen_recall(R))
+    if "wire" in which:
+        _save("g11_wire", gen_wire(R))
 
 
 if __name__ == "__main__":

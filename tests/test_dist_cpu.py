@@ -43,12 +43,33 @@ def _worker(rank, world, port, case_names, q):
             embs = {f"{m}_embedding": torch.tensor(c[f"r{rank}_in_{m}"]).requires_grad_(True) for m in mods}
             ids = {m: torch.tensor(c[f"r{rank}_ids_{m}"]) for m in mods}
             s = torch.tensor(float(c["scale"]), requires_grad=True)
-            for static in ((False, True) if "uneven" not in name and "missing" not in name else (False,)):
+            from mmlearn_amd.wire import pairing_summary
+            hint, _ = pairing_summary(ids)   # what the collator would put into batch["fully_paired"] on this rank
+            said = [None] * world
+            dist.all_gather_object(said, (hint, tuple(mods)))
+            flags = [h and m == said[0][1] for h, m in said]   # ... and every rank holds the same modalities
+            for static in ((False, True, "paired") if "uneven" not in name and "missing" not in name else (False, "paired")):
                 for t in embs.values():
                     t.grad = None
                 s.grad = None
                 fn = L.ContrastiveLoss(local_loss=bool(c["local_loss"]), gather_with_grad=bool(c["gather_with_grad"]),
-                                       static_shapes=static)
+                                       static_shapes=static is True)
+                if static == "paired":   # wire-format hint: identity pairing only when EVERY rank's batch is paired
+                    before = fake_kernels.CALLS["match_ids"]
+                    loss = fn(embs, ids, s, [L.LossPairSpec(("rgb", "text"))], fully_paired=hint)
+                    if all(flags):
+                        assert fake_kernels.CALLS["match_ids"] == before, "paired batch must not run the matcher"
+                    else:
+                        assert fake_kernels.CALLS["match_ids"] > before or len(mods) < 2
+                    results.setdefault("_paired_ranks", {})[name] = all(flags)
+                    rec = {"loss": float(loss.detach()), "requires_grad": loss.requires_grad}
+                    if loss.requires_grad:
+                        loss.backward()
+                    rec["grads"] = {m: (embs[f"{m}_embedding"].grad.numpy().copy() if embs[f"{m}_embedding"].grad is not None
+                                        else np.zeros_like(c[f"r{rank}_in_{m}"])) for m in mods}
+                    rec["dscale"] = float(s.grad) if s.grad is not None else 0.0
+                    results[(name, static)] = rec
+                    continue
                 if static:  # the task starts the gathers right after each encoder; the loss must pick them up
                     for m in mods:
                         fn.prefetch_gather(m, embs[f"{m}_embedding"], ids[m])
@@ -90,7 +111,7 @@ def _check(world, case_names, out):
         c = DIST[name]
         local = bool(c["local_loss"])
         for rank in range(world):
-            for static in (False, True):
+            for static in (False, True, "paired"):
                 if (name, static) not in out[rank]:
                     continue
                 got = out[rank][(name, static)]
@@ -112,6 +133,8 @@ def test_world2_all_flag_cells_uneven_and_missing_modality():
     assert len(names) == 9
     out = _run(2, names, 29711)
     _check(2, names, out)
+    paired = out[0]["_paired_ranks"]
+    assert any(paired.values()) and not all(paired.values()), paired   # both the fast path and its refusal were exercised
 
 
 def _align_worker(rank, world, port, q):

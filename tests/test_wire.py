@@ -1,0 +1,149 @@
+"""Batch / id wire format: mmlearn_amd.wire vs outputs of the reference's Example / CombinedDataset /
+DefaultDataCollator (tests/golden/g11_wire.npz, produced by gen_golden.py::gen_wire on tests/golden/wire_scenario.py),
+the reference's own known-answer cases (tests/datasets/test_example.py, test_combined_dataset.py), and the derived
+``fully_paired`` / ``example_keys`` additions."""
+
+import os
+import sys
+from collections import namedtuple
+
+import numpy as np
+import pytest
+import torch
+from torch.utils.data import Dataset
+
+from conftest import Golden
+from mmlearn_amd.wire import (CombinedDataset, DefaultDataCollator, Example, collate_example_list, pack_example_ids,
+                              pairing_summary, unpack_example_keys)
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+
+
+def test_scenario_matches_reference_outputs():
+    import wire_scenario
+    want = Golden("g11_wire")["scenario"]
+    got = wire_scenario.run(Example, CombinedDataset, DefaultDataCollator)
+    assert sorted(got) == sorted(want), sorted(set(got) ^ set(want))
+    for k, v in want.items():
+        g = got[k]
+        assert g.shape == v.shape and g.dtype.kind == v.dtype.kind, (k, g.shape, v.shape, g.dtype, v.dtype)
+        assert np.array_equal(g, v), k   # bit-exact: ids, key order, dtypes, processed tensors
+
+
+def test_example_mapping_attribute_access_and_ids():
+    ex = Example()
+    assert len(ex) == 0
+    ex.text = "Hello"
+    assert ex["text"] == "Hello" and ex.text == "Hello" and len(ex) == 1
+    init = {"text": "Hello", "number": 123, "list": [1, 2, 3], "tensor": torch.tensor(1),
+            "point": namedtuple("Point", ["x", "y"])(1, 2), "mapping": {"a": 1, "b": 2}, "nested_mapping": {"a": {"b": 1}}}
+    ex = Example(init_dict=init)
+    assert len(ex) == 7 and init == dict(ex)
+    ex.dataset_index, ex.example_index = 1, 2
+    ex.create_ids()
+    assert set(ex.example_ids) == set(init)
+    assert all(torch.equal(ex.example_ids[k], torch.tensor([1, 2])) for k in init)
+    ex.extra = {"k": {"v": 1}}
+    assert isinstance(ex.extra, Example) and isinstance(ex.extra.k, Example)
+    with pytest.raises(TypeError, match="'int' object is not iterable.*"):
+        Example(123)
+    with pytest.raises(AttributeError):
+        Example({"text": torch.tensor(2)}).missing  # noqa: B018
+    with pytest.warns(UserWarning, match="Cannot create `example_ids`"):
+        e = Example({"text": 1})
+        e.create_ids()
+    assert "example_ids" not in e
+
+
+def test_collate_known_answers():
+    """The reference's own collate case (tests/datasets/test_example.py:57-143)."""
+    Point = namedtuple("Point", ["x", "y"])
+    exs = [Example({"image": torch.tensor(1), "class_label": torch.tensor(2)}),
+           Example({"image": torch.tensor(3), "text": "Hello"}),
+           Example({"audio": torch.tensor(4), "text": "World"}),
+           Example({"an_int": 1, "a_float": 1.0, "a_list": [1, 2, 3], "a_tuple": (1, 2, 3), "a_tensor": torch.tensor(1),
+                    "a_mapping": {"a": 1, "b": 2}, "a_nested_mapping": {"a": {"b": 1}},
+                    "a_double_nested_mapping": {"a": {"b": {"c": 1}}}, "a_namedtuple": Point(1, 2),
+                    "a_numpy_array": np.array([1, 2, 3])})]
+    out = DefaultDataCollator()(exs)
+    assert list(out) == list(collate_example_list(exs))
+    assert torch.equal(out["image"], torch.tensor([1, 3])) and torch.equal(out["class_label"], torch.tensor([2]))
+    assert out["text"] == ["Hello", "World"] and torch.equal(out["audio"], torch.tensor([4]))
+    assert torch.equal(out["an_int"], torch.tensor([1]))
+    assert torch.equal(out["a_float"], torch.tensor([1.0], dtype=torch.float64))
+    for key in ("a_list", "a_tuple"):
+        assert [int(t) for t in out[key]] == [1, 2, 3] and all(t.shape == (1,) for t in out[key])
+    assert torch.equal(out["a_mapping"]["a"], torch.tensor([1])) and torch.equal(out["a_mapping"]["b"], torch.tensor([2]))
+    assert torch.equal(out["a_nested_mapping"]["a"]["b"], torch.tensor([1]))
+    assert torch.equal(out["a_double_nested_mapping"]["a"]["b"]["c"], torch.tensor([1]))
+    assert torch.equal(out["a_namedtuple"].x, torch.tensor([1])) and torch.equal(out["a_namedtuple"].y, torch.tensor([2]))
+    assert torch.equal(out["a_numpy_array"], torch.tensor([[1, 2, 3]]))
+    assert "fully_paired" not in out   # no example_ids, nothing to summarise
+
+
+def test_batch_processor_contract():
+    exs = [Example({"text": torch.tensor([i, i + 1]), "rgb": torch.ones(2) * i}) for i in range(3)]
+    out = DefaultDataCollator(batch_processors={"text": lambda t: {"text": t * 2, "mask": t > 1}, "rgb": lambda x: x + 1})(exs)
+    assert torch.equal(out["text"], torch.tensor([[0, 2], [2, 4], [4, 6]])) and out["mask"].dtype == torch.bool
+    assert torch.equal(out["rgb"][:, 0], torch.tensor([1.0, 2.0, 3.0]))
+    with pytest.raises(ValueError, match="must return a dictionary with 'text' in it"):
+        DefaultDataCollator(batch_processors={"text": lambda t: {"other": t}})(exs)
+
+
+class _Ds(Dataset):
+    def __init__(self, n, mods):
+        self.n, self.mods = n, mods
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return Example({**{m: torch.full((2,), float(i)) for m in self.mods}, "example_index": i})
+
+
+def test_combined_dataset_indexing_and_errors():
+    ds = CombinedDataset([_Ds(3, ("rgb", "text")), _Ds(2, ("text",))])
+    assert len(ds) == 5
+    assert [int(ds[i].dataset_index) for i in range(5)] == [0, 0, 0, 1, 1]
+    assert [int(ds[i].example_index) for i in range(5)] == [0, 1, 2, 0, 1]
+    assert torch.equal(ds[-1].example_ids["text"], torch.tensor([1, 1])) and torch.equal(ds[-5].example_ids["rgb"], torch.tensor([0, 0]))
+    with pytest.raises(IndexError):
+        ds[-6]
+    with pytest.raises(ValueError, match="non-empty"):
+        CombinedDataset([])
+    with pytest.raises(TypeError, match="iterable of `Dataset`"):
+        CombinedDataset([_Ds(1, ("rgb",)), "not a dataset"])
+
+    class Bad(Dataset):
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            return {"rgb": 1}
+
+    with pytest.raises(TypeError, match="instances of `Example`"):
+        CombinedDataset([Bad()])[0]
+
+
+def test_pairing_flag_and_packed_keys():
+    ds = CombinedDataset([_Ds(6, ("rgb", "text")), _Ds(3, ("text",))])
+    coll = DefaultDataCollator()
+    paired = coll([ds[i] for i in (4, 0, 2, 5)])
+    assert paired["fully_paired"] is True
+    assert set(paired["example_keys"]) == {"rgb", "text"}
+    assert paired["example_keys"]["rgb"].tolist() == [4, 0, 2, 5] and paired["example_keys"]["rgb"].dtype == torch.int64
+    mixed = coll([ds[i] for i in (0, 7, 1)])          # a text-only sample: text has 3 rows, rgb 2
+    assert mixed["fully_paired"] is False
+    assert mixed["example_keys"]["text"].tolist() == [0, (1 << 32) | 1, 1]
+    assert "fully_paired" not in DefaultDataCollator(wire_format=False)([ds[0], ds[1]])
+    # same ids, different order: not paired by position
+    ids = {"rgb": torch.tensor([[0, 1], [0, 2]]), "text": torch.tensor([[0, 2], [0, 1]])}
+    assert pairing_summary(ids)[0] is False
+    ids["text"] = ids["rgb"].clone()
+    assert pairing_summary(ids)[0] is True
+    wide = torch.tensor([[3, 2**32 - 1], [2**31, 0], [0, 0]])
+    assert torch.equal(unpack_example_keys(pack_example_ids(wide)), wide)
+    with pytest.raises(ValueError, match="32 unsigned bits"):
+        pack_example_ids(torch.tensor([[0, -1]]))
+    with pytest.raises(ValueError, match=r"\[N, 2\]"):
+        pack_example_ids(torch.tensor([1, 2, 3]))

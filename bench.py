@@ -129,13 +129,16 @@ def build_task(loss, small: bool, fused: bool = False):
         add_ln = os.environ.get("MMK_BENCH_NO_ADD_LN") is None   # A/B switch for the fused residual add + LayerNorm
         accelerate_encoder(rgb, low_precision_ln=("layer_norm1", "layer_norm2", "post_layernorm"), fuse_qkv=True, fuse_add_ln=add_ln)
         accelerate_encoder(text, fuse_qkv=True, fuse_add_ln=add_ln)
-    return ContrastivePretraining(
+    task = ContrastivePretraining(
         encoders={"rgb": rgb, "text": text},
         loss=loss,
         optimizer=_adamw(fused),
         compute_validation_loss=False,
         compute_test_loss=False,
     )
+    if fused and os.environ.get("MMK_BENCH_NO_STREAMS") is None:   # one HIP stream per tower (A/B switch: single stream)
+        task.concurrent_encoders = True
+    return task
 
 
 def cpu_baseline(seconds_budget: float = 25.0):

@@ -40,30 +40,72 @@ class Match:
     repeats_b: bool = False
 
 
-def match_ids(ids_a: torch.Tensor, ids_b: torch.Tensor) -> Match:
-    """All (i, j) with ids_a[i] == ids_b[j] in row-major order; one 16-byte D2H read of the status."""
+@dataclass
+class PendingMatch:
+    """A matcher launch whose 16-byte status has not been read yet (``match_ids_launch`` -> ``match_ids_finish``)."""
+
+    ids_a: torch.Tensor
+    ids_b: torch.Tensor
+    counts: torch.Tensor
+    idx_a: torch.Tensor
+    idx_b: torch.Tensor
+    status: torch.Tensor                      # device int32[4]: total, identity, repeats_a, repeats_b
+    status_host: Optional[torch.Tensor] = None  # pinned copy, valid once ``event`` has completed
+    event: Optional[torch.cuda.Event] = None
+    side_stream: Optional[torch.cuda.Stream] = None
+
+
+def match_ids_launch(ids_a: torch.Tensor, ids_b: torch.Tensor, read_back_async: bool = False) -> PendingMatch:
+    """Enqueue the matcher on the current stream.  With ``read_back_async`` the status is also copied to pinned host
+    memory behind an event, so a later ``match_ids_finish`` costs no device drain if the stream has moved on."""
     require_gpu(ids_a, "example_ids")
     require_gpu(ids_b, "example_ids")
     ids_a = ids_a.contiguous()
     ids_b = ids_b.contiguous()
     n_a, n_b = ids_a.shape[0], ids_b.shape[0]
     dev = ids_a.device
-    if n_a == 0 or n_b == 0:
-        return Match(0, False, torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev))
     cap = max(n_a, n_b)
     counts = torch.empty(_lib.lib().mmk_match_workspace_ints(n_a, n_b), dtype=torch.int32, device=dev)
     idx_a = torch.empty(cap, dtype=torch.int32, device=dev)
     idx_b = torch.empty(cap, dtype=torch.int32, device=dev)
     status = torch.empty(4, dtype=torch.int32, device=dev)
     check(_lib.lib().mmk_match_ids(ptr(ids_a), n_a, ptr(ids_b), n_b, ptr(counts), ptr(idx_a), ptr(idx_b), cap, ptr(status), stream()))
-    total, ident, rep_a, rep_b = status.tolist()  # the one host sync of the loss path
-    if total > cap:  # heavy duplication: re-run the fill pass with the exact capacity
+    pm = PendingMatch(ids_a, ids_b, counts, idx_a, idx_b, status)
+    if read_back_async:
+        pm.status_host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+        pm.status_host.copy_(status, non_blocking=True)
+        pm.event = torch.cuda.Event()
+        pm.event.record()
+    return pm
+
+
+def match_ids_finish(pm: PendingMatch) -> Match:
+    n_a, n_b = pm.ids_a.shape[0], pm.ids_b.shape[0]
+    dev = pm.ids_a.device
+    if pm.event is not None:
+        pm.event.synchronize()     # waits for the matcher only, not for whatever the compute stream is doing
+        total, ident, rep_a, rep_b = pm.status_host.tolist()
+    else:
+        total, ident, rep_a, rep_b = pm.status.tolist()  # the one host sync of the loss path
+    idx_a, idx_b = pm.idx_a, pm.idx_b
+    if total > idx_a.numel():  # heavy duplication: re-run the fill pass with the exact capacity
         idx_a = torch.empty(total, dtype=torch.int32, device=dev)
         idx_b = torch.empty(total, dtype=torch.int32, device=dev)
-        check(_lib.lib().mmk_match_ids(ptr(ids_a), n_a, ptr(ids_b), n_b, ptr(counts), ptr(idx_a), ptr(idx_b), total, ptr(status), stream()))
+        check(_lib.lib().mmk_match_ids(ptr(pm.ids_a), n_a, ptr(pm.ids_b), n_b, ptr(pm.counts), ptr(idx_a), ptr(idx_b), total,
+                                       ptr(pm.status), stream()))
     if ident:
         return Match(total, True, None, None)
     return Match(total, False, idx_a[:total], idx_b[:total], bool(rep_a), bool(rep_b))
+
+
+def match_ids(ids_a: torch.Tensor, ids_b: torch.Tensor) -> Match:
+    """All (i, j) with ids_a[i] == ids_b[j] in row-major order; one 16-byte D2H read of the status."""
+    require_gpu(ids_a, "example_ids")
+    require_gpu(ids_b, "example_ids")
+    if ids_a.shape[0] == 0 or ids_b.shape[0] == 0:
+        dev = ids_a.device
+        return Match(0, False, torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev))
+    return match_ids_finish(match_ids_launch(ids_a, ids_b))
 
 
 # ------------------------------------------------------------------ packing

@@ -261,7 +261,7 @@ class _Run:
             if ma not in views or mb not in views:
                 continue  # contrastive.py:266-274 / :303-307
             va, vb = views[ma], views[mb]
-            mg = self._paired_match(va.counts, vb.counts, ma, mb) if self.paired else K.match_ids(va.ids, vb.ids)
+            mg = self._paired_match(va.counts, vb.counts, ma, mb) if self.paired else o._matched(va.ids, vb.ids)
             if mg.n == 0:
                 continue  # :283-287 / :314-316
             p = _Pair(spec=spec, r_global=mg.n)
@@ -275,7 +275,7 @@ class _Run:
                 elif self.paired:
                     p.ml = self._paired_match([va.local.shape[0]], [vb.local.shape[0]], ma, mb)
                 else:
-                    p.ml = K.match_ids(self.example_ids[ma].to(torch.int64), self.example_ids[mb].to(torch.int64))
+                    p.ml = o._matched(self.example_ids[ma].to(torch.int64), self.example_ids[mb].to(torch.int64))
                 local_counts_needed.append(p)
             self.pairs.append(p)
 
@@ -638,6 +638,8 @@ class ContrastiveLoss(nn.Module):
         self.compute_dtype = compute_dtype
         self.static_shapes = static_shapes
         self._pending: dict[str, tuple] = {}
+        self._pending_match: list = []
+        self._match_stream = None
 
     # ------------------------------------------------------------------ gather / encoder overlap
     def prefetch_gather(self, modality: str, embedding: torch.Tensor, example_ids: torch.Tensor) -> None:
@@ -655,6 +657,48 @@ class ContrastiveLoss(nn.Module):
         works = [dist.all_gather_into_tensor(all_e.view(-1), e.view(-1), async_op=True),
                  dist.all_gather_into_tensor(all_i.view(-1), i.view(-1), async_op=True)]
         self._pending[modality] = (embedding, all_e, all_i, works, (e, i))
+
+    # ------------------------------------------------------------------ matcher / encoder overlap
+    def prefetch_match(self, example_ids: dict[str, torch.Tensor], modality_loss_pairs: Sequence[Any]) -> None:
+        """Run the id matcher NOW, on its own stream, and park its status in pinned memory: the ids exist before the
+        encoders run, so by the time ``forward`` asks for the pairing the answer has been on the host for tens of
+        milliseconds and reading it does not drain the compute stream (without this the read-back is the one host sync
+        of the loss path and holds back the queueing of the backward pass).  Called by ``ContrastivePretraining.forward``
+        before the encoders.  Single-process only: across ranks the matcher needs the gathered ids."""
+        self._pending_match = []
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return
+        todo = []
+        for spec in modality_loss_pairs:
+            ma, mb = (Modalities.get_modality(m).name if Modalities.has_modality(m) else m for m in spec.modalities)
+            ia, ib = example_ids.get(ma), example_ids.get(mb)
+            if not all(isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 2 and t.dtype == torch.int64 and t.shape[0] for t in (ia, ib)):
+                continue
+            todo.append((ia, ib))
+        if not todo:
+            return
+        if self._match_stream is None:
+            self._match_stream = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        self._match_stream.wait_stream(main)   # the ids may still be in flight (H2D copy) on the caller's stream
+        with torch.cuda.stream(self._match_stream):
+            for ia, ib in todo:
+                pm = K.match_ids_launch(ia, ib, read_back_async=True)
+                pm.side_stream = self._match_stream
+                self._pending_match.append(pm)
+
+    def _matched(self, ids_a: torch.Tensor, ids_b: torch.Tensor) -> "K.Match":
+        """The pairing of two id columns: the prefetched answer if it was computed for exactly these tensors."""
+        for k, pm in enumerate(self._pending_match):
+            if pm.ids_a.data_ptr() == ids_a.data_ptr() and pm.ids_b.data_ptr() == ids_b.data_ptr() \
+                    and pm.ids_a.shape == ids_a.shape and pm.ids_b.shape == ids_b.shape:
+                del self._pending_match[k]
+                main = torch.cuda.current_stream()
+                main.wait_stream(pm.side_stream)          # idx_a / idx_b were written on the matcher's stream
+                for t in (pm.idx_a, pm.idx_b, pm.counts, pm.status):
+                    t.record_stream(main)
+                return K.match_ids_finish(pm)
+        return K.match_ids(ids_a, ids_b)
 
     def _take_prefetched(self, local: dict[str, torch.Tensor]):
         """Prefetched gathers, if there is one for every local modality and it belongs to exactly these tensors."""
@@ -679,6 +723,12 @@ class ContrastiveLoss(nn.Module):
         if not isinstance(logit_scale, torch.Tensor):
             raise TypeError("logit_scale must be a 0-dim tensor")
         run = _Run(self, embeddings, example_ids, logit_scale, list(modality_loss_pairs), fully_paired)
+        try:
+            return self._forward(run, embeddings, logit_scale)
+        finally:
+            self._pending_match = []   # answers belong to one batch
+
+    def _forward(self, run: "_Run", embeddings, logit_scale) -> torch.Tensor:
         first = next(iter(embeddings.values()))
         run.needs_grad = torch.is_grad_enabled() and (logit_scale.requires_grad or any(t.requires_grad for t in embeddings.values()))
         if not run.needs_grad:

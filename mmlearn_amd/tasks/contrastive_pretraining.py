@@ -185,16 +185,39 @@ class ContrastivePretraining(TrainingTask):
             output = l2_normalize(output)
         return output
 
+    def _encoder_streams(self, n: int) -> list:
+        have = self.__dict__.setdefault("_side_streams", [])
+        while len(have) < n:
+            have.append(torch.cuda.Stream())
+        return have
+
     def forward(self, inputs: dict[str, Any]) -> dict[str, torch.Tensor]:
         outputs = {}
         prefetch = getattr(self.loss_fn, "prefetch_gather", None) if "example_ids" in inputs else None
-        for m in self._available_modalities:
-            if m.name not in inputs:
-                continue
-            outputs[m.embedding] = self.encode(inputs, m, normalize=True)
+        mods = [m for m in self._available_modalities if m.name in inputs]
+        early_match = getattr(self.loss_fn, "prefetch_match", None) if "example_ids" in inputs and self.loss_fn is not None else None
+        if early_match is not None and inputs.get("fully_paired") is not True:
+            early_match(inputs["example_ids"], self.modality_loss_pairs)   # matcher + status read-back overlap the encoders
+        # opt-in (``task.concurrent_encoders = True``): the encoders are independent until the loss, so every modality
+        # after the first gets its own HIP stream; forward AND backward kernels of the towers then overlap (autograd
+        # replays each node on the stream its forward ran on), which fills the tails of kernels that do not cover 256 CUs.
+        side = self._encoder_streams(len(mods) - 1) if getattr(self, "concurrent_encoders", False) and len(mods) > 1 else None
+        main = torch.cuda.current_stream() if side else None
+        for k, m in enumerate(mods):
+            if side and k:
+                side[k - 1].wait_stream(main)
+                with torch.cuda.stream(side[k - 1]):
+                    out = self.encode(inputs, m, normalize=True)
+                out.record_stream(main)
+                outputs[m.embedding] = out
+            else:
+                outputs[m.embedding] = self.encode(inputs, m, normalize=True)
             if prefetch is not None and m.name in inputs["example_ids"]:
                 # start the global-batch all-gather of this modality while the next encoder runs (RCCL stream)
                 prefetch(m.name, outputs[m.embedding], inputs["example_ids"][m.name])
+        if side:
+            for st in side[: len(mods) - 1]:
+                main.wait_stream(st)
         dims = {o.size(-1) for o in outputs.values()}
         if len(dims) > 1:
             raise ValueError("Expected all model outputs to have the same dimension.")

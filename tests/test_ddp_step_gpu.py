@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, streams):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -37,6 +37,7 @@ def _worker(rank, world, port, q):
         dev = torch.device("cuda", 0)
         torch.manual_seed(0)  # same initial weights on both ranks
         task = bench.build_task(ContrastiveLoss(static_shapes=True), small=True, fused=True).to(dev)
+        task.concurrent_encoders = streams
         stepper = torch.nn.parallel.DistributedDataParallel(bench._Step(task), device_ids=[0])
         opt = task.configure_optimizers()
         batch = bench.synthetic_batch(1024, rank, dev)   # 1024 x 17 tokens >= 16k rows: the wgrad path is live
@@ -57,11 +58,12 @@ def _worker(rank, world, port, q):
             dist.destroy_process_group()
 
 
-def test_ddp_step_with_fused_encoders():
+@pytest.mark.parametrize("streams", [False, True])
+def test_ddp_step_with_fused_encoders(streams):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port + int(streams), q, streams)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]

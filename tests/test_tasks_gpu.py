@@ -228,6 +228,47 @@ def test_fused_encoder_training_trajectory_matches_stock():
     assert cos >= 0.98 and abs(da.norm() / db.norm() - 1) <= 0.05, (cos.item(), (da.norm() / db.norm()).item())
 
 
+def test_concurrent_encoder_streams_give_the_same_step():
+    """``task.concurrent_encoders = True`` (one HIP stream per tower, forward and backward) is a scheduling change only:
+    same loss and gradients as the single-stream step, over several steps with optimizer updates in between (a missing
+    stream dependency would show up as stale or torn tensors)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from mmlearn_amd import ContrastiveLoss
+
+    dev = torch.device("cuda", 0)
+    runs = []
+    for streams in (False, False, True):   # two single-stream runs give the run-to-run noise floor (stream-K GEMMs, f32 atomics)
+        task = bench.build_task(ContrastiveLoss(), small=True, fused=True).to(dev)
+        task.eval()   # dropout off: all runs must see the same function
+        task.concurrent_encoders = streams
+        opt = torch.optim.SGD(task.parameters(), lr=0.1)
+        batch = bench.synthetic_batch(1024, 0, dev)
+        rec = []
+        for _ in range(4):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = task.training_step(batch, 0)
+            loss.backward()
+            grads = torch.cat([p.grad.detach().float().flatten() for p in task.parameters() if p.grad is not None])
+            opt.step()
+            rec.append((loss.detach().float().clone(), grads))
+        runs.append(rec)
+        if streams:
+            assert len(task._side_streams) == 1
+    for k, ((l0, g0), (l1, g1), (l2, g2)) in enumerate(zip(*runs)):
+        noise = (g0 - g1).abs().max().item()
+        diff = (g0 - g2).abs().max().item()
+        assert torch.allclose(l0, l2, rtol=1e-4, atol=1e-6), (l0.item(), l2.item())
+        if k == 0:   # same weights, same inputs: equal up to the reordering of f32 atomics
+            assert diff <= 1e-5 * g0.abs().max().item(), (diff, noise)
+        else:        # after updates the runs drift apart chaotically -- the streamed run no faster than a repeat of the plain one
+            cos = torch.dot(g0, g2) / (g0.norm() * g2.norm())
+            cos_noise = torch.dot(g0, g1) / (g0.norm() * g1.norm())
+            assert diff <= max(4 * noise, 1e-5 * g0.abs().max().item()) and cos >= cos_noise - 2e-4, (k, diff, noise, cos.item(), cos_noise.item())
+
+
 def test_hip_adamw_matches_torch_adamw():
     from mmlearn_amd.optim import AdamW
 

@@ -61,3 +61,33 @@ def test_hint_with_unequal_rows_is_refused_and_permuted_ids_still_match():
     assert torch.allclose(base[0], moved[0], rtol=1e-5, atol=1e-6)
     inv = torch.argsort(perm)   # b2[j] = b[perm[j]]  =>  grad_b[i] = grad_b2[inv[i]]
     assert torch.allclose(base[2], moved[2][inv], rtol=1e-4, atol=1e-6)
+
+
+def test_prefetched_matcher_answer_is_used_once_and_equals_the_synchronous_one():
+    """``prefetch_match`` (matcher on its own stream before the encoders, status parked in pinned memory) must give the
+    pairing the synchronous matcher gives -- incl. a permuted, partially overlapping id set -- and must not be reused
+    for other tensors or a later batch."""
+    from mmlearn_amd import ContrastiveLoss, LossPairSpec, _lib
+    a, b, s, ids = _case(n=160)
+    ids_b = ids[torch.randperm(160, generator=torch.Generator().manual_seed(5)).cuda()].clone()
+    ids_b[:7, 1] += 1000          # seven rows of b have no partner
+    pairs = [LossPairSpec(("rgb", "text"))]
+    fn = ContrastiveLoss(l2_normalize=True)
+    want = _run(fn, a, b, s, ids, ids_b)
+    _lib.profile_enable(True)
+    _lib.profile_read()
+    fn.prefetch_match({"rgb": ids, "text": ids_b}, pairs)
+    assert len(fn._pending_match) == 1
+    got = _run(fn, a, b, s, ids, ids_b)
+    torch.cuda.synchronize()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    assert prof["match_ids"][0] == 1 and not fn._pending_match     # one launch: the prefetched one
+    for w, g in zip(want, got):
+        assert torch.equal(w, g)
+    # answers for other tensors are not picked up: same values, different storage -> the synchronous matcher runs
+    fn.prefetch_match({"rgb": ids, "text": ids_b}, pairs)
+    other = _run(fn, a, b, s, ids.clone(), ids_b.clone())
+    assert not fn._pending_match
+    for w, g in zip(want, other):
+        assert torch.equal(w, g)

@@ -196,7 +196,7 @@ class ContrastivePretraining(TrainingTask):
         prefetch = getattr(self.loss_fn, "prefetch_gather", None) if "example_ids" in inputs else None
         mods = [m for m in self._available_modalities if m.name in inputs]
         early_match = getattr(self.loss_fn, "prefetch_match", None) if "example_ids" in inputs and self.loss_fn is not None else None
-        if early_match is not None and inputs.get("fully_paired") is not True:
+        if early_match is not None and inputs.get("fully_paired") is not True and getattr(self, "match_ahead", True):
             early_match(inputs["example_ids"], self.modality_loss_pairs)   # matcher + status read-back overlap the encoders
         # opt-in (``task.concurrent_encoders = True``): the encoders are independent until the loss, so every modality
         # after the first gets its own HIP stream; forward AND backward kernels of the towers then overlap (autograd

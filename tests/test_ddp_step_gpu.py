@@ -76,3 +76,54 @@ def test_ddp_step_with_fused_encoders(streams):
     assert all(map(lambda v: v == v and abs(v) < 1e6, (l0, l1, g0, g1)))
     assert abs(g0 - g1) <= 1e-3 * max(g0, 1e-6)          # DDP left the same averaged gradients on both ranks
     assert res[0][1][1][0] == res[0][1][1][0]            # second step finite
+
+
+def _nccl_world1_worker(port, q):
+    """One rank over RCCL (world_size 1 still goes through DDP's reducer: gradient hooks, bucket copies, the collective's
+    stream hand-off) -- the real process-group type of the bench, which two ranks on one device cannot use."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        if ROOT not in sys.path:
+            sys.path.insert(0, ROOT)
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        import bench
+        from mmlearn_amd import ContrastiveLoss
+
+        dev = torch.device("cuda", 0)
+        out = []
+        for streams in (False, True, True):
+            task = bench.build_task(ContrastiveLoss(static_shapes=True), small=True, fused=True).to(dev)
+            task.eval()   # dropout off
+            task.concurrent_encoders = streams
+            stepper = torch.nn.parallel.DistributedDataParallel(bench._Step(task), device_ids=[0], bucket_cap_mb=1)  # many buckets
+            batch = bench.synthetic_batch(1024, 0, dev)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = stepper(batch)
+            loss.backward()
+            torch.cuda.synchronize()
+            g = torch.cat([p.grad.detach().float().flatten() for p in task.parameters() if p.grad is not None])
+            out.append((float(loss.detach().float().item()), g.cpu()))
+        q.put((out, None))
+    except Exception:  # pragma: no cover
+        q.put((None, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_ddp_over_rccl_gives_the_same_gradients_with_tower_streams():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(29500 + (os.getpid() % 2000) + 7, q))
+    p.start()
+    out, err = q.get(timeout=600)
+    p.join(timeout=60)
+    assert err is None, err
+    (l0, g0), (l1, g1), (l2, g2) = out
+    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0)) and abs(l0 - l2) <= 1e-5 * max(1.0, abs(l0))
+    scale = g0.abs().max().item()
+    assert scale > 0
+    for g in (g1, g2):   # same weights, same batch: only f32 atomics may reorder
+        assert (g0 - g).abs().max().item() <= 1e-5 * scale, (g0 - g).abs().max().item() / scale

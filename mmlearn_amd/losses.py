@@ -659,12 +659,14 @@ class ContrastiveLoss(nn.Module):
         self._pending[modality] = (embedding, all_e, all_i, works, (e, i))
 
     # ------------------------------------------------------------------ matcher / encoder overlap
-    def prefetch_match(self, example_ids: dict[str, torch.Tensor], modality_loss_pairs: Sequence[Any]) -> None:
+    def prefetch_match(self, example_ids: dict[str, torch.Tensor], modality_loss_pairs: Sequence[Any],
+                       stream: Optional["torch.cuda.Stream"] = None) -> None:
         """Run the id matcher NOW, on its own stream, and park its status in pinned memory: the ids exist before the
         encoders run, so by the time ``forward`` asks for the pairing the answer has been on the host for tens of
         milliseconds and reading it does not drain the compute stream (without this the read-back is the one host sync
         of the loss path and holds back the queueing of the backward pass).  Called by ``ContrastivePretraining.forward``
-        before the encoders.  Single-process only: across ranks the matcher needs the gathered ids."""
+        before the encoders (``stream``: a side stream to run on instead of the loss's own).  Single-process only: across
+        ranks the matcher needs the gathered ids."""
         self._pending_match = []
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             return
@@ -677,14 +679,16 @@ class ContrastiveLoss(nn.Module):
             todo.append((ia, ib))
         if not todo:
             return
-        if self._match_stream is None:
-            self._match_stream = torch.cuda.Stream()
+        if stream is None:   # the caller may lend a side stream it already has (HW queues are few: keep the stream count low)
+            if self._match_stream is None:
+                self._match_stream = torch.cuda.Stream()
+            stream = self._match_stream
         main = torch.cuda.current_stream()
-        self._match_stream.wait_stream(main)   # the ids may still be in flight (H2D copy) on the caller's stream
-        with torch.cuda.stream(self._match_stream):
+        stream.wait_stream(main)   # the ids may still be in flight (H2D copy) on the caller's stream
+        with torch.cuda.stream(stream):
             for ia, ib in todo:
                 pm = K.match_ids_launch(ia, ib, read_back_async=True)
-                pm.side_stream = self._match_stream
+                pm.side_stream = stream
                 self._pending_match.append(pm)
 
     def _matched(self, ids_a: torch.Tensor, ids_b: torch.Tensor) -> "K.Match":

@@ -195,14 +195,15 @@ class ContrastivePretraining(TrainingTask):
         outputs = {}
         prefetch = getattr(self.loss_fn, "prefetch_gather", None) if "example_ids" in inputs else None
         mods = [m for m in self._available_modalities if m.name in inputs]
-        early_match = getattr(self.loss_fn, "prefetch_match", None) if "example_ids" in inputs and self.loss_fn is not None else None
-        if early_match is not None and inputs.get("fully_paired") is not True and getattr(self, "match_ahead", True):
-            early_match(inputs["example_ids"], self.modality_loss_pairs)   # matcher + status read-back overlap the encoders
         # opt-in (``task.concurrent_encoders = True``): the encoders are independent until the loss, so every modality
         # after the first gets its own HIP stream; forward AND backward kernels of the towers then overlap (autograd
         # replays each node on the stream its forward ran on), which fills the tails of kernels that do not cover 256 CUs.
         side = self._encoder_streams(len(mods) - 1) if getattr(self, "concurrent_encoders", False) and len(mods) > 1 else None
         main = torch.cuda.current_stream() if side else None
+        early_match = getattr(self.loss_fn, "prefetch_match", None) if "example_ids" in inputs and self.loss_fn is not None else None
+        if early_match is not None and inputs.get("fully_paired") is not True and getattr(self, "match_ahead", True):
+            # matcher + status read-back overlap the encoders; on the second tower's stream when there is one
+            early_match(inputs["example_ids"], self.modality_loss_pairs, **({"stream": side[0]} if side else {}))
         for k, m in enumerate(mods):
             if side and k:
                 side[k - 1].wait_stream(main)

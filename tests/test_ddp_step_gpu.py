@@ -97,7 +97,8 @@ def _nccl_world1_worker(port, q):
             task = bench.build_task(ContrastiveLoss(static_shapes=True), small=True, fused=True).to(dev)
             task.eval()   # dropout off
             task.concurrent_encoders = streams
-            stepper = torch.nn.parallel.DistributedDataParallel(bench._Step(task), device_ids=[0], bucket_cap_mb=1)  # many buckets
+            stepper = torch.nn.parallel.DistributedDataParallel(bench._Step(task), device_ids=[0], bucket_cap_mb=1,   # many buckets
+                                                                gradient_as_bucket_view=True)  # as in bench.py
             batch = bench.synthetic_batch(1024, 0, dev)
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 loss = stepper(batch)

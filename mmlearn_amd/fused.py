@@ -233,13 +233,13 @@ class _LinearWgradFn(torch.autograd.Function):
 
 def _wgrad_linear_ok(weight: torch.Tensor, x: torch.Tensor) -> bool:
     rows = x.numel() // max(x.shape[-1], 1)
-    return (x.is_cuda and weight.dim() == 2 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0 and rows >= 16384
+    return (x.is_cuda and weight.dim() == 2 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0 and rows >= 6144
             and torch.is_grad_enabled() and weight.requires_grad
             and (x.dtype == torch.bfloat16 or _autocast_bf16()))
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``F.linear`` with the HIP weight-gradient kernel in its backward where that applies (bf16, >= 16k rows)."""
+    """``F.linear`` with the HIP weight-gradient kernel in its backward where that applies (bf16, >= 6k rows)."""
     x16 = getattr(x, "_mmk_bf16", None)   # bf16 twin attached by add_layer_norm(twin=True)
     if x16 is not None and x16.shape == x.shape and _autocast_bf16():
         x = x16

@@ -40,7 +40,7 @@ def _worker(rank, world, port, q, streams):
         task.concurrent_encoders = streams
         stepper = torch.nn.parallel.DistributedDataParallel(bench._Step(task), device_ids=[0])
         opt = task.configure_optimizers()
-        batch = bench.synthetic_batch(1024, rank, dev)   # 1024 x 17 tokens >= 16k rows: the wgrad path is live
+        batch = bench.synthetic_batch(1024, rank, dev)   # 1024 x 17 tokens >= 6k rows: the wgrad path is live
         losses = []
         for _ in range(2):
             opt.zero_grad(set_to_none=True)

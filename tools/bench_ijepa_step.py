@@ -113,11 +113,12 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--small", action="store_true")
+    ap.add_argument("--only", choices=("stock", "fused"), default=None, help="run one variant (for profiling)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     imgs = torch.rand(args.batch, 3, 224, 224, generator=torch.Generator().manual_seed(1)).to(dev)
     out = {"batch": args.batch, "model": "small" if args.small else "ViT-L/16 + 12x384 predictor"}
-    for fused in (False, True):
+    for fused in ((False, True) if args.only is None else (args.only == "fused",)):
         task = build(args.small, fused, dev)
         opt = task.configure_optimizers()
         opt = opt["optimizer"] if isinstance(opt, dict) else opt

@@ -10,8 +10,12 @@ def t(fn, it=10):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(it): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / it * 1e6
-for M in (1024 * 197, 1024 * 77):
-    for N, K_ in ((768, 768), (768, 3072), (3072, 768), (2304, 768)):
+SHAPES = [(M, N, K_) for M in (1024 * 197, 1024 * 77) for N, K_ in ((768, 768), (768, 3072), (3072, 768), (2304, 768))]
+if os.environ.get("SHAPES") == "ijepa":   # ViT-L/16 context / target rows and the 384-wide predictor (tools/bench_ijepa_step.py)
+    SHAPES = [(M, N, K_) for M in (4096, 8192, 12288, 25088) for N, K_ in ((1024, 1024), (3072, 1024), (4096, 1024), (1024, 4096))]
+    SHAPES += [(M, N, K_) for M in (16384, 53760) for N, K_ in ((384, 384), (1152, 384), (1536, 384), (384, 1536))]
+for M, N, K_ in SHAPES:
+    if True:
         dy = torch.randn(M, N, device=dev).bfloat16()
         x = torch.randn(M, K_, device=dev).bfloat16()
         res = {"M": M, "N": N, "K": K_, "GF": round(2 * M * N * K_ / 1e9)}

@@ -185,9 +185,13 @@ class _Run:
         pre = self.o._take_prefetched(local)
         if pre is not None:  # gathers were started right after each encoder (overlapped with the next one)
             views = {}
+            cur = torch.cuda.current_stream() if next(iter(local.values())).is_cuda else None
             for n, (all_e, all_i, works) in pre.items():
                 for w in works:
                     w.wait()  # stream-level wait on the collective's stream, no host block
+                if cur is not None:   # the buffers may have been allocated on a tower's side stream
+                    all_e.record_stream(cur)
+                    all_i.record_stream(cur)
                 views[n] = _View(n, local[n], all_e, all_i, None, [local[n].shape[0]] * self.world)
             return views
         any_t = next(iter(local.values()))

@@ -205,17 +205,20 @@ class ContrastivePretraining(TrainingTask):
             # matcher + status read-back overlap the encoders; on the second tower's stream when there is one
             early_match(inputs["example_ids"], self.modality_loss_pairs, **({"stream": side[0]} if side else {}))
         for k, m in enumerate(mods):
+            gather = prefetch is not None and m.name in inputs["example_ids"]
             if side and k:
                 side[k - 1].wait_stream(main)
                 with torch.cuda.stream(side[k - 1]):
                     out = self.encode(inputs, m, normalize=True)
+                    if gather:   # launched from the producing stream: the collective must wait for THIS tower
+                        prefetch(m.name, out, inputs["example_ids"][m.name])
                 out.record_stream(main)
                 outputs[m.embedding] = out
             else:
                 outputs[m.embedding] = self.encode(inputs, m, normalize=True)
-            if prefetch is not None and m.name in inputs["example_ids"]:
-                # start the global-batch all-gather of this modality while the next encoder runs (RCCL stream)
-                prefetch(m.name, outputs[m.embedding], inputs["example_ids"][m.name])
+                if gather:
+                    # start the global-batch all-gather of this modality while the next encoder runs (RCCL stream)
+                    prefetch(m.name, outputs[m.embedding], inputs["example_ids"][m.name])
         if side:
             for st in side[: len(mods) - 1]:
                 main.wait_stream(st)

@@ -169,7 +169,7 @@ class _Run:
                 raise ValueError(f"embedding of modality {name!r} must be [B, D], got {tuple(t.shape)}")
             if name not in self.example_ids:
                 raise KeyError(f"example_ids has no entry for modality {name!r}")
-        if self.world == 1:
+        if self.world == 1 and not (self.o._force_gather and dist.is_available() and dist.is_initialized()):
             self.paired = self.paired_hint
             return {n: _View(n, t, t.detach().contiguous(), self.example_ids[n].to(torch.int64), None, [t.shape[0]])
                     for n, t in local.items()}
@@ -184,6 +184,7 @@ class _Run:
                 raise ValueError(f"modality {n!r} is not registered")
         pre = self.o._take_prefetched(local)
         if pre is not None:  # gathers were started right after each encoder (overlapped with the next one)
+            self.o.prefetched_gathers_used += 1
             views = {}
             cur = torch.cuda.current_stream() if next(iter(local.values())).is_cuda else None
             for n, (all_e, all_i, works) in pre.items():
@@ -642,6 +643,8 @@ class ContrastiveLoss(nn.Module):
         self.compute_dtype = compute_dtype
         self.static_shapes = static_shapes
         self._pending: dict[str, tuple] = {}
+        self.prefetched_gathers_used = 0   # forward() calls that consumed gathers started by prefetch_gather
+        self._force_gather = False   # test seam: run the gather path (packed all-gathers, prefetch) on a 1-rank process group
         self._pending_match: list = []
         self._match_stream = None
 
@@ -651,7 +654,8 @@ class ContrastiveLoss(nn.Module):
         overlaps with the encoders that still have to run; ``forward`` picks the result up.  Called by
         ``ContrastivePretraining.forward`` after each ``encode``.  Only with ``static_shapes=True`` (all ranks hold
         the same modalities and batch size); otherwise a no-op and the packed gather in ``forward`` is used."""
-        if not (self.static_shapes and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if not (self.static_shapes and dist.is_available() and dist.is_initialized()
+                and (dist.get_world_size() > 1 or self._force_gather)):
             return
         world = dist.get_world_size()
         e = embedding.detach().contiguous()

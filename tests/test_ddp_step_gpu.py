@@ -93,8 +93,12 @@ def _nccl_world1_worker(port, q):
 
         dev = torch.device("cuda", 0)
         out = []
-        for streams in (False, True, True):
-            task = bench.build_task(ContrastiveLoss(static_shapes=True), small=True, fused=True).to(dev)
+        # (tower streams, gather path forced on the 1-rank group, static_shapes): the last two run the packed all-gathers of
+        # the N > 1 loss over real RCCL -- prefetched from the towers' streams, and in forward() behind the size header
+        for streams, gather, static in ((False, False, True), (True, False, True), (True, True, True), (True, True, False)):
+            loss_fn = ContrastiveLoss(static_shapes=static)
+            loss_fn._force_gather = gather
+            task = bench.build_task(loss_fn, small=True, fused=True).to(dev)
             task.eval()   # dropout off
             task.concurrent_encoders = streams
             stepper = torch.nn.parallel.DistributedDataParallel(bench._Step(task), device_ids=[0], bucket_cap_mb=1,   # many buckets
@@ -105,7 +109,7 @@ def _nccl_world1_worker(port, q):
             loss.backward()
             torch.cuda.synchronize()
             g = torch.cat([p.grad.detach().float().flatten() for p in task.parameters() if p.grad is not None])
-            out.append((float(loss.detach().float().item()), g.cpu()))
+            out.append((float(loss.detach().float().item()), g.cpu(), loss_fn.prefetched_gathers_used))
         q.put((out, None))
     except Exception:  # pragma: no cover
         q.put((None, traceback.format_exc()))
@@ -122,9 +126,11 @@ def test_ddp_over_rccl_gives_the_same_gradients_with_tower_streams():
     out, err = q.get(timeout=600)
     p.join(timeout=60)
     assert err is None, err
-    (l0, g0), (l1, g1), (l2, g2) = out
-    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0)) and abs(l0 - l2) <= 1e-5 * max(1.0, abs(l0))
+    assert [o[2] for o in out] == [0, 0, 1, 0]   # only the static-shapes gather variant takes the prefetched collectives
+    out = [o[:2] for o in out]
+    (l0, g0) = out[0]
     scale = g0.abs().max().item()
     assert scale > 0
-    for g in (g1, g2):   # same weights, same batch: only f32 atomics may reorder
+    for l, g in out[1:]:   # same weights, same batch: only f32 atomics may reorder
+        assert abs(l0 - l) <= 1e-5 * max(1.0, abs(l0)), (l0, l)
         assert (g0 - g).abs().max().item() <= 1e-5 * scale, (g0 - g).abs().max().item() / scale

@@ -201,16 +201,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # MMK_BENCH_FORCE_DIST=1: run the N > 1 code path (RCCL process group, DDP, gathered negatives) on a 1-rank group --
+    # a dry run of the multi-GPU bench on a single-GPU box; the JSON line says so in config.parallelism
+    force_dist = world == 1 and os.environ.get("MMK_BENCH_FORCE_DIST") is not None
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29631")
+        dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
     from mmlearn_amd import ContrastiveLoss, _lib
 
     _lib.check(_lib.lib().mmk_device_check())
-    task = build_task(ContrastiveLoss(static_shapes=True), args.small, fused=not args.no_fused_encoder_ops).to(dev)
+    loss_fn = ContrastiveLoss(static_shapes=True)
+    loss_fn._force_gather = force_dist
+    task = build_task(loss_fn, args.small, fused=not args.no_fused_encoder_ops).to(dev)
     opt = task.configure_optimizers()
     stepper = _Step(task)
-    if world > 1:
+    if world > 1 or force_dist:
         stepper = nn.parallel.DistributedDataParallel(stepper, device_ids=[local_rank], gradient_as_bucket_view=True)
     batch = synthetic_batch(args.batch, rank, dev)
 
@@ -223,7 +232,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -258,7 +267,7 @@ def main():
     prof = _lib.profile_read()
     _lib.profile_enable(False)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
     final_loss = float(loss.detach().float().item())
@@ -323,7 +332,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: CLIP ViT-B/16 + BERT-base, D=512 projection, bf16 autocast, "
                                    f"per-GPU batch {args.batch}, {'local' if world == 1 else 'global-batch (all-gather)'} negatives"
                                    + (" [DEBUG small encoders]" if args.small else ""),
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": "mmlearn_amd.ContrastiveLoss (HIP)",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}" + (" (1-rank RCCL dry run of the N > 1 path)" if force_dist else ""), "loss": "mmlearn_amd.ContrastiveLoss (HIP)",
                        "encoder_ops": "torch" if args.no_fused_encoder_ops else "HIP LayerNorm (+ fused residual add / dropout / deferred biases), bias+activation, fused-QKV attention, weight-gradient GEMM (mmlearn_amd.fused / .attention)",
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline,
@@ -332,7 +341,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

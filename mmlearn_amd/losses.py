@@ -644,8 +644,10 @@ class ContrastiveLoss(nn.Module):
         self.static_shapes = static_shapes
         self._pending: dict[str, tuple] = {}
         self.prefetched_gathers_used = 0   # forward() calls that consumed gathers started by prefetch_gather
+        self.prefetched_matches_used = 0   # pairings answered by prefetch_match
         self._force_gather = False   # test seam: run the gather path (packed all-gathers, prefetch) on a 1-rank process group
         self._pending_match: list = []
+        self._early_ids: dict[str, tuple] = {}
         self._match_stream = None
 
     # ------------------------------------------------------------------ gather / encoder overlap
@@ -659,11 +661,15 @@ class ContrastiveLoss(nn.Module):
             return
         world = dist.get_world_size()
         e = embedding.detach().contiguous()
-        i = example_ids.to(torch.int64).contiguous()
         all_e = torch.empty((world * e.shape[0], e.shape[1]), dtype=e.dtype, device=e.device)
-        all_i = torch.empty((world * i.shape[0], 2), dtype=torch.int64, device=i.device)
-        works = [dist.all_gather_into_tensor(all_e.view(-1), e.view(-1), async_op=True),
-                 dist.all_gather_into_tensor(all_i.view(-1), i.view(-1), async_op=True)]
+        works = [dist.all_gather_into_tensor(all_e.view(-1), e.view(-1), async_op=True)]
+        early = self._early_ids.get(modality)
+        if early is not None and early[0] is example_ids and early[1].shape[0] == world * e.shape[0]:
+            i, all_i = early[2], early[1]   # gathered (and matched) ahead of the encoders by prefetch_match
+        else:
+            i = example_ids.to(torch.int64).contiguous()
+            all_i = torch.empty((world * i.shape[0], 2), dtype=torch.int64, device=i.device)
+            works.append(dist.all_gather_into_tensor(all_i.view(-1), i.view(-1), async_op=True))
         self._pending[modality] = (embedding, all_e, all_i, works, (e, i))
 
     # ------------------------------------------------------------------ matcher / encoder overlap
@@ -673,19 +679,22 @@ class ContrastiveLoss(nn.Module):
         encoders run, so by the time ``forward`` asks for the pairing the answer has been on the host for tens of
         milliseconds and reading it does not drain the compute stream (without this the read-back is the one host sync
         of the loss path and holds back the queueing of the backward pass).  Called by ``ContrastivePretraining.forward``
-        before the encoders (``stream``: a side stream to run on instead of the loss's own).  Single-process only: across
-        ranks the matcher needs the gathered ids."""
-        self._pending_match = []
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return
-        todo = []
+        before the encoders (``stream``: a side stream to run on instead of the loss's own).  Across ranks (with
+        ``static_shapes=True``) the id columns are all-gathered here as well -- they do not depend on the encoders -- and
+        ``prefetch_gather`` then only moves embeddings."""
+        self._pending_match, self._early_ids = [], {}
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        gathered = world > 1 or (self._force_gather and dist.is_available() and dist.is_initialized())
+        if gathered and not self.static_shapes:
+            return   # row counts are only known after the size header: the matcher stays in forward()
+        names = []
         for spec in modality_loss_pairs:
             ma, mb = (Modalities.get_modality(m).name if Modalities.has_modality(m) else m for m in spec.modalities)
             ia, ib = example_ids.get(ma), example_ids.get(mb)
             if not all(isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 2 and t.dtype == torch.int64 and t.shape[0] for t in (ia, ib)):
                 continue
-            todo.append((ia, ib))
-        if not todo:
+            names.append((ma, mb))
+        if not names:
             return
         if stream is None:   # the caller may lend a side stream it already has (HW queues are few: keep the stream count low)
             if self._match_stream is None:
@@ -694,6 +703,21 @@ class ContrastiveLoss(nn.Module):
         main = torch.cuda.current_stream()
         stream.wait_stream(main)   # the ids may still be in flight (H2D copy) on the caller's stream
         with torch.cuda.stream(stream):
+            cols = {}
+            for n in sorted({n for pair in names for n in pair}):   # same order on every rank: these are collectives
+                ids = example_ids[n]
+                if gathered:
+                    # the ids do not depend on the encoders: gather them now; prefetch_gather then moves embeddings only
+                    src = ids.contiguous()
+                    all_i = torch.empty((world * src.shape[0], 2), dtype=torch.int64, device=src.device)
+                    dist.all_gather_into_tensor(all_i.view(-1), src.view(-1), async_op=True).wait()   # stream-level wait
+                    self._early_ids[n] = (ids, all_i, src)
+                    cols[n] = all_i
+                else:
+                    cols[n] = ids
+            todo = [(cols[ma], cols[mb]) for ma, mb in names]
+            if gathered and self.local_loss:   # local_loss also pairs this rank's own rows
+                todo += [(example_ids[ma], example_ids[mb]) for ma, mb in names]
             for ia, ib in todo:
                 pm = K.match_ids_launch(ia, ib, read_back_async=True)
                 pm.side_stream = stream
@@ -705,6 +729,7 @@ class ContrastiveLoss(nn.Module):
             if pm.ids_a.data_ptr() == ids_a.data_ptr() and pm.ids_b.data_ptr() == ids_b.data_ptr() \
                     and pm.ids_a.shape == ids_a.shape and pm.ids_b.shape == ids_b.shape:
                 del self._pending_match[k]
+                self.prefetched_matches_used += 1
                 main = torch.cuda.current_stream()
                 main.wait_stream(pm.side_stream)          # idx_a / idx_b were written on the matcher's stream
                 for t in (pm.idx_a, pm.idx_b, pm.counts, pm.status):
@@ -738,7 +763,7 @@ class ContrastiveLoss(nn.Module):
         try:
             return self._forward(run, embeddings, logit_scale)
         finally:
-            self._pending_match = []   # answers belong to one batch
+            self._pending_match, self._early_ids = [], {}   # answers belong to one batch
 
     def _forward(self, run: "_Run", embeddings, logit_scale) -> torch.Tensor:
         first = next(iter(embeddings.values()))

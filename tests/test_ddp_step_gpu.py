@@ -109,7 +109,7 @@ def _nccl_world1_worker(port, q):
             loss.backward()
             torch.cuda.synchronize()
             g = torch.cat([p.grad.detach().float().flatten() for p in task.parameters() if p.grad is not None])
-            out.append((float(loss.detach().float().item()), g.cpu(), loss_fn.prefetched_gathers_used))
+            out.append((float(loss.detach().float().item()), g.cpu(), loss_fn.prefetched_gathers_used, loss_fn.prefetched_matches_used))
         q.put((out, None))
     except Exception:  # pragma: no cover
         q.put((None, traceback.format_exc()))
@@ -127,6 +127,7 @@ def test_ddp_over_rccl_gives_the_same_gradients_with_tower_streams():
     p.join(timeout=60)
     assert err is None, err
     assert [o[2] for o in out] == [0, 0, 1, 0]   # only the static-shapes gather variant takes the prefetched collectives
+    assert [o[3] for o in out] == [1, 1, 1, 0]   # matcher ahead of the encoders; not behind a size header
     out = [o[:2] for o in out]
     (l0, g0) = out[0]
     scale = g0.abs().max().item()

@@ -76,10 +76,13 @@ def _worker(rank, world, port, q):
                     s.grad = None
                     fn = L.ContrastiveLoss(local_loss=bool(c["local_loss"]), gather_with_grad=bool(c["gather_with_grad"]),
                                            static_shapes=static, modality_alignment=align)
-                    if static:
+                    if static:   # what the task does: ids gathered + matched ahead of the encoders, then one gather per tower
+                        fn.prefetch_match(ids, [L.LossPairSpec(("rgb", "text"))])
                         for m in mods:
                             fn.prefetch_gather(m, embs[f"{m}_embedding"], ids[m])
                     loss = fn(embs, ids, s, [L.LossPairSpec(("rgb", "text"))])
+                    if static and len(mods) == 2:
+                        assert fn.prefetched_matches_used >= 1 and not fn._pending_match and not fn._early_ids
                     rec = {"loss": float(loss.detach()), "requires_grad": loss.requires_grad}
                     if loss.requires_grad:
                         loss.backward()

@@ -74,3 +74,27 @@ for it in range(int(os.environ.get("N", 60)) // 2):
         bad2 += 1; print("BIASACT MISMATCH", rows, d, act, e)
 torch.cuda.synchronize()
 print("row-kernel fuzz done, mismatches:", bad2)
+
+# ---- rank-of-positive kernel (retrieval recall / zero-shot top-k): exact integer ranks vs a float64 count, ties by index
+bad3 = 0
+for it in range(int(os.environ.get("N", 60)) // 2):
+    n, m, d = rng.randint(1, 700), rng.randint(1, 900), rng.randint(1, 300)
+    x = torch.nn.functional.normalize(torch.randn(n, d, device=dev), dim=-1)
+    y = torch.nn.functional.normalize(torch.randn(m, d, device=dev), dim=-1)
+    if m > 4 and rng.random() < 0.5:   # exact duplicates in the database: the tie rule decides
+        y[rng.randrange(m)] = y[rng.randrange(m)]
+    pos = torch.randint(0, m, (n,), device=dev)
+    got = K.recall_ranks(x, y, pos)
+    s = x.double() @ y.double().T
+    t = s.gather(1, pos[:, None])
+    col = torch.arange(m, device=dev)[None, :]
+    margin = (s - t).abs()
+    margin[torch.arange(n, device=dev), pos] = 1.0
+    safe = margin.min(dim=1).values > 1e-5    # f32 vs f64 rounding can flip a comparison only on near-ties (duplicates excepted)
+    dup = (s == t) & (col != pos[:, None])
+    want = ((s > t) | ((s == t) & (col < pos[:, None]))).sum(1)
+    ok = (got.long() == want) | ~(safe | dup.any(1))
+    if not bool(ok.all()):
+        bad3 += 1; print("RECALL MISMATCH", n, m, d, int((~ok).sum()))
+torch.cuda.synchronize()
+print("fuzz recall kernel done, mismatches:", bad3)

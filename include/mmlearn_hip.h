@@ -302,11 +302,16 @@ int mmk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* 
  * [B, L, H, 64] views with element strides grad_strides = {batch, row} (heads 64 apart), so the three gradients can be
  * written straight into one packed [B, L, 3, H, 64] buffer for a fused QKV projection;
  * delta_ws an f32 workspace of B * H * 512 elements (per (batch, head): 256 scaled-LSE values and 256 rowsum(dout . out)).
+ * colsum_part (optional, may be NULL; packed layout only): f32 [B * ceil(L / 32)][3][H][64] -- per 32-row tile, the column
+ * sums of the dq / dk / dv values as stored (rounded to bf16); summed over its first dimension it is the bias gradient
+ * `dY.sum(0)` of the fused QKV projection (reference: autograd of the q/k/v nn.Linear biases), without re-reading dY.
+ * Only where mmk_attn_bwd_has_colsum(L) == 1 (all L <= 224 except 97..128); passing it elsewhere is an error.
  * Replaces autograd through the same reference expressions (softmax(QK^T)V backward). */
+int mmk_attn_bwd_has_colsum(int L);
 int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
                  float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
                  const int64_t* k_strides, const int64_t* v_strides, const int64_t* grad_strides, float scale,
-                 float dropout_p, uint64_t seed, void* stream);
+                 float dropout_p, uint64_t seed, float* colsum_part, void* stream);
 
 #ifdef __cplusplus
 }

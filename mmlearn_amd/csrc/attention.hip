@@ -194,6 +194,49 @@ __device__ __forceinline__ void store_rows_staged(char* stage, bf16_t* dst, long
   }
 }
 
+// The same store for the five-product backward (32-row slabs), which can also hand out column sums: cs (optional) = 64
+// floats that receive the sums over the rows stored -- of the ROUNDED values, i.e. exactly what a later dY.sum(0) over the
+// stored tensor would add up (the bias gradient of a fused QKV projection, one partial per 32-row tile).
+__device__ __forceinline__ void store_rows_staged_cs(char* stage, bf16_t* dst, long row_stride, int row0, int nrows_valid,
+                                                     const f32x16 (&acc)[2], float mul, int lane, float* cs) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      bf16x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(acc[dt][4 * q4 + e] * mul);
+      *reinterpret_cast<bf16x4*>(stage + r * 128 + (((dt * 4 + q4) ^ (r & 7)) << 4) + 8 * h) = w;
+    }
+  float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + (lane >> 3), ch = lane & 7;
+    const bf16x8 val = *reinterpret_cast<const bf16x8*>(stage + row * 128 + ((ch ^ (row & 7)) << 4));
+    const int grow = row0 + row;
+    if (grow < nrows_valid) {
+      *reinterpret_cast<bf16x8*>(dst + (long)grow * row_stride + ch * 8) = val;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs8[e] += (float)val[e];
+    }
+  }
+  if (cs) {  // wave-uniform; lanes with equal (lane & 7) hold the same 8 columns for different rows
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = cs8[e];
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      cs8[e] = v;
+    }
+    if (lane < 8) {
+      *reinterpret_cast<float4*>(cs + lane * 8) = make_float4(cs8[0], cs8[1], cs8[2], cs8[3]);
+      *reinterpret_cast<float4*>(cs + lane * 8 + 4) = make_float4(cs8[4], cs8[5], cs8[6], cs8[7]);
+    }
+  }
+}
+
 // v_max3_f32 as one instruction: fmaxf on MFMA results makes the compiler canonicalise each operand first (v_max x, x)
 __device__ __forceinline__ float max3(float a, float b, float c) {
   float r;
@@ -402,7 +445,13 @@ struct AttnBwdArgs {
   float scale;
   uint32_t seed_lo, seed_hi, drop_thr;
   float drop_scale;
+  float* cs;  // optional [B * ceil(L / 32)][3][H][64] f32: per 32-row tile column sums of the stored dq / dk / dv (packed layout)
 };
+
+// where the column sums of tile `tile` of (batch b, head hh), part 0 = dq / 1 = dk / 2 = dv, go (nullptr: not wanted)
+__device__ __forceinline__ float* cs_slot(const AttnBwdArgs& a, int b, int hh, int tile, int part) {
+  return a.cs ? a.cs + (((long)b * ((a.L + 31) >> 5) + tile) * 3 + part) * ((long)a.H * ATT_DH) + hh * ATT_DH : nullptr;
+}
 
 // Row constants of the backward, one 2-KiB record per (batch, head):  ws[bh][0][l] = lse[bh][l] * log2(e) (+inf for
 // l >= L, which makes P = 0 on padded rows), ws[bh][1][l] = delta = sum_d dO[b, l, h, d] * O[b, l, h, d] (0 for l >= L).
@@ -804,13 +853,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
             acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Ks + ks * 2048 + ktr[0][mt], Ks + ks * 2048 + ktr[1][mt]), bfr,
                                                                acc1[mt], 0, 0, 0);
         }
-        store_rows_staged(stage, a.dq + gbase, a.g_sl, (it - 1) * 32, a.L, acc1, a.scale, opaque(lane));
+        store_rows_staged_cs(stage, a.dq + gbase, a.g_sl, (it - 1) * 32, a.L, acc1, a.scale, opaque(lane), cs_slot(a, b, hh, it - 1, 0));
       }
       __syncthreads();
     }
     if (keyw) {
-      store_rows_staged(stage, a.dk + gbase, a.g_sl, wave * 32, a.L, acc1, a.scale, opaque(lane));
-      store_rows_staged(stage, a.dv + gbase, a.g_sl, wave * 32, a.L, acc2, 1.f, opaque(lane));
+      store_rows_staged_cs(stage, a.dk + gbase, a.g_sl, wave * 32, a.L, acc1, a.scale, opaque(lane), cs_slot(a, b, hh, wave, 1));
+      store_rows_staged_cs(stage, a.dv + gbase, a.g_sl, wave * 32, a.L, acc2, 1.f, opaque(lane), cs_slot(a, b, hh, wave, 2));
     }
   }
 }
@@ -911,10 +960,18 @@ extern "C" int mmk_attn_fwd(const void* q, const void* k, const void* v, void* o
   }
 }
 
+// 1 when mmk_attn_bwd can fill colsum_part for sequences of L rows (the five-product kernel serves them: every tile count
+// with a spare wave, i.e. all but 97..128 and 225..256 rows), 0 otherwise.
+extern "C" int mmk_attn_bwd_has_colsum(int L) {
+  static const bool seven = getenv("MMK_ATTN_BWD7") != nullptr;
+  const int nt = (L + 31) / 32;
+  return !seven && L > 0 && nt != 4 && nt < 8;
+}
+
 extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
                             float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
                             const int64_t* k_strides, const int64_t* v_strides, const int64_t* grad_strides, float scale,
-                            float dropout_p, uint64_t seed, void* stream) {
+                            float dropout_p, uint64_t seed, float* colsum_part, void* stream) {
   MMK_REQUIRE(q && k && v && out && dout && lse && delta_ws && dq && dk && dv && q_strides && k_strides && v_strides &&
                   grad_strides,
               "null pointer");
@@ -926,6 +983,7 @@ extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const v
   a.q = static_cast<const bf16_t*>(q); a.k = static_cast<const bf16_t*>(k); a.v = static_cast<const bf16_t*>(v);
   a.o = static_cast<const bf16_t*>(out); a.dout = static_cast<const bf16_t*>(dout); a.lse = lse; a.delta = delta_ws;
   a.dq = static_cast<bf16_t*>(dq); a.dk = static_cast<bf16_t*>(dk); a.dv = static_cast<bf16_t*>(dv);
+  a.cs = colsum_part;
   a.g_sb = grad_strides[0]; a.g_sl = grad_strides[1];
   MMK_REQUIRE(a.g_sb % 8 == 0 && a.g_sl % 8 == 0 && a.g_sl >= (long)H * ATT_DH, "gradient rows must be 16-byte aligned");
   a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sl = q_strides[2];
@@ -936,6 +994,7 @@ extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const v
   const bool drop = drop_params(dropout_p, seed, &a.seed_lo, &a.seed_hi, &a.drop_thr, &a.drop_scale);
   hipStream_t st = static_cast<hipStream_t>(stream);
   static const bool seven = getenv("MMK_ATTN_BWD7") != nullptr;  // force the seven-product kernel (A/B runs)
+  MMK_REQUIRE(!colsum_part || mmk_attn_bwd_has_colsum(L), "attn_bwd: column sums are not available for this sequence length");
 #define MMK_ATTN_BWD_CASE(NT, NW) \
   case NT: return drop ? launch_attn_bwd<NT, NW, true>(a, st) : launch_attn_bwd<NT, NW, false>(a, st);
 #define MMK_ATTN_BWD5_CASE(NT, NW)                                                                                   \

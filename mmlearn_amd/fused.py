@@ -28,6 +28,8 @@ from __future__ import annotations
 import types
 from typing import Iterable, Optional
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -231,6 +233,63 @@ class _LinearWgradFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class _QKVAttentionFn(torch.autograd.Function):
+    """Packed QKV projection + attention as ONE autograd node: ``softmax(q k^T scale) v`` of ``x @ W^T + b`` split into
+    heads of 64.  Same kernels as ``linear`` -> ``attention_qkvpacked``; what the fusion buys is in the backward -- the
+    attention kernel hands over the column sums of the packed gradient it has just written, so the projection's bias
+    gradient needs no ``dY.sum(0)`` pass over the [rows, 3E] gradient (0.19 ms per ViT-B/16 layer at B = 1024)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, heads, scale, dropout_p, seed):
+        B, L, E = x.shape
+        x2 = x.reshape(-1, E).to(torch.bfloat16)
+        w16 = w.detach().to(torch.bfloat16)
+        with torch.autocast("cuda", enabled=False):
+            qkv = x2 @ w16.t() if b is None else torch.addmm(b.detach().to(torch.bfloat16), x2, w16.t())
+        qkv = qkv.view(B, L, 3, heads, 64)
+        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+        out, lse = K.attn_fwd(q, k, v, scale, dropout_p, seed)
+        ctx.save_for_backward(x2, w16, qkv, out, lse)
+        ctx.meta = (x.shape, x.dtype, w.dtype, None if b is None else b.dtype, scale, dropout_p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, w16, qkv, out, lse = ctx.saved_tensors
+        x_shape, x_dtype, w_dtype, b_dtype, scale, dropout_p, seed = ctx.meta
+        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+        want_db = b_dtype is not None and ctx.needs_input_grad[2]
+        res = K.attn_bwd(q, k, v, out, lse, dout.contiguous(), scale, dropout_p, seed, packed=True, colsum=want_db)
+        dqkv, db = res if want_db else (res, None)
+        dy2 = dqkv.view(x2.shape[0], -1)
+        dx = dw = None
+        with torch.autocast("cuda", enabled=False):
+            if ctx.needs_input_grad[0]:
+                dx = (dy2 @ w16).view(x_shape).to(x_dtype)
+            if ctx.needs_input_grad[1]:
+                dw = K.wgrad(dy2, x2, w_dtype if w_dtype in (torch.float32, torch.bfloat16) else torch.float32).to(w_dtype)
+        return dx, dw, (None if db is None else db.to(b_dtype)), None, None, None, None
+
+
+def qkv_attention(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], heads: int, scale: float, dropout_p: float):
+    """``[B, L, E]`` -> ``[B, L, heads, 64]`` through the packed projection ``w [3E, E]`` / ``b [3E]`` and the HIP
+    attention kernels; one autograd node where the weight-gradient kernel applies, two (``linear`` +
+    ``attention_qkvpacked``) otherwise.  None when the projection does not come out in bf16."""
+    from .attention import attention_qkvpacked, draw_seed
+
+    x16 = getattr(x, "_mmk_bf16", None)   # bf16 twin attached by add_layer_norm(twin=True)
+    if x16 is not None and x16.shape == x.shape and _autocast_bf16():
+        x = x16
+    B, L, E = x.shape
+    if _wgrad_linear_ok(w, x) and L <= 256 and w.shape[0] == 3 * heads * 64 and not os.environ.get("MMK_NO_QKV_NODE"):   # (A/B switch)
+        seed = draw_seed() if dropout_p > 0.0 else 0
+        return _QKVAttentionFn.apply(x, w, b, int(heads), float(scale), float(dropout_p), int(seed))
+    qkv = linear(x, w, b)
+    if qkv.dtype != torch.bfloat16:
+        return None
+    return attention_qkvpacked(qkv.view(B, L, 3, heads, 64), scale, dropout_p)
+
+
 def _wgrad_linear_ok(weight: torch.Tensor, x: torch.Tensor) -> bool:
     rows = x.numel() // max(x.shape[-1], 1)
     return (x.is_cuda and weight.dim() == 2 and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0 and rows >= 6144
@@ -393,10 +452,9 @@ def _preln_block_forward(self, x, return_attention: bool = False):
     xn = getattr(x, "_mmk_prenormed", None)
     if xn is None:
         xn = self.norm1(x)
-    qkv = linear(xn, attn.qkv.weight, attn.qkv.bias)
-    if qkv.dtype != torch.bfloat16:
+    ctx = qkv_attention(xn, attn.qkv.weight, attn.qkv.bias, attn.num_heads, float(attn.scale), p_attn)
+    if ctx is None:
         return self._mmk_stock_layer_forward(x, return_attention)
-    ctx = attention_qkvpacked(qkv.view(B, L, 3, attn.num_heads, 64), float(attn.scale), p_attn)
     y = linear_nobias(attn.proj, ctx.reshape(B, L, E))
     h, x2 = add_layer_norm(y, x, self.norm2, p_proj, xbias=attn.proj.bias)
     fused = _seq_mlp_nobias(self.mlp, x2, self.training)
@@ -476,11 +534,8 @@ def _fused_qkv(self, hidden_states: torch.Tensor, names, scale: float, dropout_p
         return None
     w = torch.cat([q.weight, k.weight, v.weight], 0)
     b = None if q.bias is None else torch.cat([q.bias, k.bias, v.bias], 0)
-    qkv = linear(hidden_states, w, b)                        # [B, L, 3E] in the autocast dtype
-    if qkv.dtype != torch.bfloat16:
-        return None
-    out = attention_qkvpacked(qkv.view(B, L, 3, E // 64, 64), scale, dropout_p)
-    return out.reshape(B, L, E)
+    out = qkv_attention(hidden_states, w, b, E // 64, scale, dropout_p)
+    return None if out is None else out.reshape(B, L, E)
 
 
 def _clip_attention_forward(self, hidden_states, attention_mask=None, **kwargs):

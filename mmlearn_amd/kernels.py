@@ -560,10 +560,12 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, dr
 
 
 def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, lse: torch.Tensor, dout: torch.Tensor, scale: float,
-             dropout_p: float = 0.0, seed: int = 0, packed: bool = False):
+             dropout_p: float = 0.0, seed: int = 0, packed: bool = False, colsum: bool = False):
     """Backward of ``attn_fwd``: out / dout are [B, L, H, 64] contiguous.  Returns dq, dk, dv as [B, H, L, 64] VIEWS of
     [B, L, H, 64] buffers (the layout the q/k/v projections' backward consumes without a copy), or with ``packed`` one
-    [B, L, 3, H, 64] buffer holding the three (the gradient of a fused QKV projection's output)."""
+    [B, L, 3, H, 64] buffer holding the three (the gradient of a fused QKV projection's output); ``packed`` + ``colsum``
+    returns ``(dqkv, f32 [3 * H * 64])``, the second being ``dqkv.view(-1, 3 * H * 64).sum(0)`` -- the projection's bias
+    gradient -- accumulated from per-tile sums the kernel takes while it stores, instead of a pass over the gradient."""
     require_gpu(q)
     B, H, L, dh = q.shape
     assert out.is_contiguous() and dout.is_contiguous() and out.shape == (B, L, H, dh) == dout.shape
@@ -575,9 +577,13 @@ def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
     gs = (C.c_int64 * 2)(dq.stride(0), dq.stride(1))
     delta = torch.empty((B * H, 2, 256), dtype=torch.float32, device=q.device)  # lse2 / delta records (csrc/attention.hip)
     qs, ks, vs = _strides3(q), _strides3(k), _strides3(v)
+    in_kernel = packed and colsum and bool(_lib.lib().mmk_attn_bwd_has_colsum(L))   # else: one pass over the gradient afterwards
+    part = torch.empty((B * ((L + 31) // 32), 3 * H * dh), dtype=torch.float32, device=q.device) if in_kernel else None
     check(_lib.lib().mmk_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), B, H, L, dh,
                                   C.cast(qs, C.c_void_p), C.cast(ks, C.c_void_p), C.cast(vs, C.c_void_p), C.cast(gs, C.c_void_p),
-                                  float(scale), float(dropout_p), int(seed), stream()))
+                                  float(scale), float(dropout_p), int(seed), ptr(part), stream()))
+    if packed and colsum:
+        return dqkv, (part.sum(0) if in_kernel else dqkv.view(B * L, -1).sum(0, dtype=torch.float32))
     if packed:
         return dqkv
     return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)

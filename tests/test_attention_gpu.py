@@ -165,3 +165,22 @@ def test_fused_qkv_modules_match_stock_hf_models():
         gmax = max(v.abs().max().item() for v in g0.values())
         for n in g0:
             assert (g0[n] - g1[n]).abs().max() <= 6e-2 * max(g0[n].abs().max().item(), 1e-2 * gmax), n
+
+
+@pytest.mark.parametrize("B,H,L,p", [(3, 2, 197, 0.0), (2, 3, 77, 0.1), (2, 2, 256, 0.0), (4, 1, 1, 0.0), (2, 2, 130, 0.0), (1, 2, 33, 0.0)])
+def test_packed_backward_column_sums_equal_the_sum_over_the_stored_gradient(B, H, L, p):
+    """mmk_attn_bwd(colsum_part): the per-tile sums taken while dq / dk / dv are stored add up to dqkv.sum over rows --
+    the fused QKV projection's bias gradient -- for every kernel variant (5- and 7-product, 16-row staging at L = 256)."""
+    from mmlearn_amd import kernels as K
+    g = torch.Generator().manual_seed(L * 7 + H)
+    qkv = (torch.randn(B, L, 3, H, 64, generator=g) * 1.3).bfloat16().cuda()
+    q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
+    out, lse = K.attn_fwd(q, k, v, 0.125, p, 99)
+    dout = torch.randn(B, L, H, 64, generator=g).bfloat16().cuda()
+    plain = K.attn_bwd(q, k, v, out, lse, dout, 0.125, p, 99, packed=True)
+    dqkv, cs = K.attn_bwd(q, k, v, out, lse, dout, 0.125, p, 99, packed=True, colsum=True)
+    assert torch.equal(plain, dqkv)                      # asking for the sums does not change the gradient
+    want = dqkv.view(B * L, -1).double().sum(0)
+    assert cs.shape == (3 * H * 64,) and cs.dtype == torch.float32
+    scale = max(1.0, want.abs().max().item())
+    assert (cs.double() - want).abs().max().item() <= 1e-5 * scale * max(1.0, (B * L) ** 0.5 / 8), (cs.double() - want).abs().max().item()

@@ -97,3 +97,39 @@ def test_zero_shot_prototypes_logits_and_accuracy():
         want = (torch.topk(ref_logits, k, dim=1)[1] == targets[:, None]).any(dim=1).float().mean()
         assert abs(float(got[k]) - float(want)) < 1e-6, (k, float(got[k]), float(want))
     assert 0.2 < float(got[1]) < 1.0   # the case is neither trivial nor saturated
+
+
+def test_rank_kernel_properties_at_evaluation_scale():
+    """Size-independent properties at a COCO-5k-style / ImageNet-style scale (too big for the float64 oracle):
+    self-retrieval ranks are 0, ranks are invariant under a permutation of the database, a query's rank never exceeds the
+    database size, and top-k accuracy from the rank histogram equals torch.topk membership on the same scores."""
+    from mmlearn_amd import kernels as K
+    from mmlearn_amd.metrics import ZeroShotTopKAccuracy
+    from mmlearn_amd.ops import l2_normalize
+    g = torch.Generator().manual_seed(20)
+    n, d = 20000, 512
+    base = torch.randn(n, d, generator=g)
+    y = l2_normalize(base.cuda())
+    idx = torch.arange(n, device="cuda")
+    assert int(K.recall_ranks(y, y, idx).max()) == 0                       # every row is its own best match
+    x = l2_normalize((base + 7.0 * torch.randn(n, d, generator=g)).cuda())   # cos(x_i, y_i) ~ 0.14: ranks spread out
+    r = K.recall_ranks(x, y, idx)
+    assert 0 <= int(r.min()) and int(r.max()) < n and 0 < float((r < 10).float().mean()) < 1
+    perm = torch.randperm(n, generator=g).cuda()
+    inv = torch.empty_like(perm)
+    inv[perm] = idx
+    r2 = K.recall_ranks(x, y[perm], inv)                                   # database shuffled, positives follow
+    assert torch.equal(r, r2)                                              # continuous scores: no ties to reorder
+    # ImageNet-sized zero-shot head: 1000 classes, 50k queries in batches
+    C, B = 1000, 50000
+    proto = l2_normalize(torch.randn(C, d, generator=g).cuda())
+    t = torch.randint(0, C, (B,), generator=g).cuda()
+    q = proto[t] * 0.35 + 0.05 * torch.randn(B, d, generator=g).cuda()
+    m = ZeroShotTopKAccuracy(top_k=(1, 5))
+    for s in range(0, B, 8192):
+        m.update(q[s:s + 8192], proto, t[s:s + 8192])
+    got = m.compute()
+    logits = 100.0 * l2_normalize(q) @ proto.T
+    for k in (1, 5):
+        want = (torch.topk(logits, k, dim=1)[1] == t[:, None]).any(1).float().mean()
+        assert abs(float(got[k]) - float(want)) <= 2.0 / B, (k, float(got[k]), float(want))   # hipBLAS vs MFMA-f32 near-ties

@@ -97,10 +97,8 @@ def build(small: bool, fused: bool, dev):
     pred = Predictor(196, dim, 128 if small else 384, 2 if small else 12, 2 if small else 6)   # 64-wide predictor heads
     if fused:
         from mmlearn_amd.fused import accelerate_encoder
-        # norm1 / norm2 only feed autocast Linears: they may emit bf16 directly (no f32 -> bf16 cast per GEMM input)
-        lowp = () if os.environ.get("IJEPA_F32_LN_OUT") else ("norm1", "norm2")   # A/B switch
-        accelerate_encoder(enc, low_precision_ln=lowp, fuse_qkv=True, fuse_add_ln=True)
-        accelerate_encoder(pred, low_precision_ln=lowp, fuse_qkv=True, fuse_add_ln=True)
+        accelerate_encoder(enc, fuse_qkv=True, fuse_add_ln=True)    # norm1 / norm2 of the pre-LN blocks emit bf16 (automatic)
+        accelerate_encoder(pred, fuse_qkv=True, fuse_add_ln=True)
         from mmlearn_amd.optim import AdamW
         optimizer = partial(AdamW, lr=1e-4, weight_decay=0.05)
     else:

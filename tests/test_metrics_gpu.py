@@ -133,3 +133,72 @@ def test_rank_kernel_properties_at_evaluation_scale():
     for k in (1, 5):
         want = (torch.topk(logits, k, dim=1)[1] == t[:, None]).any(1).float().mean()
         assert abs(float(got[k]) - float(want)) <= 2.0 / B, (k, float(got[k]), float(want))   # hipBLAS vs MFMA-f32 near-ties
+
+
+def _recall_rank_worker(rank, world, port, q):
+    import os, sys, traceback
+    import torch.distributed as dist
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for p in (root, os.path.join(root, "tests")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from test_dist_gpu import _stage_collectives_through_host
+        _stage_collectives_through_host()   # two ranks share cuda:0: device collectives go through host copies
+        from mmlearn_amd.metrics import RetrievalRecallAtK
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(2, world, 48, 32, generator=g)                     # [update, rank, rows, D]
+        y = x + 3.0 * torch.randn(2, world, 48, 32, generator=g)
+        idx = torch.stack([torch.randperm(48, generator=g) for _ in range(2 * world)]).view(2, world, 48)
+        m = RetrievalRecallAtK(top_k=3, reduction="none")
+        for u in range(2):
+            # the positives index THIS rank's y rows of THIS update, as in the reference's update()
+            perm = idx[u, rank]
+            yy = torch.empty_like(y[u, rank])
+            yy[perm] = y[u, rank]                                          # row perm[i] of yy matches query i
+            m.update(x[u, rank].cuda(), yy.cuda(), perm.cuda())
+        q.put((rank, float(m.compute()), m.ranks().cpu(), None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, None, None, traceback.format_exc()))
+
+
+def test_recall_metric_across_ranks_matches_the_oracle_on_the_gathered_set():
+    """Two ranks, two updates each: every rank ends up with the global set in (update, rank) order with the positives
+    shifted by what came before -- retrieval_recall.py:137-160 -- and computes the same value; checked against the numpy
+    oracle fed the same concatenation."""
+    import torch.multiprocessing as mp
+    from oracle import metrics_oracle as mo
+    world, port = 2, 29500 + (os.getpid() % 2000) + 31
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_recall_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[3] is None, r[3]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, world, 48, 32, generator=g)
+    y = x + 3.0 * torch.randn(2, world, 48, 32, generator=g)
+    idx = torch.stack([torch.randperm(48, generator=g) for _ in range(2 * world)]).view(2, world, 48)
+    xs, ys, ids = [], [], []
+    for u in range(2):
+        for rk in range(world):   # an update's all-gather is rank-major
+            perm = idx[u, rk]
+            yy = torch.empty_like(y[u, rk])
+            yy[perm] = y[u, rk]
+            xs.append(x[u, rk].numpy()); ys.append(yy.numpy()); ids.append(perm.numpy())
+    X, Y, I = mo.concat_batches(xs, ys, ids)
+    want_ranks = mo.ranks(X, Y, I)
+    want = mo.recall_at_k(X, Y, I, 3)
+    for rk, val, ranks, _ in res:
+        assert np.array_equal(ranks.numpy(), want_ranks), rk
+        assert abs(val - want) < 1e-6, (rk, val, want)
+    assert 0.0 < want < 1.0

@@ -184,6 +184,10 @@ def cpu_baseline(seconds_budget: float = 25.0):
 
 
 def main():
+    # HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  At N > 1 the step has the two towers' streams
+    # plus RCCL's, and with 4 queues two of them can land on one queue: the towers' overlap was then lost (216 vs 207.6 ms in
+    # the 1-rank dry run).  Must be set before the first HIP call of the process.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -220,7 +224,12 @@ def main():
     opt = task.configure_optimizers()
     stepper = _Step(task)
     if world > 1 or force_dist:
-        stepper = nn.parallel.DistributedDataParallel(stepper, device_ids=[local_rank], gradient_as_bucket_view=True)
+        if getattr(task, "concurrent_encoders", False) and not os.environ.get("MMK_BENCH_OUTER_DDP"):
+            # one DDP instance per tower, each built under its tower's stream: gradient accumulation, buckets and all-reduces
+            # stay on that stream and the towers' backward passes keep overlapping (a single outer DDP serialises them)
+            task.wrap_towers_in_ddp()
+        else:
+            stepper = nn.parallel.DistributedDataParallel(stepper, device_ids=[local_rank], gradient_as_bucket_view=True)
     batch = synthetic_batch(args.batch, rank, dev)
 
     def step():

@@ -12,6 +12,7 @@ Differences from the reference, all inside the hot path:
 
 from __future__ import annotations
 
+import contextlib
 import inspect
 
 import itertools
@@ -173,6 +174,47 @@ class ContrastivePretraining(TrainingTask):
     def configure_model(self) -> None:
         for task in self.auxiliary_tasks.values():
             task.configure_model()
+
+    def wrap_towers_in_ddp(self, **ddp_kwargs: Any) -> None:
+        """DistributedDataParallel for a task with ``concurrent_encoders``: one DDP instance PER TOWER (encoder, and that
+        modality's postprocessor / head if they have parameters), each constructed under the stream its tower runs on,
+        instead of one DDP around the whole task.
+
+        Why: autograd runs a parameter's gradient accumulation -- and DDP's bucket hooks with it -- on the stream that was
+        current when the accumulator node was created, and DDP's constructor creates them all.  With a single outer DDP
+        they all sit on one stream: every gradient of a side-stream tower then makes that stream wait for the tower, the
+        backward passes run one after the other (measured: 152 vs 140 ms), and a gradient bucket can mix gradients written
+        on two streams while its all-reduce only waits for one.  Per-tower instances keep each tower's accumulation,
+        buckets and collectives on that tower's stream.  Parameters outside the towers (``log_logit_scale``) get a
+        hook that all-reduces their gradient directly.  Call once, after ``.to(device)`` and before the first step."""
+        import torch.distributed as dist
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        world = dist.get_world_size()
+        mods = list(self._available_modalities)
+        side = self._encoder_streams(len(mods) - 1) if getattr(self, "concurrent_encoders", False) else []
+        dev = next(self.parameters()).device
+        kw = dict(device_ids=[dev.index], gradient_as_bucket_view=True)
+        kw.update(ddp_kwargs)
+        wrapped = set()
+        for k, m in enumerate(mods):
+            ctx = torch.cuda.stream(side[k - 1]) if (side and k) else contextlib.nullcontext()
+            with ctx:
+                for group in (self.encoders, self.postprocessors, self.heads):
+                    if group and m.name in group and id(group[m.name]) not in wrapped \
+                            and any(p.requires_grad for p in group[m.name].parameters()):
+                        group[m.name] = DDP(group[m.name], **kw)
+                        wrapped.add(id(group[m.name].module))
+        tower_params = {id(p) for g in (self.encoders, self.postprocessors, self.heads) if g for p in g.parameters()}
+
+        def _reduce(p: torch.Tensor) -> None:
+            dist.all_reduce(p.grad)
+            p.grad.div_(world)
+
+        for p in self.parameters():
+            if p.requires_grad and id(p) not in tower_params:
+                p.register_post_accumulate_grad_hook(_reduce)
+        torch.cuda.synchronize(dev)   # the constructors broadcast rank 0's weights on the towers' streams
 
     def encode(self, inputs: dict[str, Any], modality: Any, normalize: bool = False) -> torch.Tensor:
         """encoder -> postprocessor -> head -> (optional) L2 normalisation (reference :400-431)."""

@@ -38,7 +38,11 @@ def _worker(rank, world, port, q, streams):
         torch.manual_seed(0)  # same initial weights on both ranks
         task = bench.build_task(ContrastiveLoss(static_shapes=True), small=True, fused=True).to(dev)
         task.concurrent_encoders = streams
-        stepper = torch.nn.parallel.DistributedDataParallel(bench._Step(task), device_ids=[0])
+        if streams:   # one DDP instance per tower, built under the tower's stream (what bench.py does at N > 1)
+            task.wrap_towers_in_ddp()
+            stepper = bench._Step(task)
+        else:
+            stepper = torch.nn.parallel.DistributedDataParallel(bench._Step(task), device_ids=[0])
         opt = task.configure_optimizers()
         batch = bench.synthetic_batch(1024, rank, dev)   # 1024 x 17 tokens >= 6k rows: the wgrad path is live
         losses = []
@@ -101,8 +105,12 @@ def _nccl_world1_worker(port, q):
             task = bench.build_task(loss_fn, small=True, fused=True).to(dev)
             task.eval()   # dropout off
             task.concurrent_encoders = streams
-            stepper = torch.nn.parallel.DistributedDataParallel(bench._Step(task), device_ids=[0], bucket_cap_mb=1,   # many buckets
-                                                                gradient_as_bucket_view=True)  # as in bench.py
+            if streams:   # per-tower DDP instances with many small buckets, bucket-view gradients as in bench.py
+                task.wrap_towers_in_ddp(bucket_cap_mb=1)
+                stepper = bench._Step(task)
+            else:
+                stepper = torch.nn.parallel.DistributedDataParallel(bench._Step(task), device_ids=[0], bucket_cap_mb=1,
+                                                                    gradient_as_bucket_view=True)
             batch = bench.synthetic_batch(1024, 0, dev)
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 loss = stepper(batch)

@@ -645,7 +645,8 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
 
     ``low_precision_ln``: substrings of qualified module names whose LayerNorm may emit the autocast dtype directly
     (only LayerNorms that feed autocast ``Linear`` layers, e.g. ``("layer_norm1", "layer_norm2", "post_layernorm")``
-    for HF CLIP); ``norm1`` / ``norm2`` of timm-style pre-LN blocks (mmlearn's own ViT / predictor) get it automatically.
+    for HF CLIP); ``norm1`` / ``norm2`` of timm-style pre-LN blocks (mmlearn's own ViT / predictor) and ``layer_norm1`` /
+    ``layer_norm2`` of HF ``CLIPEncoderLayer`` get it automatically -- they feed nothing but that block's Linears.
     Returns the number of modules swapped per kind.
     """
     swapped = {"layernorm": 0, "quick_gelu": 0, "fused_qkv": fuse_qkv_attention(module) if fuse_qkv else 0, "fused_add_ln": 0}
@@ -656,7 +657,8 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
             if type(child) is nn.LayerNorm and len(child.normalized_shape) == 1 and child.normalized_shape[0] % 4 == 0 \
                     and child.normalized_shape[0] <= 2048:
                 # norm1 / norm2 of a timm-style pre-LN block feed nothing but its qkv / fc1 Linear: bf16 out is always safe there
-                lowp = any(s in full for s in low) or (child_name in ("norm1", "norm2") and _is_preln_block(parent))
+                lowp = any(s in full for s in low) or (child_name in ("norm1", "norm2") and _is_preln_block(parent)) \
+                    or (type(parent).__name__ == "CLIPEncoderLayer" and child_name in ("layer_norm1", "layer_norm2"))
                 setattr(parent, child_name, LayerNorm.from_torch(child, lowp))
                 swapped["layernorm"] += 1
             elif type(child).__name__ in ("QuickGELUActivation", "QuickGELU") and not isinstance(child, QuickGELU):

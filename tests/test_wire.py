@@ -147,3 +147,34 @@ def test_pairing_flag_and_packed_keys():
         pack_example_ids(torch.tensor([[0, -1]]))
     with pytest.raises(ValueError, match=r"\[N, 2\]"):
         pack_example_ids(torch.tensor([1, 2, 3]))
+
+
+def test_combined_dataset_index_map_property():
+    """For random member sizes every global index (and its negative twin) lands in the member the cumulative sizes say,
+    with the member-local index, and a collated batch of whole samples is flagged paired exactly when all samples come
+    from members that carry the same modalities."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.lists(st.integers(min_value=1, max_value=7), min_size=1, max_size=5), st.data())
+    def check(sizes, data):
+        members = [_Ds(n, ("rgb", "text") if k % 2 == 0 else ("text",)) for k, n in enumerate(sizes)]
+        ds = CombinedDataset(members)
+        total = sum(sizes)
+        assert len(ds) == total
+        bounds = np.cumsum([0] + sizes)
+        for g in range(total):
+            k = int(np.searchsorted(bounds, g, side="right") - 1)
+            for idx in (g, g - total):
+                ex = ds[idx]
+                assert int(ex.dataset_index) == k and int(ex.example_index) == g - bounds[k]
+                assert all(v.tolist() == [k, g - bounds[k]] for v in ex.example_ids.values())
+        picks = data.draw(st.lists(st.integers(min_value=0, max_value=total - 1), min_size=1, max_size=6))
+        batch = DefaultDataCollator()([ds[i] for i in picks])
+        owners = [int(np.searchsorted(bounds, i, side="right") - 1) for i in picks]
+        assert batch["fully_paired"] == (len({o % 2 for o in owners}) == 1)
+        for name, keys in batch["example_keys"].items():
+            assert torch.equal(unpack_example_keys(keys), batch["example_ids"][name])
+
+    check()

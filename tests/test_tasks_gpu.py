@@ -269,6 +269,60 @@ def test_concurrent_encoder_streams_give_the_same_step():
             assert diff <= max(4 * noise, 1e-5 * g0.abs().max().item()) and cos >= cos_noise - 2e-4, (k, diff, noise, cos.item(), cos_noise.item())
 
 
+def test_three_towers_on_three_streams_with_a_shared_head():
+    """BASELINE configs[3] shape of the task (three modalities, one shared projection head, three weighted pairs) with
+    ``concurrent_encoders``: two side streams, the shared head's parameters used from all three; same loss and gradients
+    as the single-stream step, and the matcher answers for all three pairs are prefetched."""
+    from mmlearn_amd import ContrastiveLoss
+    from mmlearn_amd.tasks import ContrastivePretraining, LossPairSpec, ModuleKeySpec
+
+    dev = _dev()
+    D, B = 64, 512
+
+    class Enc(torch.nn.Module):
+        def __init__(self, key):
+            super().__init__()
+            self.key = key
+            self.net = torch.nn.Sequential(torch.nn.Linear(96, 256), torch.nn.GELU(), torch.nn.Linear(256, D))
+
+        def forward(self, inputs):
+            return (self.net(inputs[self.key]),)
+
+    def build():
+        torch.manual_seed(3)
+        return ContrastivePretraining(
+            encoders={"rgb": Enc("rgb"), "text": Enc("text"), "audio": Enc("audio")},
+            heads={"shared": {"proj": torch.nn.Linear(D, D)}},
+            modality_module_mapping={m: ModuleKeySpec(encoder_key=m, head_key="shared") for m in ("rgb", "text", "audio")},
+            loss=ContrastiveLoss(), optimizer=partial(torch.optim.SGD, lr=0.1),
+            modality_loss_pairs=[LossPairSpec(("rgb", "text")), LossPairSpec(("rgb", "audio"), 0.5), LossPairSpec(("text", "audio"), 0.25)],
+            compute_validation_loss=False, compute_test_loss=False).to(dev)
+
+    g = torch.Generator().manual_seed(8)
+    batch = {m: torch.randn(B, 96, generator=g).to(dev) for m in ("rgb", "text", "audio")}
+    perm = torch.randperm(B, generator=g)
+    batch["example_ids"] = {"rgb": _ids(B, dev), "text": _ids(B, dev), "audio": _ids(B, dev)[perm.to(dev)]}
+    batch["audio"] = batch["audio"][perm.to(dev)]     # audio rows arrive in another order: the matcher has real work
+    results = []
+    for streams in (False, True):
+        task = build()
+        task.concurrent_encoders = streams
+        recs = []
+        opt = task.configure_optimizers()
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            loss = task.training_step(batch, 0)
+            loss.backward()
+            recs.append((loss.detach().clone(), torch.cat([p.grad.flatten() for p in task.parameters() if p.grad is not None]).clone()))
+            opt.step()
+        results.append(recs)
+        if streams:
+            assert len(task._side_streams) == 2 and task.loss_fn.prefetched_matches_used == 9
+    for (l0, g0), (l1, g1) in zip(*results):
+        assert torch.allclose(l0, l1, rtol=1e-6, atol=1e-7), (l0.item(), l1.item())
+        assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()
+
+
 def test_hip_adamw_matches_torch_adamw():
     from mmlearn_amd.optim import AdamW
 

@@ -178,7 +178,8 @@ class ContrastivePretraining(TrainingTask):
     def wrap_towers_in_ddp(self, **ddp_kwargs: Any) -> None:
         """DistributedDataParallel for a task with ``concurrent_encoders``: one DDP instance PER TOWER (encoder, and that
         modality's postprocessor / head if they have parameters), each constructed under the stream its tower runs on,
-        instead of one DDP around the whole task.
+        instead of one DDP around the whole task.  A module shared between towers (a common projection head) is wrapped once,
+        for the first tower that uses it; the other towers call it unwrapped and autograd sums their contributions first.
 
         Why: autograd runs a parameter's gradient accumulation -- and DDP's bucket hooks with it -- on the stream that was
         current when the accumulator node was created, and DDP's constructor creates them all.  With a single outer DDP
@@ -196,15 +197,20 @@ class ContrastivePretraining(TrainingTask):
         dev = next(self.parameters()).device
         kw = dict(device_ids=[dev.index], gradient_as_bucket_view=True)
         kw.update(ddp_kwargs)
-        wrapped = set()
+        owned: set[int] = set()   # parameters that already belong to a DDP instance (modules can be shared between towers)
         for k, m in enumerate(mods):
             ctx = torch.cuda.stream(side[k - 1]) if (side and k) else contextlib.nullcontext()
             with ctx:
                 for group in (self.encoders, self.postprocessors, self.heads):
-                    if group and m.name in group and id(group[m.name]) not in wrapped \
-                            and any(p.requires_grad for p in group[m.name].parameters()):
-                        group[m.name] = DDP(group[m.name], **kw)
-                        wrapped.add(id(group[m.name].module))
+                    if not (group and m.name in group):
+                        continue
+                    mine = {id(p) for p in group[m.name].parameters() if p.requires_grad}
+                    if not mine or mine <= owned:
+                        continue   # nothing to reduce, or a module shared with an earlier tower: that tower's instance reduces it
+                    if mine & owned:
+                        raise NotImplementedError(f"{m.name}: module shares only part of its parameters with another tower")
+                    group[m.name] = DDP(group[m.name], **kw)
+                    owned |= mine
         tower_params = {id(p) for g in (self.encoders, self.postprocessors, self.heads) if g for p in g.parameters()}
 
         def _reduce(p: torch.Tensor) -> None:

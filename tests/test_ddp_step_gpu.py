@@ -143,3 +143,84 @@ def test_ddp_over_rccl_gives_the_same_gradients_with_tower_streams():
     for l, g in out[1:]:   # same weights, same batch: only f32 atomics may reorder
         assert abs(l0 - l) <= 1e-5 * max(1.0, abs(l0)), (l0, l)
         assert (g0 - g).abs().max().item() <= 1e-5 * scale, (g0 - g).abs().max().item() / scale
+
+
+def _three_tower_worker(port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        if ROOT not in sys.path:
+            sys.path.insert(0, ROOT)
+        from functools import partial
+
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from mmlearn_amd import ContrastiveLoss
+        from mmlearn_amd.tasks import ContrastivePretraining, LossPairSpec, ModuleKeySpec
+
+        dev = torch.device("cuda", 0)
+        D, B = 64, 256
+
+        class Enc(torch.nn.Module):
+            def __init__(self, key):
+                super().__init__()
+                self.key = key
+                self.net = torch.nn.Sequential(torch.nn.Linear(96, 128), torch.nn.GELU(), torch.nn.Linear(128, D))
+
+            def forward(self, inputs):
+                return (self.net(inputs[self.key]),)
+
+        g = torch.Generator().manual_seed(8)
+        batch = {m: torch.randn(B, 96, generator=g).to(dev) for m in ("rgb", "text", "audio")}
+        ids = torch.stack([torch.zeros(B, dtype=torch.long), torch.arange(B)], 1).to(dev)
+        batch["example_ids"] = {m: ids.clone() for m in ("rgb", "text", "audio")}
+        out = []
+        for ddp in (False, True):
+            torch.manual_seed(3)
+            task = ContrastivePretraining(
+                encoders={"rgb": Enc("rgb"), "text": Enc("text"), "audio": Enc("audio")},
+                heads={"shared": {"proj": torch.nn.Linear(D, D)}},
+                modality_module_mapping={m: ModuleKeySpec(encoder_key=m, head_key="shared") for m in ("rgb", "text", "audio")},
+                loss=ContrastiveLoss(static_shapes=True), optimizer=partial(torch.optim.SGD, lr=0.1),
+                modality_loss_pairs=[LossPairSpec(("rgb", "text")), LossPairSpec(("rgb", "audio"), 0.5)],
+                compute_validation_loss=False, compute_test_loss=False).to(dev)
+            task.concurrent_encoders = True
+            if ddp:
+                task.wrap_towers_in_ddp(bucket_cap_mb=1)
+                kinds = {k: type(v).__name__ for k, v in task.encoders.items()}
+                assert set(kinds.values()) == {"DistributedDataParallel"}, kinds
+                # the shared head is wrapped once (by the first tower); the other towers call the same module unwrapped
+                assert sum(type(h).__name__ == "DistributedDataParallel" for h in task.heads.values()) == 1
+            rec = []
+            opt = task.configure_optimizers()
+            for _ in range(2):
+                opt.zero_grad(set_to_none=True)
+                loss = task.training_step(batch, 0)
+                loss.backward()
+                torch.cuda.synchronize()
+                names = sorted(n.replace("module.", "") for n, p in task.named_parameters() if p.grad is not None)
+                grads = {n.replace("module.", ""): p.grad.detach().clone() for n, p in task.named_parameters() if p.grad is not None}
+                rec.append((float(loss), names, torch.cat([grads[n].flatten() for n in names]).cpu()))
+                opt.step()
+            out.append(rec)
+        q.put((out, None))
+    except Exception:  # pragma: no cover
+        q.put((None, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_per_tower_ddp_with_three_towers_and_a_shared_head():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_three_tower_worker, args=(29500 + (os.getpid() % 2000) + 13, q))
+    p.start()
+    out, err = q.get(timeout=600)
+    p.join(timeout=60)
+    assert err is None, err
+    plain, wrapped = out
+    for (l0, n0, g0), (l1, n1, g1) in zip(plain, wrapped):
+        assert n0 == n1 and "log_logit_scale" in n0
+        assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0))
+        assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()

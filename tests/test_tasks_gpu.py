@@ -296,7 +296,7 @@ def test_three_towers_on_three_streams_with_a_shared_head():
             modality_module_mapping={m: ModuleKeySpec(encoder_key=m, head_key="shared") for m in ("rgb", "text", "audio")},
             loss=ContrastiveLoss(), optimizer=partial(torch.optim.SGD, lr=0.1),
             modality_loss_pairs=[LossPairSpec(("rgb", "text")), LossPairSpec(("rgb", "audio"), 0.5), LossPairSpec(("text", "audio"), 0.25)],
-            compute_validation_loss=False, compute_test_loss=False).to(dev)
+            compute_validation_loss=True, compute_test_loss=False).to(dev)
 
     g = torch.Generator().manual_seed(8)
     batch = {m: torch.randn(B, 96, generator=g).to(dev) for m in ("rgb", "text", "audio")}
@@ -315,9 +315,11 @@ def test_three_towers_on_three_streams_with_a_shared_head():
             loss.backward()
             recs.append((loss.detach().clone(), torch.cat([p.grad.flatten() for p in task.parameters() if p.grad is not None]).clone()))
             opt.step()
+        with torch.no_grad():   # the no-grad loss path (validation) under the same scheduling
+            recs.append((task.validation_step(batch, 0).detach().clone(), recs[-1][1]))
         results.append(recs)
         if streams:
-            assert len(task._side_streams) == 2 and task.loss_fn.prefetched_matches_used == 9
+            assert len(task._side_streams) == 2 and task.loss_fn.prefetched_matches_used == 12
     for (l0, g0), (l1, g1) in zip(*results):
         assert torch.allclose(l0, l1, rtol=1e-6, atol=1e-7), (l0.item(), l1.item())
         assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()

@@ -349,3 +349,36 @@ def test_hip_adamw_matches_torch_adamw():
             assert (a - b).abs().max() <= 2e-6 * max(1.0, a.abs().max().item()), it
     sd = hip.state_dict()
     assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_ijepa_vit_step_with_fused_blocks_matches_stock_blocks():
+    """The I-JEPA task over a timm-style ViT + block predictor (tools/bench_ijepa_step.py, small sizes): with
+    ``accelerate_encoder`` on encoder and predictor the first training steps give the same losses as the stock blocks
+    (same seeds, hence same masks), and the EMA target stays a copy of the student."""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_ijepa_step", os.path.join(root, "tools", "bench_ijepa_step.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    dev = _dev()
+    imgs = torch.rand(32, 3, 224, 224, generator=torch.Generator().manual_seed(1)).to(dev)
+    curves = []
+    for fused in (False, True):
+        task = tool.build(True, fused, dev)
+        opt = task.configure_optimizers()
+        opt = opt["optimizer"] if isinstance(opt, dict) else opt
+        torch.manual_seed(7)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = task.training_step({"rgb": imgs}, 0)
+            loss.backward()
+            opt.step()
+            task.on_before_zero_grad(opt)
+            losses.append(float(loss.detach().float()))
+        curves.append(losses)
+        for (k, t), (_, s) in zip(task.target_encoder.model.state_dict().items(), task.encoder.state_dict().items()):
+            assert torch.equal(t, s), k
+    for a, b in zip(*curves):
+        assert abs(a - b) <= 1e-2 * max(1.0, abs(a)), curves

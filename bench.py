@@ -349,9 +349,21 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+    # RCCL leaves its version banner in the C stdout buffer of a process until exit: every rank pushes its buffer out, then all
+    # meet, and only then rank 0 prints the result line -- the last line on stdout
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     if world > 1 or force_dist:
         dist.barrier()
+        torch.cuda.synchronize()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -110,3 +110,17 @@ def test_training_task_optimizer_split():
         T()
     with pytest.warns(UserWarning):
         assert T(loss_fn=lambda a, b: a).configure_optimizers() is None
+
+
+def test_tools_and_entry_points_parse_and_bench_checks_its_launch():
+    """Every script shipped next to the package is at least syntactically valid (they are run by hand on the GPU box), and
+    bench.py refuses a --gpus that does not match the launcher's WORLD_SIZE before touching the GPU."""
+    import ast, glob, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "tools", "*.py")) + [os.path.join(root, f) for f in ("bench.py", "__graft_entry__.py")]
+    assert len(files) >= 10
+    for f in files:
+        ast.parse(open(f).read(), filename=f)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

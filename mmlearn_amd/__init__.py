@@ -12,6 +12,6 @@ from .modalities import Modalities  # noqa: F401
 from .ema import ExponentialMovingAverage  # noqa: F401
 from .layers import L2Norm, LearnableLogitScaling  # noqa: F401
 from .masking import IJEPAMaskGenerator  # noqa: F401
-from .ops import apply_masks, ijepa_loss, ijepa_target, l2_normalize, predictor_assemble, repeat_interleave_batch  # noqa: F401
+from .ops import IndexedMasks, apply_masks, ijepa_loss, ijepa_target, l2_normalize, predictor_assemble, repeat_interleave_batch  # noqa: F401
 
 __version__ = "0.1.0"

@@ -106,7 +106,10 @@ class ExponentialMovingAverage:
     @torch.no_grad()
     def _update_weights(self, new_model: torch.nn.Module) -> None:
         if self.decay < 1:
-            key = id(new_model)
+            # keyed on the storages themselves: ``.to()`` / ``.half()`` / re-wrapping re-allocates parameters, and a table
+            # built for the old storages would keep updating tensors nobody reads
+            key = (id(new_model), tuple(t.data_ptr() for t in self.model.state_dict().values()),
+                   tuple(t.data_ptr() for t in new_model.state_dict().values()))
             if key not in self._tables:
                 self._tables = {key: self._build_tables(new_model)}
             tables, slow, _ = self._tables[key]

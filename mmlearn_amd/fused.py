@@ -539,8 +539,11 @@ def _fused_qkv(self, hidden_states: torch.Tensor, names, scale: float, dropout_p
 
 
 def _clip_attention_forward(self, hidden_states, attention_mask=None, **kwargs):
-    """Replaces HF ``CLIPAttention.forward`` (modeling_clip.py): same parameters, same return contract."""
-    if attention_mask is None and getattr(self, "head_dim", 0) == 64:
+    """Replaces HF ``CLIPAttention.forward`` (modeling_clip.py): same parameters, same return contract.  The fused kernel
+    is bidirectional: a causal call (HF's CLIP text tower passes no mask for sdpa-style implementations and signals
+    causality only through ``is_causal=True``) takes the stock forward."""
+    causal = bool(kwargs.get("is_causal", False)) or bool(getattr(self, "is_causal", False))
+    if attention_mask is None and not causal and getattr(self, "head_dim", 0) == 64:
         ctx = _fused_qkv(self, hidden_states, ("q_proj", "k_proj", "v_proj"), self.scale, self.dropout if self.training else 0.0)
         if ctx is not None:
             if getattr(self, "_mmk_defer_out_bias", False):   # the enclosing patched layer adds out_proj.bias itself
@@ -551,8 +554,10 @@ def _clip_attention_forward(self, hidden_states, attention_mask=None, **kwargs):
 
 
 def _bert_self_attention_forward(self, hidden_states, attention_mask=None, past_key_values=None, **kwargs):
-    """Replaces HF ``BertSelfAttention.forward`` (modeling_bert.py); the output ``dense`` lives in ``BertSelfOutput``."""
-    if attention_mask is None and past_key_values is None and getattr(self, "attention_head_size", 0) == 64:
+    """Replaces HF ``BertSelfAttention.forward`` (modeling_bert.py); the output ``dense`` lives in ``BertSelfOutput``.
+    Decoder / causal configurations take the stock forward (the fused kernel is bidirectional)."""
+    causal = bool(kwargs.get("is_causal", False)) or bool(getattr(self, "is_causal", False)) or bool(getattr(self, "is_decoder", False))
+    if attention_mask is None and past_key_values is None and not causal and getattr(self, "attention_head_size", 0) == 64:
         ctx = _fused_qkv(self, hidden_states, ("query", "key", "value"), self.scaling, self.dropout.p if self.training else 0.0)
         if ctx is not None:
             return ctx, None

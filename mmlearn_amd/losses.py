@@ -199,6 +199,7 @@ class _Run:
         dev, dt, d = any_t.device, any_t.dtype, any_t.shape[1]
         W, rank = self.world, self.rank
         if self.o.static_shapes:
+            self.o._check_static_shapes({n: t.shape[0] for n, t in local.items()})
             counts = {n: [t.shape[0]] * W for n, t in local.items()}
         else:
             header = torch.tensor([local[n].shape[0] if n in local else -1 for n in names_all] + [int(self.paired_hint), d],
@@ -285,11 +286,18 @@ class _Run:
             self.pairs.append(p)
 
         if local_mode and self.pairs:
-            # per-rank row counts of every pair (the reference all-gathers them per pair, contrastive.py:196-206)
-            mine = torch.tensor([p.ml.n for p in self.pairs], dtype=torch.int64, device=dev)
-            table = _all_gather(mine, W).tolist()
-            for k, p in enumerate(self.pairs):
-                p.local_sizes = [table[r][k] for r in range(W)]
+            # per-rank row counts of every pair (the reference all-gathers them per pair, contrastive.py:196-206).  When the
+            # pairing of the GATHERED ids is the identity (every rank sees the same answer, so the branch is taken
+            # collectively) rank r's local pairing is the identity over its own rows: the counts are known, no exchange,
+            # no host read.
+            if all(p.mg.identity and list(views[p.ma].counts) == list(views[p.mb].counts) for p in self.pairs):
+                for p in self.pairs:
+                    p.local_sizes = list(views[p.ma].counts)
+            else:
+                mine = torch.tensor([p.ml.n for p in self.pairs], dtype=torch.int64, device=dev)
+                table = _all_gather(mine, W).tolist()
+                for k, p in enumerate(self.pairs):
+                    p.local_sizes = [table[r][k] for r in range(W)]
 
         dirs_all = []
         for p in self.pairs:
@@ -649,6 +657,34 @@ class ContrastiveLoss(nn.Module):
         self._pending_match: list = []
         self._early_ids: dict[str, tuple] = {}
         self._match_stream = None
+        self._static_validated: dict[str, int] = {}
+
+    # ------------------------------------------------------------------ static_shapes: a checked promise
+    def _check_static_shapes(self, rows: dict[str, int]) -> None:
+        """``static_shapes=True`` promises that every rank holds the same modalities with the same row counts; a broken
+        promise would otherwise show up as mismatched collectives (a hang or corrupted rows).  Whenever THIS rank sees a
+        (modality, rows) it has not validated yet -- the first step, or a shorter last batch, which ``DistributedSampler``
+        hands to every rank at the same step -- the ranks exchange a small header and compare (one collective + one host
+        read, only on those steps).  ``MMK_CHECK_STATIC_SHAPES=1`` validates on every call (debug: it also catches ranks
+        whose shapes change at different steps, which the on-change trigger cannot see)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        import os
+
+        if all(self._static_validated.get(n) == r for n, r in rows.items()) and not os.environ.get("MMK_CHECK_STATIC_SHAPES"):
+            return
+        names_all = [m.name for m in Modalities.list_modalities()]
+        unknown = [n for n in rows if n not in names_all]
+        if unknown:
+            raise ValueError(f"modality {unknown[0]!r} is not registered")
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        header = torch.tensor([rows.get(n, -1) for n in names_all], dtype=torch.int64, device=dev)
+        table = _all_gather(header, dist.get_world_size()).tolist()
+        if any(row != table[0] for row in table):
+            bad = {names_all[i]: [row[i] for row in table] for i in range(len(names_all)) if len({row[i] for row in table}) > 1}
+            raise ValueError("ContrastiveLoss(static_shapes=True): ranks disagree on the rows per modality (-1 = modality absent) "
+                             f"{bad}; use static_shapes=False for ragged / missing-modality batches")
+        self._static_validated.update(rows)
 
     # ------------------------------------------------------------------ gather / encoder overlap
     def prefetch_gather(self, modality: str, embedding: torch.Tensor, example_ids: torch.Tensor) -> None:
@@ -660,6 +696,7 @@ class ContrastiveLoss(nn.Module):
                 and (dist.get_world_size() > 1 or self._force_gather)):
             return
         world = dist.get_world_size()
+        self._check_static_shapes({modality: embedding.shape[0]})
         e = embedding.detach().contiguous()
         all_e = torch.empty((world * e.shape[0], e.shape[1]), dtype=e.dtype, device=e.device)
         works = [dist.all_gather_into_tensor(all_e.view(-1), e.view(-1), async_op=True)]
@@ -696,6 +733,8 @@ class ContrastiveLoss(nn.Module):
             names.append((ma, mb))
         if not names:
             return
+        if gathered:
+            self._check_static_shapes({n: example_ids[n].shape[0] for pair in names for n in pair})
         if stream is None:   # the caller may lend a side stream it already has (HW queues are few: keep the stream count low)
             if self._match_stream is None:
                 self._match_stream = torch.cuda.Stream()

@@ -48,6 +48,20 @@ def l2_normalize(x: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ masks -> indices
+class IndexedMasks(list):
+    """A list of 0/1 patch masks (what the reference's encoders receive in ``batch["<modality>_mask"]``) that also carries
+    the sorted keep-indices of those masks, ``indices`` int32 ``[n_masks, B or 1, keep]`` on the device.  A consumer that
+    only knows lists of masks (the reference's ``apply_masks``, masking.py:241-287) sees exactly that; this package's
+    ``apply_masks`` reads ``indices`` and never looks at the boolean masks -- no ``nonzero``, no host synchronisation
+    (the reference syncs once per mask inside boolean-mask indexing, masking.py:264-283)."""
+
+    def __init__(self, masks, indices: torch.Tensor):
+        super().__init__(masks)
+        if indices.dim() != 3 or indices.dtype != torch.int32 or indices.shape[0] != len(self):
+            raise ValueError(f"indices must be int32 [n_masks={len(self)}, B or 1, keep], got {indices.dtype} {tuple(indices.shape)}")
+        self.indices = indices
+
+
 def masks_to_indices(masks: MaskList, batch_size: int, device: torch.device, keep: Optional[int] = None) -> torch.Tensor:
     """Stack a list of 0/1 masks of shape (N,), (1, N) or (B, N) into sorted keep-indices
     ``int32[n_masks, B or 1, keep]`` on ``device``.
@@ -109,8 +123,18 @@ def gather_patches(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 def apply_masks(x: torch.Tensor, masks: MaskList) -> torch.Tensor:
     """Drop-in for ``mmlearn.datasets.processors.masking.apply_masks``: keep the patches selected by
-    each mask and concatenate along the batch dimension."""
-    idx = masks_to_indices(masks, x.size(0), x.device)
+    each mask and concatenate along the batch dimension.  ``masks`` may be an :class:`IndexedMasks` (or any object with an
+    ``indices`` attribute): the precomputed indices are used and nothing is read back from the device; plain CPU masks are
+    converted on the host (no device sync either); plain device masks cost one read-back of the keep count, like the
+    reference's boolean indexing."""
+    idx = getattr(masks, "indices", None)
+    if idx is not None:
+        if idx.shape[1] not in (1, x.size(0)):
+            raise ValueError(f"mask batch dimension {idx.shape[1]} does not match batch size {x.size(0)}")
+        if idx.device != x.device:
+            idx = idx.to(x.device, non_blocking=True)
+    else:
+        idx = masks_to_indices(masks, x.size(0), x.device)
     return gather_patches(x, idx)
 
 

@@ -38,9 +38,15 @@ class AdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables: Dict[int, Any] = {}
 
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)
+        self._tables = {}   # the restored moment tensors are new storages
+
     def _table(self, gi: int, plist: List[torch.Tensor]):
-        """Static device tables of one group (rebuilt when the set of parameters with gradients changes)."""
-        key = tuple(p.data_ptr() for p in plist)
+        """Static device tables of one group, rebuilt when the set of parameters with gradients changes or when any of the
+        storages the table points at has been replaced (``load_state_dict`` swaps the moment tensors: a table keyed on the
+        parameters alone would keep updating the freed buffers)."""
+        key = tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in plist)
         tab = self._tables.get(gi)
         if tab is not None and tab["key"] == key:
             return tab
@@ -74,6 +80,15 @@ class AdamW(torch.optim.Optimizer):
                 if p.dtype != torch.float32 or not p.is_contiguous() or p.grad.is_sparse:
                     raise RuntimeError("mmlearn_amd.optim.AdamW supports dense contiguous f32 parameters")
                 st = self.state[p]
+                if st and (st["exp_avg"].device != p.device or st["exp_avg"].dtype != torch.float32 or not st["exp_avg"].is_contiguous()
+                           or st["exp_avg_sq"].device != p.device or st["exp_avg_sq"].dtype != torch.float32 or not st["exp_avg_sq"].is_contiguous()):
+                    # state restored from a checkpoint in another layout: bring it to what the kernel reads
+                    st["exp_avg"] = st["exp_avg"].to(device=p.device, dtype=torch.float32).contiguous()
+                    st["exp_avg_sq"] = st["exp_avg_sq"].to(device=p.device, dtype=torch.float32).contiguous()
+                if st and not isinstance(st["step"], torch.Tensor):
+                    st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
+                if st and st["step"].is_cuda:
+                    st["step"] = st["step"].cpu()   # load_state_dict moves the state to the parameter's device; the step counter lives on the host
                 if not st:
                     st["step"] = torch.zeros((), dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)

@@ -116,10 +116,12 @@ class IJEPA(TrainingTask):
         device = images.device
 
         mask_info = self.mask_generator(batch_size=batch_size)       # host RNG, same call sequence as the reference
-        encoder_masks = [m.to(device, non_blocking=True) for m in mask_info["encoder_masks"]]
-        predictor_masks = [m.to(device, non_blocking=True) for m in mask_info["predictor_masks"]]
         enc_idx = mask_info["encoder_indices"].to(device, non_blocking=True)      # int32 [nenc, 1, n_ctxt]
         pred_idx = mask_info["predictor_indices"].to(device, non_blocking=True)   # int32 [npred, 1, keep]
+        # the masks travel as the reference's lists of 0/1 tensors, with the host-built indices attached: this package's
+        # apply_masks (context encoder, vision.py:335-337) gathers by index and never syncs; a foreign consumer sees lists
+        encoder_masks = ops.IndexedMasks([m.to(device, non_blocking=True) for m in mask_info["encoder_masks"]], enc_idx)
+        predictor_masks = ops.IndexedMasks([m.to(device, non_blocking=True) for m in mask_info["predictor_masks"]], pred_idx)
         n_enc = len(encoder_masks)
 
         with torch.no_grad():  # teacher sees every patch
@@ -142,8 +144,6 @@ class IJEPA(TrainingTask):
         ):
             # target rows are ordered (pred mask, enc mask, sample): one index row per (pred, enc) pair
             idx = pred_idx if n_enc == 1 else pred_idx.repeat_interleave(n_enc, dim=0)
-            if n_enc > 1:
-                h = h  # the same teacher tokens serve every encoder mask
             if self._fused_kind is not None:
                 loss = ops.ijepa_loss(z_pred, h, idx, kind=self._fused_kind)
             else:

@@ -102,7 +102,9 @@ def collate_example_list(examples: list) -> dict[str, Any]:
 
 
 def pairing_summary(example_ids: Mapping[str, torch.Tensor]) -> tuple[bool, dict[str, torch.Tensor]]:
-    """(fully_paired, packed keys) of a collated ``example_ids`` dict; host tensors, no device work."""
+    """(fully_paired, packed keys) of a collated ``example_ids`` dict; host tensors, no device work.  ``fully_paired``
+    needs the common id column to be duplicate-free as well: for a repeated id ``find_matching_indices`` yields every
+    (i, j) combination, more pairs than the identity pairing the flag stands for."""
     keys, first, paired = {}, None, len(example_ids) > 0
     for name, ids in example_ids.items():
         if not (isinstance(ids, torch.Tensor) and ids.dim() == 2 and ids.shape[1] == 2):
@@ -113,6 +115,8 @@ def pairing_summary(example_ids: Mapping[str, torch.Tensor]) -> tuple[bool, dict
             first = k
         elif paired:
             paired = k.shape == first.shape and bool(torch.equal(k, first))
+    if paired and first is not None and first.numel() and torch.unique(first).numel() != first.numel():
+        paired = False
     return paired, keys
 
 

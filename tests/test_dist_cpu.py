@@ -202,3 +202,89 @@ def test_world4_all_flag_cells():
     assert len(names) == 4
     out = _run(4, names, 29712)
     _check(4, names, out)
+
+
+def _static_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import fake_kernels
+        import mmlearn_amd.losses as L
+
+        L.K = fake_kernels
+        res = {}
+        torch.manual_seed(rank)
+
+        def batch(b, mods=("rgb", "text")):
+            embs = {f"{m}_embedding": torch.randn(b, 8, dtype=torch.float64).requires_grad_(True) for m in mods}
+            ids = {m: torch.stack([torch.zeros(b, dtype=torch.long), torch.arange(rank * 100, rank * 100 + b)], 1) for m in mods}
+            return embs, ids
+
+        s = torch.tensor(3.0, requires_grad=True)
+        pairs = [L.LossPairSpec(("rgb", "text"))]
+        fn = L.ContrastiveLoss(static_shapes=True, local_loss=True, gather_with_grad=True)
+        # (1) equal shapes: validated once, then no header collective (and, the global pairing being the identity, no
+        #     per-pair row-count exchange either)
+        calls = {"n": 0}
+        orig = L._all_gather
+
+        def counting(t, w):
+            calls["n"] += 1
+            return orig(t, w)
+
+        L._all_gather = counting
+        for step in range(3):
+            embs, ids = batch(6)
+            fn(embs, ids, s, pairs).backward()
+            res[f"gathers_step{step}"] = calls["n"]
+            calls["n"] = 0
+        # (2) a shorter last batch on EVERY rank: re-validated, passes
+        embs, ids = batch(4)
+        fn(embs, ids, s, pairs).backward()
+        res["short_ok"] = True
+        # (3) one rank with a different batch size / without a modality: a clear error on every rank instead of a hang
+        for tag, (b, mods) in {"rows": (5 if rank == 1 else 7, ("rgb", "text")), "missing": (7, ("rgb", "text") if rank == 0 else ("rgb",))}.items():
+            embs, ids = batch(b, mods)
+            try:
+                fn(embs, ids, s, pairs)
+                res[tag] = "no error"
+            except ValueError as e:
+                res[tag] = str(e)
+        L._all_gather = orig
+        q.put((rank, res, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, None, traceback.format_exc()))
+
+
+@pytest.mark.timeout(300)
+def test_static_shapes_is_a_checked_promise():
+    """``static_shapes=True`` used to be unchecked -- a rank with a short batch or without a modality made the
+    ranks issue mismatched collectives.  Now the first step (and any step on which the local shapes change) exchanges a
+    header and raises on disagreement; steady-state steps add no collective, and with an identity global pairing the
+    local-loss cell no longer exchanges its per-pair row counts."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_static_worker, args=(r, 2, 29714, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in procs:
+        rank, res, err = q.get(timeout=240)
+        assert err is None, f"rank {rank} failed:\n{err}"
+        out[rank] = res
+    for p in procs:
+        p.join(timeout=60)
+    for rank in range(2):
+        r = out[rank]
+        # embeddings + ids gathers every step; the validation header only on the first
+        assert r["gathers_step0"] == r["gathers_step1"] + 1 == r["gathers_step2"] + 1, r
+        assert r["gathers_step1"] == 2, r
+        assert r["short_ok"]
+        assert "ranks disagree" in r["rows"] and "[7, 5]" in r["rows"], r["rows"]
+        assert "ranks disagree" in r["missing"] and "-1" in r["missing"], r["missing"]

@@ -385,3 +385,44 @@ def test_embedding_backward_matches_torch(ids_kind):
         grads.append((out.detach().clone(), emb.weight.grad.clone()))
     assert torch.equal(grads[0][0], grads[1][0])
     assert (grads[0][1] - grads[1][1]).abs().max() <= 1e-3 * max(1.0, grads[0][1].abs().max().item())
+
+
+def test_causal_text_towers_keep_their_causality_under_the_fused_qkv_patch():
+    """HF's CLIP text tower (and a BERT configured as decoder) signal causality through ``is_causal`` / ``is_decoder`` with
+    NO attention mask for sdpa-style implementations.  The fused-QKV patch is bidirectional, so it must step aside there:
+    patched outputs and every parameter gradient equal the stock model's, and a probe shows position 0 does not see
+    later tokens.  (head dim 64, bf16 autocast: exactly the configuration the fused path would otherwise accept.)"""
+    from transformers import BertConfig, BertModel, CLIPTextConfig, CLIPTextModelWithProjection
+
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    tcfg = CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                          max_position_embeddings=32, projection_dim=64, eos_token_id=999)
+    bcfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, is_decoder=True,
+                      hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=1000)
+    ids = torch.randint(1, 990, (4, 16), device=dev)
+    ids[:, -1] = 999
+    cases = [(CLIPTextModelWithProjection(tcfg).to(dev), "last_hidden_state"), (BertModel(bcfg, add_pooling_layer=False).to(dev), "last_hidden_state")]
+    for model, field in cases:
+        outs = []
+        for patched in (False, True):
+            if patched:
+                n = fused.accelerate_encoder(model, fuse_qkv=True, fuse_add_ln=True)
+                assert n["fused_qkv"] == 2
+            model.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                h = getattr(model(input_ids=ids), field)
+                ids2 = ids.clone()
+                ids2[:, 8:15] = torch.randint(1, 990, (4, 7), device=dev)      # change LATER tokens only
+                h2 = getattr(model(input_ids=ids2), field)
+            h.float().square().mean().backward()
+            outs.append((h.float().detach(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+            # causal: the first 8 positions cannot depend on tokens 8..14
+            assert (h[:, :8].float() - h2[:, :8].float()).abs().max().item() <= 1e-6, type(model).__name__
+        (e0, g0), (e1, g1) = outs
+        assert (e0 - e1).abs().max() <= 3e-2 * e0.abs().max()
+        gmax = max(v.abs().max().item() for v in g0.values())
+        for k in g0:
+            assert (g0[k] - g1[k]).abs().max() <= 6e-2 * max(g0[k].abs().max().item(), 1e-2 * gmax), k

@@ -349,6 +349,29 @@ def test_hip_adamw_matches_torch_adamw():
             assert (a - b).abs().max() <= 2e-6 * max(1.0, a.abs().max().item()), it
     sd = hip.state_dict()
     assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    # mid-run resume: load_state_dict replaces the moment tensors (new storages, the old ones are freed); the device pointer
+    # table must follow them.  Restore BOTH optimizers from their own snapshots, poison the allocator's free list so a stale
+    # pointer would show, and keep stepping.
+    import copy
+    ref_sd, hip_sd = copy.deepcopy(ref.state_dict()), copy.deepcopy(hip.state_dict())
+    old_ptrs = {hip.state[p]["exp_avg"].data_ptr() for p in hip_p}
+    ref.load_state_dict(ref_sd)
+    hip.load_state_dict(hip_sd)
+    assert not (old_ptrs & {hip.state[p]["exp_avg"].data_ptr() for p in hip_p})
+    del ref_sd, hip_sd, sd
+    junk = [torch.full((s.numel() if hasattr(s, "numel") else 1,), float("nan"), device=dev) for s in hip_p]   # may reuse the freed moment blocks
+    for it in range(3):
+        for a, b in zip(ref_p, hip_p):
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+        ref.step()
+        hip.step()
+        for a, b in zip(ref_p, hip_p):
+            assert torch.isfinite(b).all()
+            assert (a - b).abs().max() <= 2e-6 * max(1.0, a.abs().max().item()), ("after load_state_dict", it)
+        for a, b in zip(ref_p, hip_p):
+            assert (ref.state[a]["exp_avg"] - hip.state[b]["exp_avg"]).abs().max() <= 1e-6
+    del junk
 
 
 def test_ijepa_vit_step_with_fused_blocks_matches_stock_blocks():
@@ -382,3 +405,56 @@ def test_ijepa_vit_step_with_fused_blocks_matches_stock_blocks():
             assert torch.equal(t, s), k
     for a, b in zip(*curves):
         assert abs(a - b) <= 1e-2 * max(1.0, abs(a)), curves
+
+
+def test_ijepa_step_makes_no_host_synchronisation():
+    """the whole I-JEPA training step -- teacher forward, context-encoder mask branch (vision.py:335-337,
+    here ``ops.apply_masks`` on the host-built indices that ride on the mask list), predictor assembly, fused target /
+    loss kernel, backward, AdamW, EMA update -- runs under ``torch.cuda.set_sync_debug_mode("error")``: any
+    ``.item()`` / ``nonzero`` / blocking copy on the way raises.  (The reference syncs once per mask in boolean-mask
+    indexing, masking.py:264-283.)  Also: the drop-in ``apply_masks`` with IndexedMasks equals boolean indexing."""
+    import importlib.util, os
+    from mmlearn_amd import IndexedMasks, apply_masks
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_ijepa_step", os.path.join(root, "tools", "bench_ijepa_step.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    dev = _dev()
+    imgs = torch.rand(16, 3, 224, 224, generator=torch.Generator().manual_seed(1)).to(dev)
+    task = tool.build(True, True, dev)
+    opt = task.configure_optimizers()
+    opt = opt["optimizer"] if isinstance(opt, dict) else opt
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = task.training_step({"rgb": imgs}, 0)
+        loss.backward()
+        opt.step()
+        task.on_before_zero_grad(opt)
+        return loss
+
+    torch.manual_seed(7)
+    step()                      # first step: lazy one-time set-up (pointer tables, workspaces) may read back
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        losses = [step() for _ in range(3)]
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    vals = [float(l.detach().float()) for l in losses]
+    assert all(v == v and v > 0 for v in vals), vals
+
+    # drop-in apply_masks: indices attached to the mask list == boolean-mask indexing of every mask
+    x = torch.randn(4, 196, 32, device=dev)
+    info = task.mask_generator(batch_size=4)
+    masks = IndexedMasks([m.to(dev) for m in info["predictor_masks"]], info["predictor_indices"].to(dev))
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        got = apply_masks(x, masks)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    ref = torch.cat([x[m.bool()].view(4, -1, 32) for m in masks], 0)
+    assert torch.equal(got, ref)
+    with pytest.raises(ValueError):
+        IndexedMasks(list(masks), info["predictor_indices"][:2].to(dev))

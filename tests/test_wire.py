@@ -136,6 +136,10 @@ def test_pairing_flag_and_packed_keys():
     assert mixed["fully_paired"] is False
     assert mixed["example_keys"]["text"].tolist() == [0, (1 << 32) | 1, 1]
     assert "fully_paired" not in DefaultDataCollator(wire_format=False)([ds[0], ds[1]])
+    # a repeated sample (DistributedSampler pads the last batch that way): the reference's matcher yields 2 x 2 pairs for
+    # the duplicate, the identity pairing would yield 2 -- so the flag must stay off
+    dup = coll([ds[i] for i in (4, 0, 4, 5)])
+    assert dup["fully_paired"] is False and dup["example_keys"]["rgb"].tolist() == [4, 0, 4, 5]
     # same ids, different order: not paired by position
     ids = {"rgb": torch.tensor([[0, 1], [0, 2]]), "text": torch.tensor([[0, 2], [0, 1]])}
     assert pairing_summary(ids)[0] is False
@@ -152,7 +156,7 @@ def test_pairing_flag_and_packed_keys():
 def test_combined_dataset_index_map_property():
     """For random member sizes every global index (and its negative twin) lands in the member the cumulative sizes say,
     with the member-local index, and a collated batch of whole samples is flagged paired exactly when all samples come
-    from members that carry the same modalities."""
+    from members that carry the same modalities and no sample repeats."""
     hyp = pytest.importorskip("hypothesis")
     from hypothesis import given, settings, strategies as st
 
@@ -173,7 +177,8 @@ def test_combined_dataset_index_map_property():
         picks = data.draw(st.lists(st.integers(min_value=0, max_value=total - 1), min_size=1, max_size=6))
         batch = DefaultDataCollator()([ds[i] for i in picks])
         owners = [int(np.searchsorted(bounds, i, side="right") - 1) for i in picks]
-        assert batch["fully_paired"] == (len({o % 2 for o in owners}) == 1)
+        # paired = one kind of member only AND no sample drawn twice (a duplicate id pairs 2 x 2 in the reference's matcher)
+        assert batch["fully_paired"] == (len({o % 2 for o in owners}) == 1 and len(set(picks)) == len(picks))
         for name, keys in batch["example_keys"].items():
             assert torch.equal(unpack_example_keys(keys), batch["example_ids"][name])
 

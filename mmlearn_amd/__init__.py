@@ -14,4 +14,6 @@ from .layers import L2Norm, LearnableLogitScaling  # noqa: F401
 from .masking import IJEPAMaskGenerator  # noqa: F401
 from .ops import IndexedMasks, apply_masks, ijepa_loss, ijepa_target, l2_normalize, predictor_assemble, repeat_interleave_batch  # noqa: F401
 
+from .strategy import TowerDDPStrategy  # noqa: F401  (registers "tower_ddp" in Lightning's StrategyRegistry when Lightning is there)
+
 __version__ = "0.1.0"

@@ -134,3 +134,45 @@ def test_tools_and_entry_points_parse_and_bench_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+def test_tower_ddp_strategy_hands_the_wrapping_to_the_task():
+    """``trainer.strategy: tower_ddp`` (mmlearn/cli/run.py:52-61 builds the Trainer from YAML): a task with
+    ``concurrent_encoders`` gets ``wrap_towers_in_ddp`` with the strategy's DDP kwargs and NO outer DDP (the model is
+    returned as is, so Lightning's ``Strategy.training_step`` calls the module directly); any other module falls through
+    to the base class; the hardware-queue setting is exported before any HIP call."""
+    import os
+    from mmlearn_amd import strategy as S
+
+    os.environ.pop("GPU_MAX_HW_QUEUES", None)
+    st = S.TowerDDPStrategy(bucket_cap_mb=50)
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    calls = []
+
+    class Task(torch.nn.Module):
+        concurrent_encoders = True
+
+        def wrap_towers_in_ddp(self, **kw):
+            calls.append(kw)
+
+    class Wrapper(torch.nn.Module):   # Lightning's forward-redirection wrappers keep the module in ``_forward_module``
+        def __init__(self, m):
+            super().__init__()
+            self._forward_module = m
+
+    t = Task()
+    assert st._setup_model(t) is t and calls == [{"bucket_cap_mb": 50, "gradient_as_bucket_view": True}]
+    st._register_ddp_hooks()     # no outer DDP instance: nothing to register, must not assert
+    w = Wrapper(Task())
+    assert S.TowerDDPStrategy()._setup_model(w) is w and len(calls) == 2
+    # a task that does not overlap its towers, or any plain module: stock DDP path of the base class
+    base_calls = []
+    orig = S.DDPStrategy._setup_model
+    S.DDPStrategy._setup_model = lambda self, m: base_calls.append(m) or "ddp"
+    try:
+        t2 = Task()
+        t2.concurrent_encoders = False
+        assert S.TowerDDPStrategy()._setup_model(t2) == "ddp" and S.TowerDDPStrategy()._setup_model(torch.nn.Linear(2, 2)) == "ddp"
+    finally:
+        S.DDPStrategy._setup_model = orig
+    assert len(base_calls) == 2 and len(calls) == 2

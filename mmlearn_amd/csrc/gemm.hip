@@ -1,0 +1,406 @@
+// forward / input-gradient GEMM of the encoders' Linear layers for gfx950 (MI355X),
+//
+//     C[M, N] = A[M, K] . B[N, K]^T  (+ bias[N]) (-> activation)        bf16 operands, f32 accumulation
+//
+// i.e. nn.Linear's  y = x W^T + b  (A = x, B = W) and its  dX = dY W  (A = dY, B = W^T).  Both operands have the contraction
+// along their rows' fast axis.  Replaces the hipBLASLt calls under every nn.Linear of mmlearn/modules/encoders/clip.py:29-470,
+// text.py:20-178 and modules/layers/{attention,mlp}.py where the shape qualifies (see mmk_gemm_nt_supported).
+//
+// Structure (one persistent workgroup per CU, 8 waves as 2 (m) x 4 (n), 256 x 256 output tile, K step 64):
+//   * LDS = a RING of ten 16-KiB sub-slots (160 KiB); a K step owns four of them: A rows 0-127 / 128-255, B rows 0-127 /
+//     128-255 of the tile, each [128 rows][64 k] bf16 with 128-byte rows.  Sub-slots are filled by LDS-DMA
+//     (global_load_lds_dwordx4: 1 KiB = 8 rows per wave-instruction, two per wave and sub-slot) with the 16-byte chunk index
+//     XORed by (row >> 1) & 7 on the SOURCE side, so the ds_read_b128 fragment reads are bank-conflict free.
+//   * the ring never drains: while step g is computed the DMA of step g + 1 (second half) and g + 2 (first half) is issued,
+//     and the wait at the top of a step is a counted vmcnt(4) that leaves the two youngest sub-slots in flight across the
+//     barrier.  The step sequence runs across tile boundaries (persistent workgroup), so the next tile's operands arrive
+//     during the current tile's last steps and its epilogue.
+//   * MFMA v_mfma_f32_32x32x16_bf16 with the WEIGHT rows on the accumulator registers and the activation rows on the lanes:
+//     a lane then holds 4 consecutive output columns of one output row per register group, one v_permlane32_swap pair makes
+//     that 8 (16 bytes), and C leaves as global_store_dwordx4 straight from registers (no LDS staging: the ring is busy).
+//   * XCD-aware tile order: the 32 workgroups of an XCD work on 32 consecutive (m-tile, n-tile) tiles, n fastest, so the
+//     n-tiles that share an A row block read it from that XCD's L2 at the same time.
+#include <hip/hip_ext.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace mmk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int LG_TILE = 256;          // output tile edge
+constexpr int LG_BK = 64;             // K per step
+constexpr int LG_SUB = 128 * 128;     // bytes of one sub-slot: 128 rows x 64 bf16
+constexpr int LG_RING = 10;           // sub-slots in the ring
+constexpr int LG_LDS = LG_RING * LG_SUB;
+
+enum { LG_ACT_NONE = 0, LG_ACT_QUICK_GELU = 1, LG_ACT_GELU = 2 };
+
+struct LinArgs {
+  const bf16_t* A;    // [M, K] row stride lda
+  const bf16_t* B;    // [N, K] row stride ldb
+  void* C;            // [M, N] row stride ldc (bf16 or f32)
+  void* C2;           // optional second output: the pre-activation values (same dtype / stride as C), or null
+  const float* bias;  // [N] or null
+  long lda, ldb, ldc;
+  int M, N, K;
+  int tiles_m, tiles_n;
+  int dbg;   // timing ablations only (MMK_GEMM_DBG): 1 = no DMA after the prologue, 2 = no fragment reads / MFMAs, 4 = no C stores
+};
+
+__device__ __forceinline__ void lg_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+  const uint64_t pb = reinterpret_cast<uint64_t>(sbase);
+  const uint64_t ps = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pb >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb);
+  lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(reinterpret_cast<const void*>(ps)), "s"(lds_addr) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void lg_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ float lg_act(float x, int act) {
+  if (act == LG_ACT_QUICK_GELU) return x / (1.f + __expf(-1.702f * x));
+  if (act == LG_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+  return x;
+}
+
+// pack two f32 into one dword of two bf16 (RNE, NaN-preserving: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t lg_pk(float lo, float hi) {
+  typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
+  bf2 v;
+  v[0] = (bf16_t)lo;
+  v[1] = (bf16_t)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+template <int OUT_F32, int ACT, int HAS_C2>
+__global__ __launch_bounds__(512, 2) void lin_gemm_kernel(const LinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // wave tile: output rows 128 wm .., output columns 64 wn ..
+  const int r = lane & 31, h = lane >> 5;
+  const uint32_t ring = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smem);
+
+  // ---- this workgroup's tiles: XCD x = blockIdx % 8 takes tiles [(i * 8 + x) * per_xcd, + per_xcd), i = 0, 1, ...
+  const int per_xcd = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int total = a.tiles_m * a.tiles_n;
+  const int nk = a.K / LG_BK;
+  int n_my = 0;
+  for (int i = 0;; ++i) {
+    if ((i * 8 + xcd) * per_xcd + slot >= total) break;
+    ++n_my;
+  }
+  const int G = n_my * nk;
+  if (G == 0) return;
+
+  // ---- loader state.  Piece p = 2 * wave + u (u = 0, 1) of a sub-slot covers its rows 8p .. 8p + 7; lane L lands at LDS
+  // row 8p + (L >> 3), chunk slot L & 7 and therefore fetches source chunk (L & 7) ^ swizzle(row).
+  int lrow[2];
+  uint32_t lchunk[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    lrow[u] = 8 * (2 * wave + u) + (lane >> 3);
+    lchunk[u] = (uint32_t)(((lane & 7) ^ ((lrow[u] >> 1) & 7)) << 4);
+  }
+  // cursors: cA = the step whose A sub-slots are issued next, cB = the step whose B sub-slots are issued next
+  struct Cur {
+    int step, kt, i, tm, tn;
+  };
+  auto tile_of = [&](Cur& c) {
+    const int t = (c.i * 8 + xcd) * per_xcd + slot;
+    c.tm = t / a.tiles_n;
+    c.tn = t - c.tm * a.tiles_n;
+  };
+  auto advance = [&](Cur& c) {
+    ++c.step;
+    if (++c.kt == nk) {
+      c.kt = 0;
+      ++c.i;
+      if (c.step < G) tile_of(c);
+    }
+  };
+  Cur cA{0, 0, 0, 0, 0}, cB{0, 0, 0, 0, 0};
+  tile_of(cA);
+  cB = cA;
+  auto issue_sub = [&](const bf16_t* tile_base, long ld, int half, int last_row, int kt, int pos) {
+    // tile_base = first row of the 256-row tile (always a valid row); rows past the operand's end read the operand's last
+    // row instead: they only reach output rows / columns that are never stored
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int lr = min(128 * half + lrow[u], last_row);
+      const uint32_t voff = (uint32_t)lr * (uint32_t)(ld * 2) + lchunk[u];
+      lg_dma16(tile_base + (long)kt * LG_BK, voff, ring + (uint32_t)pos * LG_SUB + (uint32_t)(2 * wave + u) * 1024u);
+    }
+  };
+  auto issue_A = [&](const Cur& c) {   // ring positions (4 step + 0, 1) mod 10
+    const int p0 = (4 * c.step) % LG_RING;
+    const bf16_t* tb = a.A + (long)c.tm * LG_TILE * a.lda;
+    const int last = a.M - 1 - c.tm * LG_TILE;
+    issue_sub(tb, a.lda, 0, last, c.kt, p0);
+    issue_sub(tb, a.lda, 1, last, c.kt, (p0 + 1) % LG_RING);
+  };
+  auto issue_B = [&](const Cur& c) {   // ring positions (4 step + 2, 3) mod 10
+    const int p0 = (4 * c.step + 2) % LG_RING;
+    const bf16_t* tb = a.B + (long)c.tn * LG_TILE * a.ldb;
+    const int last = a.N - 1 - c.tn * LG_TILE;
+    issue_sub(tb, a.ldb, 0, last, c.kt, p0);
+    issue_sub(tb, a.ldb, 1, last, c.kt, (p0 + 1) % LG_RING);
+  };
+
+  // ---- fragment read offsets inside a sub-slot: row (32 blk + r), chunk (2 kk + h) ^ ((r >> 1) & 7)
+  uint32_t offk[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) offk[kk] = (uint32_t)(r * 128 + (((2 * kk + h) ^ ((r >> 1) & 7)) << 4));
+
+  f32x16 acc[2][4];   // [n block][m block]
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nb][mb][e] = 0.f;
+
+  // ---- prologue: step 0 entirely, A half of step 1
+  issue_A(cA);
+  advance(cA);
+  issue_B(cB);
+  advance(cB);
+  if (cA.step < G) {
+    issue_A(cA);
+    advance(cA);
+  }
+
+  int ci = 0, ckt = 0;   // compute cursor
+  int ctm, ctn;
+  {
+    const int t = xcd * per_xcd + slot;
+    ctm = t / a.tiles_n;
+    ctn = t - ctm * a.tiles_n;
+  }
+  // number of C store instructions of one epilogue (all issued when the tile is interior): they sit in the same in-order
+  // vmcnt queue as the DMA, YOUNGER than the sub-slots issued before the epilogue, so the first wait after an epilogue may
+  // leave them in flight too instead of waiting for the stores to retire
+  constexpr int NST = (OUT_F32 ? 32 : 16) * (HAS_C2 ? 2 : 1);
+  bool young_stores = false;
+  for (int g = 0; g < G; ++g) {
+    // step g landed once at most the A half of step g + 1 (4 instructions of this wave) is still in flight
+    if (a.dbg & 8) { if (g + 1 >= G) lg_wait_vmcnt<0>(); }   // ablation: never wait for the DMA (wrong results)
+    else if (g + 1 >= G) lg_wait_vmcnt<0>();
+    else if (young_stores) lg_wait_vmcnt<4 + NST>();
+    else lg_wait_vmcnt<4>();
+    young_stores = false;
+    __builtin_amdgcn_s_barrier();   // every wave's pieces of step g are in LDS; every wave is done reading step g - 1
+    if (a.dbg & 1) { cA.step = G; cB.step = G; }
+    // DMA of this iteration: B half of step g + 1 and A half of step g + 2 go into the sub-slots step g - 1 released.  It is
+    // issued one sub-slot (two wave-instructions) per k block, between that block's MFMAs, not in one burst before them.
+    const bool do_b = cB.step < G, do_a = cA.step < G;
+    const int pb0 = (4 * cB.step + 2) % LG_RING, pa0 = (4 * cA.step) % LG_RING;
+    const bf16_t* tbB = a.B + (long)cB.tn * LG_TILE * a.ldb;
+    const bf16_t* tbA = a.A + (long)cA.tm * LG_TILE * a.lda;
+    const int lastB = a.N - 1 - cB.tn * LG_TILE, lastA = a.M - 1 - cA.tm * LG_TILE;
+    const int ktB = cB.kt, ktA = cA.kt;
+    const int p0 = (4 * g) % LG_RING;
+    const uint32_t sa = ring + (uint32_t)((p0 + wm) % LG_RING) * LG_SUB;                                        // activation rows (m): lanes
+    const uint32_t sb = ring + (uint32_t)((p0 + 2 + (wn >> 1)) % LG_RING) * LG_SUB + (uint32_t)(wn & 1) * 8192u;  // weight rows (n): registers
+    // Hand-placed fragment reads (inline asm: hipcc otherwise re-serialises them into read -> wait -> MFMA): the six
+    // ds_read_b128 of k block kk + 1 are issued behind the first two MFMAs of block kk, so their latency hides behind the
+    // other six.  Two fragment register sets.
+    bf16x8 fw[2][2], fx[2][4];
+#define LG_READ_W(SET, KK)                                                                        \
+  {                                                                                               \
+    const uint32_t vb = sb + offk[KK];                                                            \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(fw[SET][0]) : "v"(vb));                             \
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fw[SET][1]) : "v"(vb));                 \
+  }
+#define LG_READ_X(SET, KK, LO)                                                                                   \
+  {                                                                                                              \
+    const uint32_t va = sa + offk[KK];                                                                           \
+    if (LO) {                                                                                                    \
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fx[SET][0]) : "v"(va));                                          \
+      asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fx[SET][1]) : "v"(va));                              \
+    } else {                                                                                                     \
+      asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fx[SET][2]) : "v"(va));                              \
+      asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(fx[SET][3]) : "v"(va));                             \
+    }                                                                                                            \
+  }
+#define LG_MFMA(SET, NB, MB) acc[NB][MB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[SET][NB], fx[SET][MB], acc[NB][MB], 0, 0, 0)
+#define LG_PIN __builtin_amdgcn_sched_barrier(0)
+    // one k block: wait for its fragments, then MFMAs with the next block's reads and one sub-slot of DMA in between
+#define LG_BLOCK(CUR, NXT, KK, DMA)                                                       \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+  LG_PIN;                                                                                 \
+  LG_MFMA(CUR, 0, 0); LG_PIN;                                                             \
+  if (KK < 3) { LG_READ_W(NXT, (KK + 1) & 3) LG_READ_X(NXT, (KK + 1) & 3, 1) }                        \
+  LG_PIN;                                                                                 \
+  LG_MFMA(CUR, 0, 1); LG_PIN;                                                             \
+  if (KK < 3) { LG_READ_X(NXT, (KK + 1) & 3, 0) }                                               \
+  LG_PIN;                                                                                 \
+  LG_MFMA(CUR, 0, 2); LG_PIN;                                                             \
+  DMA;                                                                                    \
+  LG_PIN;                                                                                 \
+  LG_MFMA(CUR, 0, 3); LG_MFMA(CUR, 1, 0); LG_MFMA(CUR, 1, 1); LG_MFMA(CUR, 1, 2); LG_MFMA(CUR, 1, 3); \
+  LG_PIN;
+    if (!(a.dbg & 2)) {
+      LG_READ_W(0, 0) LG_READ_X(0, 0, 1) LG_READ_X(0, 0, 0)
+      LG_BLOCK(0, 1, 0, if (do_b) issue_sub(tbB, a.ldb, 0, lastB, ktB, pb0))
+      LG_BLOCK(1, 0, 1, if (do_b) issue_sub(tbB, a.ldb, 1, lastB, ktB, (pb0 + 1) % LG_RING))
+      LG_BLOCK(0, 1, 2, if (do_a) issue_sub(tbA, a.lda, 0, lastA, ktA, pa0))
+      LG_BLOCK(1, 0, 3, if (do_a) issue_sub(tbA, a.lda, 1, lastA, ktA, (pa0 + 1) % LG_RING))
+    } else {
+      if (do_b) { issue_sub(tbB, a.ldb, 0, lastB, ktB, pb0); issue_sub(tbB, a.ldb, 1, lastB, ktB, (pb0 + 1) % LG_RING); }
+      if (do_a) { issue_sub(tbA, a.lda, 0, lastA, ktA, pa0); issue_sub(tbA, a.lda, 1, lastA, ktA, (pa0 + 1) % LG_RING); }
+    }
+#undef LG_BLOCK
+#undef LG_READ_W
+#undef LG_READ_X
+#undef LG_MFMA
+#undef LG_PIN
+    if (do_b) advance(cB);
+    if (do_a) advance(cA);
+    if (++ckt == nk) {
+      // ---- epilogue of tile (ctm, ctn): acc[nb][mb][e] = C[m = 128 wm + 32 mb + r][n = 64 wn + 32 nb + (e&3) + 8 (e>>2) + 4 h]
+      const int m_base = ctm * LG_TILE + 128 * wm + r;
+      const int n_base = ctn * LG_TILE + 64 * wn;
+      // every lane of every store instruction active (then exactly NST store instructions are issued)
+      young_stores = (ctm + 1) * LG_TILE <= a.M && (ctn + 1) * LG_TILE <= a.N && !(a.dbg & 4);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        float bv[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n_base + 32 * nb + 8 * q + 4 * h;
+          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.bias != nullptr && n + 3 < a.N) t = *reinterpret_cast<const float4*>(a.bias + n);
+          else if (a.bias != nullptr) {
+            if (n < a.N) t.x = a.bias[n];
+            if (n + 1 < a.N) t.y = a.bias[n + 1];
+            if (n + 2 < a.N) t.z = a.bias[n + 2];
+          }
+          bv[4 * q] = t.x; bv[4 * q + 1] = t.y; bv[4 * q + 2] = t.z; bv[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          const int m = m_base + 32 * mb;
+          float v[16], pre[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            pre[e] = acc[nb][mb][e] + bv[e];
+            v[e] = lg_act(pre[e], ACT);
+            acc[nb][mb][e] = 0.f;
+          }
+          if (OUT_F32) {
+            // 4 consecutive columns per register group: one 16-byte store each
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int n = n_base + 32 * nb + 8 * q + 4 * h;
+              if (m < a.M && n + 3 < a.N && !(a.dbg & 4)) {
+                *reinterpret_cast<float4*>(static_cast<float*>(a.C) + (size_t)m * a.ldc + n) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                if (HAS_C2)
+                  *reinterpret_cast<float4*>(static_cast<float*>(a.C2) + (size_t)m * a.ldc + n) = make_float4(pre[4 * q], pre[4 * q + 1], pre[4 * q + 2], pre[4 * q + 3]);
+              }
+            }
+          } else {
+            // bf16: register group q of a lane holds columns 8q + 4h + 0..3 as two packed dwords.  For the group pair
+            // (q0 = 2j, q1 = 2j + 1) one v_permlane32_swap per dword gives the lower lane (h = 0) columns 16j + 0..7 and the
+            // upper lane (h = 1) columns 16j + 8..15 of the SAME row: 16 contiguous bytes per lane.
+#pragma unroll
+            for (int pass = 0; pass < (HAS_C2 ? 2 : 1); ++pass) {
+              const float* src = pass ? pre : v;
+              bf16_t* out = static_cast<bf16_t*>(pass ? a.C2 : a.C);
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                uint32_t d0[2], d1[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                  d0[i] = lg_pk(src[8 * j + 2 * i], src[8 * j + 2 * i + 1]);          // group q0: columns 16j + 4h + 2i, +1
+                  d1[i] = lg_pk(src[8 * j + 4 + 2 * i], src[8 * j + 4 + 2 * i + 1]);  // group q1: columns 16j + 8 + 4h + 2i, +1
+                  // d0.upper_half <-> d1.lower_half
+                  const auto sw = __builtin_amdgcn_permlane32_swap(d0[i], d1[i], false, false);
+                  d0[i] = sw[0];
+                  d1[i] = sw[1];
+                }
+                // lower lanes now hold {own q0, partner's q0} = columns 16j + 0..7; upper lanes {partner's q1, own q1} = 16j + 8..15
+                const int n = n_base + 32 * nb + 16 * j + 8 * h;
+                if (m < a.M && n + 7 < a.N && !(a.dbg & 4)) {
+                  uint4 o = make_uint4(d0[0], d0[1], d1[0], d1[1]);
+                  *reinterpret_cast<uint4*>(out + (size_t)m * a.ldc + n) = o;
+                }
+              }
+            }
+          }
+        }
+      }
+      ckt = 0;
+      ++ci;
+      if (g + 1 < G) {
+        const int t = (ci * 8 + xcd) * per_xcd + slot;
+        ctm = t / a.tiles_n;
+        ctn = t - ctm * a.tiles_n;
+      }
+    }
+  }
+}
+
+}  // namespace mmk
+
+using namespace mmk;
+
+extern "C" {
+
+// 1 when mmk_gemm_nt serves the shape; otherwise the caller keeps its library GEMM
+int mmk_gemm_nt_supported(int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc) {
+  return M >= 256 && N >= 8 && N % 8 == 0 && K >= LG_BK && K % LG_BK == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
+         M < (1ll << 31) - 512 && (int64_t)255 * std::max(lda, ldb) * 2 + 128 < (1ll << 32);
+}
+
+int mmk_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bias, int64_t M, int N, int K, int64_t lda, int64_t ldb,
+                int64_t ldc, int out_dtype, int act, void* stream) {
+  MMK_REQUIRE(A && B && C, "null pointer");
+  MMK_REQUIRE(mmk_gemm_nt_supported(M, N, K, lda, ldb, ldc), "gemm_nt: unsupported shape (need M >= 256, N % 8 == 0, K % 64 == 0, strides % 8 == 0)");
+  MMK_REQUIRE(out_dtype == MMK_BF16 || out_dtype == MMK_F32, "gemm_nt: output must be bf16 or f32");
+  MMK_REQUIRE(act >= LG_ACT_NONE && act <= LG_ACT_GELU, "gemm_nt: unknown activation");
+  MMK_REQUIRE(C2 == nullptr || act != LG_ACT_NONE, "gemm_nt: a pre-activation output needs an activation");
+  LinArgs a;
+  a.A = static_cast<const bf16_t*>(A); a.B = static_cast<const bf16_t*>(B); a.C = C; a.C2 = C2; a.bias = bias;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = N; a.K = K;
+  a.tiles_m = cdiv((int)M, LG_TILE); a.tiles_n = cdiv(N, LG_TILE);
+  a.dbg = getenv("MMK_GEMM_DBG") ? atoi(getenv("MMK_GEMM_DBG")) : 0;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    MMK_HIP(hipGetDevice(&dev));
+    MMK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = std::max(8, n_cu / 8 * 8);
+    if (const char* e = getenv("MMK_GEMM_GRID")) n_cu = std::max(8, atoi(e) / 8 * 8);
+  }
+  const int total = a.tiles_m * a.tiles_n;
+  const int grid = std::min(n_cu, round_up(total, 8));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const void* kern = nullptr;
+#define LG_PICK(F32_, ACT_, TWO_)                                                              \
+  if ((out_dtype == MMK_F32) == (F32_ == 1) && act == ACT_ && (TWO_ == 1) == (a.C2 != nullptr)) \
+    kern = reinterpret_cast<const void*>(lin_gemm_kernel<F32_, ACT_, TWO_>);
+  LG_PICK(0, LG_ACT_NONE, 0) LG_PICK(1, LG_ACT_NONE, 0)
+  LG_PICK(0, LG_ACT_QUICK_GELU, 0) LG_PICK(0, LG_ACT_QUICK_GELU, 1)
+  LG_PICK(0, LG_ACT_GELU, 0) LG_PICK(0, LG_ACT_GELU, 1)
+#undef LG_PICK
+  MMK_REQUIRE(kern != nullptr, "gemm_nt: this (dtype, activation, second output) combination is not built");
+  MMK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LG_LDS));
+  {
+    ProfEvents pe(MMK_K_GEMM);
+    void* params[] = {&a};
+    MMK_HIP(hipExtLaunchKernel(kern, dim3(grid), dim3(512), params, LG_LDS, st, pe.start, pe.stop, 0));
+  }
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+}

@@ -49,6 +49,8 @@ struct LinArgs {
   long lda, ldb, ldc;
   int M, N, K;
   int tiles_m, tiles_n;
+  int desync_sleeps;   // spread of the workgroups' start times in units of s_sleep(127) (~8k cycles): see mmk_gemm_nt
+  int var;   // schedule variant bits (MMK_GEMM_VAR; A/B experiments): 2 = no s_setprio, 4 = no stagger, 8 = no phase barriers (timing only), 16 = no barrier after the MFMA segment (timing only)
   int dbg;   // timing ablations only (MMK_GEMM_DBG): 1 = no DMA after the prologue, 2 = no fragment reads / MFMAs, 4 = no C stores
 };
 
@@ -80,8 +82,10 @@ __device__ __forceinline__ uint32_t lg_pk(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
-template <int OUT_F32, int ACT, int HAS_C2>
+template <int OUT_F32, int ACT, int HAS_C2, bool DBGMODE>
 __global__ __launch_bounds__(512, 2) void lin_gemm_kernel(const LinArgs a) {
+#define LG_DBG(BIT) (DBGMODE && (a.dbg & (BIT)))
+#define LG_VAR(BIT) (DBGMODE && (a.var & (BIT)))
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,15 +173,22 @@ __global__ __launch_bounds__(512, 2) void lin_gemm_kernel(const LinArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[nb][mb][e] = 0.f;
 
-  // ---- prologue: step 0 entirely, A half of step 1
-  issue_A(cA);
-  advance(cA);
-  issue_B(cB);
-  advance(cB);
-  if (cA.step < G) {
-    issue_A(cA);
-    advance(cA);
+  // ---- de-synchronise the workgroups: every tile takes the same time, so without this all 256 workgroups reach their
+  // epilogues together and the C stores arrive as 33-MB bursts that stall every storing wave (measured: the stores of a
+  // [201728 x 3072] output cost 21 % of the kernel, although they are 25 % of HBM bandwidth on average).  A start offset of
+  // up to ~one tile period, different per workgroup, spreads the store traffic over the whole tile period.
+  if (a.desync_sleeps > 0) {
+    const int w = (slot * 13 + xcd * 5) & 31;                 // 0..31, different for neighbouring workgroups
+    const int n = (w * a.desync_sleeps) >> 5;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
   }
+
+  // ---- prologue: fill the ring: steps 0 and 1 entirely, A half of step 2 (issue order A0 B0 A1 B1 A2)
+  issue_A(cA); advance(cA);
+  issue_B(cB); advance(cB);
+  if (cA.step < G) { issue_A(cA); advance(cA); }
+  if (cB.step < G) { issue_B(cB); advance(cB); }
+  if (cA.step < G) { issue_A(cA); advance(cA); }
 
   int ci = 0, ckt = 0;   // compute cursor
   int ctm, ctn;
@@ -186,82 +197,82 @@ __global__ __launch_bounds__(512, 2) void lin_gemm_kernel(const LinArgs a) {
     ctm = t / a.tiles_n;
     ctn = t - ctm * a.tiles_n;
   }
-  // number of C store instructions of one epilogue (all issued when the tile is interior): they sit in the same in-order
-  // vmcnt queue as the DMA, YOUNGER than the sub-slots issued before the epilogue, so the first wait after an epilogue may
-  // leave them in flight too instead of waiting for the stores to retire
-  constexpr int NST = (OUT_F32 ? 32 : 16) * (HAS_C2 ? 2 : 1);
-  bool young_stores = false;
+  // step 0 has landed when at most steps 1 and the A half of 2 (12 instructions of this wave) are in flight
+  if (G >= 3) lg_wait_vmcnt<12>();
+  else lg_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  // Two wave groups (waves 0-3 / 4-7: the two waves of every SIMD) run the same phase sequence half a phase apart: the
+  // second group passes one extra barrier here, so while one group is in the MFMA segment of a phase the other is in the
+  // load segment (fragment reads + LDS-DMA issue) of its own -- the matrix pipe always has one wave's MFMAs back to back
+  // and DMA / LDS issue stalls never sit inside an MFMA chain.
+  const bool lag = wave >= 4 && !LG_VAR(4);
+  const uint64_t t0_cyc = __builtin_readcyclecounter(), t0_rt = __builtin_amdgcn_s_memrealtime();
+  if (lag) __builtin_amdgcn_s_barrier();
   for (int g = 0; g < G; ++g) {
-    // step g landed once at most the A half of step g + 1 (4 instructions of this wave) is still in flight
-    if (a.dbg & 8) { if (g + 1 >= G) lg_wait_vmcnt<0>(); }   // ablation: never wait for the DMA (wrong results)
-    else if (g + 1 >= G) lg_wait_vmcnt<0>();
-    else if (young_stores) lg_wait_vmcnt<4 + NST>();
-    else lg_wait_vmcnt<4>();
-    young_stores = false;
-    __builtin_amdgcn_s_barrier();   // every wave's pieces of step g are in LDS; every wave is done reading step g - 1
-    if (a.dbg & 1) { cA.step = G; cB.step = G; }
-    // DMA of this iteration: B half of step g + 1 and A half of step g + 2 go into the sub-slots step g - 1 released.  It is
-    // issued one sub-slot (two wave-instructions) per k block, between that block's MFMAs, not in one burst before them.
-    const bool do_b = cB.step < G, do_a = cA.step < G;
+    if LG_DBG(1) { cA.step = G; cB.step = G; }
+    // DMA of this step, issued in the load segments of its k blocks 1-3.  The ring holds step g, step g + 1 and the A half
+    // of step g + 2; the four sub-slots step g - 1 released take the B half of g + 2 ... no wait for them: see LG_PHASE(3).
+    // (Step 0 issues nothing: the prologue filled the whole ring.)
+    const bool do_b = g > 0 && cB.step < G, do_a = g > 0 && cA.step < G;
     const int pb0 = (4 * cB.step + 2) % LG_RING, pa0 = (4 * cA.step) % LG_RING;
-    const bf16_t* tbB = a.B + (long)cB.tn * LG_TILE * a.ldb;
-    const bf16_t* tbA = a.A + (long)cA.tm * LG_TILE * a.lda;
-    const int lastB = a.N - 1 - cB.tn * LG_TILE, lastA = a.M - 1 - cA.tm * LG_TILE;
-    const int ktB = cB.kt, ktA = cA.kt;
+    const bool hot = LG_DBG(64);   // ablation: every DMA reads the same 64 KiB (cache-resident): issue + LDS writes, no memory traffic
+    const bf16_t* tbB = a.B + (hot ? 0 : (long)cB.tn * LG_TILE * a.ldb);
+    const bf16_t* tbA = a.A + (hot ? 0 : (long)cA.tm * LG_TILE * a.lda);
+    const int lastB = a.N - 1 - (hot ? 0 : cB.tn * LG_TILE), lastA = a.M - 1 - (hot ? 0 : cA.tm * LG_TILE);
+    const int ktB = hot ? 0 : cB.kt, ktA = hot ? 0 : cA.kt;
     const int p0 = (4 * g) % LG_RING;
     const uint32_t sa = ring + (uint32_t)((p0 + wm) % LG_RING) * LG_SUB;                                        // activation rows (m): lanes
     const uint32_t sb = ring + (uint32_t)((p0 + 2 + (wn >> 1)) % LG_RING) * LG_SUB + (uint32_t)(wn & 1) * 8192u;  // weight rows (n): registers
-    // Hand-placed fragment reads (inline asm: hipcc otherwise re-serialises them into read -> wait -> MFMA): the six
-    // ds_read_b128 of k block kk + 1 are issued behind the first two MFMAs of block kk, so their latency hides behind the
-    // other six.  Two fragment register sets.
-    bf16x8 fw[2][2], fx[2][4];
-#define LG_READ_W(SET, KK)                                                                        \
-  {                                                                                               \
-    const uint32_t vb = sb + offk[KK];                                                            \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(fw[SET][0]) : "v"(vb));                             \
-    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fw[SET][1]) : "v"(vb));                 \
+    bf16x8 fw[2][2], fx[2][4];   // [k block of the phase][fragment]
+#define LG_READS(S, KK)                                                                      \
+  {                                                                                          \
+    const uint32_t va = sa + offk[KK], vb = sb + offk[KK];                                   \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(fw[S][0]) : "v"(vb));                          \
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fw[S][1]) : "v"(vb));              \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(fx[S][0]) : "v"(va));                          \
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fx[S][1]) : "v"(va));              \
+    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fx[S][2]) : "v"(va));              \
+    asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(fx[S][3]) : "v"(va));             \
   }
-#define LG_READ_X(SET, KK, LO)                                                                                   \
-  {                                                                                                              \
-    const uint32_t va = sa + offk[KK];                                                                           \
-    if (LO) {                                                                                                    \
-      asm volatile("ds_read_b128 %0, %1" : "=v"(fx[SET][0]) : "v"(va));                                          \
-      asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fx[SET][1]) : "v"(va));                              \
-    } else {                                                                                                     \
-      asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(fx[SET][2]) : "v"(va));                              \
-      asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(fx[SET][3]) : "v"(va));                             \
-    }                                                                                                            \
-  }
-#define LG_MFMA(SET, NB, MB) acc[NB][MB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[SET][NB], fx[SET][MB], acc[NB][MB], 0, 0, 0)
+#define LG_MFMA(S, NB, MB) acc[NB][MB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[S][NB], fx[S][MB], acc[NB][MB], 0, 0, 0)
 #define LG_PIN __builtin_amdgcn_sched_barrier(0)
-    // one k block: wait for its fragments, then MFMAs with the next block's reads and one sub-slot of DMA in between
-#define LG_BLOCK(CUR, NXT, KK, DMA)                                                       \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
-  LG_PIN;                                                                                 \
-  LG_MFMA(CUR, 0, 0); LG_PIN;                                                             \
-  if (KK < 3) { LG_READ_W(NXT, (KK + 1) & 3) LG_READ_X(NXT, (KK + 1) & 3, 1) }                        \
-  LG_PIN;                                                                                 \
-  LG_MFMA(CUR, 0, 1); LG_PIN;                                                             \
-  if (KK < 3) { LG_READ_X(NXT, (KK + 1) & 3, 0) }                                               \
-  LG_PIN;                                                                                 \
-  LG_MFMA(CUR, 0, 2); LG_PIN;                                                             \
-  DMA;                                                                                    \
-  LG_PIN;                                                                                 \
-  LG_MFMA(CUR, 0, 3); LG_MFMA(CUR, 1, 0); LG_MFMA(CUR, 1, 1); LG_MFMA(CUR, 1, 2); LG_MFMA(CUR, 1, 3); \
-  LG_PIN;
-    if (!(a.dbg & 2)) {
-      LG_READ_W(0, 0) LG_READ_X(0, 0, 1) LG_READ_X(0, 0, 0)
-      LG_BLOCK(0, 1, 0, if (do_b) issue_sub(tbB, a.ldb, 0, lastB, ktB, pb0))
-      LG_BLOCK(1, 0, 1, if (do_b) issue_sub(tbB, a.ldb, 1, lastB, ktB, (pb0 + 1) % LG_RING))
-      LG_BLOCK(0, 1, 2, if (do_a) issue_sub(tbA, a.lda, 0, lastA, ktA, pa0))
-      LG_BLOCK(1, 0, 3, if (do_a) issue_sub(tbA, a.lda, 1, lastA, ktA, (pa0 + 1) % LG_RING))
-    } else {
-      if (do_b) { issue_sub(tbB, a.ldb, 0, lastB, ktB, pb0); issue_sub(tbB, a.ldb, 1, lastB, ktB, (pb0 + 1) % LG_RING); }
+    // one phase = two k blocks (32 of the step's 64 k): load segment (their twelve fragment reads, then the phase's share of
+    // the DMA, then at most one counted wait), barrier, MFMA segment (sixteen MFMAs at raised priority), barrier
+#define LG_PHASE(P, LOADS)                                                                                   \
+  LG_PIN;                                                                                                    \
+  if (!LG_DBG(2 | 128)) { LG_READS(0, 2 * P) LG_READS(1, 2 * P + 1) }                                            \
+  LG_PIN;                                                                                                    \
+  LOADS;                                                                                                     \
+  LG_PIN;                                                                                                    \
+  if (!LG_VAR(8)) __builtin_amdgcn_s_barrier();                                                               \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+  LG_PIN;                                                                                                    \
+  if (!LG_DBG(2)) {                                                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                                                    \
+    LG_MFMA(0, 0, 0); LG_MFMA(0, 0, 1); LG_MFMA(0, 0, 2); LG_MFMA(0, 0, 3);                                  \
+    LG_MFMA(0, 1, 0); LG_MFMA(0, 1, 1); LG_MFMA(0, 1, 2); LG_MFMA(0, 1, 3);                                  \
+    LG_MFMA(1, 0, 0); LG_MFMA(1, 0, 1); LG_MFMA(1, 0, 2); LG_MFMA(1, 0, 3);                                  \
+    LG_MFMA(1, 1, 0); LG_MFMA(1, 1, 1); LG_MFMA(1, 1, 2); LG_MFMA(1, 1, 3);                                  \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+  }                                                                                                          \
+  LG_PIN;                                                                                                    \
+  if (!LG_VAR(24)) __builtin_amdgcn_s_barrier();
+    // The sub-slots step g - 1 released take the B half of step g + 1 (cB, phase 0) and the A half of step g + 2 (cA, phase
+    // 1).  (Phase 0 of the leading group issues while the lagging group retires its last reads of step g - 1 behind the
+    // same barrier: those ds_reads were issued before the barrier and return within ~100 cycles, the DMA lands >= 500
+    // cycles after issue.)
+    LG_PHASE(0, if (do_b) { issue_sub(tbB, a.ldb, 0, lastB, ktB, pb0); issue_sub(tbB, a.ldb, 1, lastB, ktB, (pb0 + 1) % LG_RING); })
+    LG_PHASE(1, {
       if (do_a) { issue_sub(tbA, a.lda, 0, lastA, ktA, pa0); issue_sub(tbA, a.lda, 1, lastA, ktA, (pa0 + 1) % LG_RING); }
-    }
-#undef LG_BLOCK
-#undef LG_READ_W
-#undef LG_READ_X
+      // step g + 1 must have landed before the barrier that precedes its first read; the only younger pieces of this
+      // wave are the A half of step g + 2 (4 instructions)
+      if (g + 1 < G && !LG_DBG(8)) {
+        if (g + 2 < G) lg_wait_vmcnt<4>();
+        else lg_wait_vmcnt<0>();
+      }
+    })
+#undef LG_PHASE
+#undef LG_READS
 #undef LG_MFMA
 #undef LG_PIN
     if (do_b) advance(cB);
@@ -270,8 +281,9 @@ __global__ __launch_bounds__(512, 2) void lin_gemm_kernel(const LinArgs a) {
       // ---- epilogue of tile (ctm, ctn): acc[nb][mb][e] = C[m = 128 wm + 32 mb + r][n = 64 wn + 32 nb + (e&3) + 8 (e>>2) + 4 h]
       const int m_base = ctm * LG_TILE + 128 * wm + r;
       const int n_base = ctn * LG_TILE + 64 * wn;
-      // every lane of every store instruction active (then exactly NST store instructions are issued)
-      young_stores = (ctm + 1) * LG_TILE <= a.M && (ctn + 1) * LG_TILE <= a.N && !(a.dbg & 4);
+      // both groups run the epilogue side by side: the leading group waits one barrier for the lagging one here, the
+      // lagging group drops back by one barrier after it
+      if (!lag) __builtin_amdgcn_s_barrier();
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         float bv[16];
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void lin_gemm_kernel(const LinArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int n = n_base + 32 * nb + 8 * q + 4 * h;
-              if (m < a.M && n + 3 < a.N && !(a.dbg & 4)) {
+              if (m < a.M && n + 3 < a.N && !LG_DBG(4)) {
                 *reinterpret_cast<float4*>(static_cast<float*>(a.C) + (size_t)m * a.ldc + n) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
                 if (HAS_C2)
                   *reinterpret_cast<float4*>(static_cast<float*>(a.C2) + (size_t)m * a.ldc + n) = make_float4(pre[4 * q], pre[4 * q + 1], pre[4 * q + 2], pre[4 * q + 3]);
@@ -330,8 +342,12 @@ __global__ __launch_bounds__(512, 2) void lin_gemm_kernel(const LinArgs a) {
                 }
                 // lower lanes now hold {own q0, partner's q0} = columns 16j + 0..7; upper lanes {partner's q1, own q1} = 16j + 8..15
                 const int n = n_base + 32 * nb + 16 * j + 8 * h;
-                if (m < a.M && n + 7 < a.N && !(a.dbg & 4)) {
+                if (m < a.M && n + 7 < a.N && !LG_DBG(4)) {
                   uint4 o = make_uint4(d0[0], d0[1], d1[0], d1[1]);
+                  if (LG_DBG(256)) {   // timing ablation: the same bytes as one contiguous KiB per wave-instruction (wrong layout)
+                    const size_t blk = ((size_t)(ctm * a.tiles_n + ctn) * 8 + wave) * 16 + (size_t)((nb * 4 + mb) * 2 + j);
+                    *reinterpret_cast<uint4*>(out + blk * 512 + lane * 8) = o;
+                  } else
                   *reinterpret_cast<uint4*>(out + (size_t)m * a.ldc + n) = o;
                 }
               }
@@ -341,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void lin_gemm_kernel(const LinArgs a) {
       }
       ckt = 0;
       ++ci;
+      if (lag && g + 1 < G) __builtin_amdgcn_s_barrier();
       if (g + 1 < G) {
         const int t = (ci * 8 + xcd) * per_xcd + slot;
         ctm = t / a.tiles_n;
@@ -348,6 +365,14 @@ __global__ __launch_bounds__(512, 2) void lin_gemm_kernel(const LinArgs a) {
       }
     }
   }
+  if (LG_DBG(16) && blockIdx.x == 0 && tid == 0) {   // clock probe (debug runs only: overwrites C[0..1] as two uint64)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint64_t* o = reinterpret_cast<uint64_t*>(a.C);
+    o[0] = __builtin_readcyclecounter() - t0_cyc;
+    o[1] = __builtin_amdgcn_s_memrealtime() - t0_rt;
+  }
+#undef LG_DBG
+#undef LG_VAR
 }
 
 }  // namespace mmk
@@ -374,6 +399,8 @@ int mmk_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bi
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = (int)M; a.N = N; a.K = K;
   a.tiles_m = cdiv((int)M, LG_TILE); a.tiles_n = cdiv(N, LG_TILE);
   a.dbg = getenv("MMK_GEMM_DBG") ? atoi(getenv("MMK_GEMM_DBG")) : 0;
+  a.var = getenv("MMK_GEMM_VAR") ? atoi(getenv("MMK_GEMM_VAR")) : 0;
+  a.desync_sleeps = getenv("MMK_GEMM_DESYNC") ? atoi(getenv("MMK_GEMM_DESYNC")) : 0;
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -386,13 +413,15 @@ int mmk_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bi
   const int grid = std::min(n_cu, round_up(total, 8));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const void* kern = nullptr;
+  const bool dbgmode = a.dbg != 0 || a.var != 0;   // ablation build of the plain bf16 kernel only
 #define LG_PICK(F32_, ACT_, TWO_)                                                              \
   if ((out_dtype == MMK_F32) == (F32_ == 1) && act == ACT_ && (TWO_ == 1) == (a.C2 != nullptr)) \
-    kern = reinterpret_cast<const void*>(lin_gemm_kernel<F32_, ACT_, TWO_>);
+    kern = reinterpret_cast<const void*>(lin_gemm_kernel<F32_, ACT_, TWO_, false>);
   LG_PICK(0, LG_ACT_NONE, 0) LG_PICK(1, LG_ACT_NONE, 0)
   LG_PICK(0, LG_ACT_QUICK_GELU, 0) LG_PICK(0, LG_ACT_QUICK_GELU, 1)
   LG_PICK(0, LG_ACT_GELU, 0) LG_PICK(0, LG_ACT_GELU, 1)
 #undef LG_PICK
+  if (dbgmode && out_dtype == MMK_BF16 && act == LG_ACT_NONE && a.C2 == nullptr) kern = reinterpret_cast<const void*>(lin_gemm_kernel<0, LG_ACT_NONE, 0, true>);
   MMK_REQUIRE(kern != nullptr, "gemm_nt: this (dtype, activation, second output) combination is not built");
   MMK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LG_LDS));
   {

@@ -122,7 +122,37 @@ typedef struct {
    * loss_part = block sums of (pos_r/npos_r + neg_r/nneg_r); backward writes the symmetrised d/dlogits. */
   int32_t mode;
   const int32_t* hmax;
+  /* Mirrored direction.  On one rank the two directions of a pair see transposed logits (logits_per_b = logits_per_a^T,
+   * contrastive.py:327-340): with mirror_part set (mode 0, r == c, label_off == 0) the forward takes the mirrored
+   * direction's row statistics = this direction's COLUMN statistics from the same similarity tiles -- one GEMM pass per
+   * pair instead of two -- and fills mirror_lse / mirror_loss_part like lse / loss_part of a direction with x and y
+   * swapped.  Backward: with gT set the gradient-tile pass also stores G^T, which is the mirrored direction's G; that
+   * direction is then passed with g = this gT and g_ready = 1 and skips its own tile pass. */
+  float* mirror_part;      /* fwd workspace: float2[mmk_clip_mirror_tiles(r) * c] */
+  float* mirror_lse;       /* fwd out: float[c] */
+  float* mirror_loss_part; /* fwd out: float[ceil(c/256)] */
+  void* gT;                /* bwd (optional): [round_up(c,128), ldgt] compute type */
+  int32_t ldgt;            /* >= round_up(r, 128) */
+  int32_t g_ready;         /* bwd: g already holds this direction's G (written as another direction's gT) */
+  /* fwd, first direction of a call only: workspace of mmk_clip_forward_loss's in-launch loss combine -- one ticket word
+   * + one float per reduction workgroup (ceil(max rows / 256) x (directions + mirrors)); NULL = no in-launch combine */
+  float* fin_ws;
+  int32_t fin_ws_floats;
 } mmk_clip_dir;
+
+/* rows of the mirror_part workspace for r owned rows */
+int mmk_clip_mirror_tiles(int r);
+
+/* Several operands packed by ONE launch (gather + optional L2 normalise + cast to the compute type + zero pad, and the
+ * transposed copy when dstT != NULL): the operands of a pair, which mmk_pack_rows would pack with two launches each. */
+typedef struct mmk_pack_req {
+  const void* src;      /* [n_src, d] rows of the user dtype */
+  const int32_t* idx;   /* int32[r] source row per packed row, or NULL (identity) */
+  void* dst;            /* [r_pad, k_pad] compute type */
+  void* dstT;           /* [k_pad, ldt] compute type, or NULL */
+  int32_t r, r_pad, normalize, ldt;
+} mmk_pack_req;
+int mmk_pack_rows_many(const mmk_pack_req* reqs, int n, int src_dtype, int d, int k_pad, int compute, void* stream);
 
 /* tile configuration query: n_col_tiles for `part`, blocks for `ds_part`, split-K factor for `slab` */
 int mmk_clip_plan(int r, int c, int k_pad, int compute, int32_t* n_col_tiles, int32_t* n_grad_blocks,
@@ -133,6 +163,12 @@ int mmk_clip_plan(int r, int c, int k_pad, int compute, int32_t* n_col_tiles, in
  * directions in one launch; scale is a device float (the reference's 0-dim logit_scale). */
 int mmk_clip_forward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale,
                      void* stream);
+/* The same, and for small problems the weighted loss value  sum_k loss_w[k] * sum_i (lse_i - diag_i)  (contrastive.py:134-144,160)
+ * is formed by the reduction launch itself: loss_w (host) holds one weight per direction, followed by its mirror's when
+ * it has one; *loss_written = 1 when loss_out (device float) was written (needs dirs[0].fin_ws), 0 when the caller has to
+ * combine the loss_part arrays with mmk_reduce_sums. */
+int mmk_clip_forward_loss(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale,
+                          const float* loss_w, float* loss_out, int32_t* loss_written, void* stream);
 /* separate=0: out[0] = sum_k weights[k] * sum(ptrs[k][0..counts[k]))  -- the loss value
  * (contrastive.py:134-144,160; weight = w / (2 * rows in the mean));  separate=1: out[k] = weights[k] * sum(ptrs[k]) */
 int mmk_reduce_sums(const float* const* ptrs, const int32_t* counts, const float* weights, int n, int separate, float* out,

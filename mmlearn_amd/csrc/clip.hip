@@ -71,6 +71,10 @@ struct Prob {
   int part_ld;
   float* diag;    // [N]
   int label_off;
+  float2* mpart;  // EPI_STATS, mirrored direction: [tiles_n * 2][mpart_ld = M] column (max2, sum) partials, or null
+  int mpart_ld;
+  char* GT;       // EPI_GRAD: optional transposed G [>= tiles_m*BM][ldgt]
+  int ldgt;
   // EPI_GRAD
   const float* lse_row;  // [N]
   const float* lse_col;  // [M]
@@ -89,6 +93,7 @@ struct Prob {
 struct ProbBatch {
   Prob p[MAX_PROBS];
   int n_split;
+  unsigned* clear_word;   // EPI_STATS: cleared by the first workgroup (ticket counter of the reduction that follows), or null
 };
 
 // ------------------------------------------------------------------ main loop
@@ -111,6 +116,31 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Transpose-reduce over the 32 lanes of a half-wave: every lane holds CNT values (one per "column"), on return lane L holds
+// in v[0] the reduction over the 32 lanes (same lane >> 5) of column L & (CNT - 1)  (CNT = 32: 31 shuffles instead of 160;
+// CNT = 16: the xor-16 partner pairs are combined at the end, both lanes of a pair hold the same column).
+template <int CNT, bool IS_MAX>
+__device__ __forceinline__ float half_wave_transpose_reduce(float (&v)[CNT], int lane) {
+  static_assert(CNT == 32 || CNT == 16, "16 or 32 columns");
+  constexpr int STEPS = CNT == 32 ? 5 : 4;
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const bool bit = (lane >> s) & 1;
+#pragma unroll
+    for (int i = 0; i < (CNT >> (s + 1)); ++i) {
+      const float keep = bit ? v[2 * i + 1] : v[2 * i];
+      const float send = bit ? v[2 * i] : v[2 * i + 1];
+      const float recv = __shfl_xor(send, 1 << s);
+      v[i] = IS_MAX ? fmaxf(keep, recv) : keep + recv;
+    }
+  }
+  if (CNT == 16) {
+    const float o = __shfl_xor(v[0], 16);
+    v[0] = IS_MAX ? fmaxf(v[0], o) : v[0] + o;
+  }
+  return v[0];
+}
+
 template <typename T, int BM, int BN, int EPI, int LOADER, int NSTAGE>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, const float* __restrict__ scale_ptr) {
   typedef Atom<T> A;
@@ -121,6 +151,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
   constexpr int STAGE_BYTES = ROWS * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // NSTAGE * STAGE_BYTES (dynamic: may exceed 64 KiB)
 
+  if (EPI == EPI_STATS && batch.clear_word != nullptr && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+    __hip_atomic_store(batch.clear_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int zsplit = (EPI == EPI_PLAIN) ? (blockIdx.z % batch.n_split) : 0;
   const int zprob = (EPI == EPI_PLAIN) ? (blockIdx.z / batch.n_split) : blockIdx.z;
   const Prob& p = batch.p[zprob];
@@ -309,14 +341,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
 #pragma unroll
           for (int e = 0; e < 16; ++e) sum += fast_exp2(fmaf(acc[a][b][e], s2, -m2));
       } else {  // edge tiles / negative scale: masked extremum of u = s2*t, masked sum
-        float umax = -INFINITY;
+        float umax = -INFINITY;   // (the accumulators stay untouched: the mirrored column statistics read them again)
 #pragma unroll
         for (int a = 0; a < MT; ++a)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int j = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             const float u = (j < p.M) ? acc[a][b][e] * s2 : -INFINITY;
-            acc[a][b][e] = u;
             umax = fmaxf(umax, u);
           }
         umax = fmaxf(umax, __shfl_xor(umax, 32));
@@ -325,7 +356,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
 #pragma unroll
           for (int a = 0; a < MT; ++a)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sum += (acc[a][b][e] > -INFINITY) ? fast_exp2(acc[a][b][e] - umax) : 0.f;
+            for (int e = 0; e < 16; ++e) {
+              const int j = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+              sum += (j < p.M) ? fast_exp2(acc[a][b][e] * s2 - umax) : 0.f;
+            }
         }
       }
       sum += __shfl_xor(sum, 32);
@@ -340,6 +374,52 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
       if (y.x > -INFINITY) l += y.y * fast_exp2(y.x - mx);
       const int i = n0 + tid;
       if (i < p.N) p.part[(size_t)tm * p.part_ld + i] = make_float2(mx, l);  // log2 domain
+    }
+    if (p.mpart != nullptr) {
+      // Mirrored direction (W = 1: logits_per_b = logits_per_a^T): the SAME tile gives, per column j (a P row, on the
+      // accumulator registers), the (max2, sum) over this wave's 32 * NT rows i (the lanes).  Per lane first over its NT
+      // rows, then a transpose-reduce over the 32 lanes of the half-wave: max pass, maxima handed back through a
+      // wave-private LDS line, exponentials against the column maximum, sum pass.  One partial per (row tile, wn half).
+      constexpr int CNT = 16 * MT;
+      __syncthreads();   // the row partials in `red` have been consumed
+      float* cmax_lds = reinterpret_cast<float*>(smem) + wave * 64;   // [h][CNT] per wave (CNT <= 32)
+      float vmax[CNT];
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float m = -INFINITY;
+#pragma unroll
+          for (int b = 0; b < NT; ++b) {
+            const int i = n0 + wn * (BN / 2) + b * 32 + r;
+            const float u = (i < p.N) ? acc[a][b][e] * s2 : -INFINITY;
+            m = fmaxf(m, u);
+          }
+          vmax[a * 16 + e] = m;
+        }
+      const float cm = half_wave_transpose_reduce<CNT, true>(vmax, lane);   // lane L: column L & (CNT - 1) of half h
+      cmax_lds[h * 32 + (lane & (CNT - 1))] = cm;   // CNT = 16: two lanes write the same value
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      float vsum[CNT];
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float mref = cmax_lds[h * 32 + a * 16 + e];   // broadcast read
+          float t = 0.f;
+          if (mref > -INFINITY) {
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+              const int i = n0 + wn * (BN / 2) + b * 32 + r;
+              if (i < p.N) t += fast_exp2(fmaf(acc[a][b][e], s2, -mref));
+            }
+          }
+          vsum[a * 16 + e] = t;
+        }
+      const float cs = half_wave_transpose_reduce<CNT, false>(vsum, lane);
+      const int cidx = lane & (CNT - 1);
+      const int j = m0 + wm * (BM / 2) + (cidx >> 4) * 32 + (cidx & 3) + 8 * ((cidx & 15) >> 2) + 4 * h;
+      if (j < p.M && (CNT == 32 || (lane & 16) == 0)) p.mpart[(size_t)(tn * 2 + wn) * p.mpart_ld + j] = make_float2(cm, cs);
     }
   } else if (EPI == EPI_GRAD) {
     const float s = *scale_ptr;
@@ -400,6 +480,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
             }
             if (use_ds) ds_acc = fmaf(gs, t, ds_acc);
             g4[e] = g;
+            acc[a][b][4 * q + e] = g;   // kept for the transposed copy below (the logit is no longer needed)
           }
           Vec4<T>::store(reinterpret_cast<T*>(stg + r * STRIDE) + jl, make_float4(g4[0], g4[1], g4[2], g4[3]));
         }
@@ -411,6 +492,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
         const int gi = n0 + wn * (BN / 2) + b * 32 + row;
         const int gj = m0 + wm * (BM / 2) + c4 * 4;
         *reinterpret_cast<Piece*>(reinterpret_cast<T*>(p.G) + (size_t)gi * p.ldg + gj) = v;
+      }
+      if (p.GT != nullptr) {
+        // G^T = the mirrored direction's G: the same values staged transposed ([COLS columns j][32 rows i], the wave's
+        // staging area again: its LDS operations are in order) and streamed out as whole 32-element row segments
+        T* st = reinterpret_cast<T*>(stg);
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) st[(a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = from_f32<T>(acc[a][b][e]);
+        constexpr int TLPR = 32 * (int)sizeof(T) / 16;   // lanes per staged row (16-byte pieces)
+        constexpr int TRPI = 64 / TLPR;                  // rows per read-back instruction
+#pragma unroll
+        for (int t = 0; t < COLS / TRPI; ++t) {
+          const int row = t * TRPI + lane / TLPR, c16 = lane % TLPR;
+          const uint4 v = *reinterpret_cast<const uint4*>(stg + row * 32 * (int)sizeof(T) + c16 * 16);
+          const int gj = m0 + wm * (BM / 2) + row;
+          const int gi = n0 + wn * (BN / 2) + b * 32 + c16 * (16 / (int)sizeof(T));
+          *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.GT) + (size_t)gj * p.ldgt + gi) = v;
+        }
       }
     }
     __syncthreads();  // staging tiles are dead; reuse LDS for the d/dscale reduction
@@ -548,32 +648,63 @@ struct ReduceProb {
   float* loss_part;
 };
 struct ReduceBatch {
-  ReduceProb p[MAX_PROBS];
+  ReduceProb p[2 * MAX_PROBS];   // a direction with a mirror contributes two entries
 };
-__global__ __launch_bounds__(256) void lse_reduce_kernel(const ReduceBatch batch) {
+__device__ __forceinline__ float lse_reduce_row(const ReduceProb& p, int i) {
+  float mx = -INFINITY;
+#pragma unroll 8
+  for (int t = 0; t < p.tiles_m; ++t) mx = fmaxf(mx, p.part[(size_t)t * p.part_ld + i].x);
+  float l = 0.f;
+#pragma unroll 8
+  for (int t = 0; t < p.tiles_m; ++t) {
+    const float2 v = p.part[(size_t)t * p.part_ld + i];
+    if (v.x > -INFINITY) l += v.y * exp2f(v.x - mx);
+  }
+  const float lse = (mx + log2f(l)) * 0.6931471805599453f;  // partials are in the log2 domain
+  p.lse[i] = lse;
+  return lse - p.diag[i];
+}
+// Row reductions of every direction; optionally also the weighted loss value (contrastive.py:134-144,160) in the same
+// launch: every workgroup publishes its weighted partial with an agent-scope (write-through) atomic store, drains it, draws
+// a ticket, and the workgroup that draws the last ticket adds the partials in a fixed order (deterministic) with
+// agent-scope loads and re-arms the counter.  The counter is zero on entry: the similarity kernel clears it.
+struct ReduceFinal {
+  float w[2 * MAX_PROBS];
+  float* scratch;       // [gridDim.y][gridDim.x]
+  unsigned* counter;    // [1]
+  float* loss_out;      // [1] or null (no in-launch combine)
+};
+__global__ __launch_bounds__(256) void lse_reduce_kernel(const ReduceBatch batch, const ReduceFinal fin) {
   const ReduceProb& p = batch.p[blockIdx.y];
-  if (blockIdx.x * 256 >= p.N) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   float local = 0.f;
-  if (i < p.N) {
-    float mx = -INFINITY;
-#pragma unroll 8
-    for (int t = 0; t < p.tiles_m; ++t) mx = fmaxf(mx, p.part[(size_t)t * p.part_ld + i].x);
-    float l = 0.f;
-#pragma unroll 8
-    for (int t = 0; t < p.tiles_m; ++t) {
-      const float2 v = p.part[(size_t)t * p.part_ld + i];
-      if (v.x > -INFINITY) l += v.y * exp2f(v.x - mx);
-    }
-    const float lse = (mx + log2f(l)) * 0.6931471805599453f;  // partials are in the log2 domain
-    p.lse[i] = lse;
-    local = lse - p.diag[i];
-  }
+  if (i < p.N) local = lse_reduce_row(p, i);
   __shared__ float red[4];
+  __shared__ unsigned ticket_s;
   local = wave_sum(local);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
   __syncthreads();
-  if (threadIdx.x == 0) p.loss_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  const float block_sum = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0 && (int)(blockIdx.x * 256) < p.N) p.loss_part[blockIdx.x] = block_sum;
+  if (fin.loss_out == nullptr) return;
+  const unsigned n_blocks = gridDim.x * gridDim.y;
+  if (threadIdx.x == 0) {
+    const float mine = (int)(blockIdx.x * 256) < p.N ? fin.w[blockIdx.y] * block_sum : 0.f;
+    __hip_atomic_store(fin.scratch + blockIdx.y * gridDim.x + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ticket_s = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (ticket_s != n_blocks - 1) return;
+  if (threadIdx.x < 64) {   // last arriver: fixed-order sum over all partials
+    float t = 0.f;
+    for (unsigned k = threadIdx.x; k < n_blocks; k += 64) t += __hip_atomic_load(fin.scratch + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = wave_sum(t);
+    if (threadIdx.x == 0) {
+      *fin.loss_out = t;
+      __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // alignment: loss_r = pos/npos + neg/nneg per owned row; block sums to loss_part (the caller scales by 1/M)
@@ -682,6 +813,86 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const S* __restrict__ sr
   }
 }
 
+// Batched pack: gather + optional L2 normalise + cast + zero pad AND the transposed copy, for several operands in ONE
+// launch (grid.y = operand).  A workgroup owns 64 destination rows: row norms first (one wave per 16 rows), then the
+// row block walks the k axis in 64-column steps through a [64][64] LDS tile that is written out both ways.
+struct PackEntry {
+  const void* src;
+  const int32_t* idx;
+  void* dst;
+  void* dstT;   // or null
+  int r, r_pad, normalize, ldt;
+};
+struct PackBatch {
+  PackEntry e[MAX_PROBS];
+};
+template <typename S, typename T>
+__global__ __launch_bounds__(256) void pack_tr_kernel(const PackBatch batch, int d, int k_pad) {
+  // 16 destination rows per workgroup (many small workgroups: the operands are a few MB).  Thread (row = tid >> 4,
+  // c4 = tid & 15) owns 4 consecutive columns of every 64-column step.
+  const PackEntry& en = batch.e[blockIdx.y];
+  const int r0 = blockIdx.x * 16;
+  if (r0 >= en.r_pad) return;
+  __shared__ float inv_s[16];
+  __shared__ T tile[16][68];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const S* src = static_cast<const S*>(en.src);
+  const bool vec = (d & 3) == 0;
+  if (en.normalize) {
+    for (int rr = wave * 4; rr < wave * 4 + 4; ++rr) {
+      const int row = r0 + rr;
+      float ss = 0.f;
+      if (row < en.r) {
+        const S* in = src + (size_t)(en.idx ? en.idx[row] : row) * d;
+        if (vec) {
+          for (int c = lane * 4; c < d; c += 256) {
+            const float4 v = Vec4<S>::load(in + c);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+          }
+        } else {
+          for (int c = lane; c < d; c += 64) {
+            const float v = to_f32(in[c]);
+            ss += v * v;
+          }
+        }
+      }
+      ss = wave_sum(ss);
+      if (lane == 0) inv_s[rr] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    }
+    __syncthreads();
+  }
+  const int rr = tid >> 4, c4 = (tid & 15) * 4;
+  const int row = r0 + rr;
+  const S* in = row < en.r ? src + (size_t)(en.idx ? en.idx[row] : row) * d : nullptr;
+  const float inv = en.normalize ? inv_s[rr] : 1.f;
+  T* dst = static_cast<T*>(en.dst) + (size_t)row * k_pad;
+  T* dstT = static_cast<T*>(en.dstT);
+  const int kr = tid >> 2, s4 = (tid & 3) * 4;   // transposed write: k row kr of the step, tile rows s4 .. s4 + 3
+  for (int k0 = 0; k0 < k_pad; k0 += 64) {
+    const int c = k0 + c4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in != nullptr) {
+      if (vec) {
+        if (c < d) v = Vec4<S>::load(in + c);
+      } else {
+        if (c + 0 < d) v.x = to_f32(in[c + 0]);
+        if (c + 1 < d) v.y = to_f32(in[c + 1]);
+        if (c + 2 < d) v.z = to_f32(in[c + 2]);
+        if (c + 3 < d) v.w = to_f32(in[c + 3]);
+      }
+    }
+    v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+    Vec4<T>::store(dst + c, v);
+    if (dstT != nullptr) {
+      Vec4<T>::store(&tile[rr][c4], v);
+      __syncthreads();
+      Vec4<T>::store(dstT + (size_t)(k0 + kr) * en.ldt + r0 + s4,
+                     make_float4(to_f32(tile[s4][kr]), to_f32(tile[s4 + 1][kr]), to_f32(tile[s4 + 2][kr]), to_f32(tile[s4 + 3][kr])));
+      __syncthreads();
+    }
+  }
+}
+
 // dstT[k][p] = dst[p][k]; 64x64 tiles through LDS (+1 padding), both dims multiples of 64
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int rows, int cols,
@@ -713,10 +924,31 @@ struct FinBatch {
   int n_split;
   int d;
 };
+struct DsBatch {
+  const float* part[MAX_PROBS];
+  int n[MAX_PROBS];
+  float kappa[MAX_PROBS];
+  int n_probs;
+};
 template <typename U>
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinBatch batch, const float* __restrict__ scale_ptr,
-                                                            const float* __restrict__ upstream) {
+                                                            const float* __restrict__ upstream, const DsBatch ds, float* ds_out, int n_dirs) {
   extern __shared__ __attribute__((aligned(16))) float rowbuf[];  // [4][slab_ld]
+  if ((int)blockIdx.y == n_dirs) {
+    // extra grid row: d loss / d scale = upstream * sum_k kappa_k * sum(tile partials of the gradient-tile pass)
+    if (blockIdx.x != 0) return;
+    float local = 0.f;
+    for (int k = 0; k < ds.n_probs; ++k) {
+      float t = 0.f;
+      for (int i = threadIdx.x; i < ds.n[k]; i += 256) t += ds.part[k][i];
+      local += ds.kappa[k] * t;
+    }
+    local = wave_sum(local);
+    if ((threadIdx.x & 63) == 0) rowbuf[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) *ds_out += (*upstream) * (rowbuf[0] + rowbuf[1] + rowbuf[2] + rowbuf[3]);
+    return;
+  }
   const FinProb& p = batch.p[blockIdx.y];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
@@ -779,26 +1011,6 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinBatch batch
         if (c + e < d) reinterpret_cast<U*>(p.dx)[(size_t)dst_row * d + c + e] = from_f32<U>(o[e]);
     }
   }
-}
-
-struct DsBatch {
-  const float* part[MAX_PROBS];
-  int n[MAX_PROBS];
-  float kappa[MAX_PROBS];
-  int n_probs;
-};
-__global__ __launch_bounds__(256) void ds_reduce_kernel(const DsBatch b, const float* __restrict__ upstream, float* out) {
-  float local = 0.f;
-  for (int k = 0; k < b.n_probs; ++k) {
-    float t = 0.f;
-    for (int i = threadIdx.x; i < b.n[k]; i += 256) t += b.part[k][i];
-    local += b.kappa[k] * t;
-  }
-  __shared__ float red[4];
-  local = wave_sum(local);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
-  __syncthreads();
-  if (threadIdx.x == 0) *out += (*upstream) * (red[0] + red[1] + red[2] + red[3]);
 }
 
 // ------------------------------------------------------------------ host side
@@ -893,7 +1105,8 @@ static int launch_gemm(const ProbBatch& b, int n_probs, int bm, int bn, int max_
 }
 
 template <typename T>
-static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, const float* scale, hipStream_t st) {
+static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, const float* scale, const float* loss_w, float* loss_out,
+                             int32_t* loss_written, hipStream_t st) {
   int r_max = 0, c_max = 0;
   for (int k = 0; k < n_dirs; ++k) {
     r_max = std::max(r_max, dirs[k].r);
@@ -903,7 +1116,7 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
   ProbBatch b;
   ReduceBatch rb;
   AlignReduceBatch ab;
-  int max_tiles = 0;
+  int max_tiles = 0, n_red = 0, r_red_max = 0;
   for (int k = 0; k < n_dirs; ++k) {
     const mmk_clip_dir& d = dirs[k];
     Prob& p = b.p[k];
@@ -922,10 +1135,19 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
     p.label_off = d.label_off;
     p.hmax = d.hmax;
     max_tiles = std::max(max_tiles, p.tiles_m * p.tiles_n);
-    rb.p[k] = ReduceProb{p.part, p.part_ld, p.tiles_m, d.r, d.diag, d.lse, d.loss_part};
+    rb.p[n_red++] = ReduceProb{p.part, p.part_ld, p.tiles_m, d.r, d.diag, d.lse, d.loss_part};
+    r_red_max = std::max(r_red_max, d.r);
     ab.p[k] = AlignReduceProb{p.part, p.part_ld, p.tiles_m, d.r, d.c, d.label_off, d.hmax, d.loss_part};
+    if (d.mirror_part != nullptr) {
+      // the mirrored direction's rows are this direction's columns: partials per (row tile, wn half), positive = same diagonal
+      p.mpart = reinterpret_cast<float2*>(d.mirror_part);
+      p.mpart_ld = d.c;
+      rb.p[n_red++] = ReduceProb{p.mpart, p.mpart_ld, 2 * p.tiles_n, d.c, d.diag, d.mirror_lse, d.mirror_loss_part};
+      r_red_max = std::max(r_red_max, d.c);
+    }
   }
   b.n_split = 1;
+  b.clear_word = (loss_out != nullptr && dirs[0].fin_ws != nullptr) ? reinterpret_cast<unsigned*>(dirs[0].fin_ws) : nullptr;
   const bool align = dirs[0].mode == 1;
   {
     int rc = align ? launch_gemm<T, EPI_ALIGN_STATS>(b, n_dirs, pl.bm, pl.bn, max_tiles, scale, st)
@@ -936,8 +1158,18 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
     ProfScope ps(MMK_K_LSE_REDUCE, st);
     if (align)
       hipLaunchKernelGGL(align_reduce_kernel, dim3(cdiv(r_max, 256), n_dirs), dim3(256), 0, st, ab);
-    else
-      hipLaunchKernelGGL(lse_reduce_kernel, dim3(cdiv(r_max, 256), n_dirs), dim3(256), 0, st, rb);
+    else {
+      ReduceFinal fin{};
+      const dim3 grid(cdiv(r_red_max, 256), n_red);
+      if (loss_out != nullptr && dirs[0].fin_ws != nullptr && (long)grid.x * grid.y <= dirs[0].fin_ws_floats - 1) {
+        for (int k = 0; k < n_red; ++k) fin.w[k] = loss_w[k];   // one weight per direction, then its mirror's
+        fin.counter = reinterpret_cast<unsigned*>(dirs[0].fin_ws);
+        fin.scratch = dirs[0].fin_ws + 1;
+        fin.loss_out = loss_out;
+        if (loss_written) *loss_written = 1;
+      }
+      hipLaunchKernelGGL(lse_reduce_kernel, grid, dim3(256), 0, st, rb, fin);
+    }
     MMK_LAUNCH_CHECK();
   }
   return 0;
@@ -956,16 +1188,16 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
   ProbBatch gb, xb;
   FinBatch fb;
   DsBatch db;
-  int max_tiles_g = 0, max_tiles_x = 0, max_r = 0;
+  int max_tiles_g = 0, max_tiles_x = 0, max_r = 0, n_tile_probs = 0;
+  db.n_probs = 0;
   const int c_pad_max = round_up(c_max, 128);
   const int k_per_split = round_up(cdiv(c_pad_max, pl.n_split), bk);
   for (int k = 0; k < n_dirs; ++k) {
     const mmk_clip_dir& d = dirs[k];
     const int r_pad = round_up(d.r, 128), c_pad = round_up(d.c, 128);
     MMK_REQUIRE(d.ldg >= c_pad && d.ldt >= c_pad, "ldg/ldt must be >= round_up(c, 128)");
-    // recompute + G
-    Prob& p = gb.p[k];
-    p = Prob{};
+    // recompute + G (a direction whose G was written as another direction's G^T has no tile pass of its own)
+    Prob p{};
     p.P = static_cast<const char*>(d.y);
     p.Q = static_cast<const char*>(d.x);
     p.M = d.c;
@@ -973,21 +1205,28 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
     p.K = k_pad;
     p.ldp = p.ldq = k_pad;
     p.tiles_m = c_pad / pl.bm;   // cover the zero padding of G up to ldg
-    p.tiles_n = cdiv(d.r, pl.bn);
+    p.tiles_n = d.gT != nullptr ? r_pad / pl.bn : cdiv(d.r, pl.bn);   // ... and of G^T up to ldgt
     p.label_off = d.label_off;
     p.lse_row = d.lse;
     p.lse_col = d.lse_col;
     p.G = static_cast<char*>(d.g);
     p.ldg = d.ldg;
+    p.GT = static_cast<char*>(d.gT);
+    p.ldgt = d.ldgt;
     p.c_row = d.c_row; p.c_col = d.c_col; p.c_diag = d.c_diag;
     p.s_row = d.s_row; p.s_col = d.s_col; p.s_diag = d.s_diag;
     p.ds_part = d.ds_part;
     p.hmax = d.hmax;
     MMK_REQUIRE(d.mode == 1 || d.lse_col != nullptr || (d.c_col == 0.f && d.s_col == 0.f), "lse_col required when c_col/s_col != 0");
-    max_tiles_g = std::max(max_tiles_g, p.tiles_m * p.tiles_n);
-    db.part[k] = d.ds_part;
-    db.n[k] = p.tiles_m * p.tiles_n;
-    db.kappa[k] = d.ds_kappa;
+    MMK_REQUIRE(d.gT == nullptr || (d.mode == 0 && d.ldgt >= r_pad), "gT needs mode 0 and ldgt >= round_up(r, 128)");
+    if (!d.g_ready) {
+      gb.p[n_tile_probs++] = p;
+      max_tiles_g = std::max(max_tiles_g, p.tiles_m * p.tiles_n);
+      db.part[db.n_probs] = d.ds_part;
+      db.n[db.n_probs] = p.tiles_m * p.tiles_n;
+      db.kappa[db.n_probs] = d.ds_kappa;
+      ++db.n_probs;
+    }
     // dX^T[dcol][i] = sum_j yT[dcol][j] * G[i][j]
     Prob& x = xb.p[k];
     x = Prob{};
@@ -1009,13 +1248,14 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
     max_r = std::max(max_r, d.r);
   }
   gb.n_split = 1;
+  gb.clear_word = nullptr;
+  xb.clear_word = nullptr;
   xb.n_split = pl.n_split;
   fb.n_split = pl.n_split;
   fb.d = d_user;
-  db.n_probs = n_dirs;
-  {
-    int rc = dirs[0].mode == 1 ? launch_gemm<T, EPI_ALIGN_GRAD>(gb, n_dirs, pl.bm, pl.bn, max_tiles_g, scale, st)
-                               : launch_gemm<T, EPI_GRAD>(gb, n_dirs, pl.bm, pl.bn, max_tiles_g, scale, st);
+  if (n_tile_probs > 0) {
+    int rc = dirs[0].mode == 1 ? launch_gemm<T, EPI_ALIGN_GRAD>(gb, n_tile_probs, pl.bm, pl.bn, max_tiles_g, scale, st)
+                               : launch_gemm<T, EPI_GRAD>(gb, n_tile_probs, pl.bm, pl.bn, max_tiles_g, scale, st);
     if (rc) return rc;
   }
   {
@@ -1024,13 +1264,10 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
   }
   {
     ProfScope ps(MMK_K_GRAD_FINALIZE, st);
-    hipLaunchKernelGGL((grad_finalize_kernel<U>), dim3(cdiv(max_r, 4), n_dirs), dim3(256), 4 * k_pad * sizeof(float), st, fb,
-                       scale, upstream);
+    // one launch: a grid row per direction, plus one for the d/dscale reduction
+    hipLaunchKernelGGL((grad_finalize_kernel<U>), dim3(cdiv(max_r, 4), n_dirs + (dscale_out ? 1 : 0)), dim3(256), 4 * k_pad * sizeof(float), st, fb,
+                       scale, upstream, db, dscale_out, n_dirs);
     MMK_LAUNCH_CHECK();
-    if (dscale_out) {
-      hipLaunchKernelGGL(ds_reduce_kernel, dim3(1), dim3(256), 0, st, db, upstream, dscale_out);
-      MMK_LAUNCH_CHECK();
-    }
   }
   return 0;
 }
@@ -1041,11 +1278,13 @@ using namespace mmk;
 
 extern "C" {
 
+int mmk_clip_mirror_tiles(int r) { return 2 * cdiv(r, 64); }
+
 int mmk_clip_plan(int r, int c, int k_pad, int compute, int32_t* n_col_tiles, int32_t* n_grad_blocks, int32_t* n_split) {
   MMK_REQUIRE(r > 0 && c > 0 && k_pad > 0, "empty problem");
   // sized for the worst case over tile choices / batch sizes so that callers need not know them
   if (n_col_tiles) *n_col_tiles = cdiv(c, 64);
-  if (n_grad_blocks) *n_grad_blocks = (round_up(c, 128) / 64) * cdiv(r, 64);
+  if (n_grad_blocks) *n_grad_blocks = (round_up(c, 128) / 64) * (round_up(r, 128) / 64);
   int split = 1;
   for (int nd = 1; nd <= MAX_PROBS; ++nd) split = std::max(split, make_plan(r, c, k_pad, nd, compute).n_split);
   if (n_split) *n_split = split;
@@ -1089,6 +1328,34 @@ int mmk_pack_rows(const void* src, int src_dtype, int n_src, int d, const int32_
   return 0;
 }
 
+int mmk_pack_rows_many(const mmk_pack_req* reqs, int n, int src_dtype, int d, int k_pad, int compute, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int bk = compute == MMK_COMPUTE_BF16 ? 64 : 32;
+  MMK_REQUIRE(reqs && n > 0 && n <= MAX_PROBS, "1..8 operands per call");
+  MMK_REQUIRE(d > 0 && k_pad % bk == 0 && k_pad >= d && k_pad % 64 == 0, "k_pad must be a multiple of 64 and >= d");
+  PackBatch b;
+  int r_pad_max = 0;
+  for (int k = 0; k < n; ++k) {
+    const mmk_pack_req& q = reqs[k];
+    MMK_REQUIRE(q.src && q.dst && q.r >= 0, "null pointer / bad shape");
+    MMK_REQUIRE(q.r_pad % 128 == 0 && q.r_pad >= q.r && q.r_pad > 0, "r_pad must be a positive multiple of 128 and >= r");
+    MMK_REQUIRE(q.dstT == nullptr || q.ldt == q.r_pad, "ldt must equal r_pad");
+    b.e[k] = PackEntry{q.src, q.idx, q.dst, q.dstT, q.r, q.r_pad, q.normalize, q.ldt};
+    r_pad_max = std::max(r_pad_max, q.r_pad);
+  }
+  ProfScope ps(MMK_K_PACK, st);
+  int rc = MMK_DISPATCH_DTYPE(src_dtype, S, [&]() -> int {
+    if (compute == MMK_COMPUTE_BF16)
+      hipLaunchKernelGGL((pack_tr_kernel<S, bf16_t>), dim3(r_pad_max / 16, n), dim3(256), 0, st, b, d, k_pad);
+    else
+      hipLaunchKernelGGL((pack_tr_kernel<S, float>), dim3(r_pad_max / 16, n), dim3(256), 0, st, b, d, k_pad);
+    return 0;
+  });
+  if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
 static int check_dirs(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int compute) {
   MMK_REQUIRE(dirs && n_dirs > 0 && n_dirs <= MAX_PROBS, "1..8 directions per call");
   const int bk = compute == MMK_COMPUTE_BF16 ? 64 : 32;
@@ -1104,16 +1371,27 @@ static int check_dirs(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int compu
   return 0;
 }
 
-int mmk_clip_forward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale, void* stream) {
+int mmk_clip_forward_loss(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale, const float* loss_w,
+                          float* loss_out, int32_t* loss_written, void* stream) {
   (void)d;
   int rc = check_dirs(dirs, n_dirs, k_pad, compute);
   if (rc) return rc;
   MMK_REQUIRE(scale, "null scale");
-  for (int k = 0; k < n_dirs; ++k)
+  MMK_REQUIRE((loss_out == nullptr) == (loss_w == nullptr), "loss_w and loss_out come together");
+  for (int k = 0; k < n_dirs; ++k) {
     MMK_REQUIRE(dirs[k].part && dirs[k].loss_part && (dirs[k].mode == 1 || (dirs[k].diag && dirs[k].lse)), "null forward buffer");
+    if (dirs[k].mirror_part != nullptr)
+      MMK_REQUIRE(dirs[k].mode == 0 && dirs[k].r == dirs[k].c && dirs[k].label_off == 0 && dirs[k].mirror_lse && dirs[k].mirror_loss_part,
+                  "a mirrored direction needs mode 0, r == c, label_off == 0 and its output buffers");
+  }
+  if (loss_written) *loss_written = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (compute == MMK_COMPUTE_BF16) return clip_forward_impl<bf16_t>(dirs, n_dirs, k_pad, scale, st);
-  return clip_forward_impl<float>(dirs, n_dirs, k_pad, scale, st);
+  if (compute == MMK_COMPUTE_BF16) return clip_forward_impl<bf16_t>(dirs, n_dirs, k_pad, scale, loss_w, loss_out, loss_written, st);
+  return clip_forward_impl<float>(dirs, n_dirs, k_pad, scale, loss_w, loss_out, loss_written, st);
+}
+
+int mmk_clip_forward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale, void* stream) {
+  return mmk_clip_forward_loss(dirs, n_dirs, k_pad, d, compute, scale, nullptr, nullptr, nullptr, stream);
 }
 
 int mmk_reduce_sums(const float* const* ptrs, const int32_t* counts, const float* weights, int n, int separate, float* out,

@@ -126,6 +126,33 @@ def pack_rows(src: torch.Tensor, idx: Optional[torch.Tensor], r: int, normalize:
     return dst, dst_t
 
 
+def pack_rows_many(reqs: Sequence[tuple], compute: int) -> list:
+    """``[(src, idx, r, normalize, want_transpose), ...]`` -> ``[(dst, dst_t), ...]`` with ONE launch when the operands share
+    dtype and width (the two sides of a pair do); otherwise falls back to one ``pack_rows`` each."""
+    srcs = [q[0] for q in reqs]
+    if len(reqs) < 2 or len(reqs) > MAX_DIRS_PER_CALL or len({(t.dtype, t.shape[1], t.device) for t in srcs}) != 1:
+        return [pack_rows(*q[:4], compute, q[4]) for q in reqs]
+    cdt = compute_torch_dtype(compute)
+    d = srcs[0].shape[1]
+    k_pad = round_up(d, 64)
+    arr = (_lib.PackReq * len(reqs))()
+    out, keep = [], []
+    for k, (src, idx, r, normalize, want_t) in enumerate(reqs):
+        require_gpu(src, "embedding")
+        src = src.contiguous()
+        keep.append(src)
+        r_pad = round_up(max(r, 1), 128)
+        dst = torch.empty((r_pad, k_pad), dtype=cdt, device=src.device)
+        dst_t = torch.empty((k_pad, r_pad), dtype=cdt, device=src.device) if want_t else None
+        if idx is not None:
+            assert idx.dtype == torch.int32 and idx.numel() >= r
+        e = arr[k]
+        e.src, e.idx, e.dst, e.dstT, e.r, e.r_pad, e.normalize, e.ldt = ptr(src), ptr(idx), ptr(dst), ptr(dst_t), r, r_pad, int(normalize), r_pad
+        out.append((dst, dst_t))
+    check(_lib.lib().mmk_pack_rows_many(C.cast(arr, C.c_void_p), len(reqs), dtype_tag(srcs[0].dtype), d, k_pad, compute, stream()))
+    return out
+
+
 # ------------------------------------------------------------------ CLIP loss
 @dataclass
 class Direction:
@@ -168,15 +195,51 @@ def _plan(r: int, c: int, k_pad: int, compute: int):
     return a.value, b.value, s.value
 
 
-def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.Tensor) -> None:
-    """Fills dir.lse / dir.diag / dir.loss_part for every direction (two launches for all of them)."""
+def _mirror_of(a: Direction, b: Direction, backward: bool = False) -> bool:
+    """``b`` is ``a`` with the operands swapped on one rank: its logits are the transposed logits of ``a``
+    (``logits_per_feature_b = logits_per_feature_a.T``, contrastive.py:327-340), so one pass over the similarity tiles
+    serves both (row statistics for ``a``, column statistics for ``b``; G for ``a``, G^T for ``b``)."""
+    ok = (a.mode == 0 and b.mode == 0 and a.r == a.c == b.r == b.c and a.label_off == 0 and b.label_off == 0
+          and a.x.data_ptr() == b.y.data_ptr() and a.y.data_ptr() == b.x.data_ptr() and a.x.shape == b.y.shape and a.y.shape == b.x.shape)
+    if ok and backward:   # G_b = G_a^T needs the same row / column weights in both directions
+        ok = (a.c_row == a.c_col == b.c_row == b.c_col and a.c_diag == b.c_diag and b.s_row == b.s_col == b.s_diag == 0.0
+              and a.lse_col is not None and b.lse is not None and a.lse_col.data_ptr() == b.lse.data_ptr()
+              and b.lse_col is not None and b.lse_col.data_ptr() == a.lse.data_ptr())
+    return ok
+
+
+def _pair_up(dirs: Sequence[Direction], backward: bool = False) -> list:
+    """[(direction, mirror or None)]: consecutive mirrored directions share one tile pass (MMK_NO_MIRROR=1: A/B switch)."""
+    import os
+    out, k = [], 0
+    no = os.environ.get("MMK_NO_MIRROR") is not None
+    while k < len(dirs):
+        if not no and k + 1 < len(dirs) and _mirror_of(dirs[k], dirs[k + 1], backward):
+            out.append((dirs[k], dirs[k + 1]))
+            k += 2
+        else:
+            out.append((dirs[k], None))
+            k += 1
+    return out
+
+
+def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.Tensor,
+                 loss_weights: Optional[Sequence[float]] = None) -> Optional[torch.Tensor]:
+    """Fills dir.lse / dir.diag / dir.loss_part for every direction (two launches for all of them).  The two directions of a
+    pair on one rank are computed from ONE pass over the similarity tiles (see ``_mirror_of``).  With ``loss_weights`` (one
+    per direction) a small problem also gets its loss value ``sum_k w_k * sum_i (lse_i - diag_i)`` from the reduction
+    launch: the 0-dim tensor is returned; ``None`` means the caller combines ``loss_part`` with ``reduce_sums``."""
     assert scale.dtype == torch.float32 and scale.is_cuda
     dev = scale.device
-    for i0 in range(0, len(dirs), MAX_DIRS_PER_CALL):
-        chunk = dirs[i0:i0 + MAX_DIRS_PER_CALL]
+    pairs = _pair_up(dirs)
+    fuse_loss = loss_weights is not None and len(pairs) <= MAX_DIRS_PER_CALL and all(x.mode == 0 for x in dirs)
+    w_of = {id(x): float(w) for x, w in zip(dirs, loss_weights)} if fuse_loss else {}
+    loss_out = None
+    for i0 in range(0, len(pairs), MAX_DIRS_PER_CALL):
+        chunk = pairs[i0:i0 + MAX_DIRS_PER_CALL]
         arr = (ClipDir * len(chunk))()
-        k_pad = chunk[0].x.shape[1]
-        for k, dr in enumerate(chunk):
+        k_pad = chunk[0][0].x.shape[1]
+        for k, (dr, mir) in enumerate(chunk):
             assert dr.x.shape[1] == k_pad and dr.y.shape[1] == k_pad
             n_col_tiles, _, _ = _plan(dr.r, dr.c, k_pad, compute)
             part = torch.empty((n_col_tiles, dr.r, 2), dtype=torch.float32, device=dev)
@@ -189,7 +252,28 @@ def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.T
             e.x, e.y, e.r, e.c, e.label_off = ptr(dr.x), ptr(dr.y), dr.r, dr.c, dr.label_off
             e.part, e.diag, e.lse, e.loss_part = ptr(part), ptr(dr.diag), ptr(dr.lse), ptr(dr.loss_part)
             e.mode, e.hmax = dr.mode, ptr(dr.hmax)
-        check(_lib.lib().mmk_clip_forward(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), stream()))
+            if mir is not None:
+                mpart = torch.empty((_lib.lib().mmk_clip_mirror_tiles(dr.r), dr.c, 2), dtype=torch.float32, device=dev)
+                mir.lse = torch.empty(mir.r, dtype=torch.float32, device=dev)
+                mir.diag = dr.diag          # label_off = 0 on both sides: the same diagonal
+                mir.loss_part = torch.empty((mir.r + 255) // 256, dtype=torch.float32, device=dev)
+                mir._keep.append(mpart)
+                e.mirror_part, e.mirror_lse, e.mirror_loss_part = ptr(mpart), ptr(mir.lse), ptr(mir.loss_part)
+        if fuse_loss:
+            n_red = sum(1 + (m is not None) for _, m in chunk)
+            fin = torch.empty(1 + n_red * ((max(max(x.r, x.c) for x, _ in chunk) + 255) // 256), dtype=torch.float32, device=dev)
+            arr[0].fin_ws, arr[0].fin_ws_floats = ptr(fin), fin.numel()
+            chunk[0][0]._keep.append(fin)
+            ws = [w_of[id(x)] for pair in chunk for x in pair if x is not None]
+            w_arr = (C.c_float * len(ws))(*ws)
+            out = torch.empty((), dtype=torch.float32, device=dev)
+            written = C.c_int32(0)
+            check(_lib.lib().mmk_clip_forward_loss(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), C.cast(w_arr, C.c_void_p),
+                                                   ptr(out), C.addressof(written), stream()))
+            loss_out = out if written.value else None
+        else:
+            check(_lib.lib().mmk_clip_forward(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), stream()))
+    return loss_out
 
 
 def reduce_sums(parts: Sequence[torch.Tensor], weights: Sequence[float], separate: bool = False,
@@ -212,21 +296,32 @@ def reduce_sums(parts: Sequence[torch.Tensor], weights: Sequence[float], separat
 
 def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.Tensor, upstream: torch.Tensor,
                   dscale: Optional[torch.Tensor]) -> None:
-    """dX for every direction (scattered into dir.dx) and dscale += d loss / d scale."""
+    """dX for every direction (scattered into dir.dx) and dscale += d loss / d scale.  Mirrored directions share one
+    gradient-tile pass: it stores G for the first and G^T, which is the second one's G."""
     dev = scale.device
     assert upstream.dtype == torch.float32 and upstream.is_cuda
     cdt = compute_torch_dtype(compute)
+    mirror_src = {}
+    for a, b in _pair_up(dirs, backward=True):
+        if b is not None:
+            mirror_src[id(b)] = a
     for i0 in range(0, len(dirs), MAX_DIRS_PER_CALL):
         chunk = dirs[i0:i0 + MAX_DIRS_PER_CALL]
+        if any(id(x) in mirror_src for x in chunk[:1]):   # a pair must not straddle two calls
+            mirror_src.pop(id(chunk[0]), None)
         arr = (ClipDir * len(chunk))()
         k_pad = chunk[0].x.shape[1]
         r_max, c_max = max(x.r for x in chunk), max(x.c for x in chunk)
         _, _, n_split = _plan(r_max, c_max, k_pad, compute)
         keep = []
+        gbuf = {}
+        in_chunk = {id(x) for x in chunk}
         for k, dr in enumerate(chunk):
             r_pad, c_pad = round_up(dr.r, 128), round_up(dr.c, 128)
             _, n_grad_blocks, _ = _plan(dr.r, dr.c, k_pad, compute)
-            g = torch.empty((r_pad, c_pad), dtype=cdt, device=dev)
+            src = mirror_src.get(id(dr))
+            ready = src is not None and id(src) in gbuf
+            g = gbuf[id(src)][1] if ready else torch.empty((r_pad, c_pad), dtype=cdt, device=dev)
             slab = torch.empty((n_split, r_pad, k_pad), dtype=torch.float32, device=dev)
             ds_part = torch.empty(n_grad_blocks, dtype=torch.float32, device=dev)
             keep += [g, slab, ds_part]
@@ -242,6 +337,13 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.
             e.src, e.normalize = ptr(dr.src), int(dr.normalize)
             e.mode, e.hmax = dr.mode, ptr(dr.hmax)
             e.src_dtype = dtype_tag(dr.src.dtype) if dr.src is not None else 0
+            e.g_ready = int(ready)
+            mir = next((b for b in chunk[k + 1:k + 2] if mirror_src.get(id(b)) is dr), None)
+            if mir is not None and id(mir) in in_chunk:
+                gt = torch.empty((c_pad, r_pad), dtype=cdt, device=dev)     # = the mirror's [r_pad', c_pad'] G
+                gbuf[id(dr)] = (g, gt)
+                keep.append(gt)
+                e.gT, e.ldgt = ptr(gt), r_pad
         check(_lib.lib().mmk_clip_backward(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), ptr(upstream),
                                            ptr(dscale), stream()))
         del keep  # the caching allocator keeps the blocks alive until the stream has consumed them

@@ -272,8 +272,9 @@ class _Run:
                 continue  # :283-287 / :314-316
             p = _Pair(spec=spec, r_global=mg.n)
             p.ma, p.mb, p.mg = ma, mb, mg
-            p.a_g, p.a_gt = K.pack_rows(va.src, _compose(va.rows, mg.idx_a), mg.n, o.l2_normalize, self.compute, self.needs_grad)
-            p.b_g, p.b_gt = K.pack_rows(vb.src, _compose(vb.rows, mg.idx_b), mg.n, o.l2_normalize, self.compute, self.needs_grad)
+            (p.a_g, p.a_gt), (p.b_g, p.b_gt) = K.pack_rows_many(
+                [(va.src, _compose(va.rows, mg.idx_a), mg.n, o.l2_normalize, self.needs_grad),
+                 (vb.src, _compose(vb.rows, mg.idx_b), mg.n, o.l2_normalize, self.needs_grad)], self.compute)
             if local_mode:
                 has_local = va.local is not None and vb.local is not None
                 if not has_local:
@@ -303,8 +304,11 @@ class _Run:
         for p in self.pairs:
             self._build_dirs(p)
             dirs_all += p.dirs
+        self.fused_loss = None
         if dirs_all:
-            K.clip_forward(dirs_all, self.d, self.compute, self.scale32)
+            # one rank, plain pairs: the reduction launch can form the loss value itself (weights = kappa of each direction)
+            w = [p.kappa_loss for p in self.pairs for _ in p.dirs] if W == 1 else None
+            self.fused_loss = K.clip_forward(dirs_all, self.d, self.compute, self.scale32, loss_weights=w)
         self.align_dirs = []
         if o.modality_alignment:
             self._build_alignment(views, dev)
@@ -492,6 +496,8 @@ class _Run:
                 p.lse_global = {r: d.lse for r, d in by_role.items()}
         if not terms:  # this rank owns no rows (e.g. it lacks a modality): graph-attached zero
             return torch.zeros((), dtype=torch.float32, device=dev)
+        if self.fused_loss is not None and not exchange_sum:
+            return self.fused_loss
         out = None
         for i0 in range(0, len(terms), 2 * K.MAX_DIRS_PER_CALL):
             part = K.reduce_sums(terms[i0:i0 + 2 * K.MAX_DIRS_PER_CALL], weights[i0:i0 + 2 * K.MAX_DIRS_PER_CALL])

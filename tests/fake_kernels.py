@@ -55,7 +55,11 @@ def pack_rows(src, idx, r, normalize, compute, want_transpose):
     return dst, (dst.T.contiguous() if want_transpose else None)
 
 
-def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.Tensor) -> None:
+def pack_rows_many(reqs, compute):
+    return [pack_rows(*q[:4], compute, q[4]) for q in reqs]
+
+
+def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.Tensor, loss_weights=None) -> None:
     CALLS["clip_forward"] += 1
     s = scale.double().item()
     for dr in dirs:

@@ -444,6 +444,74 @@ def loss_n8192_leg(dev, n: int = 8192, d: int = 512, iters: int = 10):
     return roof
 
 
+def _leg_eager(args, dev):
+    return eager_gpu_leg(args.batch, int(os.environ.get("RANK", "0")), dev, args.small)
+
+
+def _leg_loss_n8192(args, dev):
+    return loss_n8192_leg(dev)
+
+
+def _leg_three_tower(args, dev):
+    return three_tower_leg(64 if args.small else 256, dev, args.small)
+
+
+def _leg_ijepa(args, dev):
+    return ijepa_leg(16 if args.small else 128, dev, args.small)
+
+
+LEGS = {"eager_gpu": _leg_eager, "loss_n8192": _leg_loss_n8192, "three_tower": _leg_three_tower, "ijepa_vitl": _leg_ijepa}
+LEG_TIMEOUT_S = {"eager_gpu": 240, "loss_n8192": 120, "three_tower": 240, "ijepa_vitl": 240}
+
+
+def leg_main(args) -> int:
+    """``python bench.py --leg NAME``: one bounded leg on cuda:LOCAL_RANK, its JSON object as the last stdout line."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    if not torch.cuda.is_available():
+        raise SystemExit("[bench] no GPU visible; the legs have no CPU path")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from mmlearn_amd import _lib
+
+    _lib.check(_lib.lib().mmk_device_check())
+    out = LEGS[args.leg](args, dev)
+    torch.cuda.synchronize()
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+def run_leg(name: str, args) -> dict:
+    """Start ``bench.py --leg name`` as a CHILD process (never an exec of this one: it has initialised the GPU) and read the
+    JSON object it prints.  A leg that fails -- a Python error, a GPU fault that aborts the child, the time bound -- becomes
+    ``{"error": ...}`` in the line; the headline numbers are already taken by then."""
+    import subprocess
+
+    if os.environ.get("MMK_BENCH_LEGS_INPROCESS") is not None:   # debugging switch: the leg in this very process
+        print(f"[bench] leg {name} (in process) ...", file=sys.stderr, flush=True)
+        return LEGS[name](args, torch.device("cuda", torch.cuda.current_device()))
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--batch", str(args.batch)] + (["--small"] if args.small else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "MASTER_ADDR", "MASTER_PORT", "MMK_BENCH_FORCE_DIST")}
+    print(f"[bench] leg {name} ...", file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
+    try:
+        cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=LEG_TIMEOUT_S[name])
+    except subprocess.TimeoutExpired:
+        print(f"[bench] leg {name}: no result within {LEG_TIMEOUT_S[name]} s", file=sys.stderr, flush=True)
+        return {"error": f"timed out after {LEG_TIMEOUT_S[name]} s"}
+    lines = [ln for ln in cp.stdout.splitlines() if ln.strip()]
+    if cp.returncode == 0 and lines:
+        try:
+            out = json.loads(lines[-1])
+            print(f"[bench] leg {name}: done in {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+            return out
+        except ValueError:
+            pass
+    tail = " | ".join(cp.stderr.strip().splitlines()[-3:])[-400:]
+    print(f"[bench] leg {name}: exit code {cp.returncode}: {tail}", file=sys.stderr, flush=True)
+    return {"error": f"exit code {cp.returncode}: {tail}"}
+
+
 def _free_port() -> int:
     import socket
 
@@ -521,7 +589,12 @@ def main():
     ap.add_argument("--no-eager-leg", action="store_true", help="skip the stock-step leg (vs_baseline becomes null)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the bounded configs[3] / configs[4] / N=8192 legs")
     ap.add_argument("--no-fused-encoder-ops", action="store_true", help="keep torch LayerNorm / HF quick-GELU in the encoders")
+    ap.add_argument("--leg", choices=sorted(LEGS), default=None,
+                    help="run ONE of the bounded legs alone and print its JSON object (how the headline run starts them: each in a "
+                         "process of its own, so that a leg can fail without taking the headline line with it)")
     args = ap.parse_args()
+    if args.leg is not None:
+        raise SystemExit(leg_main(args))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare ``python bench.py --gpus N``: be the launcher (the torchrun form keeps working: it sets WORLD_SIZE)
@@ -618,24 +691,15 @@ def main():
     # ---- legs outside the headline timed region (bounded; all on the driver's clock) ------------------------------
     del stepper, opt, task, batch, loss, loss_fn
     torch.cuda.empty_cache()
+    # Each leg runs in a child process of its own (run_leg): this process keeps its result whatever happens there.
     eager = None
     if not args.no_eager_leg and not args.no_fused_encoder_ops:
         # every rank times the stock step on its own GPU (no collectives); rank 0's figure is reported
-        eager = eager_gpu_leg(args.batch, rank, dev, args.small)
+        eager = run_leg("eager_gpu", args)
     extra = {}
     if rank == 0 and world == 1 and not force_dist and not args.no_extra_legs:
-        try:
-            extra["loss_n8192"] = loss_n8192_leg(dev)
-        except Exception as e:   # an extra leg must never take the headline line down with it
-            extra["loss_n8192"] = {"error": repr(e)[:300]}
-        try:
-            extra["three_tower"] = three_tower_leg(64 if args.small else 256, dev, args.small)
-        except Exception as e:
-            extra["three_tower"] = {"error": repr(e)[:300]}
-        try:
-            extra["ijepa_vitl"] = ijepa_leg(16 if args.small else 128, dev, args.small)
-        except Exception as e:
-            extra["ijepa_vitl"] = {"error": repr(e)[:300]}
+        for name in ("loss_n8192", "three_tower", "ijepa_vitl"):
+            extra[name] = run_leg(name, args)
 
     if rank == 0:
         n_rows, n_cols, d = args.batch, args.batch * world, 512
@@ -674,7 +738,7 @@ def main():
             "scaling": "weak",
             # value / (N x the stock step's pairs/s on one GPU): the stock step is timed at N = 1 shape (local negatives, no
             # gradient all-reduce), i.e. the baseline is credited with perfect scaling
-            "vs_baseline": round(args.batch * world * args.steps / dt / (eager["pairs_s"] * world), 3) if eager else None,
+            "vs_baseline": round(args.batch * world * args.steps / dt / (eager["pairs_s"] * world), 3) if eager and "pairs_s" in eager else None,
             "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: CLIP ViT-B/16 + BERT-base, D=512 projection, bf16 autocast, "

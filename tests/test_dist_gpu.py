@@ -139,6 +139,27 @@ def _seeded_inputs(rank, b, d, dtype):
     return a, t, ids
 
 
+def _seeded_rank(rank, b, d, dtype):
+    """Both flag cells of one rank of the seeded case; collectives are whatever `dist` currently provides."""
+    import mmlearn_amd.losses as L
+
+    dev = torch.device("cuda", 0)
+    tdt = torch.bfloat16 if dtype == "bfloat16" else torch.float32
+    a, t, ids = _seeded_inputs(rank, b, d, dtype)
+    res = {}
+    for ll, gwg in ((False, False), (True, True)):
+        ea, et = a.to(dev, tdt).requires_grad_(True), t.to(dev, tdt).requires_grad_(True)
+        s = torch.tensor(1 / 0.07, device=dev, requires_grad=True)
+        fn = L.ContrastiveLoss(local_loss=ll, gather_with_grad=gwg, static_shapes=True)
+        fn.prefetch_gather("rgb", ea, ids.to(dev))
+        fn.prefetch_gather("text", et, ids.to(dev))
+        loss = fn({"rgb_embedding": ea, "text_embedding": et}, {"rgb": ids.to(dev), "text": ids.to(dev)}, s, [L.LossPairSpec(("rgb", "text"))])
+        loss.float().backward()
+        res[(ll, gwg)] = {"loss": float(loss.detach().float()), "ga": ea.grad.float().cpu().numpy(), "gt": et.grad.float().cpu().numpy(),
+                          "ds": float(s.grad)}
+    return res
+
+
 def _seeded_worker(rank, world, port, b, d, dtype, q):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -148,44 +169,120 @@ def _seeded_worker(rank, world, port, b, d, dtype, q):
                 sys.path.insert(0, p)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         _stage_collectives_through_host()
-        import mmlearn_amd.losses as L
-
-        dev = torch.device("cuda", 0)
-        tdt = torch.bfloat16 if dtype == "bfloat16" else torch.float32
-        a, t, ids = _seeded_inputs(rank, b, d, dtype)
-        res = {}
-        for ll, gwg in ((False, False), (True, True)):
-            ea, et = a.to(dev, tdt).requires_grad_(True), t.to(dev, tdt).requires_grad_(True)
-            s = torch.tensor(1 / 0.07, device=dev, requires_grad=True)
-            fn = L.ContrastiveLoss(local_loss=ll, gather_with_grad=gwg, static_shapes=True)
-            fn.prefetch_gather("rgb", ea, ids.to(dev))
-            fn.prefetch_gather("text", et, ids.to(dev))
-            loss = fn({"rgb_embedding": ea, "text_embedding": et}, {"rgb": ids.to(dev), "text": ids.to(dev)}, s, [L.LossPairSpec(("rgb", "text"))])
-            loss.float().backward()
-            res[(ll, gwg)] = {"loss": float(loss.detach().float()), "ga": ea.grad.float().cpu().numpy(), "gt": et.grad.float().cpu().numpy(),
-                              "ds": float(s.grad)}
-        q.put((rank, res, None))
+        q.put((rank, _seeded_rank(rank, b, d, dtype), None))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
         q.put((rank, None, traceback.format_exc()))
 
 
+class _ThreadRanks:
+    """`world` ranks as threads of ONE process (a GPU box admits at most 6 processes on its card, so eight rank processes
+    plus the test runner cannot share it).  Same seam as _stage_collectives_through_host: all_gather_into_tensor /
+    all_reduce exchange host copies — here through a barrier-guarded slot list, reduced in rank order — and the rank /
+    world queries answer per thread.  The loss code and every HIP launch are the real ones.  Backward passes run on
+    autograd's single device thread, one after the other, so a collective issued there cannot meet its peers: the one the
+    path has (the SUM of the scalar d loss / d scale) is recorded in `deferred` and applied by the caller afterwards."""
+
+    def __init__(self, world):
+        import threading
+
+        self.world, self.tl = world, threading.local()
+        self.bar = threading.Barrier(world, timeout=300)
+        self.slots = [None] * world
+        self.deferred = []
+
+    def _exchange(self, h):
+        self.slots[self.tl.rank] = h
+        self.bar.wait()
+        got = list(self.slots)
+        self.bar.wait()
+        return got
+
+    def install(self):
+        def all_gather_into_tensor(out, inp, group=None, async_op=False):
+            parts = self._exchange(inp.detach().cpu().clone().view(-1))
+            out.copy_(torch.cat(parts).view(out.shape))
+            return _Done() if async_op else None
+
+        def all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+            assert op == dist.ReduceOp.SUM
+            if getattr(self.tl, "rank", None) is None:   # autograd's device thread (see the class docstring)
+                assert t.numel() == 1
+                self.deferred.append(t)
+                return _Done() if async_op else None
+            parts = self._exchange(t.detach().cpu().clone())
+            tot = parts[0].clone()
+            for p_ in parts[1:]:
+                tot += p_
+            t.copy_(tot)
+            return _Done() if async_op else None
+
+        dist.all_gather_into_tensor, dist.all_reduce = all_gather_into_tensor, all_reduce
+        dist.is_initialized = lambda: True
+        dist.get_world_size = lambda group=None: self.world
+        dist.get_rank = lambda group=None: self.tl.rank
+        dist.get_backend = lambda group=None: "gloo"
+
+
+def _seeded_threads_worker(world, b, d, dtype, q):
+    try:
+        import threading
+
+        for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        tr = _ThreadRanks(world)
+        tr.install()
+        torch.cuda.init()
+        out, errs = {}, {}
+
+        def run(rank):
+            tr.tl.rank = rank
+            try:
+                torch.cuda.set_device(0)
+                out[rank] = _seeded_rank(rank, b, d, dtype)
+            except Exception:
+                errs[rank] = traceback.format_exc()
+                tr.bar.abort()
+
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if not errs:
+            # the deferred collective: cell (F,F) all-reduces d loss / d scale in backward (one call per rank); cell (T,T)
+            # is local_loss and has none
+            assert len(tr.deferred) == world, len(tr.deferred)
+            total = sum(out[r][(False, False)]["ds"] for r in range(world))
+            for r in range(world):
+                out[r][(False, False)]["ds"] = total
+        for r in range(world):
+            q.put((r, out.get(r), errs.get(r)))
+    except Exception:
+        for r in range(world):
+            q.put((r, None, traceback.format_exc()))
+
+
 @pytest.mark.parametrize("world,b,d,dtype", [(2, 1024, 512, "bfloat16"), (4, 333, 200, "float32"), (8, 1024, 512, "bfloat16")])
 @pytest.mark.timeout(900)
 def test_multi_rank_hip_path_seeded_vs_oracle(world, b, d, dtype):
     """BASELINE-sized shards (per-rank 1024 x 512 bf16: 128x128 tiles, label offsets, r != c) against the oracle.  The
-    world = 8 case IS BASELINE configs[2]: eight ranks (sharing this one GPU), per-rank batch 1024, global batch 8192, every
+    world = 8 case IS BASELINE configs[2]: eight ranks (threads of one process sharing this one GPU), per-rank batch 1024, global batch 8192, every
     rank computing its R = 1024 x C = 8192 row shard with label_off = 1024 r, cells (F,F) and (T,T)."""
     from oracle import clip_oracle as co
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_seeded_worker, args=(r, world, 29730 + world, b, d, dtype, q)) for r in range(world)]
+    if world > 4:   # process guard of the GPU box: ranks become threads of one child
+        procs = [ctx.Process(target=_seeded_threads_worker, args=(world, b, d, dtype, q))]
+    else:
+        procs = [ctx.Process(target=_seeded_worker, args=(r, world, 29730 + world, b, d, dtype, q)) for r in range(world)]
     for p in procs:
         p.start()
     out = {}
-    for _ in procs:
+    for _ in range(world):
         rank, res, err = q.get(timeout=800)
         assert err is None, f"rank {rank} failed:\n{err}"
         out[rank] = res

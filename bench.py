@@ -461,12 +461,16 @@ def _leg_ijepa(args, dev):
 
 
 LEGS = {"eager_gpu": _leg_eager, "loss_n8192": _leg_loss_n8192, "three_tower": _leg_three_tower, "ijepa_vitl": _leg_ijepa}
-LEG_TIMEOUT_S = {"eager_gpu": 240, "loss_n8192": 120, "three_tower": 240, "ijepa_vitl": 240}
+LEG_TIMEOUT_S = {"eager_gpu": 240, "loss_n8192": 120, "three_tower": 150, "ijepa_vitl": 240}
 
 
 def leg_main(args) -> int:
     """``python bench.py --leg NAME``: one bounded leg on cuda:LOCAL_RANK, its JSON object as the last stdout line."""
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    import faulthandler
+
+    # a leg that stops making progress says where (all Python threads) shortly before the parent gives up on it
+    faulthandler.dump_traceback_later(max(LEG_TIMEOUT_S[args.leg] - 20, 20), exit=False)
     if not torch.cuda.is_available():
         raise SystemExit("[bench] no GPU visible; the legs have no CPU path")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -496,8 +500,9 @@ def run_leg(name: str, args) -> dict:
     t0 = time.perf_counter()
     try:
         cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=LEG_TIMEOUT_S[name])
-    except subprocess.TimeoutExpired:
-        print(f"[bench] leg {name}: no result within {LEG_TIMEOUT_S[name]} s", file=sys.stderr, flush=True)
+    except subprocess.TimeoutExpired as e:
+        err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+        print(f"[bench] leg {name}: no result within {LEG_TIMEOUT_S[name]} s; its stderr ended with:\n{err[-3000:]}", file=sys.stderr, flush=True)
         return {"error": f"timed out after {LEG_TIMEOUT_S[name]} s"}
     lines = [ln for ln in cp.stdout.splitlines() if ln.strip()]
     if cp.returncode == 0 and lines:

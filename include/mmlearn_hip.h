@@ -76,10 +76,12 @@ int mmk_match_ids(const int64_t* ids_a, int n_a, const int64_t* ids_b, int n_b, 
  *   src  : [n_src, d] of src_dtype; idx: int32[r] or NULL (identity)
  *   dst  : [r_pad, k_pad] of compute type (bf16 or f32), rows >= r and columns >= d zero
  *   dstT : [k_pad, ldt] transpose of dst (NULL to skip), ldt >= r_pad, zero padded
+ *   norm_out : float[r_pad] L2 norm of every packed row (of the values as rounded to the compute type; 0 for
+ *          the padding rows), or NULL.  The forward uses them to bound the logits of a tile (mmk_clip_dir.x_norm).
  * k_pad is a multiple of 64 (bf16) / 32 (f32); r_pad a multiple of 128.
  */
 int mmk_pack_rows(const void* src, int src_dtype, int n_src, int d, const int32_t* idx, int r, int normalize,
-                  void* dst, void* dstT, int r_pad, int k_pad, int ldt, int compute, void* stream);
+                  void* dst, void* dstT, int r_pad, int k_pad, int ldt, int compute, float* norm_out, void* stream);
 
 /* ------------------------------------------------------------------ CLIP loss
  * One "direction" = CE over the rows of  s * X @ Y^T  with label(i) = label_off + i.
@@ -94,10 +96,10 @@ typedef struct {
   int32_t c;          /* columns                                            */
   int32_t label_off;  /* positive column of row i is label_off + i         */
   int32_t ldt;        /* leading dimension of yT                            */
-  float* part;        /* fwd workspace: float2[n_col_tiles * r] (max,sum)   */
+  float* part;        /* fwd workspace: float2[n_col_tiles * r] (ref,sum)   */
   float* diag;        /* fwd out: float[r] positive logit                    */
   float* lse;         /* fwd out: float[r] row log-sum-exp                   */
-  float* loss_part;   /* fwd out: float[ceil(r/256)] block sums of (lse_i - diag_i) */
+  float* loss_part;   /* fwd out: float[ceil(r/64)] sums of (lse_i - diag_i) over blocks of 64 rows */
   /* backward */
   const float* lse_col; /* float[c]: LSE of the opposite direction for every column */
   void* g;            /* bwd workspace: [r_pad, ldg] compute type            */
@@ -130,14 +132,15 @@ typedef struct {
    * direction is then passed with g = this gT and g_ready = 1 and skips its own tile pass. */
   float* mirror_part;      /* fwd workspace: float2[mmk_clip_mirror_tiles(r) * c] */
   float* mirror_lse;       /* fwd out: float[c] */
-  float* mirror_loss_part; /* fwd out: float[ceil(c/256)] */
+  float* mirror_loss_part; /* fwd out: float[ceil(c/64)] */
   void* gT;                /* bwd (optional): [round_up(c,128), ldgt] compute type */
   int32_t ldgt;            /* >= round_up(r, 128) */
   int32_t g_ready;         /* bwd: g already holds this direction's G (written as another direction's gT) */
-  /* fwd, first direction of a call only: workspace of mmk_clip_forward_loss's in-launch loss combine -- one ticket word
-   * + one float per reduction workgroup (ceil(max rows / 256) x (directions + mirrors)); NULL = no in-launch combine */
-  float* fin_ws;
-  int32_t fin_ws_floats;
+  /* fwd (optional): L2 norms of the packed rows of x / y (mmk_pack_rows norm_out).  With both set, an interior tile whose
+   * logits are bounded by |s| log2(e) max|x_i| max|y_j| <= 48 takes ONE exponential per element for the row and the column
+   * statistics and searches no maximum; without them every tile takes per-row / per-column maxima. */
+  const float* x_norm;
+  const float* y_norm;
 } mmk_clip_dir;
 
 /* rows of the mirror_part workspace for r owned rows */
@@ -151,6 +154,7 @@ typedef struct mmk_pack_req {
   void* dst;            /* [r_pad, k_pad] compute type */
   void* dstT;           /* [k_pad, ldt] compute type, or NULL */
   int32_t r, r_pad, normalize, ldt;
+  float* norm;          /* float[r_pad] L2 norms of the packed rows, or NULL */
 } mmk_pack_req;
 int mmk_pack_rows_many(const mmk_pack_req* reqs, int n, int src_dtype, int d, int k_pad, int compute, void* stream);
 
@@ -158,17 +162,20 @@ int mmk_pack_rows_many(const mmk_pack_req* reqs, int n, int src_dtype, int d, in
 int mmk_clip_plan(int r, int c, int k_pad, int compute, int32_t* n_col_tiles, int32_t* n_grad_blocks,
                   int32_t* n_split);
 
-/* forward: similarity tiles + online row log-sum-exp + positive logit (K5-K6 of SURVEY 2.3:
- * _safe_matmul, logit_scale*, F.cross_entropy of contrastive.py:134-144,327-340), all
- * directions in one launch; scale is a device float (the reference's 0-dim logit_scale). */
+/* forward: similarity tiles + per-tile softmax statistics + positive logit, then the merge of the tile partials into the
+ * row log-sum-exp (K5-K6 of SURVEY 2.3: _safe_matmul, logit_scale*, F.cross_entropy of contrastive.py:134-144,327-340): two
+ * launches for all directions; scale is a device float (the reference's 0-dim logit_scale).
+ * `tickets`: 4-byte slots [n_tickets >= mmk_clip_tickets(dirs, n_dirs)], only used by mmk_clip_forward_loss; slot 0 is a
+ * counter that must be ZERO on entry and is zero again when the call's launches have completed (one buffer per stream can
+ * be reused call after call), the other slots need no initialisation. */
+int mmk_clip_tickets(const mmk_clip_dir* dirs, int n_dirs);
 int mmk_clip_forward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale,
-                     void* stream);
-/* The same, and for small problems the weighted loss value  sum_k loss_w[k] * sum_i (lse_i - diag_i)  (contrastive.py:134-144,160)
- * is formed by the reduction launch itself: loss_w (host) holds one weight per direction, followed by its mirror's when
- * it has one; *loss_written = 1 when loss_out (device float) was written (needs dirs[0].fin_ws), 0 when the caller has to
- * combine the loss_part arrays with mmk_reduce_sums. */
+                     int32_t* tickets, int n_tickets, void* stream);
+/* The same, and the weighted loss value  sum_k loss_w[k] * sum_i (lse_i - diag_i)  (contrastive.py:134-144,160) is written
+ * to loss_out (device float) by the merge launch (the workgroup that draws the last ticket adds the block sums in a fixed
+ * order): loss_w (host) holds one weight per direction, followed by its mirror's when it has one. */
 int mmk_clip_forward_loss(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale,
-                          const float* loss_w, float* loss_out, int32_t* loss_written, void* stream);
+                          const float* loss_w, float* loss_out, int32_t* tickets, int n_tickets, void* stream);
 /* separate=0: out[0] = sum_k weights[k] * sum(ptrs[k][0..counts[k]))  -- the loss value
  * (contrastive.py:134-144,160; weight = w / (2 * rows in the mean));  separate=1: out[k] = weights[k] * sum(ptrs[k]) */
 int mmk_reduce_sums(const float* const* ptrs, const int32_t* counts, const float* weights, int n, int separate, float* out,

@@ -47,7 +47,7 @@ class ClipDir(C.Structure):
         ("mode", C.c_int32), ("hmax", C.c_void_p),
         ("mirror_part", C.c_void_p), ("mirror_lse", C.c_void_p), ("mirror_loss_part", C.c_void_p),
         ("gT", C.c_void_p), ("ldgt", C.c_int32), ("g_ready", C.c_int32),
-        ("fin_ws", C.c_void_p), ("fin_ws_floats", C.c_int32),
+        ("x_norm", C.c_void_p), ("y_norm", C.c_void_p),
     ]
 
 
@@ -55,7 +55,7 @@ class PackReq(C.Structure):
     """mirror of ``mmk_pack_req``"""
 
     _fields_ = [("src", C.c_void_p), ("idx", C.c_void_p), ("dst", C.c_void_p), ("dstT", C.c_void_p),
-                ("r", C.c_int32), ("r_pad", C.c_int32), ("normalize", C.c_int32), ("ldt", C.c_int32)]
+                ("r", C.c_int32), ("r_pad", C.c_int32), ("normalize", C.c_int32), ("ldt", C.c_int32), ("norm", C.c_void_p)]
 
 
 class EmaEntry(C.Structure):
@@ -75,10 +75,11 @@ _SIGNATURES = {
     "mmk_match_ids": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "mmk_clip_mirror_tiles": [_i],
     "mmk_pack_rows_many": [_vp, _i, _i, _i, _i, _i, _vp],
-    "mmk_clip_forward_loss": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "mmk_pack_rows": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mmk_clip_forward_loss": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "mmk_clip_tickets": [_vp, _i],
+    "mmk_pack_rows": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "mmk_clip_plan": [_i, _i, _i, _i, _vp, _vp, _vp],
-    "mmk_clip_forward": [_vp, _i, _i, _i, _i, _vp, _vp],
+    "mmk_clip_forward": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "mmk_reduce_sums": [_vp, _vp, _vp, _i, _i, _vp, _vp],
     "mmk_match_workspace_ints": [_i, _i],
     "mmk_clip_backward": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

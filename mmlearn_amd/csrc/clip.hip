@@ -67,12 +67,14 @@ struct Prob {
   int ldp, ldq;   // elements
   int tiles_m, tiles_n;
   // EPI_STATS
-  float2* part;   // [tiles_m][part_ld = N]  (column-tile major: coalesced for the reduce)
+  float2* part;   // [tiles_m][part_ld = N]  (column-tile major: coalesced for the merge)
   int part_ld;
   float* diag;    // [N]
   int label_off;
-  float2* mpart;  // EPI_STATS, mirrored direction: [tiles_n * 2][mpart_ld = M] column (max2, sum) partials, or null
+  float2* mpart;  // EPI_STATS, mirrored direction: [tiles_n * 2][mpart_ld = M] column (ref2, sum) partials, or null
   int mpart_ld;
+  const float* qn;      // [>= N] L2 norms of the Q rows as packed (what the MFMA multiplies), or null: no bounded fast path
+  const float* pn;      // [>= M] the same for the P rows
   char* GT;       // EPI_GRAD: optional transposed G [>= tiles_m*BM][ldgt]
   int ldgt;
   // EPI_GRAD
@@ -93,8 +95,21 @@ struct Prob {
 struct ProbBatch {
   Prob p[MAX_PROBS];
   int n_split;
-  unsigned* clear_word;   // EPI_STATS: cleared by the first workgroup (ticket counter of the reduction that follows), or null
+  int n_probs;
+  int dbg;                // timing ablations (MMK_SIM_DBG, wrong results): 1 = no row statistics, 2 = no column statistics,
+                          // 4 = no MFMAs; 8 = never take the bounded fast path (results stay right)
 };
+
+// device-coherent accesses for data that one workgroup writes and another reads within the same launch (block sums of
+// the merge kernel): sc1 stores / loads that do not linger in a non-coherent XCD L2
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float2* p, float2 v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_agent(const float2* p) {
+  return __builtin_bit_cast(float2, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 
 // ------------------------------------------------------------------ main loop
 // LOADER 0: global -> VGPR -> ds_write_b128 staging (2 LDS stages).
@@ -151,8 +166,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
   constexpr int STAGE_BYTES = ROWS * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // NSTAGE * STAGE_BYTES (dynamic: may exceed 64 KiB)
 
-  if (EPI == EPI_STATS && batch.clear_word != nullptr && blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0)
-    __hip_atomic_store(batch.clear_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int zsplit = (EPI == EPI_PLAIN) ? (blockIdx.z % batch.n_split) : 0;
   const int zprob = (EPI == EPI_PLAIN) ? (blockIdx.z / batch.n_split) : blockIdx.z;
   const Prob& p = batch.p[zprob];
@@ -211,6 +224,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
       base = p.Q + ((size_t)g * p.ldq + k_begin) * sizeof(T);
     }
     gsrc[u] = base + ch * 16;
+  }
+
+  // EPI_STATS / EPI_GRAD: L2 norm of "this thread's" operand row (threads 0 .. BN-1: the tile's Q rows, BN .. BN+BM-1: its P rows),
+  // fetched now, reduced to the tile's bound after the main loop
+  float my_nrm = 0.f;
+  if ((EPI == EPI_STATS || EPI == EPI_GRAD) && p.qn != nullptr) {
+    if (tid < BN) my_nrm = (n0 + tid < p.N) ? p.qn[n0 + tid] : 0.f;
+    else if (tid < BN + BM) my_nrm = (m0 + tid - BN < p.M) ? p.pn[m0 + tid - BN] : 0.f;
   }
 
   f32x16 acc[MT][NT];
@@ -295,29 +316,57 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();  // every wave's share of stage kt is in LDS; stage kt-1 fully consumed
       if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);  // refill the buffer that stage kt-1 just released
-      compute_stage(smem + (kt % NSTAGE) * STAGE_BYTES);
+      if (!(batch.dbg & 4)) compute_stage(smem + (kt % NSTAGE) * STAGE_BYTES);
     }
     wait_vmcnt<0>();
     __syncthreads();
   }
 
+  // Bound of the tile's logits in the log2 domain from the operand norms (Cauchy-Schwarz): |u| <= R for every element.
+  // Returns 0 when the norms are unknown.  Block-uniform; contains a barrier (call it from uniform control flow only).
+  auto tile_bound = [&](float s2) -> float {
+    float* wmax = reinterpret_cast<float*>(smem + 2 * BN * 8);        // [4] (behind the [2][BN] float2 area of EPI_STATS)
+    float v = my_nrm;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if (lane == 0) wmax[wave] = v;
+    __syncthreads();
+    float nq = 0.f, np = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w * 64 < BN) nq = fmaxf(nq, wmax[w]);
+      else if (w * 64 < BN + BM) np = fmaxf(np, wmax[w]);
+    }
+    __syncthreads();   // wmax may be overwritten by the caller's LDS use
+    return fabsf(s2) * nq * np * 1.0001f;   // margin: f32 accumulation error of the dot product
+  };
+
   // -------------------------------------------------------------- epilogues
   // element (a, b, e): m = m0 + wm*BM/2 + a*32 + (e&3) + 8*(e>>2) + 4*h ; n = n0 + wn*BN/2 + b*32 + r
   constexpr float LOG2E = 1.4426950408889634f;
   if (EPI == EPI_STATS) {
-    // All softmax arithmetic runs in the log2 domain (u = s*log2e*t): one v_fma/v_sub + v_exp per element.
-    // The per-tile partial (max2, sum) is converted back by the reduce kernel.  INTERIOR tiles (all BM
-    // columns valid) skip the column mask; only the tile that holds the labels looks for the positive.
+    // All softmax arithmetic runs in the log2 domain (u = s*log2e*t): one v_fma + v_exp per element.  A tile leaves one
+    // partial (ref2, sum) per owned row -- sum of 2^(u - ref2) over the tile's columns -- and, for a mirrored direction,
+    // one per column and wn half; lse_merge_kernel combines them.
+    //   FAST path (interior tile, norms known, 2 R <= 96): by Cauchy-Schwarz every |u| of the tile is <= R = |s2| max|q| max|p|,
+    //   so ref2 = R for the whole tile: no maximum search, and ONE exponential per element serves the row sum and the
+    //   column sum (each term is >= 2^-96: nothing flushes, the result is exact to rounding).
+    //   EXACT path (edge tiles, unknown or large norms): per-row / per-column maxima as references.
     const float s = *scale_ptr;
     const float s2 = s * LOG2E;
     const bool interior = (m0 + BM <= p.M);
     const bool has_diag = (m0 < p.label_off + n0 + BN) && (m0 + BM > p.label_off + n0);
-    float2* red = reinterpret_cast<float2*>(smem);  // [2][BN]
+    float2* red = reinterpret_cast<float2*>(smem);                    // [2][BN]
+    bool fast = false;
+    float R = 0.f;
+    if (p.qn != nullptr && interior && (n0 + BN <= p.N) && !(batch.dbg & 8)) {
+      R = tile_bound(s2);
+      fast = (2.f * R <= 96.f);
+    }
+    if (has_diag) {
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
-      const int nl = wn * (BN / 2) + b * 32 + r;
-      const int i = n0 + nl;
-      if (has_diag) {
+      for (int b = 0; b < NT; ++b) {
+        const int i = n0 + wn * (BN / 2) + b * 32 + r;
         const int lab = p.label_off + i;
 #pragma unroll
         for (int a = 0; a < MT; ++a)
@@ -327,99 +376,138 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
             if (j == lab && i < p.N && j < p.M) p.diag[i] = s * acc[a][b][e];
           }
       }
-      float sum = 0.f, m2;
-      if (interior && s2 >= 0.f) {  // fast path: every column valid, max of s*t is at max of t
-        float vmax = -INFINITY;
+    }
+    const bool want_col = p.mpart != nullptr && !(batch.dbg & 2);
+    constexpr int CNT = 16 * MT;
+    if (fast) {
+      float csum[CNT];
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+      for (int c = 0; c < CNT; ++c) csum[c] = 0.f;
+      if (!(batch.dbg & 1)) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e) vmax = fmaxf(vmax, acc[a][b][e]);
-        vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
-        m2 = vmax * s2;
+        for (int b = 0; b < NT; ++b) {
+          float rs = 0.f;
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+          for (int a = 0; a < MT; ++a)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) sum += fast_exp2(fmaf(acc[a][b][e], s2, -m2));
-      } else {  // edge tiles / negative scale: masked extremum of u = s2*t, masked sum
-        float umax = -INFINITY;   // (the accumulators stay untouched: the mirrored column statistics read them again)
+            for (int e = 0; e < 16; ++e) {
+              const float pv = fast_exp2(fmaf(acc[a][b][e], s2, -R));
+              rs += pv;
+              csum[a * 16 + e] += pv;
+            }
+          rs += __shfl_xor(rs, 32);
+          if (h == 0) red[wm * BN + wn * (BN / 2) + b * 32 + r] = make_float2(R, rs);
+        }
+      }
+      __syncthreads();
+      if (tid < BN) {
+        const float2 x = red[tid], y = red[BN + tid];
+        p.part[(size_t)tm * p.part_ld + n0 + tid] = make_float2(R, x.y + y.y);
+      }
+      if (want_col) {
+        const float cs = half_wave_transpose_reduce<CNT, false>(csum, lane);   // lane L: column L & (CNT - 1) of half h
+        const int cidx = lane & (CNT - 1);
+        const int j = m0 + wm * (BM / 2) + (cidx >> 4) * 32 + (cidx & 3) + 8 * ((cidx & 15) >> 2) + 4 * h;
+        if (CNT == 32 || (lane & 16) == 0) p.mpart[(size_t)(tn * 2 + wn) * p.mpart_ld + j] = make_float2(R, cs);
+      }
+    } else {
+      if (!(batch.dbg & 1))
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
+      for (int b = 0; b < NT; ++b) {
+        const int nl = wn * (BN / 2) + b * 32 + r;
+        float sum = 0.f, m2;
+        if (interior && s2 >= 0.f) {  // every column valid, max of s*t is at max of t
+          float vmax = -INFINITY;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int j = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float u = (j < p.M) ? acc[a][b][e] * s2 : -INFINITY;
-            umax = fmaxf(umax, u);
-          }
-        umax = fmaxf(umax, __shfl_xor(umax, 32));
-        m2 = umax;
-        if (umax > -INFINITY) {
+          for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) vmax = fmaxf(vmax, acc[a][b][e]);
+          vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+          m2 = vmax * s2;
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sum += fast_exp2(fmaf(acc[a][b][e], s2, -m2));
+        } else {  // edge tiles / negative scale: masked extremum of u = s2*t, masked sum
+          float umax = -INFINITY;   // (the accumulators stay untouched: the mirrored column statistics read them again)
 #pragma unroll
           for (int a = 0; a < MT; ++a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               const int j = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-              sum += (j < p.M) ? fast_exp2(acc[a][b][e] * s2 - umax) : 0.f;
+              const float u = (j < p.M) ? acc[a][b][e] * s2 : -INFINITY;
+              umax = fmaxf(umax, u);
             }
-        }
-      }
-      sum += __shfl_xor(sum, 32);
-      if (h == 0) red[wm * BN + nl] = make_float2(m2, sum);
-    }
-    __syncthreads();
-    if (tid < BN) {
-      const float2 x = red[tid], y = red[BN + tid];
-      const float mx = fmaxf(x.x, y.x);
-      float l = 0.f;
-      if (x.x > -INFINITY) l += x.y * fast_exp2(x.x - mx);
-      if (y.x > -INFINITY) l += y.y * fast_exp2(y.x - mx);
-      const int i = n0 + tid;
-      if (i < p.N) p.part[(size_t)tm * p.part_ld + i] = make_float2(mx, l);  // log2 domain
-    }
-    if (p.mpart != nullptr) {
-      // Mirrored direction (W = 1: logits_per_b = logits_per_a^T): the SAME tile gives, per column j (a P row, on the
-      // accumulator registers), the (max2, sum) over this wave's 32 * NT rows i (the lanes).  Per lane first over its NT
-      // rows, then a transpose-reduce over the 32 lanes of the half-wave: max pass, maxima handed back through a
-      // wave-private LDS line, exponentials against the column maximum, sum pass.  One partial per (row tile, wn half).
-      constexpr int CNT = 16 * MT;
-      __syncthreads();   // the row partials in `red` have been consumed
-      float* cmax_lds = reinterpret_cast<float*>(smem) + wave * 64;   // [h][CNT] per wave (CNT <= 32)
-      float vmax[CNT];
+          umax = fmaxf(umax, __shfl_xor(umax, 32));
+          m2 = umax;
+          if (umax > -INFINITY) {
 #pragma unroll
-      for (int a = 0; a < MT; ++a)
+            for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          float m = -INFINITY;
-#pragma unroll
-          for (int b = 0; b < NT; ++b) {
-            const int i = n0 + wn * (BN / 2) + b * 32 + r;
-            const float u = (i < p.N) ? acc[a][b][e] * s2 : -INFINITY;
-            m = fmaxf(m, u);
+              for (int e = 0; e < 16; ++e) {
+                const int j = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                sum += (j < p.M) ? fast_exp2(acc[a][b][e] * s2 - umax) : 0.f;
+              }
           }
-          vmax[a * 16 + e] = m;
         }
-      const float cm = half_wave_transpose_reduce<CNT, true>(vmax, lane);   // lane L: column L & (CNT - 1) of half h
-      cmax_lds[h * 32 + (lane & (CNT - 1))] = cm;   // CNT = 16: two lanes write the same value
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      float vsum[CNT];
+        sum += __shfl_xor(sum, 32);
+        if (h == 0) red[wm * BN + nl] = make_float2(m2, sum);
+      }
+      __syncthreads();
+      if (tid < BN) {
+        const float2 x = red[tid], y = red[BN + tid];
+        const float mx = fmaxf(x.x, y.x);
+        float l = 0.f;
+        if (x.x > -INFINITY) l += x.y * fast_exp2(x.x - mx);
+        if (y.x > -INFINITY) l += y.y * fast_exp2(y.x - mx);
+        const int i = n0 + tid;
+        if (i < p.N) p.part[(size_t)tm * p.part_ld + i] = make_float2(mx, l);  // log2 domain
+      }
+      if (want_col) {
+        // Mirrored direction (W = 1: logits_per_b = logits_per_a^T): the SAME tile gives, per column j (a P row, on the
+        // accumulator registers), the (max2, sum) over this wave's 32 * NT rows i (the lanes).  Per lane first over its NT
+        // rows, then a transpose-reduce over the 32 lanes of the half-wave: max pass, maxima handed back through a
+        // wave-private LDS line, exponentials against the column maximum, sum pass.  One partial per (row tile, wn half).
+        __syncthreads();   // the row partials in `red` have been consumed
+        float* cmax_lds = reinterpret_cast<float*>(smem) + wave * 64;   // [h][CNT] per wave (CNT <= 32)
+        float vmax[CNT];
 #pragma unroll
-      for (int a = 0; a < MT; ++a)
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float mref = cmax_lds[h * 32 + a * 16 + e];   // broadcast read
-          float t = 0.f;
-          if (mref > -INFINITY) {
+          for (int e = 0; e < 16; ++e) {
+            float m = -INFINITY;
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
               const int i = n0 + wn * (BN / 2) + b * 32 + r;
-              if (i < p.N) t += fast_exp2(fmaf(acc[a][b][e], s2, -mref));
+              const float u = (i < p.N) ? acc[a][b][e] * s2 : -INFINITY;
+              m = fmaxf(m, u);
             }
+            vmax[a * 16 + e] = m;
           }
-          vsum[a * 16 + e] = t;
-        }
-      const float cs = half_wave_transpose_reduce<CNT, false>(vsum, lane);
-      const int cidx = lane & (CNT - 1);
-      const int j = m0 + wm * (BM / 2) + (cidx >> 4) * 32 + (cidx & 3) + 8 * ((cidx & 15) >> 2) + 4 * h;
-      if (j < p.M && (CNT == 32 || (lane & 16) == 0)) p.mpart[(size_t)(tn * 2 + wn) * p.mpart_ld + j] = make_float2(cm, cs);
+        const float cm = half_wave_transpose_reduce<CNT, true>(vmax, lane);   // lane L: column L & (CNT - 1) of half h
+        cmax_lds[h * 32 + (lane & (CNT - 1))] = cm;   // CNT = 16: two lanes write the same value
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float vsum[CNT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float mref = cmax_lds[h * 32 + a * 16 + e];   // broadcast read
+            float t = 0.f;
+            if (mref > -INFINITY) {
+#pragma unroll
+              for (int b = 0; b < NT; ++b) {
+                const int i = n0 + wn * (BN / 2) + b * 32 + r;
+                if (i < p.N) t += fast_exp2(fmaf(acc[a][b][e], s2, -mref));
+              }
+            }
+            vsum[a * 16 + e] = t;
+          }
+        const float cs = half_wave_transpose_reduce<CNT, false>(vsum, lane);
+        const int cidx = lane & (CNT - 1);
+        const int j = m0 + wm * (BM / 2) + (cidx >> 4) * 32 + (cidx & 3) + 8 * ((cidx & 15) >> 2) + 4 * h;
+        if (j < p.M && (CNT == 32 || (lane & 16) == 0)) p.mpart[(size_t)(tn * 2 + wn) * p.mpart_ld + j] = make_float2(cm, cs);
+      }
     }
   } else if (EPI == EPI_GRAD) {
     const float s = *scale_ptr;
@@ -429,6 +517,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
     const bool has_diag = (m0 < p.label_off + n0 + BN) && (m0 + BM > p.label_off + n0);
     float ds_acc = 0.f;
+    // FAST path (interior tile, operand norms known, 2 R <= 96; see EPI_STATS): ONE exponential per element,
+    // p0 = 2^(u - R); the row / column softmax values are p0 * 2^(R - lse_row_i) and p0 * 2^(R - lse_col_j), whose
+    // factors are per row / per column.  Both lse are >= -R, so the factors stay below 2^96.
+    bool fast = false;
+    float R = 0.f;
+    if (p.qn != nullptr && interior && !(batch.dbg & 8)) {
+      R = tile_bound(s2);
+      fast = (2.f * R <= 96.f);
+    }
+    const bool same_s = p.s_row == p.c_row && p.s_col == p.c_col && p.s_diag == p.c_diag;
+    float ccf[MT][4][4], scf[MT][4][4];   // c_col * 2^(R - lse_col_j), s_col * ... for this lane's 16 MT columns
+    if (fast) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int jb = m0 + wm * (BM / 2) + a * 32 + 8 * q + 4 * h;
+          float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (use_col) t4 = *reinterpret_cast<const float4*>(p.lse_col + jb);
+          const float f0 = use_col ? fast_exp2(R - t4.x * LOG2E) : 0.f, f1 = use_col ? fast_exp2(R - t4.y * LOG2E) : 0.f;
+          const float f2 = use_col ? fast_exp2(R - t4.z * LOG2E) : 0.f, f3 = use_col ? fast_exp2(R - t4.w * LOG2E) : 0.f;
+          ccf[a][q][0] = p.c_col * f0; ccf[a][q][1] = p.c_col * f1; ccf[a][q][2] = p.c_col * f2; ccf[a][q][3] = p.c_col * f3;
+          scf[a][q][0] = p.s_col * f0; scf[a][q][1] = p.s_col * f1; scf[a][q][2] = p.s_col * f2; scf[a][q][3] = p.s_col * f3;
+        }
+    }
     // G leaves through a wave-private LDS staging tile so that global stores are whole row segments
     // (COLS*sizeof(T) = 128/256 B contiguous per row) instead of 8/16-byte pieces scattered over 32 rows.
     constexpr int COLS = BM / 2;                   // j (columns of G) per wave
@@ -445,12 +558,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
       const bool iv = i < p.N;
       const float lr2 = (iv ? p.lse_row[i] : 0.f) * LOG2E;
       const int lab = p.label_off + i;
+      const float fr = fast ? fast_exp2(R - lr2) : 0.f;
+      const float crf = p.c_row * fr, srf = p.s_row * fr;
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int jl = a * 32 + 8 * q + 4 * h;  // column inside the wave's strip
           const int jb = m0 + wm * (BM / 2) + jl;
+          float g4[4];
+          if (fast) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float t = acc[a][b][4 * q + e];
+              const float p0 = fast_exp2(fmaf(t, s2, -R));
+              float g = p0 * (crf + ccf[a][q][e]);
+              float gs = same_s ? g : p0 * (srf + scf[a][q][e]);
+              if (has_diag && (jb + e == lab)) {
+                g -= p.c_diag;
+                gs -= p.s_diag;
+              }
+              if (use_ds) ds_acc = fmaf(gs, t, ds_acc);
+              g4[e] = g;
+              acc[a][b][4 * q + e] = g;
+            }
+            Vec4<T>::store(reinterpret_cast<T*>(stg + r * STRIDE) + jl, make_float4(g4[0], g4[1], g4[2], g4[3]));
+            continue;
+          }
           float lc2[4] = {0.f, 0.f, 0.f, 0.f};
           if (use_col) {
             if (jb + 3 < p.M) {
@@ -462,7 +596,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
                 if (jb + e < p.M) lc2[e] = p.lse_col[jb + e] * LOG2E;
             }
           }
-          float g4[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float t = acc[a][b][4 * q + e];
@@ -637,72 +770,86 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
   }
 }
 
-// ------------------------------------------------------------------ LSE reduce
-// one thread per owned row: lse[i] = logsumexp over the column-tile partials (coalesced: partials are
-// tile-major); block partial sums of (lse_i - diag_i) go to loss_part[dir][block].
-struct ReduceProb {
+// ------------------------------------------------------------------ merge of the tile partials
+// lse[i] = log-sum-exp over the tile partials of row i (coalesced: partials are tile-major), loss_part[block] = sum over the
+// block's 64 rows of (lse_i - diag_i).  A workgroup takes 64 rows; its four waves each merge a quarter of the partials of
+// those rows (online: one pass), wave 0 combines the quarters.  Optionally the weighted loss value
+// (contrastive.py:134-144,160) in the same launch: every workgroup publishes its weighted block sum with a device-scope
+// store, drains it and draws a ticket; the workgroup that draws the last ticket adds all block sums in a fixed order
+// (deterministic) and re-arms the counter, which is zero on entry and zero on exit.
+struct MergeProb {
   const float2* part;
-  int part_ld, tiles_m, N;
+  int part_ld, n_part, N;
   const float* diag;
   float* lse;
-  float* loss_part;
+  float* loss_part;   // [cdiv(N, 64)]
+  float w;
 };
-struct ReduceBatch {
-  ReduceProb p[2 * MAX_PROBS];   // a direction with a mirror contributes two entries
-};
-__device__ __forceinline__ float lse_reduce_row(const ReduceProb& p, int i) {
-  float mx = -INFINITY;
-#pragma unroll 8
-  for (int t = 0; t < p.tiles_m; ++t) mx = fmaxf(mx, p.part[(size_t)t * p.part_ld + i].x);
-  float l = 0.f;
-#pragma unroll 8
-  for (int t = 0; t < p.tiles_m; ++t) {
-    const float2 v = p.part[(size_t)t * p.part_ld + i];
-    if (v.x > -INFINITY) l += v.y * exp2f(v.x - mx);
-  }
-  const float lse = (mx + log2f(l)) * 0.6931471805599453f;  // partials are in the log2 domain
-  p.lse[i] = lse;
-  return lse - p.diag[i];
-}
-// Row reductions of every direction; optionally also the weighted loss value (contrastive.py:134-144,160) in the same
-// launch: every workgroup publishes its weighted partial with an agent-scope (write-through) atomic store, drains it, draws
-// a ticket, and the workgroup that draws the last ticket adds the partials in a fixed order (deterministic) with
-// agent-scope loads and re-arms the counter.  The counter is zero on entry: the similarity kernel clears it.
-struct ReduceFinal {
-  float w[2 * MAX_PROBS];
-  float* scratch;       // [gridDim.y][gridDim.x]
+struct MergeBatch {
+  MergeProb p[2 * MAX_PROBS];   // a direction with a mirror contributes two entries
+  float* scratch;       // [gridDim.y][gridDim.x] (only with loss_out)
   unsigned* counter;    // [1]
   float* loss_out;      // [1] or null (no in-launch combine)
 };
-__global__ __launch_bounds__(256) void lse_reduce_kernel(const ReduceBatch batch, const ReduceFinal fin) {
-  const ReduceProb& p = batch.p[blockIdx.y];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  float local = 0.f;
-  if (i < p.N) local = lse_reduce_row(p, i);
-  __shared__ float red[4];
+__global__ __launch_bounds__(256) void lse_merge_kernel(const MergeBatch batch) {
+  const MergeProb& p = batch.p[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float2 quarter[4][64];
   __shared__ unsigned ticket_s;
-  local = wave_sum(local);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
-  __syncthreads();
-  const float block_sum = red[0] + red[1] + red[2] + red[3];
-  if (threadIdx.x == 0 && (int)(blockIdx.x * 256) < p.N) p.loss_part[blockIdx.x] = block_sum;
-  if (fin.loss_out == nullptr) return;
+  const int i = blockIdx.x * 64 + lane;
+  const bool active = (int)(blockIdx.x * 64) < p.N;
+  float block_sum = 0.f;
+  if (active) {
+    float mx = -INFINITY, l = 0.f;
+    if (i < p.N) {
+#pragma unroll 4
+      for (int t = wave; t < p.n_part; t += 4) {
+        const float2 v = p.part[(size_t)t * p.part_ld + i];
+        if (v.x > -INFINITY) {
+          const float nm = fmaxf(mx, v.x);
+          l = l * exp2f(mx - nm) + v.y * exp2f(v.x - nm);
+          mx = nm;
+        }
+      }
+    }
+    quarter[wave][lane] = make_float2(mx, l);
+    __syncthreads();
+    if (wave == 0) {
+      float local = 0.f;
+      if (i < p.N) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m = fmaxf(m, quarter[q][lane].x);
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // fixed order
+          const float2 v = quarter[q][lane];
+          if (v.x > -INFINITY) sum += v.y * exp2f(v.x - m);
+        }
+        const float lse = (m + log2f(sum)) * 0.6931471805599453f;  // partials are in the log2 domain
+        p.lse[i] = lse;
+        local = lse - p.diag[i];
+      }
+      block_sum = wave_sum(local);
+      if (lane == 0) p.loss_part[blockIdx.x] = block_sum;
+    }
+  }
+  if (batch.loss_out == nullptr) return;
   const unsigned n_blocks = gridDim.x * gridDim.y;
-  if (threadIdx.x == 0) {
-    const float mine = (int)(blockIdx.x * 256) < p.N ? fin.w[blockIdx.y] * block_sum : 0.f;
-    __hip_atomic_store(fin.scratch + blockIdx.y * gridDim.x + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    st_agent(batch.scratch + blockIdx.y * gridDim.x + blockIdx.x, active ? p.w * block_sum : 0.f);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ticket_s = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket_s = __hip_atomic_fetch_add(batch.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   if (ticket_s != n_blocks - 1) return;
-  if (threadIdx.x < 64) {   // last arriver: fixed-order sum over all partials
+  if (tid < 64) {   // last arriver: fixed-order sum over all block sums
     float t = 0.f;
-    for (unsigned k = threadIdx.x; k < n_blocks; k += 64) t += __hip_atomic_load(fin.scratch + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned k = tid; k < n_blocks; k += 64) t += ld_agent(batch.scratch + k);
     t = wave_sum(t);
-    if (threadIdx.x == 0) {
-      *fin.loss_out = t;
-      __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      *batch.loss_out = t;
+      __hip_atomic_store(batch.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -767,13 +914,15 @@ __global__ __launch_bounds__(64) void reduce_sums_kernel(const CombineArgs a, fl
 // one wave per destination row: gather, optional L2 normalise (eps 1e-12, F.normalize), cast, zero pad
 template <typename S, typename T>
 __global__ __launch_bounds__(256) void pack_rows_kernel(const S* __restrict__ src, int d, const int32_t* __restrict__ idx,
-                                                        int r, int normalize, T* __restrict__ dst, int r_pad, int k_pad) {
+                                                        int r, int normalize, T* __restrict__ dst, int r_pad, int k_pad,
+                                                        float* __restrict__ norm_out) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= r_pad) return;
   T* out = dst + (size_t)row * k_pad;
   if (row >= r) {
     for (int c = lane * 4; c < k_pad; c += 256) Vec4<T>::store(out + c, make_float4(0.f, 0.f, 0.f, 0.f));
+    if (norm_out != nullptr && lane == 0) norm_out[row] = 0.f;
     return;
   }
   const S* in = src + (size_t)(idx ? idx[row] : row) * d;
@@ -795,6 +944,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const S* __restrict__ sr
     ss = wave_sum(ss);
     inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
   }
+  float nrm2 = 0.f;
   for (int c = lane * 4; c < k_pad; c += 256) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (vec) {
@@ -810,6 +960,13 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const S* __restrict__ sr
     v.z *= inv;
     v.w *= inv;
     Vec4<T>::store(out + c, v);
+    // the norm of what the MFMA will multiply: the values as rounded to T
+    const float q0 = to_f32(from_f32<T>(v.x)), q1 = to_f32(from_f32<T>(v.y)), q2 = to_f32(from_f32<T>(v.z)), q3 = to_f32(from_f32<T>(v.w));
+    nrm2 += q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
+  }
+  if (norm_out != nullptr) {
+    nrm2 = wave_sum(nrm2);
+    if (lane == 0) norm_out[row] = sqrtf(nrm2);
   }
 }
 
@@ -822,6 +979,7 @@ struct PackEntry {
   void* dst;
   void* dstT;   // or null
   int r, r_pad, normalize, ldt;
+  float* norm;  // [r_pad] L2 norms of the packed rows, or null
 };
 struct PackBatch {
   PackEntry e[MAX_PROBS];
@@ -868,6 +1026,7 @@ __global__ __launch_bounds__(256) void pack_tr_kernel(const PackBatch batch, int
   T* dst = static_cast<T*>(en.dst) + (size_t)row * k_pad;
   T* dstT = static_cast<T*>(en.dstT);
   const int kr = tid >> 2, s4 = (tid & 3) * 4;   // transposed write: k row kr of the step, tile rows s4 .. s4 + 3
+  float nrm2 = 0.f;
   for (int k0 = 0; k0 < k_pad; k0 += 64) {
     const int c = k0 + c4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -883,6 +1042,10 @@ __global__ __launch_bounds__(256) void pack_tr_kernel(const PackBatch batch, int
     }
     v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
     Vec4<T>::store(dst + c, v);
+    {
+      const float q0 = to_f32(from_f32<T>(v.x)), q1 = to_f32(from_f32<T>(v.y)), q2 = to_f32(from_f32<T>(v.z)), q3 = to_f32(from_f32<T>(v.w));
+      nrm2 += q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
+    }
     if (dstT != nullptr) {
       Vec4<T>::store(&tile[rr][c4], v);
       __syncthreads();
@@ -890,6 +1053,11 @@ __global__ __launch_bounds__(256) void pack_tr_kernel(const PackBatch batch, int
                      make_float4(to_f32(tile[s4][kr]), to_f32(tile[s4 + 1][kr]), to_f32(tile[s4 + 2][kr]), to_f32(tile[s4 + 3][kr])));
       __syncthreads();
     }
+  }
+  if (en.norm != nullptr) {   // the 16 threads of a row are 16 consecutive lanes
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) nrm2 += __shfl_xor(nrm2, o);
+    if ((tid & 15) == 0) en.norm[row] = sqrtf(nrm2);
   }
 }
 
@@ -1106,7 +1274,7 @@ static int launch_gemm(const ProbBatch& b, int n_probs, int bm, int bn, int max_
 
 template <typename T>
 static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, const float* scale, const float* loss_w, float* loss_out,
-                             int32_t* loss_written, hipStream_t st) {
+                             int32_t* tickets, int n_tickets, hipStream_t st) {
   int r_max = 0, c_max = 0;
   for (int k = 0; k < n_dirs; ++k) {
     r_max = std::max(r_max, dirs[k].r);
@@ -1114,9 +1282,10 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
   }
   const Plan pl = make_plan(r_max, c_max, k_pad, n_dirs, sizeof(T) == 2 ? MMK_COMPUTE_BF16 : MMK_COMPUTE_F32);
   ProbBatch b;
-  ReduceBatch rb;
+  MergeBatch mb;
   AlignReduceBatch ab;
   int max_tiles = 0, n_red = 0, r_red_max = 0;
+  const bool align = dirs[0].mode == 1;
   for (int k = 0; k < n_dirs; ++k) {
     const mmk_clip_dir& d = dirs[k];
     Prob& p = b.p[k];
@@ -1134,21 +1303,29 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
     p.diag = d.diag;
     p.label_off = d.label_off;
     p.hmax = d.hmax;
+    if (d.x_norm != nullptr && d.y_norm != nullptr) {
+      p.qn = d.x_norm;
+      p.pn = d.y_norm;
+    }
     max_tiles = std::max(max_tiles, p.tiles_m * p.tiles_n);
-    rb.p[n_red++] = ReduceProb{p.part, p.part_ld, p.tiles_m, d.r, d.diag, d.lse, d.loss_part};
-    r_red_max = std::max(r_red_max, d.r);
     ab.p[k] = AlignReduceProb{p.part, p.part_ld, p.tiles_m, d.r, d.c, d.label_off, d.hmax, d.loss_part};
-    if (d.mirror_part != nullptr) {
-      // the mirrored direction's rows are this direction's columns: partials per (row tile, wn half), positive = same diagonal
-      p.mpart = reinterpret_cast<float2*>(d.mirror_part);
-      p.mpart_ld = d.c;
-      rb.p[n_red++] = ReduceProb{p.mpart, p.mpart_ld, 2 * p.tiles_n, d.c, d.diag, d.mirror_lse, d.mirror_loss_part};
-      r_red_max = std::max(r_red_max, d.c);
+    if (!align) {
+      mb.p[n_red] = MergeProb{p.part, p.part_ld, p.tiles_m, d.r, d.diag, d.lse, d.loss_part, loss_w ? loss_w[n_red] : 0.f};
+      ++n_red;
+      r_red_max = std::max(r_red_max, d.r);
+      if (d.mirror_part != nullptr) {
+        // the mirrored direction's rows are this direction's columns: partials per (row tile, wn half), positive = same diagonal
+        p.mpart = reinterpret_cast<float2*>(d.mirror_part);
+        p.mpart_ld = d.c;
+        mb.p[n_red] = MergeProb{p.mpart, p.mpart_ld, 2 * p.tiles_n, d.c, d.diag, d.mirror_lse, d.mirror_loss_part, loss_w ? loss_w[n_red] : 0.f};
+        ++n_red;
+        r_red_max = std::max(r_red_max, d.c);
+      }
     }
   }
   b.n_split = 1;
-  b.clear_word = (loss_out != nullptr && dirs[0].fin_ws != nullptr) ? reinterpret_cast<unsigned*>(dirs[0].fin_ws) : nullptr;
-  const bool align = dirs[0].mode == 1;
+  b.n_probs = n_dirs;
+  b.dbg = getenv("MMK_SIM_DBG") ? atoi(getenv("MMK_SIM_DBG")) : 0;
   {
     int rc = align ? launch_gemm<T, EPI_ALIGN_STATS>(b, n_dirs, pl.bm, pl.bn, max_tiles, scale, st)
                    : launch_gemm<T, EPI_STATS>(b, n_dirs, pl.bm, pl.bn, max_tiles, scale, st);
@@ -1159,16 +1336,17 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
     if (align)
       hipLaunchKernelGGL(align_reduce_kernel, dim3(cdiv(r_max, 256), n_dirs), dim3(256), 0, st, ab);
     else {
-      ReduceFinal fin{};
-      const dim3 grid(cdiv(r_red_max, 256), n_red);
-      if (loss_out != nullptr && dirs[0].fin_ws != nullptr && (long)grid.x * grid.y <= dirs[0].fin_ws_floats - 1) {
-        for (int k = 0; k < n_red; ++k) fin.w[k] = loss_w[k];   // one weight per direction, then its mirror's
-        fin.counter = reinterpret_cast<unsigned*>(dirs[0].fin_ws);
-        fin.scratch = dirs[0].fin_ws + 1;
-        fin.loss_out = loss_out;
-        if (loss_written) *loss_written = 1;
+      const dim3 grid(cdiv(r_red_max, 64), n_red);
+      mb.loss_out = nullptr;
+      mb.counter = nullptr;
+      mb.scratch = nullptr;
+      if (loss_out != nullptr) {
+        MMK_REQUIRE(tickets != nullptr && (long)grid.x * grid.y + 1 <= n_tickets, "ticket workspace too small (see mmk_clip_tickets)");
+        mb.loss_out = loss_out;
+        mb.counter = reinterpret_cast<unsigned*>(tickets);
+        mb.scratch = reinterpret_cast<float*>(tickets) + 1;
       }
-      hipLaunchKernelGGL(lse_reduce_kernel, grid, dim3(256), 0, st, rb, fin);
+      hipLaunchKernelGGL(lse_merge_kernel, grid, dim3(256), 0, st, mb);
     }
     MMK_LAUNCH_CHECK();
   }
@@ -1217,6 +1395,10 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
     p.s_row = d.s_row; p.s_col = d.s_col; p.s_diag = d.s_diag;
     p.ds_part = d.ds_part;
     p.hmax = d.hmax;
+    if (d.x_norm != nullptr && d.y_norm != nullptr && d.mode == 0) {
+      p.qn = d.x_norm;
+      p.pn = d.y_norm;
+    }
     MMK_REQUIRE(d.mode == 1 || d.lse_col != nullptr || (d.c_col == 0.f && d.s_col == 0.f), "lse_col required when c_col/s_col != 0");
     MMK_REQUIRE(d.gT == nullptr || (d.mode == 0 && d.ldgt >= r_pad), "gT needs mode 0 and ldgt >= round_up(r, 128)");
     if (!d.g_ready) {
@@ -1248,8 +1430,9 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
     max_r = std::max(max_r, d.r);
   }
   gb.n_split = 1;
-  gb.clear_word = nullptr;
-  xb.clear_word = nullptr;
+  gb.n_probs = n_tile_probs;
+  xb.n_probs = n_dirs;
+  gb.dbg = xb.dbg = 0;
   xb.n_split = pl.n_split;
   fb.n_split = pl.n_split;
   fb.d = d_user;
@@ -1292,7 +1475,7 @@ int mmk_clip_plan(int r, int c, int k_pad, int compute, int32_t* n_col_tiles, in
 }
 
 int mmk_pack_rows(const void* src, int src_dtype, int n_src, int d, const int32_t* idx, int r, int normalize, void* dst,
-                  void* dstT, int r_pad, int k_pad, int ldt, int compute, void* stream) {
+                  void* dstT, int r_pad, int k_pad, int ldt, int compute, float* norm_out, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int bk = compute == MMK_COMPUTE_BF16 ? 64 : 32;
   MMK_REQUIRE(src && dst, "null pointer");
@@ -1305,10 +1488,10 @@ int mmk_pack_rows(const void* src, int src_dtype, int n_src, int d, const int32_
     int rc = MMK_DISPATCH_DTYPE(src_dtype, S, [&]() -> int {
       if (compute == MMK_COMPUTE_BF16)
         hipLaunchKernelGGL((pack_rows_kernel<S, bf16_t>), dim3(r_pad / 4), dim3(256), 0, st, static_cast<const S*>(src), d,
-                           idx, r, normalize, static_cast<bf16_t*>(dst), r_pad, k_pad);
+                           idx, r, normalize, static_cast<bf16_t*>(dst), r_pad, k_pad, norm_out);
       else
         hipLaunchKernelGGL((pack_rows_kernel<S, float>), dim3(r_pad / 4), dim3(256), 0, st, static_cast<const S*>(src), d,
-                           idx, r, normalize, static_cast<float*>(dst), r_pad, k_pad);
+                           idx, r, normalize, static_cast<float*>(dst), r_pad, k_pad, norm_out);
       return 0;
     });
     if (rc) return rc;
@@ -1340,7 +1523,7 @@ int mmk_pack_rows_many(const mmk_pack_req* reqs, int n, int src_dtype, int d, in
     MMK_REQUIRE(q.src && q.dst && q.r >= 0, "null pointer / bad shape");
     MMK_REQUIRE(q.r_pad % 128 == 0 && q.r_pad >= q.r && q.r_pad > 0, "r_pad must be a positive multiple of 128 and >= r");
     MMK_REQUIRE(q.dstT == nullptr || q.ldt == q.r_pad, "ldt must equal r_pad");
-    b.e[k] = PackEntry{q.src, q.idx, q.dst, q.dstT, q.r, q.r_pad, q.normalize, q.ldt};
+    b.e[k] = PackEntry{q.src, q.idx, q.dst, q.dstT, q.r, q.r_pad, q.normalize, q.ldt, q.norm};
     r_pad_max = std::max(r_pad_max, q.r_pad);
   }
   ProfScope ps(MMK_K_PACK, st);
@@ -1371,27 +1554,39 @@ static int check_dirs(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int compu
   return 0;
 }
 
+// 4-byte slots of the workspace mmk_clip_forward_loss needs: [0] the ticket counter (zero on entry, zero on exit), then one
+// float per merge workgroup (their contents need no initialisation)
+int mmk_clip_tickets(const mmk_clip_dir* dirs, int n_dirs) {
+  int rows = 1, n = 0;
+  for (int k = 0; k < n_dirs; ++k) {
+    rows = std::max(rows, std::max(dirs[k].r, dirs[k].mirror_part != nullptr ? dirs[k].c : 0));
+    n += dirs[k].mirror_part != nullptr ? 2 : 1;
+  }
+  return 1 + n * cdiv(rows, 64);
+}
+
 int mmk_clip_forward_loss(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale, const float* loss_w,
-                          float* loss_out, int32_t* loss_written, void* stream) {
+                          float* loss_out, int32_t* tickets, int n_tickets, void* stream) {
   (void)d;
   int rc = check_dirs(dirs, n_dirs, k_pad, compute);
   if (rc) return rc;
   MMK_REQUIRE(scale, "null scale");
   MMK_REQUIRE((loss_out == nullptr) == (loss_w == nullptr), "loss_w and loss_out come together");
+  MMK_REQUIRE(loss_out == nullptr || dirs[0].mode == 0, "the in-launch loss value is for cross-entropy directions");
   for (int k = 0; k < n_dirs; ++k) {
     MMK_REQUIRE(dirs[k].part && dirs[k].loss_part && (dirs[k].mode == 1 || (dirs[k].diag && dirs[k].lse)), "null forward buffer");
     if (dirs[k].mirror_part != nullptr)
       MMK_REQUIRE(dirs[k].mode == 0 && dirs[k].r == dirs[k].c && dirs[k].label_off == 0 && dirs[k].mirror_lse && dirs[k].mirror_loss_part,
                   "a mirrored direction needs mode 0, r == c, label_off == 0 and its output buffers");
   }
-  if (loss_written) *loss_written = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (compute == MMK_COMPUTE_BF16) return clip_forward_impl<bf16_t>(dirs, n_dirs, k_pad, scale, loss_w, loss_out, loss_written, st);
-  return clip_forward_impl<float>(dirs, n_dirs, k_pad, scale, loss_w, loss_out, loss_written, st);
+  if (compute == MMK_COMPUTE_BF16) return clip_forward_impl<bf16_t>(dirs, n_dirs, k_pad, scale, loss_w, loss_out, tickets, n_tickets, st);
+  return clip_forward_impl<float>(dirs, n_dirs, k_pad, scale, loss_w, loss_out, tickets, n_tickets, st);
 }
 
-int mmk_clip_forward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale, void* stream) {
-  return mmk_clip_forward_loss(dirs, n_dirs, k_pad, d, compute, scale, nullptr, nullptr, nullptr, stream);
+int mmk_clip_forward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale, int32_t* tickets,
+                     int n_tickets, void* stream) {
+  return mmk_clip_forward_loss(dirs, n_dirs, k_pad, d, compute, scale, nullptr, nullptr, tickets, n_tickets, stream);
 }
 
 int mmk_reduce_sums(const float* const* ptrs, const int32_t* counts, const float* weights, int n, int separate, float* out,

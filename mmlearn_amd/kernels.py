@@ -119,11 +119,27 @@ def pack_rows(src: torch.Tensor, idx: Optional[torch.Tensor], r: int, normalize:
     cdt = compute_torch_dtype(compute)
     dst = torch.empty((r_pad, k_pad), dtype=cdt, device=src.device)
     dst_t = torch.empty((k_pad, r_pad), dtype=cdt, device=src.device) if want_transpose else None
+    nrm = torch.empty(r_pad, dtype=torch.float32, device=src.device)
     if idx is not None:
         assert idx.dtype == torch.int32 and idx.numel() >= r
     check(_lib.lib().mmk_pack_rows(ptr(src), dtype_tag(src.dtype), n_src, d, ptr(idx), r, int(normalize), ptr(dst), ptr(dst_t),
-                                   r_pad, k_pad, r_pad, compute, stream()))
+                                   r_pad, k_pad, r_pad, compute, ptr(nrm), stream()))
+    dst._mmk_norm = nrm   # L2 norms of the packed rows: lets the forward bound the logits of a tile (Direction.x / .y)
     return dst, dst_t
+
+
+def row_norms(t: torch.Tensor) -> Optional[torch.Tensor]:
+    """The norms ``pack_rows`` attached to a packed operand (None for tensors that did not come from it)."""
+    return getattr(t, "_mmk_norm", None)
+
+
+def slice_packed(t: torch.Tensor, p0: int) -> torch.Tensor:
+    """Rows ``p0:`` of a packed operand, norms included."""
+    out = t[p0:]
+    n = row_norms(t)
+    if n is not None:
+        out._mmk_norm = n[p0:]
+    return out
 
 
 def pack_rows_many(reqs: Sequence[tuple], compute: int) -> list:
@@ -144,10 +160,13 @@ def pack_rows_many(reqs: Sequence[tuple], compute: int) -> list:
         r_pad = round_up(max(r, 1), 128)
         dst = torch.empty((r_pad, k_pad), dtype=cdt, device=src.device)
         dst_t = torch.empty((k_pad, r_pad), dtype=cdt, device=src.device) if want_t else None
+        nrm = torch.empty(r_pad, dtype=torch.float32, device=src.device)
         if idx is not None:
             assert idx.dtype == torch.int32 and idx.numel() >= r
         e = arr[k]
         e.src, e.idx, e.dst, e.dstT, e.r, e.r_pad, e.normalize, e.ldt = ptr(src), ptr(idx), ptr(dst), ptr(dst_t), r, r_pad, int(normalize), r_pad
+        e.norm = ptr(nrm)
+        dst._mmk_norm = nrm
         out.append((dst, dst_t))
     check(_lib.lib().mmk_pack_rows_many(C.cast(arr, C.c_void_p), len(reqs), dtype_tag(srcs[0].dtype), d, k_pad, compute, stream()))
     return out
@@ -223,12 +242,28 @@ def _pair_up(dirs: Sequence[Direction], backward: bool = False) -> list:
     return out
 
 
+_TICKETS: dict = {}
+
+
+def _tickets(dev: torch.device, n: int) -> torch.Tensor:
+    """The workspace of the in-launch loss combine: slot 0 is a ticket counter that the merge launch expects at zero and
+    leaves at zero, so ONE buffer per (device, stream) is reused call after call (launches of a stream run one after the
+    other); it is dropped whenever a call fails, because an aborted launch may leave a count behind."""
+    key = (dev.index, stream())
+    t = _TICKETS.get(key)
+    if t is None or t.numel() < n:
+        t = torch.zeros(max(n, 1024), dtype=torch.int32, device=dev)
+        _TICKETS[key] = t
+    return t
+
+
 def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.Tensor,
                  loss_weights: Optional[Sequence[float]] = None) -> Optional[torch.Tensor]:
-    """Fills dir.lse / dir.diag / dir.loss_part for every direction (two launches for all of them).  The two directions of a
-    pair on one rank are computed from ONE pass over the similarity tiles (see ``_mirror_of``).  With ``loss_weights`` (one
-    per direction) a small problem also gets its loss value ``sum_k w_k * sum_i (lse_i - diag_i)`` from the reduction
-    launch: the 0-dim tensor is returned; ``None`` means the caller combines ``loss_part`` with ``reduce_sums``."""
+    """Fills dir.lse / dir.diag / dir.loss_part for every direction (two launches for all of them: similarity tiles with
+    their statistics, merge of the tile partials).  The two directions of a pair on one rank are computed from ONE pass over
+    the similarity tiles (see ``_mirror_of``).  With ``loss_weights`` (one per direction) the merge launch also forms the
+    loss value ``sum_k w_k * sum_i (lse_i - diag_i)``: the 0-dim tensor is returned; ``None`` means the
+    caller combines ``loss_part`` with ``reduce_sums`` (more directions than one call takes, or alignment rows)."""
     assert scale.dtype == torch.float32 and scale.is_cuda
     dev = scale.device
     pairs = _pair_up(dirs)
@@ -246,33 +281,40 @@ def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.T
             if dr.mode == 0:
                 dr.lse = torch.empty(dr.r, dtype=torch.float32, device=dev)
                 dr.diag = torch.empty(dr.r, dtype=torch.float32, device=dev)
-            dr.loss_part = torch.empty((dr.r + 255) // 256, dtype=torch.float32, device=dev)
+            # mode 0: one entry per block of 64 rows; mode 1: per 256 rows
+            dr.loss_part = torch.empty((dr.r + 63) // 64 if dr.mode == 0 else (dr.r + 255) // 256, dtype=torch.float32, device=dev)
             dr._keep.append(part)
             e = arr[k]
             e.x, e.y, e.r, e.c, e.label_off = ptr(dr.x), ptr(dr.y), dr.r, dr.c, dr.label_off
             e.part, e.diag, e.lse, e.loss_part = ptr(part), ptr(dr.diag), ptr(dr.lse), ptr(dr.loss_part)
             e.mode, e.hmax = dr.mode, ptr(dr.hmax)
+            xn, yn = row_norms(dr.x), row_norms(dr.y)
+            if xn is not None and yn is not None and dr.mode == 0:
+                assert xn.numel() >= dr.r and yn.numel() >= dr.c
+                e.x_norm, e.y_norm = ptr(xn), ptr(yn)
+                dr._keep += [xn, yn]
             if mir is not None:
                 mpart = torch.empty((_lib.lib().mmk_clip_mirror_tiles(dr.r), dr.c, 2), dtype=torch.float32, device=dev)
                 mir.lse = torch.empty(mir.r, dtype=torch.float32, device=dev)
                 mir.diag = dr.diag          # label_off = 0 on both sides: the same diagonal
-                mir.loss_part = torch.empty((mir.r + 255) // 256, dtype=torch.float32, device=dev)
+                mir.loss_part = torch.empty((mir.r + 63) // 64, dtype=torch.float32, device=dev)
                 mir._keep.append(mpart)
                 e.mirror_part, e.mirror_lse, e.mirror_loss_part = ptr(mpart), ptr(mir.lse), ptr(mir.loss_part)
-        if fuse_loss:
-            n_red = sum(1 + (m is not None) for _, m in chunk)
-            fin = torch.empty(1 + n_red * ((max(max(x.r, x.c) for x, _ in chunk) + 255) // 256), dtype=torch.float32, device=dev)
-            arr[0].fin_ws, arr[0].fin_ws_floats = ptr(fin), fin.numel()
-            chunk[0][0]._keep.append(fin)
-            ws = [w_of[id(x)] for pair in chunk for x in pair if x is not None]
-            w_arr = (C.c_float * len(ws))(*ws)
-            out = torch.empty((), dtype=torch.float32, device=dev)
-            written = C.c_int32(0)
-            check(_lib.lib().mmk_clip_forward_loss(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), C.cast(w_arr, C.c_void_p),
-                                                   ptr(out), C.addressof(written), stream()))
-            loss_out = out if written.value else None
-        else:
-            check(_lib.lib().mmk_clip_forward(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), stream()))
+        n_tick = _lib.lib().mmk_clip_tickets(C.cast(arr, C.c_void_p), len(chunk))
+        tickets = _tickets(dev, n_tick)
+        try:
+            if fuse_loss:
+                ws = [w_of[id(x)] for pair in chunk for x in pair if x is not None]
+                w_arr = (C.c_float * len(ws))(*ws)
+                loss_out = torch.empty((), dtype=torch.float32, device=dev)
+                check(_lib.lib().mmk_clip_forward_loss(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), C.cast(w_arr, C.c_void_p),
+                                                       ptr(loss_out), ptr(tickets), tickets.numel(), stream()))
+            else:
+                check(_lib.lib().mmk_clip_forward(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), ptr(tickets), tickets.numel(),
+                                                  stream()))
+        except Exception:
+            _TICKETS.pop((dev.index, stream()), None)
+            raise
     return loss_out
 
 
@@ -336,6 +378,10 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.
             e.dx_accumulate = int(dr.dx_accumulate)
             e.src, e.normalize = ptr(dr.src), int(dr.normalize)
             e.mode, e.hmax = dr.mode, ptr(dr.hmax)
+            xn, yn = row_norms(dr.x), row_norms(dr.y)
+            if xn is not None and yn is not None and dr.mode == 0:
+                e.x_norm, e.y_norm = ptr(xn), ptr(yn)
+                keep += [xn, yn]
             e.src_dtype = dtype_tag(dr.src.dtype) if dr.src is not None else 0
             e.g_ready = int(ready)
             mir = next((b for b in chunk[k + 1:k + 2] if mirror_src.get(id(b)) is dr), None)

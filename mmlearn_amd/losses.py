@@ -112,7 +112,10 @@ def _compose(rows: Optional[torch.Tensor], idx: Optional[torch.Tensor]) -> Optio
 
 
 def _slice_rows(t: torch.Tensor, p0: int) -> torch.Tensor:
-    return t[p0:] if p0 else t
+    if not p0:
+        return t
+    slicer = getattr(K, "slice_packed", None)   # keeps the row norms attached to a packed operand
+    return slicer(t, p0) if slicer is not None else t[p0:]
 
 
 def _all_gather(t: torch.Tensor, world: int) -> torch.Tensor:

@@ -202,6 +202,34 @@ def test_match_large_and_errors():
         find_matching_indices(torch.zeros(3, device=dev), b.to(dev))
 
 
+@pytest.mark.parametrize("n_a,n_b,n_keys", [(1, 1, 1), (7, 2048, 50), (2048, 2048, 1500), (1024, 1024, 0), (1500, 1300, 0), (2049, 100, 64),
+                                           (300, 300, 1), (1000, 3000, 2500), (8192, 8192, 0), (4096, 5000, 4000)])
+def test_match_paths_vs_oracle(n_a, n_b, n_keys):
+    """Both matcher paths (one workgroup up to 2048 x 2048, count / scan / fill beyond) against the oracle: identity pairing
+    (n_keys = 0: a permutation-free arange on both sides when the sizes agree, a shifted window otherwise), heavy duplication
+    (n_keys = 1: every id equal, more pairs than the first capacity guess), random draws with repeats on both sides."""
+    from mmlearn_amd import find_matching_indices
+    from mmlearn_amd import kernels as K
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(n_a * 31 + n_b)
+    if n_keys == 0:
+        a = torch.stack([torch.zeros(n_a, dtype=torch.long), torch.arange(n_a)], 1)
+        b = torch.stack([torch.zeros(n_b, dtype=torch.long), torch.arange(n_b) + (0 if n_a == n_b else 100)], 1)
+    else:
+        a = torch.stack([torch.randint(0, 2, (n_a,), generator=g), torch.randint(0, n_keys, (n_a,), generator=g) + (1 << 40)], 1)
+        b = torch.stack([torch.randint(0, 2, (n_b,), generator=g), torch.randint(0, n_keys, (n_b,), generator=g) + (1 << 40)], 1)
+    ia, ib = find_matching_indices(a.to(dev), b.to(dev))
+    ra, rb = co.find_matching_indices(a.numpy(), b.numpy())
+    np.testing.assert_array_equal(ia.cpu().numpy(), ra)
+    np.testing.assert_array_equal(ib.cpu().numpy(), rb)
+    m = K.match_ids(a.to(dev), b.to(dev))
+    assert m.n == len(ra)
+    assert m.identity == (n_a == n_b == len(ra) and bool((ra == np.arange(n_a)).all()) and bool((rb == np.arange(n_a)).all()))
+    if not m.identity:
+        assert m.repeats_a == (len(set(ra.tolist())) < len(ra)) and m.repeats_b == (len(set(rb.tolist())) < len(rb))
+
+
 ALIGN = Golden("g9_align")
 
 

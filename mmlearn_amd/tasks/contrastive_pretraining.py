@@ -234,10 +234,16 @@ class ContrastivePretraining(TrainingTask):
         return output
 
     def _encoder_streams(self, n: int) -> list:
+        """The side stream of tower k >= 1 is entry k - 1.  At most ``max_side_streams`` (default 1) distinct streams are
+        created and towers share them round-robin: two compute streams give the overlap (the tails of one tower's kernels
+        filled by the other's), more streams multiply the cross-stream waits that the runtime maps onto a handful of
+        hardware queues -- a five-stream experiment stalled in the backward pass, and the three-stream
+        three-tower step was the one benchmark leg that ever hung."""
         have = self.__dict__.setdefault("_side_streams", [])
-        while len(have) < n:
+        cap = max(1, int(getattr(self, "max_side_streams", 1)))
+        while len(have) < min(n, cap):
             have.append(torch.cuda.Stream())
-        return have
+        return [have[k % len(have)] for k in range(n)] if have else []
 
     def forward(self, inputs: dict[str, Any]) -> dict[str, torch.Tensor]:
         outputs = {}

@@ -271,7 +271,8 @@ def test_concurrent_encoder_streams_give_the_same_step():
 
 def test_three_towers_on_three_streams_with_a_shared_head():
     """BASELINE configs[3] shape of the task (three modalities, one shared projection head, three weighted pairs) with
-    ``concurrent_encoders``: two side streams, the shared head's parameters used from all three; same loss and gradients
+    ``concurrent_encoders``: the second and third tower on the side stream (``max_side_streams`` = 1 by default; the test name
+    dates from one stream per tower), the shared head's parameters used from all three; same loss and gradients
     as the single-stream step, and the matcher answers for all three pairs are prefetched."""
     from mmlearn_amd import ContrastiveLoss
     from mmlearn_amd.tasks import ContrastivePretraining, LossPairSpec, ModuleKeySpec

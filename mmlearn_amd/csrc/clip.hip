@@ -1432,7 +1432,8 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
   gb.n_split = 1;
   gb.n_probs = n_tile_probs;
   xb.n_probs = n_dirs;
-  gb.dbg = xb.dbg = 0;
+  gb.dbg = getenv("MMK_SIM_DBG") ? (atoi(getenv("MMK_SIM_DBG")) & 8) : 0;   // 8 = never take the bounded fast path
+  xb.dbg = 0;
   xb.n_split = pl.n_split;
   fb.n_split = pl.n_split;
   fb.d = d_user;

@@ -171,6 +171,42 @@ def test_cpu_tensors_raise():
         ContrastiveLoss()({"rgb_embedding": a, "text_embedding": a}, {"rgb": ids, "text": ids}, torch.tensor(1.0), [LossPairSpec(("rgb", "text"))])
 
 
+@pytest.mark.parametrize("n,d,scale", [(700, 512, 1 / 0.07), (1024, 200, 10.0), (640, 512, 100.0), (8192, 512, 1 / 0.07)])
+def test_bounded_fast_path_equals_exact_path(n, d, scale, monkeypatch):
+    """The one-exponential path of the similarity-tile kernels (interior tiles whose logits the operand norms bound) against
+    the per-row / per-column maximum path of the same kernels (MMK_SIM_DBG=8): same loss, LSE-derived gradients and d/dscale
+    to f32 rounding, at sizes with interior AND edge tiles, and at scale 100 where the bound is too loose and the kernel
+    must fall back by itself (identical results)."""
+    from mmlearn_amd import ContrastiveLoss, LossPairSpec
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(n + d)
+    a = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1).bfloat16()
+    b = torch.nn.functional.normalize(0.6 * a.float() + 0.8 * torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1), dim=-1).bfloat16()
+    ids = torch.stack([torch.zeros(n, dtype=torch.long), torch.arange(n)], 1).to(dev)
+    out = {}
+    for mode in ("fast", "exact"):
+        if mode == "exact":
+            monkeypatch.setenv("MMK_SIM_DBG", "8")
+        else:
+            monkeypatch.delenv("MMK_SIM_DBG", raising=False)
+        ea, eb = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        s = torch.tensor(scale, device=dev, requires_grad=True)
+        loss = ContrastiveLoss()({"rgb_embedding": ea, "text_embedding": eb}, {"rgb": ids, "text": ids}, s, [LossPairSpec(("rgb", "text"))])
+        loss.float().backward()
+        out[mode] = (float(loss.detach().float()), ea.grad.float().cpu(), eb.grad.float().cpu(), float(s.grad))
+    monkeypatch.delenv("MMK_SIM_DBG", raising=False)
+    lf, gaf, gbf, dsf = out["fast"]
+    le, gae, gbe, dse = out["exact"]
+    assert abs(lf - le) <= 2e-6 * max(1.0, abs(le)), (lf, le)
+    assert abs(dsf - dse) <= 1e-4 * max(1e-3, abs(dse)), (dsf, dse)
+    for x, y in ((gaf, gae), (gbf, gbe)):   # bf16 gradients: equal up to one rounding of a few entries
+        assert (x - y).abs().max() <= 2e-2 * y.abs().max()
+        assert (x - y).abs().mean() <= 1e-4 * y.abs().max()
+    if scale == 100.0:   # the bound exceeds 48: both runs took the exact path
+        assert lf == le and torch.equal(gaf, gae)
+
+
 MATCH = Golden("g4_match")
 
 

@@ -320,7 +320,7 @@ def test_three_towers_on_three_streams_with_a_shared_head():
             recs.append((task.validation_step(batch, 0).detach().clone(), recs[-1][1]))
         results.append(recs)
         if streams:
-            assert len(task._side_streams) == 2 and task.loss_fn.prefetched_matches_used == 12
+            assert len(task._side_streams) == 1 and task.loss_fn.prefetched_matches_used == 12
     for (l0, g0), (l1, g1) in zip(*results):
         assert torch.allclose(l0, l1, rtol=1e-6, atol=1e-7), (l0.item(), l1.item())
         assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()

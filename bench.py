@@ -376,7 +376,7 @@ def ijepa_leg(b: int, dev, small: bool, steps: int = 4, warmup: int = 3):
     return out
 
 
-def _loss_roofline(prof: dict, n_rows: int, n_cols: int, d: int, n_pairs: int, steps: int, traffic=None):
+def _loss_roofline(prof: dict, n_rows: int, n_cols: int, d: int, n_pairs: int, steps: int, traffic=None, loss_only: bool = False):
     """Roofline object of the loss path's MFMA kernels from HIP-event durations.  Algorithmic FLOPs: at one
     rank ONE [N, N, D] product per pair in the forward (2 N^2 D) and two products in the backward (dA = G B, dB = G^T A:
     4 N^2 D); row-sharded over W ranks 2 x 2 R C D forward and 2 x 2 R C D backward per rank.  Kernels that recompute the
@@ -385,6 +385,11 @@ def _loss_roofline(prof: dict, n_rows: int, n_cols: int, d: int, n_pairs: int, s
     fwd = (2.0 if single else 4.0) * n_rows * n_cols * d * n_pairs
     bwd = 4.0 * n_rows * n_cols * d * n_pairs
     algo = {"clip_fwd": fwd, "clip_bwd": bwd, "sim_stats": fwd, "grad_gemm": bwd, "sim_grad": 0.0}
+    if loss_only and prof.get("wgrad", (0, 0.0))[0] > 0:
+        # large mirrored pair: dA = G B by the NT gradient GEMM, dB = G^T A by the transposed-read kernel, half of the
+        # backward's algorithmic work each (in a whole-step profile "wgrad" is the encoders' weight gradient: not counted)
+        algo["grad_gemm"] = bwd / 2
+        algo["wgrad"] = bwd / 2
     mfma = {k: v for k, v in prof.items() if k in algo and v[0] > 0}
     if not mfma:
         return None
@@ -435,7 +440,7 @@ def loss_n8192_leg(dev, n: int = 8192, d: int = 512, iters: int = 10):
         traffic = pmc.get("n8192", {}).get("hbm_bytes_per_launch")
     except Exception:
         traffic = None
-    roof = _loss_roofline(prof, n, n, d, 1, iters, traffic)
+    roof = _loss_roofline(prof, n, n, d, 1, iters, traffic, loss_only=True)
     if roof is not None:
         dev_us = sum(v[1] for k, v in prof.items()) / iters * 1e3
         roof["device_us_fwd_bwd"] = round(dev_us, 1)

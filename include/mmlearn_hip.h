@@ -141,6 +141,13 @@ typedef struct {
    * statistics and searches no maximum; without them every tile takes per-row / per-column maxima. */
   const float* x_norm;
   const float* y_norm;
+  /* bwd, alternative to gT for the second direction of a mirrored pair (bf16 compute): g = the FIRST direction's G
+   * [c rows, ldg >= round_up(r, 128)] with g_ready = 1 and g_transposed = 1; dX = g^T Y is then formed by the
+   * weight-gradient kernel (contraction over the rows of both operands, csrc/wgrad.hip) into tn_ws
+   * (float[tn_ws_floats >= mmk_wgrad_plan(c, round_up(r, 128), k_pad)]); yT and slab are not used, G^T is never stored. */
+  int32_t g_transposed;
+  float* tn_ws;
+  int64_t tn_ws_floats;
 } mmk_clip_dir;
 
 /* rows of the mirror_part workspace for r owned rows */
@@ -323,6 +330,9 @@ int mmk_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bi
  * (attention output projections: 768 x 768 over M = 201,728).  Split over M, partial tiles in `ws`
  * (mmk_wgrad_plan gives the element count), summed into dw (out_dtype, row stride ldw). */
 int mmk_wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* ws_floats_out);
+/* the split partial tiles only: ws[split][n_pad][k_pad] f32 (n_pad / k_pad = N / K rounded up to 256); the caller sums */
+int mmk_wgrad_partial(const void* dy, const void* x, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx,
+                      int32_t* splits_out, int32_t* n_pad_out, int32_t* k_pad_out, void* stream);
 int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx, int64_t ldw,
               int out_dtype, void* stream);
 

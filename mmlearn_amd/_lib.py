@@ -48,6 +48,7 @@ class ClipDir(C.Structure):
         ("mirror_part", C.c_void_p), ("mirror_lse", C.c_void_p), ("mirror_loss_part", C.c_void_p),
         ("gT", C.c_void_p), ("ldgt", C.c_int32), ("g_ready", C.c_int32),
         ("x_norm", C.c_void_p), ("y_norm", C.c_void_p),
+        ("g_transposed", C.c_int32), ("tn_ws", C.c_void_p), ("tn_ws_floats", C.c_int64),
     ]
 
 
@@ -109,6 +110,7 @@ _SIGNATURES = {
     "mmk_gemm_nt_supported": [C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64],
     "mmk_gemm_nt": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _i, _vp],
     "mmk_wgrad_plan": [C.c_int64, _i, _i, _vp, _vp],
+    "mmk_wgrad_partial": [_vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp],
     "mmk_wgrad": [_vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _vp],
     "mmk_bias_act_fwd": [_vp, _vp, _vp, C.c_int64, _i, _i, _i, _vp],
     "mmk_bias_act_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _i, _vp],

@@ -24,6 +24,9 @@
 
 #include "common.h"
 
+extern "C" int mmk_wgrad_partial(const void* dy, const void* x, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx, int32_t* splits_out,
+                                 int32_t* n_pad_out, int32_t* k_pad_out, void* stream);
+
 namespace mmk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1086,10 +1089,10 @@ struct FinProb {
   int accumulate;
   const void* src;  // original rows (normalize backward)
   int normalize;
+  int n_split;      // slabs to sum
 };
 struct FinBatch {
   FinProb p[MAX_PROBS];
-  int n_split;
   int d;
 };
 struct DsBatch {
@@ -1130,7 +1133,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinBatch batch
   float dot = 0.f, ss = 0.f;
   for (int c = lane * 4; c < d; c += 256) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < batch.n_split; ++s) {
+    for (int s = 0; s < p.n_split; ++s) {
       const float4 t = *reinterpret_cast<const float4*>(p.slab + (size_t)s * p.split_stride + (size_t)i * p.slab_ld + c);
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
@@ -1366,7 +1369,8 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
   ProbBatch gb, xb;
   FinBatch fb;
   DsBatch db;
-  int max_tiles_g = 0, max_tiles_x = 0, max_r = 0, n_tile_probs = 0;
+  int max_tiles_g = 0, max_tiles_x = 0, max_r = 0, n_tile_probs = 0, n_x = 0, n_tn = 0;
+  int tn[MAX_PROBS];
   db.n_probs = 0;
   const int c_pad_max = round_up(c_max, 128);
   const int k_per_split = round_up(cdiv(c_pad_max, pl.n_split), bk);
@@ -1409,8 +1413,16 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
       db.kappa[db.n_probs] = d.ds_kappa;
       ++db.n_probs;
     }
+    if (d.g_transposed) {
+      // dX = G_src^T Y with G_src = d.g [c rows, ldg] the OTHER direction's gradient tile matrix: contraction over the rows of
+      // both operands = the weight-gradient kernel's form (csrc/wgrad.hip, transposed LDS reads): G^T is never stored
+      MMK_REQUIRE(sizeof(T) == 2 && d.mode == 0 && d.g_ready && d.tn_ws != nullptr && d.ldg >= r_pad, "transposed-G direction needs bf16 compute, g_ready, tn_ws and ldg >= round_up(r, 128)");
+      tn[n_tn++] = k;
+      max_r = std::max(max_r, d.r);
+      continue;
+    }
     // dX^T[dcol][i] = sum_j yT[dcol][j] * G[i][j]
-    Prob& x = xb.p[k];
+    Prob& x = xb.p[n_x++];
     x = Prob{};
     x.P = static_cast<const char*>(d.yT);
     x.Q = static_cast<const char*>(d.g);
@@ -1426,30 +1438,39 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
     x.slab_split_stride = (long)r_pad * k_pad;
     x.k_per_split = k_per_split;
     max_tiles_x = std::max(max_tiles_x, x.tiles_m * x.tiles_n);
-    fb.p[k] = FinProb{d.slab, x.slab_split_stride, k_pad, d.r, d.kappa, d.dx, d.dx_rows, d.dx_accumulate, d.src, d.normalize};
+    fb.p[k] = FinProb{d.slab, x.slab_split_stride, k_pad, d.r, d.kappa, d.dx, d.dx_rows, d.dx_accumulate, d.src, d.normalize, pl.n_split};
     max_r = std::max(max_r, d.r);
   }
   gb.n_split = 1;
   gb.n_probs = n_tile_probs;
-  xb.n_probs = n_dirs;
+  xb.n_probs = n_x;
   gb.dbg = getenv("MMK_SIM_DBG") ? (atoi(getenv("MMK_SIM_DBG")) & 8) : 0;   // 8 = never take the bounded fast path
   xb.dbg = 0;
   xb.n_split = pl.n_split;
-  fb.n_split = pl.n_split;
   fb.d = d_user;
   if (n_tile_probs > 0) {
     int rc = dirs[0].mode == 1 ? launch_gemm<T, EPI_ALIGN_GRAD>(gb, n_tile_probs, pl.bm, pl.bn, max_tiles_g, scale, st)
                                : launch_gemm<T, EPI_GRAD>(gb, n_tile_probs, pl.bm, pl.bn, max_tiles_g, scale, st);
     if (rc) return rc;
   }
-  {
-    int rc = launch_gemm<T, EPI_PLAIN>(xb, n_dirs, pl.bm_g, pl.bn_g, max_tiles_x, scale, st);
+  if (n_x > 0) {
+    int rc = launch_gemm<T, EPI_PLAIN>(xb, n_x, pl.bm_g, pl.bn_g, max_tiles_x, scale, st);
     if (rc) return rc;
+  }
+  int ld_max = k_pad;
+  for (int t = 0; t < n_tn; ++t) {
+    const mmk_clip_dir& d = dirs[tn[t]];
+    int32_t splits = 0, n_pad = 0, kp = 0;
+    int rc = mmk_wgrad_partial(d.g, d.y, d.tn_ws, d.c, round_up(d.r, 128), k_pad, d.ldg, k_pad, &splits, &n_pad, &kp, st);
+    if (rc) return rc;
+    MMK_REQUIRE((int64_t)splits * n_pad * kp <= d.tn_ws_floats, "tn_ws too small (mmk_wgrad_plan(c, round_up(r, 128), k_pad))");
+    fb.p[tn[t]] = FinProb{d.tn_ws, (long)n_pad * kp, kp, d.r, d.kappa, d.dx, d.dx_rows, d.dx_accumulate, d.src, d.normalize, splits};
+    ld_max = std::max(ld_max, (int)kp);
   }
   {
     ProfScope ps(MMK_K_GRAD_FINALIZE, st);
     // one launch: a grid row per direction, plus one for the d/dscale reduction
-    hipLaunchKernelGGL((grad_finalize_kernel<U>), dim3(cdiv(max_r, 4), n_dirs + (dscale_out ? 1 : 0)), dim3(256), 4 * k_pad * sizeof(float), st, fb,
+    hipLaunchKernelGGL((grad_finalize_kernel<U>), dim3(cdiv(max_r, 4), n_dirs + (dscale_out ? 1 : 0)), dim3(256), 4 * ld_max * sizeof(float), st, fb,
                        scale, upstream, db, dscale_out, n_dirs);
     MMK_LAUNCH_CHECK();
   }
@@ -1617,7 +1638,7 @@ int mmk_clip_backward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, in
   const int dt = dirs[0].dx_dtype;
   for (int k = 0; k < n_dirs; ++k) {
     const mmk_clip_dir& q = dirs[k];
-    MMK_REQUIRE(q.yT && (q.lse || q.mode == 1) && q.g && q.slab && q.ds_part && q.dx, "null backward buffer");
+    MMK_REQUIRE((q.g_transposed || (q.yT && q.slab)) && (q.lse || q.mode == 1) && q.g && q.ds_part && q.dx, "null backward buffer");
     MMK_REQUIRE(q.dx_dtype == dt, "all directions of one call must share dx_dtype");
     MMK_REQUIRE(!q.dx_accumulate || q.dx_dtype == MMK_F32, "accumulating scatter needs an f32 gradient buffer");
     MMK_REQUIRE(!q.normalize || (q.src && q.src_dtype == q.dx_dtype), "normalize backward needs src of dx dtype");

@@ -232,10 +232,27 @@ int mmk_wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* ws_floats_
   return 0;
 }
 
-int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx, int64_t ldw,
-              int out_dtype, void* stream) {
-  MMK_REQUIRE(dy && x && dw && ws && M > 0 && N > 0 && K > 0, "bad arguments");
-  MMK_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldw % 4 == 0, "wgrad: N, K and the row strides must be multiples of 8");
+static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx, WgradArgs* out,
+                        hipStream_t st);
+
+// The split partial tiles only (no reduction): ws[split][n_pad][k_pad] f32 with n_pad / k_pad = N / K rounded up to 256;
+// the caller sums the splits.  Used by the contrastive loss' backward (csrc/clip.hip): dB = G^T A is this kernel's
+// "both operands contracted along their rows" form, so G^T never has to exist.
+int mmk_wgrad_partial(const void* dy, const void* x, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx, int32_t* splits_out,
+                      int32_t* n_pad_out, int32_t* k_pad_out, void* stream) {
+  MMK_REQUIRE(dy && x && ws && M > 0 && N > 0 && K > 0, "bad arguments");
+  MMK_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "wgrad: N, K and the row strides must be multiples of 8");
+  WgradArgs a;
+  int rc = wgrad_launch(dy, x, ws, M, N, K, ldy, ldx, &a, static_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  if (splits_out) *splits_out = a.splits;
+  if (n_pad_out) *n_pad_out = a.tiles_n * WG_TILE;
+  if (k_pad_out) *k_pad_out = a.tiles_k * WG_TILE;
+  return 0;
+}
+
+static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx, WgradArgs* out,
+                        hipStream_t st) {
   WgradArgs a;
   a.dy = static_cast<const bf16_t*>(dy); a.x = static_cast<const bf16_t*>(x); a.ws = ws;
   a.ldy = ldy; a.ldx = ldx; a.M = (int)M; a.N = N; a.K = K;
@@ -244,7 +261,6 @@ int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int
   mmk_wgrad_plan(M, N, K, &a.splits, &wsf);
   a.rows_per_split = round_up((int)cdiv((int)M, a.splits), WG_BM);
   a.splits = cdiv((int)M, a.rows_per_split);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   const int T = a.tiles_n * a.tiles_k;
   const int grid = T <= 32 ? 8 * cdiv(a.splits, 8) * T : 8 * cdiv(a.splits * T, 8);
   static bool attr = false;
@@ -258,6 +274,20 @@ int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int
     hipExtLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
   }
   MMK_LAUNCH_CHECK();
+  *out = a;
+  return 0;
+}
+
+int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx, int64_t ldw,
+              int out_dtype, void* stream) {
+  MMK_REQUIRE(dy && x && dw && ws && M > 0 && N > 0 && K > 0, "bad arguments");
+  MMK_REQUIRE(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldw % 4 == 0, "wgrad: N, K and the row strides must be multiples of 8");
+  WgradArgs a;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  {
+    int rc = wgrad_launch(dy, x, ws, M, N, K, ldy, ldx, &a, st);
+    if (rc) return rc;
+  }
   const long n4 = (long)N * (K / 4);
   const int n_pad = a.tiles_n * WG_TILE, k_pad = a.tiles_k * WG_TILE;
   int rc = MMK_DISPATCH_DTYPE(out_dtype, OUT, [&]() -> int {

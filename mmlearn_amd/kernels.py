@@ -245,6 +245,13 @@ def _pair_up(dirs: Sequence[Direction], backward: bool = False) -> list:
 _TICKETS: dict = {}
 
 
+def _tn_min_rows() -> int:
+    """Mirrored pairs with at least this many rows store G once and form the second direction's gradient with the
+    transposed-read kernel; smaller ones store G and G^T from the tile pass (one launch fewer).  MMK_TN_MIN_ROWS overrides."""
+    import os
+    return int(os.environ.get("MMK_TN_MIN_ROWS", "2048"))
+
+
 def _tickets(dev: torch.device, n: int) -> torch.Tensor:
     """The workspace of the in-launch loss combine: slot 0 is a ticket counter that the merge launch expects at zero and
     leaves at zero, so ONE buffer per (device, stream) is reused call after call (launches of a stream run one after the
@@ -363,8 +370,12 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.
             _, n_grad_blocks, _ = _plan(dr.r, dr.c, k_pad, compute)
             src = mirror_src.get(id(dr))
             ready = src is not None and id(src) in gbuf
-            g = gbuf[id(src)][1] if ready else torch.empty((r_pad, c_pad), dtype=cdt, device=dev)
-            slab = torch.empty((n_split, r_pad, k_pad), dtype=torch.float32, device=dev)
+            tn = ready and gbuf[id(src)][1] is None     # the mirror source kept G only: this direction reads it transposed
+            if tn:
+                g = gbuf[id(src)][0]
+            else:
+                g = gbuf[id(src)][1] if ready else torch.empty((r_pad, c_pad), dtype=cdt, device=dev)
+            slab = torch.empty((1 if tn else n_split, 1 if tn else r_pad, k_pad), dtype=torch.float32, device=dev)
             ds_part = torch.empty(n_grad_blocks, dtype=torch.float32, device=dev)
             keep += [g, slab, ds_part]
             e = arr[k]
@@ -384,12 +395,23 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.
                 keep += [xn, yn]
             e.src_dtype = dtype_tag(dr.src.dtype) if dr.src is not None else 0
             e.g_ready = int(ready)
+            if tn:
+                splits, wsf = C.c_int(0), C.c_int64(0)
+                check(_lib.lib().mmk_wgrad_plan(dr.c, r_pad, k_pad, C.cast(C.pointer(splits), C.c_void_p), C.cast(C.pointer(wsf), C.c_void_p)))
+                tn_ws = torch.empty(wsf.value, dtype=torch.float32, device=dev)
+                keep.append(tn_ws)
+                e.g_transposed, e.tn_ws, e.tn_ws_floats = 1, ptr(tn_ws), wsf.value
+                e.ldg = g.shape[1]
             mir = next((b for b in chunk[k + 1:k + 2] if mirror_src.get(id(b)) is dr), None)
             if mir is not None and id(mir) in in_chunk:
-                gt = torch.empty((c_pad, r_pad), dtype=cdt, device=dev)     # = the mirror's [r_pad', c_pad'] G
-                gbuf[id(dr)] = (g, gt)
-                keep.append(gt)
-                e.gT, e.ldgt = ptr(gt), r_pad
+                if compute == COMPUTE_BF16 and dr.r >= _tn_min_rows():
+                    # large mirrored pair: G is stored once; the mirror's dX = G^T Y comes from the transposed-read kernel
+                    gbuf[id(dr)] = (g, None)
+                else:
+                    gt = torch.empty((c_pad, r_pad), dtype=cdt, device=dev)     # = the mirror's [r_pad', c_pad'] G
+                    gbuf[id(dr)] = (g, gt)
+                    keep.append(gt)
+                    e.gT, e.ldgt = ptr(gt), r_pad
         check(_lib.lib().mmk_clip_backward(C.cast(arr, C.c_void_p), len(chunk), k_pad, d, compute, ptr(scale), ptr(upstream),
                                            ptr(dscale), stream()))
         del keep  # the caching allocator keeps the blocks alive until the stream has consumed them

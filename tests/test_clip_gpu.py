@@ -207,6 +207,33 @@ def test_bounded_fast_path_equals_exact_path(n, d, scale, monkeypatch):
         assert lf == le and torch.equal(gaf, gae)
 
 
+@pytest.mark.parametrize("n,d", [(2048, 512), (2304, 200), (4100, 64)])
+def test_transposed_read_gradient_equals_stored_transpose(n, d, monkeypatch):
+    """Large mirrored pairs store G once and form the second direction's dX = G^T Y with the transposed-read (weight-gradient)
+    kernel; smaller ones store G^T from the tile pass.  Same gradients either way (f32 sums in another order), sizes off the
+    256 grid included."""
+    from mmlearn_amd import ContrastiveLoss, LossPairSpec
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(n)
+    a = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1).bfloat16()
+    b = torch.nn.functional.normalize(0.5 * a.float() + torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1), dim=-1).bfloat16()
+    ids = torch.stack([torch.zeros(n, dtype=torch.long), torch.arange(n)], 1).to(dev)
+    out = {}
+    for mode, rows in (("tn", "1024"), ("gt", "1000000000")):
+        monkeypatch.setenv("MMK_TN_MIN_ROWS", rows)
+        ea, eb = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        s = torch.tensor(1 / 0.07, device=dev, requires_grad=True)
+        loss = ContrastiveLoss()({"rgb_embedding": ea, "text_embedding": eb}, {"rgb": ids, "text": ids}, s, [LossPairSpec(("rgb", "text"))])
+        loss.float().backward()
+        out[mode] = (float(loss.detach().float()), ea.grad.float().cpu(), eb.grad.float().cpu(), float(s.grad))
+    monkeypatch.delenv("MMK_TN_MIN_ROWS", raising=False)
+    assert out["tn"][0] == out["gt"][0] and out["tn"][3] == out["gt"][3]
+    assert torch.equal(out["tn"][1], out["gt"][1])          # first direction: same launches
+    x, y = out["tn"][2], out["gt"][2]                       # second direction: other kernel, other summation order
+    assert (x - y).abs().max() <= 1e-2 * y.abs().max() and (x - y).abs().mean() <= 1e-4 * y.abs().max()
+
+
 MATCH = Golden("g4_match")
 
 

@@ -324,6 +324,11 @@ int mmk_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx,
 int mmk_gemm_nt_supported(int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc);
 int mmk_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bias, int64_t M, int N, int K, int64_t lda, int64_t ldb,
                 int64_t ldc, int out_dtype, int act, void* stream);
+/* Second design of the same GEMM (csrc/gemm4.hip): four waves, one per SIMD, 128 x 128 register tile each (256 accumulator
+ * registers), one barrier per K step; same arguments, same results up to the f32 summation order (identical: k order kept). */
+int mmk_gemm4_nt_supported(int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc);
+int mmk_gemm4_nt(const void* A, const void* B, void* C, void* C2, const float* bias, int64_t M, int N, int K, int64_t lda, int64_t ldb,
+                int64_t ldc, int out_dtype, int act, void* stream);
 
 /* Weight gradient of a Linear, dW[N, K] = dY^T x for dY [M, N], x [M, K] (bf16, row strides ldy / ldx in elements):
  * replaces the dY.t() @ x GEMM of autograd's linear backward where its output is too small to fill the chip

@@ -109,6 +109,8 @@ _SIGNATURES = {
     "mmk_embedding_bwd": [_vp, _vp, _vp, C.c_int64, _i, C.c_int64, _i, _vp],
     "mmk_gemm_nt_supported": [C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64],
     "mmk_gemm_nt": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _i, _vp],
+    "mmk_gemm4_nt_supported": [C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64],
+    "mmk_gemm4_nt": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _i, _vp],
     "mmk_wgrad_plan": [C.c_int64, _i, _i, _vp, _vp],
     "mmk_wgrad_partial": [_vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp],
     "mmk_wgrad": [_vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _vp],

@@ -81,8 +81,12 @@ def main():
         t_hip = timeit(lambda: K.gemm_nt(a, b), args.iters)
         t_lib = timeit(lambda: torch.nn.functional.linear(a, b), args.iters)
         fl = 2.0 * M * N * Kd
-        print(json.dumps({"M": M, "N": N, "K": Kd, "hip_us": round(t_hip, 1), "hip_tflops": round(fl / t_hip / 1e6, 1),
-                          "hipblaslt_us": round(t_lib, 1), "hipblaslt_tflops": round(fl / t_lib / 1e6, 1)}), flush=True)
+        out = {"M": M, "N": N, "K": Kd, "hip_us": round(t_hip, 1), "hip_tflops": round(fl / t_hip / 1e6, 1),
+               "hipblaslt_us": round(t_lib, 1), "hipblaslt_tflops": round(fl / t_lib / 1e6, 1)}
+        if M % 256 == 0 and N % 256 == 0:   # the four-wave kernel (csrc/gemm4.hip); MMK_GEMM4_DBG=4: no C stores (timing only)
+            t4 = timeit(lambda: K.gemm4_nt(a, b), args.iters)
+            out.update({"hip4_us": round(t4, 1), "hip4_tflops": round(fl / t4 / 1e6, 1)})
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -805,12 +805,25 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(const MergeBatch batch) 
   if (active) {
     float mx = -INFINITY, l = 0.f;
     if (i < p.N) {
-#pragma unroll 4
-      for (int t = wave; t < p.n_part; t += 4) {
+      // four loads in flight per lane, then the online merge (v_exp_f32: arguments <= 0)
+      int t = wave;
+      for (; t + 12 < p.n_part; t += 16) {
+        float2 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = p.part[(size_t)(t + 4 * q) * p.part_ld + i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (v[q].x > -INFINITY) {
+            const float nm = fmaxf(mx, v[q].x);
+            l = l * fast_exp2(mx - nm) + v[q].y * fast_exp2(v[q].x - nm);
+            mx = nm;
+          }
+      }
+      for (; t < p.n_part; t += 4) {
         const float2 v = p.part[(size_t)t * p.part_ld + i];
         if (v.x > -INFINITY) {
           const float nm = fmaxf(mx, v.x);
-          l = l * exp2f(mx - nm) + v.y * exp2f(v.x - nm);
+          l = l * fast_exp2(mx - nm) + v.y * fast_exp2(v.x - nm);
           mx = nm;
         }
       }
@@ -827,7 +840,7 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(const MergeBatch batch) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {   // fixed order
           const float2 v = quarter[q][lane];
-          if (v.x > -INFINITY) sum += v.y * exp2f(v.x - m);
+          if (v.x > -INFINITY) sum += v.y * fast_exp2(v.x - m);
         }
         const float lse = (m + log2f(sum)) * 0.6931471805599453f;  // partials are in the log2 domain
         p.lse[i] = lse;

@@ -5,7 +5,7 @@ tallies 128-byte requests at 64 bytes, /opt/skills/guides/MI355X_MICROARCH.md, H
 import collections, csv, json, sys
 
 NAMES = {"Li0ELi1E": "sim_stats", "Li1ELi1E": "sim_grad", "Li2ELi1E": "grad_gemm", "lse_merge": "lse_merge", "pack_tr": "pack_rows",
-         "grad_finalize": "grad_finalize", "match_small": "match_ids", "match_kernel": "match_ids", "match_scan": "match_ids"}
+         "grad_finalize": "grad_finalize", "wgrad_kernel": "wgrad (dB = G^T A)", "match_small": "match_ids", "match_kernel": "match_ids", "match_scan": "match_ids"}
 
 
 def load(path, counter):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMK_ABI_VERSION 1
+#define MMK_ABI_VERSION 2
 
 /* element types of user tensors */
 enum { MMK_F32 = 0, MMK_BF16 = 1, MMK_F16 = 2 };

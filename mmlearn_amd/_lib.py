@@ -20,6 +20,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 F32, BF16, F16 = 0, 1, 2
 COMPUTE_BF16, COMPUTE_F32 = 1, 0
+ABI_VERSION = 2   # include/mmlearn_hip.h MMK_ABI_VERSION this ctypes mirror was written against
 
 _DTYPE_TAG = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -156,6 +157,9 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = C.c_char_p
+        if l.mmk_abi_version() != ABI_VERSION:   # a stale .so next to newer Python: struct layouts would not match
+            raise RuntimeError(f"{LIB_PATH} has ABI version {l.mmk_abi_version()}, this package needs {ABI_VERSION}: rebuild it "
+                               "(`make -C mmlearn_amd/csrc`)")
         _lib = l
     return _lib
 

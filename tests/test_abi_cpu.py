@@ -39,7 +39,7 @@ def test_header_symbols_are_exported(built):
 
 def test_library_loads_without_gpu(built):
     lib = built.lib()
-    assert lib.mmk_abi_version() == 1
+    assert lib.mmk_abi_version() == 2
     assert lib.mmk_kernel_name(3) == b"sim_stats"
     for k, name in enumerate(built.KERNEL_NAMES):
         assert lib.mmk_kernel_name(k).decode() == name

@@ -283,7 +283,7 @@ int mmk_recall_ranks(const float* x, const float* y, const int64_t* pos, float* 
  * torch.nn.LayerNorm inside the encoders the tasks drive (mmlearn/modules/encoders/{clip,text,vision}.py):
  * F.layer_norm forward / backward with f32 statistics.  x: [rows, d]; w, b: f32[d] or NULL; mean/rstd: f32[rows].
  * fwd dtype = x dtype | (y dtype << 4);  bwd dtype = x(=dx) dtype | (dy dtype << 4).
- * bwd workspaces: part f32[mmk_layernorm_part_blocks(rows), 2, d], part2 f32[64, 2, d]; dw/db f32[d] or both NULL. */
+ * bwd workspaces: part f32[mmk_layernorm_part_blocks(rows), 2, d], part2 f32[256, 2, d]; dw/db f32[d] or both NULL. */
 int mmk_layernorm_part_blocks(long rows);
 int mmk_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int64_t rows, int d,
                       float eps, int dtype, void* stream);
@@ -309,7 +309,7 @@ int mmk_add_layernorm_bwd(const float* s, const void* dy, const void* dy_twin, c
 
 /* y = act(x + bias) for a Linear run without its bias (fc1 of the encoders' MLPs: HF CLIPMLP fc1 + quick_gelu,
  * BertIntermediate dense + erf GELU); act 0 = x*sigmoid(1.702x), 1 = erf GELU.  The backward writes
- * dx = act'(x + bias) * dy and dbias = column sums of dx (part: f32[mmk_bias_act_part_blocks(rows), d], part2: f32[64, d]). */
+ * dx = act'(x + bias) * dy and dbias = column sums of dx (part: f32[mmk_bias_act_part_blocks(rows), d], part2: f32[256, d]). */
 int mmk_bias_act_part_blocks(long rows);
 int mmk_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, int d, int act, int dtype, void* stream);
 int mmk_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx, float* part, float* part2, float* dbias, int64_t rows,

@@ -571,7 +571,7 @@ def layernorm_bwd(x2: torch.Tensor, dy2: torch.Tensor, w: Optional[torch.Tensor]
     if need_wb:
         nb = _lib.lib().mmk_layernorm_part_blocks(rows)
         part = torch.empty((max(nb, 1), 2, d), dtype=torch.float32, device=dev)
-        part2 = torch.empty((64, 2, d), dtype=torch.float32, device=dev)
+        part2 = torch.empty((256, 2, d), dtype=torch.float32, device=dev)
         dw = torch.empty(d, dtype=torch.float32, device=dev)
         db = torch.empty(d, dtype=torch.float32, device=dev)
     dt = dtype_tag(x2.dtype) | (dtype_tag(dy2.dtype) << 4)
@@ -612,7 +612,7 @@ def add_layernorm_bwd(s2: torch.Tensor, dy2: Optional[torch.Tensor], ds_in: Opti
         npart = 3 if need_xbias else 2
         nb = _lib.lib().mmk_layernorm_part_blocks(rows)
         part = torch.empty((max(nb, 1), npart, d), dtype=torch.float32, device=dev)
-        part2 = torch.empty((64, npart, d), dtype=torch.float32, device=dev)
+        part2 = torch.empty((256, npart, d), dtype=torch.float32, device=dev)
         dw = torch.empty(d, dtype=torch.float32, device=dev)
         db = torch.empty(d, dtype=torch.float32, device=dev)
         dxb = torch.empty(d, dtype=torch.float32, device=dev) if need_xbias else None
@@ -732,7 +732,7 @@ def bias_act_bwd(x2: torch.Tensor, bias: torch.Tensor, dy2: torch.Tensor, act: i
     dx = torch.empty_like(x2)
     nb = _lib.lib().mmk_bias_act_part_blocks(rows)
     part = torch.empty((max(nb, 1), d), dtype=torch.float32, device=dev)
-    part2 = torch.empty((64, d), dtype=torch.float32, device=dev)
+    part2 = torch.empty((256, d), dtype=torch.float32, device=dev)
     dbias = torch.empty(d, dtype=torch.float32, device=dev)
     check(_lib.lib().mmk_bias_act_bwd(ptr(x2), ptr(bias), ptr(dy2), ptr(dx), ptr(part), ptr(part2), ptr(dbias), rows, d, int(act),
                                       dtype_tag(x2.dtype), stream()))

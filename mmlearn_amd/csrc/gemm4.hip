@@ -22,8 +22,10 @@
 // 0.76-0.97 (no stores 1.0-1.13), eight waves + ring with a K step of 32 and FOUR steps in flight 0.75-0.99 (no stores 1.0-1.09):
 // neither the LDS-DMA issue cost nor the prefetch distance is the limit.  The probe says what is: with eight LDS-DMA
 // instructions per step and wave that nobody ever waits for, the MFMA loop still runs at 2.13 PFLOP/s while they re-read one
-// hot 8 KiB, and at 1.54 PFLOP/s when every workgroup streams its own L2-resident 256 KiB (with or without a counted vmcnt):
-// the chip delivers about 12 TB/s from L2 into LDS in this pattern, a 256 x 256 tile needs one byte per 128 flop, so ~1.5
+// hot 8 KiB, and at 1.49-1.55 PFLOP/s when every workgroup streams its own data (64 KiB re-read every step = L2-resident, or
+// 256 KiB = Infinity-Cache-resident, with or without a counted vmcnt; twice the bytes per step: 1.22 = 18.6 TB/s, the saturated
+// fill rate): feeding LDS from beyond the L1 at the 11-12 TB/s a 256 x 256 tile needs (one byte per 128 flop) costs a third of
+// the MFMA rate, so ~1.5
 // PFLOP/s is the ceiling of ANY LDS-staged 256 x 256 bf16 GEMM here, and barriers / waits / the C stores take it to the
 // 1.0-1.25 that this kernel, gemm.hip and hipBLASLt all reach.  Requires M % 256 == N % 256 == 0.
 #include <hip/hip_ext.h>

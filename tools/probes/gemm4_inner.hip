@@ -127,8 +127,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const char* st = smem + (kt & 1) * 65536;
     const char* sa = st + wm * 16384;
     const char* sb = st + 32768 + (wn >> 1) * 16384 + (wn & 1) * 8192;
-    const char* sbase = (MODE >= 2) ? src + ((size_t)blockIdx.x * 262144 + (size_t)(kt & 2047) * 65536 * 0 + (size_t)(kt & 3) * 65536) + (size_t)((kt >> 2) & 255) * 0
-                                    : src + (kt & 7) * 1024;   // scalar
+    // MODE 2 / 3: 256 KiB per workgroup (64 MiB in all: Infinity-Cache resident); MODE 4: 64 KiB per workgroup, re-read every
+    // step (2 MiB per XCD: L2 resident); the per-lane offset spans 64 KiB
+    const char* sbase = (MODE == 4) ? src + (size_t)blockIdx.x * 65536
+                        : (MODE >= 2) ? src + (size_t)blockIdx.x * 262144 + (size_t)(kt & 3) * 65536
+                                      : src + (kt & 7) * 1024;   // scalar
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 fa[4], fb[2];
@@ -188,7 +191,7 @@ static void run8dma(int nk) {
   hipEventElapsedTime(&ms, a, b);
   const double flops = 256.0 * 2.0 * 256 * 256 * 64 * nk * reps;
   printf("8 waves + %d %s per step and wave: %.1f us/launch, %.1f TFLOP/s\n", NDMA,
-         MODE == 1 ? "global_load+ds_write (waited at once)" : MODE == 0 ? "LDS-DMA (fire and forget, one hot 8 KiB)" : MODE == 2 ? "LDS-DMA (fire and forget, 256 KiB per workgroup = L2-resident stream)" : "LDS-DMA (256 KiB stream, vmcnt leaves two steps in flight)",
+         MODE == 1 ? "global_load+ds_write (waited at once)" : MODE == 0 ? "LDS-DMA (fire and forget, one hot 8 KiB)" : MODE == 2 ? "LDS-DMA (fire and forget, 256 KiB per workgroup: Infinity-Cache-resident stream)" : MODE == 3 ? "LDS-DMA (256 KiB stream, vmcnt leaves two steps in flight)" : "LDS-DMA (fire and forget, 64 KiB per workgroup: L2-resident)",
          ms / reps * 1e3, flops / (ms * 1e-3) / 1e12);
   hipFree(out);
   hipFree(src);
@@ -249,5 +252,7 @@ int main() {
   run8dma<8, 1>(2048);
   run8dma<8, 2>(2048);
   run8dma<8, 3>(2048);
+  run8dma<8, 4>(2048);
+  run8dma<16, 4>(2048);
   return 0;
 }

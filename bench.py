@@ -221,9 +221,11 @@ def eager_gpu_leg(batch_size: int, rank: int, dev, small: bool, steps: int = 4, 
         sec = _timed_steps(step, warmup, steps)
     finally:
         cp.l2_normalize = saved
+    peak = torch.cuda.max_memory_allocated() / 2**30
     del task, opt
     torch.cuda.empty_cache()
     return {"ms_per_step": round(sec * 1e3, 2), "pairs_s": round(batch_size / sec, 1), "steps": steps, "warmup": warmup, "per_gpu_batch": batch_size,
+            "peak_hbm_gib": round(peak, 1),
             "what": "stock HF CLIP ViT-B/16 + BERT-base, SDPA, hipBLASLt, torch.optim.AdamW, bf16 autocast, reference loss op sequence (eager), 1 GPU, local negatives"}
 
 

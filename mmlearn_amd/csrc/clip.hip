@@ -24,6 +24,7 @@
 
 #include "common.h"
 
+extern "C" int mmk_wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* ws_floats_out);
 extern "C" int mmk_wgrad_partial(const void* dy, const void* x, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx, int32_t* splits_out,
                                  int32_t* n_pad_out, int32_t* k_pad_out, void* stream);
 
@@ -1474,9 +1475,15 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
   for (int t = 0; t < n_tn; ++t) {
     const mmk_clip_dir& d = dirs[tn[t]];
     int32_t splits = 0, n_pad = 0, kp = 0;
+    {
+      int plan_splits = 0;
+      int64_t need = 0;
+      int rc = mmk_wgrad_plan(d.c, round_up(d.r, 128), k_pad, &plan_splits, &need);   // before anything is launched into tn_ws
+      if (rc) return rc;
+      MMK_REQUIRE(need <= d.tn_ws_floats, "tn_ws too small (mmk_wgrad_plan(c, round_up(r, 128), k_pad))");
+    }
     int rc = mmk_wgrad_partial(d.g, d.y, d.tn_ws, d.c, round_up(d.r, 128), k_pad, d.ldg, k_pad, &splits, &n_pad, &kp, st);
     if (rc) return rc;
-    MMK_REQUIRE((int64_t)splits * n_pad * kp <= d.tn_ws_floats, "tn_ws too small (mmk_wgrad_plan(c, round_up(r, 128), k_pad))");
     fb.p[tn[t]] = FinProb{d.tn_ws, (long)n_pad * kp, kp, d.r, d.kappa, d.dx, d.dx_rows, d.dx_accumulate, d.src, d.normalize, splits};
     ld_max = std::max(ld_max, (int)kp);
   }

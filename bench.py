@@ -289,6 +289,8 @@ def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2):
     rgb, text, audio = _PooledVision(small), _PooledText(small), _PooledAudio(small)
     accelerate_encoder(rgb, low_precision_ln=("layer_norm1", "layer_norm2"), fuse_qkv=True, fuse_add_ln=True)
     accelerate_encoder(text, fuse_qkv=True, fuse_add_ln=True)
+    if os.environ.get("MMK_BENCH_STOCK_AUDIO") is None:
+        accelerate_encoder(audio)   # HTSAT: the LayerNorm swap only (f32 in / f32 out); its windowed attention stays on SDPA / ATen
     width = 128 if small else 768
     task = ContrastivePretraining(
         encoders={"rgb": rgb, "text": text, "audio": audio},

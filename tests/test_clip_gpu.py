@@ -293,6 +293,28 @@ def test_match_paths_vs_oracle(n_a, n_b, n_keys):
         assert m.repeats_a == (len(set(ra.tolist())) < len(ra)) and m.repeats_b == (len(set(rb.tolist())) < len(rb))
 
 
+def test_match_at_evaluation_scale():
+    """65536 x 65536 ids (64 chunks, 256 row blocks): identity pairing, and a permutation whose answer is known in closed form
+    (row i of a matches the row of b that holds id i: the inverse permutation), order = row-major."""
+    from mmlearn_amd import kernels as K
+
+    dev = _dev()
+    n = 65536
+    ids = torch.stack([torch.full((n,), 3, dtype=torch.long), torch.arange(n) * 7 + (1 << 33)], 1)
+    m = K.match_ids(ids.to(dev), ids.to(dev))
+    assert m.identity and m.n == n
+    g = torch.Generator().manual_seed(1)
+    perm = torch.randperm(n, generator=g)
+    m = K.match_ids(ids.to(dev), ids[perm].to(dev))
+    assert not m.identity and m.n == n and not m.repeats_a and not m.repeats_b
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n)
+    assert torch.equal(m.idx_a.cpu().long(), torch.arange(n)) and torch.equal(m.idx_b.cpu().long(), inv)
+    # a short b against a long a, nothing in common
+    m = K.match_ids(ids.to(dev), (ids[:33] + 1).to(dev))
+    assert m.n == 0
+
+
 ALIGN = Golden("g9_align")
 
 

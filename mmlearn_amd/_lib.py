@@ -121,6 +121,7 @@ _SIGNATURES = {
     "mmk_quick_gelu_bwd": [_vp, _vp, _vp, C.c_int64, _i, _vp],
     "mmk_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, C.c_uint64, _vp],
     "mmk_attn_bwd_has_colsum": [_i],
+    "mmk_attn_debug_stamps": [_vp, _i],
     "mmk_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, C.c_uint64, _vp, _vp],
 }
 _STR_FUNCS = {"mmk_last_error": [], "mmk_kernel_name": [_i]}

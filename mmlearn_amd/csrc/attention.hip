@@ -446,6 +446,7 @@ struct AttnBwdArgs {
   uint32_t seed_lo, seed_hi, drop_thr;
   float drop_scale;
   float* cs;  // optional [B * ceil(L / 32)][3][H][64] f32: per 32-row tile column sums of the stored dq / dk / dv (packed layout)
+  unsigned long long* stamps;  // debugging (MMK_ATTN_STAMPS): shader-clock stamps of workgroup 0, 16 per item, first 32 items
 };
 
 // where the column sums of tile `tile` of (batch b, head hh), part 0 = dq / 1 = dk / 2 = dv, go (nullptr: not wanted)
@@ -724,11 +725,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
   const float* lse2s = rowc;
   const float* dls = rowc + ROWC;
 
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  int n_mine = 0;
+  auto stamp = [&](int k) {
+    if (a.stamps != nullptr && blockIdx.x == 0 && tid == 0 && n_mine < 32) a.stamps[n_mine * 16 + k] = __builtin_readcyclecounter();
+  };
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++n_mine) {
     const int b = item / a.H, hh = item % a.H;
     const long obase = ((long)b * a.L * a.H + hh) * ATT_DH;
     const long gbase = (long)b * a.g_sb + (long)hh * ATT_DH;
     const uint32_t dkey = DROP ? drop_key(a.seed_lo, a.seed_hi, (uint32_t)item) : 0u;
+    stamp(0);
     // ---- load: V_j fragments (compiler-visible, first), then the Q, dO, K images and the row-constant record
     bf16x8 kf[4], vf[4];
     if (keyw) {
@@ -749,8 +755,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
         lds_dma16(a.delta + ((long)item * 2 + wave_s) * ROWC, (uint32_t)lo * 16u,
                   lds_addr_of(reinterpret_cast<const char*>(rowc + wave_s * ROWC)));
     }
+    stamp(1);
     wait_vmem_all();
     __syncthreads();
+    stamp(2);
 
     f32x16 acc1[2], acc2[2];  // key waves: dKᵀ, dVᵀ;  dQ wave: dQᵀ of one query tile (acc1)
     const int j = wave * 32 + r;  // key waves: this lane's key
@@ -856,11 +864,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
         store_rows_staged_cs(stage, a.dq + gbase, a.g_sl, (it - 1) * 32, a.L, acc1, a.scale, opaque(lane), cs_slot(a, b, hh, it - 1, 0));
       }
       __syncthreads();
+      stamp(3 + it);
     }
     if (keyw) {
       store_rows_staged_cs(stage, a.dk + gbase, a.g_sl, wave * 32, a.L, acc1, a.scale, opaque(lane), cs_slot(a, b, hh, wave, 1));
       store_rows_staged_cs(stage, a.dv + gbase, a.g_sl, wave * 32, a.L, acc2, 1.f, opaque(lane), cs_slot(a, b, hh, wave, 2));
     }
+    stamp(4 + NT);
   }
 }
 
@@ -960,6 +970,24 @@ extern "C" int mmk_attn_fwd(const void* q, const void* k, const void* v, void* o
   }
 }
 
+// MMK_ATTN_STAMPS=1: a 4-KiB device buffer that workgroup 0 of the five-product backward stamps (see AttnBwdArgs.stamps)
+static unsigned long long* attn_stamp_buffer() {
+  static unsigned long long* buf = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    if (getenv("MMK_ATTN_STAMPS") != nullptr && hipMalloc(reinterpret_cast<void**>(&buf), 32 * 16 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
+  }
+  return buf;
+}
+extern "C" int mmk_attn_debug_stamps(unsigned long long* out, int n) {
+  unsigned long long* buf = attn_stamp_buffer();
+  MMK_REQUIRE(buf != nullptr && out != nullptr && n > 0 && n <= 32 * 16, "no stamp buffer (set MMK_ATTN_STAMPS=1 before the first call)");
+  MMK_HIP(hipDeviceSynchronize());
+  MMK_HIP(hipMemcpy(out, buf, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // 1 when mmk_attn_bwd can fill colsum_part for sequences of L rows (the five-product kernel serves them: every tile count
 // with a spare wave, i.e. all but 97..128 and 225..256 rows), 0 otherwise.
 extern "C" int mmk_attn_bwd_has_colsum(int L) {
@@ -984,6 +1012,7 @@ extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const v
   a.o = static_cast<const bf16_t*>(out); a.dout = static_cast<const bf16_t*>(dout); a.lse = lse; a.delta = delta_ws;
   a.dq = static_cast<bf16_t*>(dq); a.dk = static_cast<bf16_t*>(dk); a.dv = static_cast<bf16_t*>(dv);
   a.cs = colsum_part;
+  a.stamps = attn_stamp_buffer();
   a.g_sb = grad_strides[0]; a.g_sl = grad_strides[1];
   MMK_REQUIRE(a.g_sb % 8 == 0 && a.g_sl % 8 == 0 && a.g_sl >= (long)H * ATT_DH, "gradient rows must be 16-byte aligned");
   a.q_sb = q_strides[0]; a.q_sh = q_strides[1]; a.q_sl = q_strides[2];

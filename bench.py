@@ -646,7 +646,8 @@ def main():
         if getattr(task, "concurrent_encoders", False) and not os.environ.get("MMK_BENCH_OUTER_DDP"):
             # one DDP instance per tower, each built under its tower's stream: gradient accumulation, buckets and all-reduces
             # stay on that stream and the towers' backward passes keep overlapping (a single outer DDP serialises them)
-            task.wrap_towers_in_ddp()
+            # buffers of these towers are constants (position ids): no per-forward broadcast
+            task.wrap_towers_in_ddp(broadcast_buffers=False)
         else:
             stepper = nn.parallel.DistributedDataParallel(stepper, device_ids=[local_rank], gradient_as_bucket_view=True)
     batch = synthetic_batch(args.batch, rank, dev)

@@ -160,13 +160,17 @@ __device__ __forceinline__ float half_wave_transpose_reduce(float (&v)[CNT], int
   return v[0];
 }
 
-template <typename T, int BM, int BN, int EPI, int LOADER, int NSTAGE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, const float* __restrict__ scale_ptr) {
+// WM = waves along the P rows (m); two waves along the Q rows (n).  WM = 2: four waves, two workgroups per CU (128 x 128 / 64 x 64
+// tiles); WM = 4: eight waves on a 256 x 128 tile, one workgroup per CU with three stages (a quarter fewer bytes into LDS per
+// output, more of them in flight).  A wave's piece is (BM / WM) x (BN / 2) in both cases.
+template <typename T, int BM, int BN, int EPI, int LOADER, int NSTAGE, int WM = 2>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_kernel(const ProbBatch batch, const float* __restrict__ scale_ptr) {
   typedef Atom<T> A;
   typedef typename A::Frag Frag;
-  constexpr int MT = BM / 64, NT = BN / 64;          // 32x32 MFMA tiles per wave per dim (2x2 waves)
+  constexpr int NWAVES = 2 * WM, NTHREADS = 64 * NWAVES;
+  constexpr int MT = BM / (32 * WM), NT = BN / 64;   // 32x32 MFMA tiles per wave per dim (WM x 2 waves)
   constexpr int ROWS = BM + BN;
-  constexpr int CPT = ROWS * 8 / 256;                // 16-byte chunks per thread per stage (= DMA instr per wave)
+  constexpr int CPT = ROWS * 8 / NTHREADS;                // 16-byte chunks per thread per stage (= DMA instr per wave)
   constexpr int STAGE_BYTES = ROWS * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // NSTAGE * STAGE_BYTES (dynamic: may exceed 64 KiB)
 
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
   const int nk = (k_end - k_begin) / A::BK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1, r = lane & 31, h = lane >> 5;
+  const int wm = wave % WM, wn = wave / WM, r = lane & 31, h = lane >> 5;
 
   // ---- staging assignment.  REG: chunk c = tid + 256*u (8 chunks per row), swizzled LDS destination.
   //      DMA: wave-instruction u of wave w covers tile rows 8*(w*CPT+u) .. +7; lane L lands at LDS row
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
   for (int u = 0; u < CPT; ++u) {
     int row, ch;
     if (LOADER == LOADER_REG) {
-      const int c = tid + 256 * u;
+      const int c = tid + NTHREADS * u;
       row = c >> 3;
       ch = c & 7;
       lds_off[u] = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
   int p_off[MT], q_off[NT], p_sw[MT], q_sw[NT];
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
-    const int row = wm * (BM / 2) + a * 32 + r;
+    const int row = wm * (BM / WM) + a * 32 + r;
     p_off[a] = row * 128;
     p_sw[a] = (row >> 1) & 7;
   }
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
   // Bound of the tile's logits in the log2 domain from the operand norms (Cauchy-Schwarz): |u| <= R for every element.
   // Returns 0 when the norms are unknown.  Block-uniform; contains a barrier (call it from uniform control flow only).
   auto tile_bound = [&](float s2) -> float {
-    float* wmax = reinterpret_cast<float*>(smem + 2 * BN * 8);        // [4] (behind the [2][BN] float2 area of EPI_STATS)
+    float* wmax = reinterpret_cast<float*>(smem + WM * BN * 8);       // [NWAVES] (behind the [WM][BN] float2 area of EPI_STATS)
     float v = my_nrm;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
     __syncthreads();
     float nq = 0.f, np = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NWAVES; ++w) {
       if (w * 64 < BN) nq = fmaxf(nq, wmax[w]);
       else if (w * 64 < BN + BM) np = fmaxf(np, wmax[w]);
     }
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
         for (int a = 0; a < MT; ++a)
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int j = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int j = m0 + wm * (BM / WM) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (j == lab && i < p.N && j < p.M) p.diag[i] = s * acc[a][b][e];
           }
       }
@@ -405,13 +409,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
       }
       __syncthreads();
       if (tid < BN) {
-        const float2 x = red[tid], y = red[BN + tid];
-        p.part[(size_t)tm * p.part_ld + n0 + tid] = make_float2(R, x.y + y.y);
+        float l = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) l += red[w * BN + tid].y;
+        p.part[(size_t)tm * p.part_ld + n0 + tid] = make_float2(R, l);
       }
       if (want_col) {
         const float cs = half_wave_transpose_reduce<CNT, false>(csum, lane);   // lane L: column L & (CNT - 1) of half h
         const int cidx = lane & (CNT - 1);
-        const int j = m0 + wm * (BM / 2) + (cidx >> 4) * 32 + (cidx & 3) + 8 * ((cidx & 15) >> 2) + 4 * h;
+        const int j = m0 + wm * (BM / WM) + (cidx >> 4) * 32 + (cidx & 3) + 8 * ((cidx & 15) >> 2) + 4 * h;
         if (CNT == 32 || (lane & 16) == 0) p.mpart[(size_t)(tn * 2 + wn) * p.mpart_ld + j] = make_float2(R, cs);
       }
     } else {
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
           for (int a = 0; a < MT; ++a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-              const int j = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+              const int j = m0 + wm * (BM / WM) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
               const float u = (j < p.M) ? acc[a][b][e] * s2 : -INFINITY;
               umax = fmaxf(umax, u);
             }
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
             for (int a = 0; a < MT; ++a)
 #pragma unroll
               for (int e = 0; e < 16; ++e) {
-                const int j = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int j = m0 + wm * (BM / WM) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 sum += (j < p.M) ? fast_exp2(acc[a][b][e] * s2 - umax) : 0.f;
               }
           }
@@ -459,11 +465,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
       }
       __syncthreads();
       if (tid < BN) {
-        const float2 x = red[tid], y = red[BN + tid];
-        const float mx = fmaxf(x.x, y.x);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) mx = fmaxf(mx, red[w * BN + tid].x);
         float l = 0.f;
-        if (x.x > -INFINITY) l += x.y * fast_exp2(x.x - mx);
-        if (y.x > -INFINITY) l += y.y * fast_exp2(y.x - mx);
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          const float2 x = red[w * BN + tid];
+          if (x.x > -INFINITY) l += x.y * fast_exp2(x.x - mx);
+        }
         const int i = n0 + tid;
         if (i < p.N) p.part[(size_t)tm * p.part_ld + i] = make_float2(mx, l);  // log2 domain
       }
@@ -509,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
           }
         const float cs = half_wave_transpose_reduce<CNT, false>(vsum, lane);
         const int cidx = lane & (CNT - 1);
-        const int j = m0 + wm * (BM / 2) + (cidx >> 4) * 32 + (cidx & 3) + 8 * ((cidx & 15) >> 2) + 4 * h;
+        const int j = m0 + wm * (BM / WM) + (cidx >> 4) * 32 + (cidx & 3) + 8 * ((cidx & 15) >> 2) + 4 * h;
         if (j < p.M && (CNT == 32 || (lane & 16) == 0)) p.mpart[(size_t)(tn * 2 + wn) * p.mpart_ld + j] = make_float2(cm, cs);
       }
     }
@@ -537,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int jb = m0 + wm * (BM / 2) + a * 32 + 8 * q + 4 * h;
+          const int jb = m0 + wm * (BM / WM) + a * 32 + 8 * q + 4 * h;
           float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
           if (use_col) t4 = *reinterpret_cast<const float4*>(p.lse_col + jb);
           const float f0 = use_col ? fast_exp2(R - t4.x * LOG2E) : 0.f, f1 = use_col ? fast_exp2(R - t4.y * LOG2E) : 0.f;
@@ -548,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
     }
     // G leaves through a wave-private LDS staging tile so that global stores are whole row segments
     // (COLS*sizeof(T) = 128/256 B contiguous per row) instead of 8/16-byte pieces scattered over 32 rows.
-    constexpr int COLS = BM / 2;                   // j (columns of G) per wave
+    constexpr int COLS = BM / WM;                   // j (columns of G) per wave
     constexpr int PB = 4 * (int)sizeof(T);         // bytes of one 4-element piece
     constexpr int RB = COLS * (int)sizeof(T);      // bytes of one staged row
     constexpr int STRIDE = RB + PB;                // padded: conflict-free piece writes, aligned piece reads
@@ -569,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int jl = a * 32 + 8 * q + 4 * h;  // column inside the wave's strip
-          const int jb = m0 + wm * (BM / 2) + jl;
+          const int jb = m0 + wm * (BM / WM) + jl;
           float g4[4];
           if (fast) {
 #pragma unroll
@@ -627,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
         const int row = t * RPI + lane / LPR, c4 = lane % LPR;
         const Piece v = *reinterpret_cast<const Piece*>(stg + row * STRIDE + c4 * PB);
         const int gi = n0 + wn * (BN / 2) + b * 32 + row;
-        const int gj = m0 + wm * (BM / 2) + c4 * 4;
+        const int gj = m0 + wm * (BM / WM) + c4 * 4;
         *reinterpret_cast<Piece*>(reinterpret_cast<T*>(p.G) + (size_t)gi * p.ldg + gj) = v;
       }
       if (p.GT != nullptr) {
@@ -644,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
         for (int t = 0; t < COLS / TRPI; ++t) {
           const int row = t * TRPI + lane / TLPR, c16 = lane % TLPR;
           const uint4 v = *reinterpret_cast<const uint4*>(stg + row * 32 * (int)sizeof(T) + c16 * 16);
-          const int gj = m0 + wm * (BM / 2) + row;
+          const int gj = m0 + wm * (BM / WM) + row;
           const int gi = n0 + wn * (BN / 2) + b * 32 + c16 * (16 / (int)sizeof(T));
           *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.GT) + (size_t)gj * p.ldgt + gi) = v;
         }
@@ -655,7 +665,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
     float* red = reinterpret_cast<float*>(smem);
     if (lane == 0) red[wave] = ds_acc;
     __syncthreads();
-    if (tid == 0) p.ds_part[tile] = red[0] + red[1] + red[2] + red[3];
+    if (tid == 0) {
+      float t_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) t_ += red[w];
+      p.ds_part[tile] = t_;
+    }
   } else if (EPI == EPI_ALIGN_STATS) {
     // modality-alignment BCE (contrastive.py:387-413): per row r sums of BCE-with-logits over its positive
     // columns [r, hmax[r]) and over the rest; pointwise, so tile partials simply add.
@@ -672,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int c = m0 + wm * (BM / 2) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const int c = m0 + wm * (BM / WM) + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
           const float v = s * acc[a][b][e];
           const bool y = (c >= row) && (c < hm);
           // max(v,0) - v*y + log1p(exp(-|v|))
@@ -687,16 +702,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
     }
     __syncthreads();
     if (tid < BN) {
-      const float2 x = red[tid], y = red[BN + tid];
+      float2 t2 = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        t2.x += red[w * BN + tid].x;
+        t2.y += red[w * BN + tid].y;
+      }
       const int i = n0 + tid;
-      if (i < p.N) p.part[(size_t)tm * p.part_ld + i] = make_float2(x.x + y.x, x.y + y.y);
+      if (i < p.N) p.part[(size_t)tm * p.part_ld + i] = make_float2(t2.x, t2.y);
     }
   } else if (EPI == EPI_ALIGN_GRAD) {
     // d/dlogits of the alignment loss, symmetrised because logits = s F F^T:  G[r][c] = a_rc + a_cr with
     // a_rc = (sigmoid(v) - y_rc) * (y_rc ? 1/npos_r : 1/nneg_r);  d/dscale uses a_rc only (each (r,c) once).
     const float s = *scale_ptr;
     float ds_acc = 0.f;
-    constexpr int COLS = BM / 2;
+    constexpr int COLS = BM / WM;
     constexpr int PB = 4 * (int)sizeof(T);
     constexpr int RB = COLS * (int)sizeof(T);
     constexpr int STRIDE = RB + PB;
@@ -717,7 +737,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int jl = a * 32 + 8 * q + 4 * h;
-          const int cb = m0 + wm * (BM / 2) + jl;
+          const int cb = m0 + wm * (BM / WM) + jl;
           float g4[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -745,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
         const int srow = t * RPI + lane / LPR, c4 = lane % LPR;
         const Piece v = *reinterpret_cast<const Piece*>(stg + srow * STRIDE + c4 * PB);
         const int gi = n0 + wn * (BN / 2) + b * 32 + srow;
-        const int gj = m0 + wm * (BM / 2) + c4 * 4;
+        const int gj = m0 + wm * (BM / WM) + c4 * 4;
         *reinterpret_cast<Piece*>(reinterpret_cast<T*>(p.G) + (size_t)gi * p.ldg + gj) = v;
       }
     }
@@ -754,7 +774,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
     float* red = reinterpret_cast<float*>(smem);
     if (lane == 0) red[wave] = ds_acc;
     __syncthreads();
-    if (tid == 0) p.ds_part[tile] = red[0] + red[1] + red[2] + red[3];
+    if (tid == 0) {
+      float t_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) t_ += red[w];
+      p.ds_part[tile] = t_;
+    }
   } else {  // EPI_PLAIN: slab[split][n][m] = acc
     float* slab = p.slab + (size_t)zsplit * p.slab_split_stride;
 #pragma unroll
@@ -764,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const ProbBatch batch, 
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int mb = m0 + wm * (BM / 2) + a * 32 + 8 * q + 4 * h;
+          const int mb = m0 + wm * (BM / WM) + a * 32 + 8 * q + 4 * h;
           if (i < p.N && mb < p.M) {
             float4 v = make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
             *reinterpret_cast<float4*>(slab + (size_t)i * p.slab_ld + mb) = v;
@@ -1251,10 +1276,10 @@ static LoaderCfg loader_cfg() {
   return cfg;
 }
 
-template <typename T, int BM, int BN, int EPI, int LOADER, int NSTAGE>
+template <typename T, int BM, int BN, int EPI, int LOADER, int NSTAGE, int WM = 2>
 static int launch_one(const ProbBatch& b, dim3 grid, const float* scale, hipStream_t st) {
   constexpr int bytes = NSTAGE * (BM + BN) * 128;
-  auto kern = gemm_nt_kernel<T, BM, BN, EPI, LOADER, NSTAGE>;
+  auto kern = gemm_nt_kernel<T, BM, BN, EPI, LOADER, NSTAGE, WM>;
   static bool attr_set = false;
   if (bytes > 64 * 1024 && !attr_set) {
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -1264,7 +1289,7 @@ static int launch_one(const ProbBatch& b, dim3 grid, const float* scale, hipStre
     constexpr int kid = (EPI == EPI_STATS || EPI == EPI_ALIGN_STATS) ? MMK_K_SIM_STATS
                         : (EPI == EPI_GRAD || EPI == EPI_ALIGN_GRAD) ? MMK_K_SIM_GRAD : MMK_K_GRAD_GEMM;
     ProfEvents pe(kid);  // null events unless profiling: then the dispatch itself is time-stamped
-    hipExtLaunchKernelGGL(kern, grid, dim3(256), bytes, st, pe.start, pe.stop, 0, b, scale);
+    hipExtLaunchKernelGGL(kern, grid, dim3(128 * WM), bytes, st, pe.start, pe.stop, 0, b, scale);
   }
   MMK_LAUNCH_CHECK();
   return 0;
@@ -1284,6 +1309,10 @@ static int launch_tile(const ProbBatch& b, dim3 grid, const float* scale, hipStr
 template <typename T, int EPI>
 static int launch_gemm(const ProbBatch& b, int n_probs, int bm, int bn, int max_tiles, const float* scale, hipStream_t st) {
   dim3 grid(max_tiles, 1, n_probs * (EPI == EPI_PLAIN ? b.n_split : 1));
+  if (bm == 256 && bn == 128) {   // the eight-wave tile of the statistics pass (see stats_tile)
+    if (EPI == EPI_STATS) return launch_one<T, 256, 128, EPI_STATS, LOADER_DMA, 3, 4>(b, grid, scale, st);
+    MMK_REQUIRE(false, "the 256 x 128 tile is built for the statistics pass only");
+  }
   if (bm == 128 && bn == 128) return launch_tile<T, 128, 128, EPI>(b, grid, scale, st);
   if (bm == 128 && bn == 64) return launch_tile<T, 128, 64, EPI>(b, grid, scale, st);
   return launch_tile<T, 64, 64, EPI>(b, grid, scale, st);
@@ -1297,7 +1326,17 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
     r_max = std::max(r_max, dirs[k].r);
     c_max = std::max(c_max, dirs[k].c);
   }
-  const Plan pl = make_plan(r_max, c_max, k_pad, n_dirs, sizeof(T) == 2 ? MMK_COMPUTE_BF16 : MMK_COMPUTE_F32);
+  Plan pl = make_plan(r_max, c_max, k_pad, n_dirs, sizeof(T) == 2 ? MMK_COMPUTE_BF16 : MMK_COMPUTE_F32);
+  // Experiment (MMK_STATS_TILE=256, off by default): 256 x 128 tiles on eight waves, three stages, one workgroup per CU -- 3/4 of
+  // the bytes into LDS per output, 96 KiB of them in flight per CU instead of 64.  Measured at N = 8192: loads alone 62 us (as
+  // with two 128 x 128 workgroups per CU), main loop 106 us instead of 77, whole kernel 121 instead of 109: one workgroup's
+  // eight waves in barrier lock-step hide the MFMAs worse than two independent four-wave workgroups do.
+  if (dirs[0].mode == 0 && loader_cfg().loader == LOADER_DMA && getenv("MMK_TILE") == nullptr &&
+      getenv("MMK_STATS_TILE") && atoi(getenv("MMK_STATS_TILE")) == 256 &&
+      (long)cdiv(c_max, 256) * cdiv(r_max, 128) * n_dirs >= 256) {
+    pl.bm = 256;
+    pl.bn = 128;
+  }
   ProbBatch b;
   MergeBatch mb;
   AlignReduceBatch ab;

@@ -43,7 +43,9 @@ for it in range(int(os.environ.get("N", 40))):
     loss = ContrastiveLoss(l2_normalize=l2)(te, {m: ids[m].to(dev) for m in mods}, s, [LossPairSpec(p, w) for p, w in pairs])
     loss.float().backward()
     ref = co.contrastive_loss({m: embs[m].float().numpy() for m in mods}, {m: ids[m].numpy() for m in mods}, scale, pairs, l2norm=l2)
-    tol = 1e-2 if dt == torch.bfloat16 else 1e-3
+    # bf16 operands: the packed (normalised) rows are rounded to bf16 before the MFMA, and a rounding of 2^-8 of a cosine is
+    # 0.4 in the logits at scale 100: the sharper the softmax, the more of it shows
+    tol = (3e-2 if abs(scale) >= 30 else 1e-2) if dt == torch.bfloat16 else 1e-3
     errs = [abs(float(loss.detach().float()) - ref["loss"]) / max(1.0, abs(ref["loss"]))]
     for m in mods:
         gr = te[f"{m}_embedding"].grad.float().cpu().numpy()

@@ -375,8 +375,8 @@ int mmk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* 
  * `dY.sum(0)` of the fused QKV projection (reference: autograd of the q/k/v nn.Linear biases), without re-reading dY.
  * Only where mmk_attn_bwd_has_colsum(L) == 1 (all L <= 224 except 97..128); passing it elsewhere is an error.
  * Replaces autograd through the same reference expressions (softmax(QK^T)V backward). */
-/* debugging: shader-clock stamps of workgroup 0 of the five-product backward (needs MMK_ATTN_STAMPS=1 in the environment
- * before the first backward call): 16 per item -- item start, loads issued, loads landed, after each of the NT + 1 step
+/* debugging: shader-clock stamps of workgroup 0 of the five-product backward (needs a library built with
+ * -DMMK_ATTN_STAMPS_BUILD and MMK_ATTN_STAMPS=1 in the environment before the first backward call): 16 per item -- item start, loads issued, loads landed, after each of the NT + 1 step
  * barriers, after the final stores were issued -- for the workgroup's first 32 items.  Synchronises the device. */
 int mmk_attn_debug_stamps(unsigned long long* out, int n);
 int mmk_attn_bwd_has_colsum(int L);

@@ -727,7 +727,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
 
   int n_mine = 0;
   auto stamp = [&](int k) {
+#ifdef MMK_ATTN_STAMPS_BUILD   // debug builds only (make EXTRA=-DMMK_ATTN_STAMPS_BUILD): the checks are not free in this kernel
     if (a.stamps != nullptr && blockIdx.x == 0 && tid == 0 && n_mine < 32) a.stamps[n_mine * 16 + k] = __builtin_readcyclecounter();
+#else
+    (void)k;
+#endif
   };
   for (int item = blockIdx.x; item < nitems; item += gridDim.x, ++n_mine) {
     const int b = item / a.H, hh = item % a.H;

@@ -461,8 +461,24 @@ def _leg_loss_n8192(args, dev):
     return loss_n8192_leg(dev)
 
 
+def _enable_tuned_gemms(args) -> bool:
+    """The product's library-GEMM selections (mmlearn_amd/tuned: TunableOp look-up, no tuning at run time) for the HIP legs;
+    the stock-step leg never calls this.  ``MMK_BENCH_NO_TUNED=1`` keeps the library's default heuristic (A/B switch)."""
+    if args.small or args.no_fused_encoder_ops or os.environ.get("MMK_BENCH_NO_TUNED"):
+        return False
+    from mmlearn_amd import tuned
+
+    ok = tuned.enable()
+    if not ok:
+        print("[bench] tuned GEMM selections refused (another PyTorch / hipBLASLt / rocBLAS build?): library defaults", file=sys.stderr)
+    return ok
+
+
 def _leg_three_tower(args, dev):
-    return three_tower_leg(64 if args.small else 256, dev, args.small)
+    tuned_gemms = _enable_tuned_gemms(args)
+    out = three_tower_leg(64 if args.small else 256, dev, args.small)
+    out["library_gemm_selection"] = "mmlearn_amd/tuned/gemm_gfx950.csv" if tuned_gemms else "library default"
+    return out
 
 
 def _leg_ijepa(args, dev):
@@ -637,6 +653,7 @@ def main():
     from mmlearn_amd import ContrastiveLoss, _lib
 
     _lib.check(_lib.lib().mmk_device_check())
+    tuned_gemms = _enable_tuned_gemms(args)
     loss_fn = ContrastiveLoss(static_shapes=True)
     loss_fn._force_gather = force_dist
     task = build_task(loss_fn, args.small, fused=not args.no_fused_encoder_ops).to(dev)
@@ -760,6 +777,7 @@ def main():
                                    f"per-GPU batch {args.batch}, {'local' if world == 1 else 'global-batch (all-gather)'} negatives"
                                    + (" [DEBUG small encoders]" if args.small else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}" + (" (1-rank RCCL dry run of the N > 1 path)" if force_dist else ""), "loss": "mmlearn_amd.ContrastiveLoss (HIP)",
+                       "library_gemm_selection": "mmlearn_amd/tuned/gemm_gfx950.csv (TunableOp look-up, no tuning at run time)" if tuned_gemms else "library default",
                        "encoder_ops": "torch" if args.no_fused_encoder_ops else "HIP LayerNorm (+ fused residual add / dropout / deferred biases), bias+activation, fused-QKV attention, weight-gradient GEMM (mmlearn_amd.fused / .attention)",
                        "final_loss": round(final_loss, 4),
                        "final_loss_note": "random-init towers on random pixels / tokens emit near-identical embeddings, so the loss sits at ln(batch); "

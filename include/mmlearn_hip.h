@@ -346,6 +346,12 @@ int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int
  * so that the convolution runs as one GEMM against weight.view(E, C P P).  in: [B, C, H, W] of `dtype`, contiguous. */
 int mmk_patchify(const void* in, void* out, int B, int C, int H, int W, int P, int dtype, void* stream);
 
+/* bf16 operands of an encoder nn.Linear from its master weight w [n, k] of `dtype` (f32 / bf16 / f16), in one pass: w16 [n, k]
+ * (may be null) for the forward x w16^T -- what autocast's per-step cast of the weight produces -- and w16t [k, n] = w16^T, so that
+ * the backward's dX = dY w (the `grad_output @ weight` of every nn.Linear under mmlearn/modules/encoders/clip.py:29-470,
+ * text.py:20-178) can run as a "x W^T"-layout product on dY and w16t.  n, k multiples of 4. */
+int mmk_cast_transpose(const void* w, void* w16, void* w16t, int n, int k, int dtype, void* stream);
+
 /* Backward of nn.Embedding (HF BertEmbeddings word / token-type tables): dw[ids[r], :] += dout[r, :], f32 dw zeroed by
  * the caller; runs of equal ids are summed in registers before one hardware float atomic per element (summation order is
  * not fixed: results can differ in the last bits between runs, as with ATen's atomic paths). */

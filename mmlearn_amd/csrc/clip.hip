@@ -101,7 +101,7 @@ struct ProbBatch {
   int n_split;
   int n_probs;
   int dbg;                // timing ablations (MMK_SIM_DBG, wrong results): 1 = no row statistics, 2 = no column statistics,
-                          // 4 = no MFMAs; 8 = never take the bounded fast path (results stay right)
+                          // 4 = no MFMAs, 16 = no main loop, 32 = return at once; 8 = never take the bounded fast path (results stay right)
 };
 
 // device-coherent accesses for data that one workgroup writes and another reads within the same launch (block sums of
@@ -199,7 +199,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_kernel(cons
     k_begin = zsplit * p.k_per_split;
     k_end = min(p.K, k_begin + p.k_per_split);
   }
-  const int nk = (k_end - k_begin) / A::BK;
+  if (batch.dbg & 32) return;                                        // timing: launch + dispatch only
+  const int nk = (batch.dbg & 16) ? 0 : (k_end - k_begin) / A::BK;   // timing: no main loop (launch + epilogue)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM, r = lane & 31, h = lane >> 5;

@@ -199,6 +199,24 @@ def bias_act(x: torch.Tensor, bias: torch.Tensor, act: str) -> torch.Tensor:
     return _BiasActFn.apply(x, bias, {"quick_gelu": K.ACT_QUICK_GELU, "gelu": K.ACT_GELU}[act])
 
 
+def _weight_operands(w: torch.Tensor):
+    """-> (bf16 w for the forward, the tensor the backward keeps, twin?).  With the twin (default) one kernel casts the master
+    weight and also writes its transpose [in, out]; the backward's dX = dY W then runs as ``F.linear(dY, W^T)`` -- the
+    operand layout of the forward, which the library serves 5-15 % faster than ``dY @ W`` at the encoder shapes (DESIGN.md
+    5.5).  ``MMK_NO_DX_TWIN=1`` keeps the plain cast and ``dY @ W`` (A/B switch)."""
+    wd = w.detach()
+    if (os.environ.get("MMK_NO_DX_TWIN") or not wd.is_contiguous() or wd.shape[0] % 4 or wd.shape[1] % 4
+            or wd.dtype not in (torch.float32, torch.bfloat16, torch.float16)):
+        w16 = wd.to(torch.bfloat16)
+        return w16, w16, False
+    w16, w16t = K.cast_transpose(wd)
+    return w16, w16t, True
+
+
+def _dx_gemm(dy2: torch.Tensor, w_bwd: torch.Tensor, twin: bool) -> torch.Tensor:
+    return F.linear(dy2, w_bwd) if twin else dy2 @ w_bwd
+
+
 class _LinearWgradFn(torch.autograd.Function):
     """``x @ W^T (+ b)`` in bf16 whose weight gradient ``dY^T x`` runs on ``csrc/wgrad.hip`` (split over the rows, f32 sums,
     written straight in the parameter's dtype).  At the encoder shapes (M = batch x tokens = 201,728 / 78,848 rows) that
@@ -210,8 +228,8 @@ class _LinearWgradFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         k = x.shape[-1]
         x2 = x.reshape(-1, k).to(torch.bfloat16)
-        w16 = w.detach().to(torch.bfloat16)
-        ctx.save_for_backward(x2, w16)
+        w16, w_bwd, ctx.w_twin = _weight_operands(w)
+        ctx.save_for_backward(x2, w_bwd)
         ctx.x_shape, ctx.x_dtype, ctx.w_dtype = x.shape, x.dtype, w.dtype
         ctx.b_dtype = None if b is None else b.dtype
         with torch.autocast("cuda", enabled=False):
@@ -220,12 +238,12 @@ class _LinearWgradFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w16 = ctx.saved_tensors
-        dy2 = dy.reshape(-1, w16.shape[0]).to(torch.bfloat16).contiguous()
+        x2, w_bwd = ctx.saved_tensors
+        dy2 = dy.reshape(-1, w_bwd.shape[1] if ctx.w_twin else w_bwd.shape[0]).to(torch.bfloat16).contiguous()
         dx = dw = db = None
         with torch.autocast("cuda", enabled=False):
             if ctx.needs_input_grad[0]:
-                dx = (dy2 @ w16).view(ctx.x_shape).to(ctx.x_dtype)
+                dx = _dx_gemm(dy2, w_bwd, ctx.w_twin).view(ctx.x_shape).to(ctx.x_dtype)
             if ctx.needs_input_grad[1]:
                 dw = K.wgrad(dy2, x2, ctx.w_dtype if ctx.w_dtype in (torch.float32, torch.bfloat16) else torch.float32).to(ctx.w_dtype)
             if ctx.b_dtype is not None and ctx.needs_input_grad[2]:
@@ -243,20 +261,20 @@ class _QKVAttentionFn(torch.autograd.Function):
     def forward(ctx, x, w, b, heads, scale, dropout_p, seed):
         B, L, E = x.shape
         x2 = x.reshape(-1, E).to(torch.bfloat16)
-        w16 = w.detach().to(torch.bfloat16)
+        w16, w_bwd, w_twin = _weight_operands(w)
         with torch.autocast("cuda", enabled=False):
             qkv = x2 @ w16.t() if b is None else torch.addmm(b.detach().to(torch.bfloat16), x2, w16.t())
         qkv = qkv.view(B, L, 3, heads, 64)
         q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
         out, lse = K.attn_fwd(q, k, v, scale, dropout_p, seed)
-        ctx.save_for_backward(x2, w16, qkv, out, lse)
-        ctx.meta = (x.shape, x.dtype, w.dtype, None if b is None else b.dtype, scale, dropout_p, seed)
+        ctx.save_for_backward(x2, w_bwd, qkv, out, lse)
+        ctx.meta = (x.shape, x.dtype, w.dtype, None if b is None else b.dtype, scale, dropout_p, seed, w_twin)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x2, w16, qkv, out, lse = ctx.saved_tensors
-        x_shape, x_dtype, w_dtype, b_dtype, scale, dropout_p, seed = ctx.meta
+        x2, w_bwd, qkv, out, lse = ctx.saved_tensors
+        x_shape, x_dtype, w_dtype, b_dtype, scale, dropout_p, seed, w_twin = ctx.meta
         q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
         want_db = b_dtype is not None and ctx.needs_input_grad[2]
         res = K.attn_bwd(q, k, v, out, lse, dout.contiguous(), scale, dropout_p, seed, packed=True, colsum=want_db)
@@ -265,7 +283,7 @@ class _QKVAttentionFn(torch.autograd.Function):
         dx = dw = None
         with torch.autocast("cuda", enabled=False):
             if ctx.needs_input_grad[0]:
-                dx = (dy2 @ w16).view(x_shape).to(x_dtype)
+                dx = _dx_gemm(dy2, w_bwd, w_twin).view(x_shape).to(x_dtype)
             if ctx.needs_input_grad[1]:
                 dw = K.wgrad(dy2, x2, w_dtype if w_dtype in (torch.float32, torch.bfloat16) else torch.float32).to(w_dtype)
         return dx, dw, (None if db is None else db.to(b_dtype)), None, None, None, None

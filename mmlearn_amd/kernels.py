@@ -678,6 +678,17 @@ def gemm4_nt(a2: torch.Tensor, b2: torch.Tensor, bias: Optional[torch.Tensor] = 
     return (c, pre) if want_pre else c
 
 
+def cast_transpose(w: torch.Tensor, want_plain: bool = True):
+    """w [n, k] (f32 / bf16 / f16, contiguous) -> (bf16 w [n, k] or None, bf16 w^T [k, n]) in one pass over w."""
+    require_gpu(w)
+    assert w.dim() == 2 and w.is_contiguous()
+    n, k = w.shape
+    w16 = torch.empty((n, k), dtype=torch.bfloat16, device=w.device) if want_plain else None
+    w16t = torch.empty((k, n), dtype=torch.bfloat16, device=w.device)
+    check(_lib.lib().mmk_cast_transpose(ptr(w), ptr(w16), ptr(w16t), n, k, dtype_tag(w.dtype), stream()))
+    return w16, w16t
+
+
 def patchify(x: torch.Tensor, patch: int) -> torch.Tensor:
     """[B, C, H, W] (f32 / bf16 / f16, contiguous) -> bf16 [B * H/P * W/P, C * P * P]: im2col of a stride == kernel conv."""
     require_gpu(x)

@@ -176,3 +176,31 @@ def test_tower_ddp_strategy_hands_the_wrapping_to_the_task():
     finally:
         S.DDPStrategy._setup_model = orig
     assert len(base_calls) == 2 and len(calls) == 2
+
+
+def test_tuned_gemm_selection_file_is_well_formed():
+    """mmlearn_amd/tuned/gemm_gfx950.csv: TunableOp validators first, then one plain / bias GEMM entry per line (no strided-batched
+    entries, every dimension a multiple of 256: the transformer towers' shapes only); enable() has no CPU path."""
+    import re
+
+    import pytest
+    import torch
+
+    from mmlearn_amd import tuned
+
+    lines = open(tuned.DEFAULT_FILE).read().splitlines()
+    vals = [ln for ln in lines if ln.startswith("Validator,")]
+    assert {ln.split(",")[1] for ln in vals} >= {"PT_VERSION", "HIPBLASLT_VERSION", "ROCBLAS_VERSION", "GCN_ARCH_NAME"}
+    assert any("gfx950" in ln for ln in vals)
+    body = lines[len(vals):]
+    assert len(body) >= 10 and len({tuple(ln.split(",")[:2]) for ln in body}) == len(body)
+    for ln in body:
+        op, key, sol, ms = ln.split(",")
+        assert op.split("_")[0] in ("GemmTunableOp", "GemmAndBiasTunableOp") and "BFloat16" in op
+        m = re.match(r"(tn|nt|nn)_(\d+)_(\d+)_(\d+)_ld_", key)
+        assert m and all(int(d) % 256 == 0 for d in m.groups()[1:])
+        assert sol == "Default" or sol.startswith(("Gemm_Hipblaslt_", "Gemm_Rocblas_"))
+        assert float(ms) > 0
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            tuned.enable()

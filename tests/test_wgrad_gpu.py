@@ -62,3 +62,47 @@ def test_wgrad_linear_function_matches_f_linear():
     for a, b, name in zip(outs[0], outs[1], ("y", "dx", "dw", "db")):
         assert a.dtype == b.dtype
         assert (a - b).abs().max() <= 2e-2 * a.abs().max(), name
+
+
+@pytest.mark.parametrize("n,k,dtype", [(768, 3072, torch.float32), (2304, 768, torch.float32), (100, 36, torch.float32),
+                                       (64, 64, torch.bfloat16), (132, 260, torch.float16), (8, 8, torch.float32)])
+def test_cast_transpose_is_the_rounded_weight_and_its_transpose(n, k, dtype):
+    """One pass over the master weight: bf16 copy (what autocast's cast produces, bit for bit) and its transpose."""
+    from mmlearn_amd import kernels as K
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(n + k)
+    w = torch.randn(n, k, device=dev).to(dtype)
+    w16, w16t = K.cast_transpose(w)
+    ref = w.to(torch.bfloat16)
+    assert w16.shape == (n, k) and w16t.shape == (k, n) and w16.dtype == w16t.dtype == torch.bfloat16
+    assert torch.equal(w16, ref)
+    assert torch.equal(w16t, ref.t().contiguous())
+    none, only_t = K.cast_transpose(w, want_plain=False)
+    assert none is None and torch.equal(only_t, w16t)
+
+
+def test_linear_backward_on_the_transposed_twin_equals_the_plain_layout(monkeypatch):
+    """dX = F.linear(dY, W16^T) (default) against dX = dY @ W16 (MMK_NO_DX_TWIN=1): same products, the library may pick
+    another kernel for the other layout, so the comparison is to bf16 rounding; forward and dW are the same code."""
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(768, 2304).to(dev)
+    x0 = torch.randn(32, 197, 768, device=dev)
+    g = torch.randn(32, 197, 2304, device=dev)
+    outs = []
+    for plain in (True, False):
+        if plain:
+            monkeypatch.setenv("MMK_NO_DX_TWIN", "1")
+        else:
+            monkeypatch.delenv("MMK_NO_DX_TWIN")
+        lin.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = fused.linear(x, lin.weight, lin.bias)
+        (y.float() * g).sum().backward()
+        outs.append((y.float().detach(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+    assert (outs[0][1] - outs[1][1]).abs().max() <= 1e-2 * outs[0][1].abs().max()

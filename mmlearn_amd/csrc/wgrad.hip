@@ -174,26 +174,38 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
     char* sa = smem + wg_opaque((st & 1) * 2 * WG_STAGE) + troff[0];
     char* sb = sa + WG_STAGE;
     const int valid = (int)min((long)WG_BM, row_end - (row0 + (long)st * WG_BM));
-    const int ksteps = (valid + 15) / 16;
+    // two 16-row steps per iteration, all sixteen fragment reads of the pair requested before its eight MFMAs: half as many
+    // LDS waits per stage, and the second step's reads land behind the first step's MFMAs.  Every row of a stage is written by
+    // the fill (rows past the split's end repeat a valid row), so a step beyond `valid` multiplies zeroed A rows by finite B rows.
+    const int kpairs = (valid + 31) / 32;
 #pragma unroll 1
-    for (int ks = 0; ks < ksteps; ++ks) {
-      bf16x8 af[2], bfr[2];
+    for (int kp = 0; kp < kpairs; ++kp) {
+      bf16x8 af[2][2], bfr[2][2];
+      const char* pa = sa + kp * 16384;
+      const char* pb = sb + kp * 16384;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = tr8(sa + ks * 8192 + xa[i]);
+      for (int u = 0; u < 2; ++u) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bfr[j] = tr8(sb + ks * 8192 + xb[j]);
-      if ((ks + 1) * 16 > valid) {  // last stage of the last split: rows >= valid hold filler (a repeated valid row)
+        for (int i = 0; i < 2; ++i) af[u][i] = tr8(pa + u * 8192 + xa[i]);
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj)
-          if (ks * 16 + 8 * h + jj >= valid) {
+        for (int j = 0; j < 2; ++j) bfr[u][j] = tr8(pb + u * 8192 + xb[j]);
+      }
+      if ((kp + 1) * 32 > valid) {  // last stage of the last split
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i][jj] = (bf16_t)0.f;
-          }
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj)
+            if ((2 * kp + u) * 16 + 8 * h + jj >= valid) {
+#pragma unroll
+              for (int i = 0; i < 2; ++i) af[u][i][jj] = (bf16_t)0.f;
+            }
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u][i], bfr[u][j], acc[i][j], 0, 0, 0);
     }
   }
   // ---- partial tile -> workspace: acc[i][j][e] = C[n = 64 wm + 32 i + (e&3) + 8(e>>2) + 4h][k = 64 wn + 32 j + (lane&31)]

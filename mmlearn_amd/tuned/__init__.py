@@ -22,9 +22,13 @@ import torch
 DEFAULT_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_gfx950.csv")
 
 
-def enable(path: str = DEFAULT_FILE) -> bool:
-    """Switch TunableOp to look-up-only mode and load ``path``.  Returns whether the selections were accepted."""
+def enable(path: str = None) -> bool:
+    """Switch TunableOp to look-up-only mode and load ``path`` (default: the shipped file, or ``$MMK_TUNED_FILE``).  Returns
+    whether the selections were accepted."""
     import torch.cuda.tunable as tunable
+
+    if path is None:
+        path = os.environ.get("MMK_TUNED_FILE", DEFAULT_FILE)
 
     if not torch.cuda.is_available():
         raise RuntimeError("mmlearn_amd.tuned.enable() needs the GPU (the selections name gfx950 library kernels)")

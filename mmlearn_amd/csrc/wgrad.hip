@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   Vec4<OUT>::store(dw + (long)n * ldw + k, acc);
 }
 
+template <bool PAIR>
 __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -177,6 +178,30 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
     // two 16-row steps per iteration, all sixteen fragment reads of the pair requested before its eight MFMAs: half as many
     // LDS waits per stage, and the second step's reads land behind the first step's MFMAs.  Every row of a stage is written by
     // the fill (rows past the split's end repeat a valid row), so a step beyond `valid` multiplies zeroed A rows by finite B rows.
+    if (!PAIR) {   // A/B form (MMK_WGRAD_PAIR=0): one 16-row step per iteration, as in round 1
+      const int ksteps = (valid + 15) / 16;
+#pragma unroll 1
+      for (int ks = 0; ks < ksteps; ++ks) {
+        bf16x8 af[2], bfr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = tr8(sa + ks * 8192 + xa[i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[j] = tr8(sb + ks * 8192 + xb[j]);
+        if ((ks + 1) * 16 > valid) {
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj)
+            if (ks * 16 + 8 * h + jj >= valid) {
+#pragma unroll
+              for (int i = 0; i < 2; ++i) af[i][jj] = (bf16_t)0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      continue;
+    }
     const int kpairs = (valid + 31) / 32;
 #pragma unroll 1
     for (int kp = 0; kp < kpairs; ++kp) {
@@ -277,13 +302,16 @@ static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int
   const int grid = T <= 32 ? 8 * cdiv(a.splits, 8) * T : 8 * cdiv(a.splits * T, 8);
   static bool attr = false;
   const int bytes = 4 * WG_STAGE;
+  static const bool pair = !(getenv("MMK_WGRAD_PAIR") && atoi(getenv("MMK_WGRAD_PAIR")) == 0);
   if (!attr) {
-    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     attr = true;
   }
   {
     ProfEvents pe(MMK_K_WGRAD);
-    hipExtLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
+    if (pair) hipExtLaunchKernelGGL(wgrad_kernel<true>, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
+    else hipExtLaunchKernelGGL(wgrad_kernel<false>, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
   }
   MMK_LAUNCH_CHECK();
   *out = a;

@@ -116,7 +116,7 @@ def _adamw(fused: bool):
     return partial(torch.optim.AdamW, lr=1e-4, weight_decay=0.1)
 
 
-def build_task(loss, small: bool, fused: bool = False):
+def build_task(loss, small: bool, fused: bool = False, cls_only: bool = False):
     from mmlearn_amd.tasks.contrastive_pretraining import ContrastivePretraining
 
     torch.manual_seed(0)
@@ -127,8 +127,9 @@ def build_task(loss, small: bool, fused: bool = False):
         # CLIP is pre-LN: these LayerNorms feed autocast Linears only, so they may emit bf16 directly;
         # BERT is post-LN (the LN output is the residual stream) and keeps f32 outputs.
         add_ln = os.environ.get("MMK_BENCH_NO_ADD_LN") is None   # A/B switch for the fused residual add + LayerNorm
-        accelerate_encoder(rgb, low_precision_ln=("layer_norm1", "layer_norm2", "post_layernorm"), fuse_qkv=True, fuse_add_ln=add_ln)
-        accelerate_encoder(text, fuse_qkv=True, fuse_add_ln=add_ln)
+        accelerate_encoder(rgb, low_precision_ln=("layer_norm1", "layer_norm2", "post_layernorm"), fuse_qkv=True, fuse_add_ln=add_ln,
+                           cls_only=cls_only)
+        accelerate_encoder(text, fuse_qkv=True, fuse_add_ln=add_ln, cls_only=cls_only)
     task = ContrastivePretraining(
         encoders={"rgb": rgb, "text": text},
         loss=loss,
@@ -274,6 +275,36 @@ class _PooledAudio(nn.Module):
     def forward(self, inputs):
         x = inputs["audio"]
         return (self.model(input_features=x, is_longer=torch.zeros(x.shape[0], 1, dtype=torch.bool, device=x.device)).pooler_output,)
+
+
+def cls_only_leg(b: int, dev, small: bool, steps: int = 6, warmup: int = 3):
+    """The headline step with ``accelerate_encoder(..., cls_only=True)`` (opt-in, NOT part of `value`): both towers are pooled at
+    token 0 (mmlearn/modules/encoders/clip.py:463-470; the text tower's ``last_hidden_state[:, 0]``), so the last layer of each
+    computes keys / values for all tokens and everything else for token 0 only -- same loss, same gradient for every parameter
+    (tests/test_cls_only_cpu.py, tests/test_fused_gpu.py), 10/12 of the last layer's GEMM work never issued.  Reported beside the
+    headline so that the headline stays the full-layer step the stock baseline is compared with."""
+    from mmlearn_amd import ContrastiveLoss
+
+    loss_fn = ContrastiveLoss(static_shapes=True)
+    task = build_task(loss_fn, small, fused=True, cls_only=True).to(dev)
+    opt = task.configure_optimizers()
+    batch = synthetic_batch(b, 0, dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = task.training_step(batch, 0)
+        loss.backward()
+        opt.step()
+        return loss
+
+    sec = _timed_steps(step, warmup, steps)
+    loss = step()
+    torch.cuda.synchronize()
+    return {"workload": f"the headline step (configs[1], per-GPU batch {b}) with the last layer of both towers computed for token 0 only "
+                        "(opt-in accelerate_encoder(cls_only=True); loss and all parameter gradients unchanged)",
+            "ms_per_step": round(sec * 1e3, 2), "pairs_s": round(b / sec, 1), "steps": steps, "warmup": warmup,
+            "loss": round(float(loss.detach().float()), 4)}
 
 
 def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2):
@@ -481,12 +512,20 @@ def _leg_three_tower(args, dev):
     return out
 
 
+def _leg_cls_only(args, dev):
+    tuned_gemms = _enable_tuned_gemms(args)
+    out = cls_only_leg(args.batch, dev, args.small)
+    out["library_gemm_selection"] = "mmlearn_amd/tuned/gemm_gfx950.csv" if tuned_gemms else "library default"
+    return out
+
+
 def _leg_ijepa(args, dev):
     return ijepa_leg(16 if args.small else 128, dev, args.small)
 
 
-LEGS = {"eager_gpu": _leg_eager, "loss_n8192": _leg_loss_n8192, "three_tower": _leg_three_tower, "ijepa_vitl": _leg_ijepa}
-LEG_TIMEOUT_S = {"eager_gpu": 240, "loss_n8192": 120, "three_tower": 150, "ijepa_vitl": 240}
+LEGS = {"eager_gpu": _leg_eager, "loss_n8192": _leg_loss_n8192, "three_tower": _leg_three_tower, "ijepa_vitl": _leg_ijepa,
+        "cls_only_last_layer": _leg_cls_only}
+LEG_TIMEOUT_S = {"eager_gpu": 240, "loss_n8192": 120, "three_tower": 150, "ijepa_vitl": 240, "cls_only_last_layer": 150}
 
 
 def leg_main(args) -> int:
@@ -730,9 +769,11 @@ def main():
         eager = run_leg("eager_gpu", args)
     extra = {}
     if rank == 0 and world == 1 and not force_dist and not args.no_extra_legs:
-        for name in ("loss_n8192", "three_tower", "ijepa_vitl"):
+        for name in ("loss_n8192", "three_tower", "ijepa_vitl", "cls_only_last_layer"):
             extra[name] = run_leg(name, args)
 
+    if rank == 0 and eager and "pairs_s" in eager and isinstance(extra.get("cls_only_last_layer"), dict) and "pairs_s" in extra["cls_only_last_layer"]:
+        extra["cls_only_last_layer"]["vs_baseline"] = round(extra["cls_only_last_layer"]["pairs_s"] / eager["pairs_s"], 3)
     if rank == 0:
         n_rows, n_cols, d = args.batch, args.batch * world, 512
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes of the same kernel and shape (profiles/)

@@ -661,7 +661,90 @@ def patch_embedding_backward(module: nn.Module) -> int:
     return n
 
 
-def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), fuse_qkv: bool = False, fuse_add_ln: bool = False) -> dict:
+def _cls_query_attention(x: torch.Tensor, q_lin: nn.Linear, k_lin: nn.Linear, v_lin: nn.Linear, heads: int, scale: float,
+                         dropout_p: float) -> torch.Tensor:
+    """Attention output of query token 0 alone, ``[B, 1, E]``: keys and values of ALL tokens through one packed ``[2E, E]``
+    projection (the HIP weight-gradient path of :func:`linear`), the query of token 0 only."""
+    B, L, E = x.shape
+    dh = E // heads
+    wkv = torch.cat([k_lin.weight, v_lin.weight], 0)
+    bkv = torch.cat([k_lin.bias, v_lin.bias], 0) if (k_lin.bias is not None and v_lin.bias is not None) else None
+    kv = linear(x, wkv, bkv).view(B, L, 2, heads, dh)
+    q = F.linear(x[:, :1], q_lin.weight, q_lin.bias).view(B, 1, heads, dh).transpose(1, 2).to(kv.dtype)
+    a = F.scaled_dot_product_attention(q, kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2), dropout_p=dropout_p, scale=scale)
+    return a.transpose(1, 2).reshape(B, 1, E)
+
+
+def _cls_forward_applies(attn, hidden_states, attention_mask, kwargs) -> bool:
+    causal = bool(kwargs.get("is_causal", False)) or bool(getattr(attn, "is_causal", False)) or bool(getattr(attn, "is_decoder", False))
+    return (attention_mask is None and not causal and hidden_states.dim() == 3 and hidden_states.shape[1] > 1
+            and kwargs.get("past_key_values") is None and not kwargs.get("output_attentions", False))
+
+
+def _clip_last_layer_cls_forward(self, hidden_states, attention_mask=None, **kwargs):
+    """LAST ``CLIPEncoderLayer`` when only token 0 of its output is consumed (``last_hidden_state[:, 0]`` -> ``post_layernorm``
+    -> projection: mmlearn/modules/encoders/clip.py:463-470, HF ``CLIPVisionTransformer``): LayerNorm 1 and the key / value
+    projections run over all tokens, everything after them -- the query, the attention row, ``out_proj``, LayerNorm 2, the MLP and
+    both residual adds -- for token 0 only.  Returns ``[B, 1, E]``: token 0 of what the full layer returns, and the same gradients
+    for every parameter (the other tokens' outputs of the last layer reach nothing).  Masked / causal calls run the full layer."""
+    attn = self.self_attn
+    if not _cls_forward_applies(attn, hidden_states, attention_mask, kwargs):
+        return self._mmk_full_forward(hidden_states, attention_mask, **kwargs)
+    x = getattr(hidden_states, "_mmk_prenormed", None)
+    if x is None:
+        x = self.layer_norm1(hidden_states)
+    a = _cls_query_attention(x, attn.q_proj, attn.k_proj, attn.v_proj, attn.num_heads, attn.scale, attn.dropout if self.training else 0.0)
+    h = hidden_states[:, :1] + attn.out_proj(a)
+    return h + self.mlp(self.layer_norm2(h))
+
+
+def _bert_last_layer_cls_forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                                 past_key_values=None, **kwargs):
+    """LAST HF ``BertLayer`` when only the [CLS] position of its output is consumed (``last_hidden_state[:, 0]``): keys and
+    values over all tokens, the rest of the layer for position 0.  Returns ``[B, 1, E]``.  Decoder / cross-attention / masked
+    calls run the full layer."""
+    sa = self.attention.self
+    if (encoder_hidden_states is not None or past_key_values is not None or getattr(self, "is_decoder", False)
+            or not _cls_forward_applies(sa, hidden_states, attention_mask, kwargs)):
+        return self._mmk_full_forward(hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask,
+                                      past_key_values=past_key_values, **kwargs)
+    a = _cls_query_attention(hidden_states, sa.query, sa.key, sa.value, sa.num_attention_heads, sa.scaling,
+                             sa.dropout.p if self.training else 0.0)
+    ao = self.attention.output(a, hidden_states[:, :1])
+    return self.output(self.intermediate(ao), ao)
+
+
+_CLS_LAST_LAYER = {"CLIPEncoder": ("layers", "CLIPEncoderLayer", _clip_last_layer_cls_forward),
+                   "BertEncoder": ("layer", "BertLayer", _bert_last_layer_cls_forward)}
+
+
+def cls_only_last_layer(module: nn.Module) -> int:
+    """Opt-in, for encoders whose consumer reads ONLY token 0 of the final hidden state (CLS pooling: mmlearn's
+    ``HFCLIPVisionEncoderWithProjection`` with ``use_all_token_embeddings=False``, a BERT text encoder pooled at [CLS]): the last
+    layer of every HF ``CLIPEncoder`` / ``BertEncoder`` inside ``module`` computes its output for token 0 only and the encoder's
+    ``last_hidden_state`` becomes ``[B, 1, E]``.  Loss and every parameter gradient are those of the full layer; what is
+    dropped is work whose result nobody reads (10/12 of the last layer's GEMMs at ViT-B/16 / BERT-base).  Do NOT use it when
+    anything reads other positions of the last hidden state (token-level heads, ``use_all_token_embeddings``, mean pooling).
+    Returns the number of layers patched."""
+    n = 0
+    for m in module.modules():
+        spec = _CLS_LAST_LAYER.get(type(m).__name__)
+        if spec is None:
+            continue
+        layers = getattr(m, spec[0], None)
+        if not layers:
+            continue
+        last = layers[len(layers) - 1]
+        if type(last).__name__ != spec[1] or hasattr(last, "_mmk_full_forward"):
+            continue
+        last._mmk_full_forward = last.forward
+        last.forward = types.MethodType(spec[2], last)
+        n += 1
+    return n
+
+
+def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), fuse_qkv: bool = False, fuse_add_ln: bool = False,
+                       cls_only: bool = False) -> dict:
     """Swap ``nn.LayerNorm`` -> :class:`LayerNorm` and quick-GELU activations -> :class:`QuickGELU` inside ``module`` (in place);
     with ``fuse_qkv`` also patch the attention modules (:func:`fuse_qkv_attention`), with ``fuse_add_ln`` the residual
     add + LayerNorm pairs (:func:`fuse_add_layer_norm`).
@@ -670,6 +753,7 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
     (only LayerNorms that feed autocast ``Linear`` layers, e.g. ``("layer_norm1", "layer_norm2", "post_layernorm")``
     for HF CLIP); ``norm1`` / ``norm2`` of timm-style pre-LN blocks (mmlearn's own ViT / predictor) and ``layer_norm1`` /
     ``layer_norm2`` of HF ``CLIPEncoderLayer`` get it automatically -- they feed nothing but that block's Linears.
+    ``cls_only``: :func:`cls_only_last_layer` (opt-in; only for encoders pooled at token 0).
     Returns the number of modules swapped per kind.
     """
     swapped = {"layernorm": 0, "quick_gelu": 0, "fused_qkv": fuse_qkv_attention(module) if fuse_qkv else 0, "fused_add_ln": 0}
@@ -691,4 +775,6 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
         swapped["fused_add_ln"] = fuse_add_layer_norm(module)
         swapped["patch_conv"] = patch_conv_as_gemm(module)
         swapped["embedding"] = patch_embedding_backward(module)
+    if cls_only:     # last: it wraps whatever forward the last layer has by now (fused or stock)
+        swapped["cls_only_last_layer"] = cls_only_last_layer(module)
     return swapped

@@ -426,3 +426,48 @@ def test_causal_text_towers_keep_their_causality_under_the_fused_qkv_patch():
         gmax = max(v.abs().max().item() for v in g0.values())
         for k in g0:
             assert (g0[k] - g1[k]).abs().max() <= 6e-2 * max(g0[k].abs().max().item(), 1e-2 * gmax), k
+
+
+def test_cls_only_last_layer_on_the_fused_towers_keeps_loss_and_gradients():
+    """accelerate_encoder(cls_only=True) on HF CLIP vision / BERT with every HIP path on (bf16 autocast): token 0 of the final
+    hidden state and all parameter gradients against the same fused model with the full last layer."""
+    from transformers import BertConfig, BertModel, CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    from mmlearn_amd import fused
+    from mmlearn_amd.attention import register_hf_attention
+
+    dev = _dev()
+    impl = register_hf_attention()
+
+    def run(model, call, cls_only, kw):
+        m = copy.deepcopy(model)
+        fused.accelerate_encoder(m, fuse_qkv=True, fuse_add_ln=True, cls_only=cls_only, **kw)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = call(m)
+        out.float().square().sum().backward()
+        return out.detach().float(), {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    torch.manual_seed(0)
+    vcfg = CLIPVisionConfig(patch_size=16, image_size=224, projection_dim=64, hidden_size=256, intermediate_size=512, num_hidden_layers=3,
+                            num_attention_heads=4)
+    vcfg._attn_implementation = impl
+    vis = CLIPVisionModelWithProjection(vcfg).to(dev).train()
+    px = torch.randn(40, 3, 224, 224, device=dev)      # 40 x 197 = 7880 rows: the HIP weight-gradient path is on
+    tcfg = BertConfig(hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=512, hidden_dropout_prob=0.0,
+                      attention_probs_dropout_prob=0.0)
+    tcfg._attn_implementation = impl
+    txt = BertModel(tcfg, add_pooling_layer=False).to(dev).train()
+    ids = torch.randint(0, 30522, (96, 77), device=dev)  # 7392 rows
+    cases = [(vis, lambda m: m(pixel_values=px).image_embeds, dict(low_precision_ln=("layer_norm1", "layer_norm2", "post_layernorm"))),
+             (txt, lambda m: m(input_ids=ids).last_hidden_state[:, 0], {})]
+    for model, call, kw in cases:
+        (o_full, g_full), (o_cls, g_cls) = run(model, call, False, kw), run(model, call, True, kw)
+        assert o_full.shape == o_cls.shape
+        assert (o_full - o_cls).abs().max() <= 3e-2 * o_full.abs().max()
+        assert g_full.keys() == g_cls.keys()
+        top = max(g.abs().max().item() for g in g_full.values())
+        for k in g_full:
+            # the key biases' gradient is zero analytically (a constant added to every key cancels in the softmax): what either run
+            # holds there is bf16 noise, so it is compared on the scale of the real gradients, like every other tiny tensor
+            scale = max(g_full[k].abs().max().item(), 1e-2 * top)
+            assert (g_full[k] - g_cls[k]).abs().max() <= 6e-2 * scale, (k, (g_full[k] - g_cls[k]).abs().max().item(), scale)

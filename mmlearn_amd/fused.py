@@ -669,9 +669,9 @@ def _cls_query_attention(x: torch.Tensor, q_lin: nn.Linear, k_lin: nn.Linear, v_
     dh = E // heads
     wkv = torch.cat([k_lin.weight, v_lin.weight], 0)
     bkv = torch.cat([k_lin.bias, v_lin.bias], 0) if (k_lin.bias is not None and v_lin.bias is not None) else None
-    kv = linear(x, wkv, bkv).view(B, L, 2, heads, dh)
-    q = F.linear(x[:, :1], q_lin.weight, q_lin.bias).view(B, 1, heads, dh).transpose(1, 2).to(kv.dtype)
-    a = F.scaled_dot_product_attention(q, kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2), dropout_p=dropout_p, scale=scale)
+    k, v = linear(x, wkv, bkv).view(B, L, 2, heads, dh).unbind(2)       # one stack in the backward, no zero-filled halves
+    q = F.linear(x[:, :1], q_lin.weight, q_lin.bias).view(B, 1, heads, dh).transpose(1, 2).to(k.dtype)
+    a = F.scaled_dot_product_attention(q, k.transpose(1, 2), v.transpose(1, 2), dropout_p=dropout_p, scale=scale)
     return a.transpose(1, 2).reshape(B, 1, E)
 
 

@@ -630,30 +630,34 @@ class _EmbeddingFn(torch.autograd.Function):
     """``F.embedding`` whose weight gradient is the run-summing atomic scatter of ``csrc/encoder_ops.hip``."""
 
     @staticmethod
-    def forward(ctx, ids, weight):
+    def forward(ctx, ids, weight, padding_idx):
         ctx.save_for_backward(ids)
-        ctx.vocab, ctx.w_dtype = weight.shape[0], weight.dtype
-        return F.embedding(ids, weight)
+        ctx.vocab, ctx.w_dtype, ctx.padding_idx = weight.shape[0], weight.dtype, padding_idx
+        return F.embedding(ids, weight, padding_idx)
 
     @staticmethod
     def backward(ctx, dout):
         (ids,) = ctx.saved_tensors
-        dw = K.embedding_bwd(dout.reshape(-1, dout.shape[-1]), ids.reshape(-1), ctx.vocab)
-        return None, dw.to(ctx.w_dtype)
+        flat = ids.reshape(-1)
+        if ctx.padding_idx is not None:   # rows looked up at padding_idx get no gradient: the kernel ignores ids outside the table
+            flat = flat.masked_fill(flat == ctx.padding_idx, -1)
+        dw = K.embedding_bwd(dout.reshape(-1, dout.shape[-1]), flat, ctx.vocab)
+        return None, dw.to(ctx.w_dtype), None
 
 
 def _embedding_forward(self, ids):
     if (ids.is_cuda and ids.dtype == torch.int64 and self.weight.requires_grad and torch.is_grad_enabled() and ids.numel() >= 4096
             and self.weight.dtype in (torch.float32, torch.bfloat16) and self.embedding_dim % 4 == 0):
-        return _EmbeddingFn.apply(ids, self.weight)
+        return _EmbeddingFn.apply(ids, self.weight, self.padding_idx)
     return self._mmk_stock_forward(ids)
 
 
 def patch_embedding_backward(module: nn.Module) -> int:
-    """Give plain ``nn.Embedding`` tables (no padding_idx / max_norm / sparse / scale_grad_by_freq) the HIP backward."""
+    """Give ``nn.Embedding`` tables (no max_norm / sparse / scale_grad_by_freq; ``padding_idx`` is honoured: HF BERT's word table
+    has one) the HIP backward."""
     n = 0
     for m in module.modules():
-        if (type(m) is nn.Embedding and m.padding_idx is None and m.max_norm is None and not m.sparse and not m.scale_grad_by_freq
+        if (type(m) is nn.Embedding and m.max_norm is None and not m.sparse and not m.scale_grad_by_freq
                 and not hasattr(m, "_mmk_stock_forward")):
             m._mmk_stock_forward = m.forward
             m.forward = types.MethodType(_embedding_forward, m)

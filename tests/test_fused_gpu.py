@@ -360,15 +360,18 @@ def test_preln_block_fusion_matches_stock_blocks():
     assert a.shape == (6, 2, 50, 50)
 
 
-@pytest.mark.parametrize("ids_kind", ["random", "constant", "runs"])
+@pytest.mark.parametrize("ids_kind", ["random", "constant", "runs", "padding"])
 def test_embedding_backward_matches_torch(ids_kind):
     from mmlearn_amd import fused
 
     dev = torch.device("cuda", 0)
     torch.manual_seed(5)
     vocab, d, B, L = 1000, 768, 64, 77
-    emb = torch.nn.Embedding(vocab, d).to(dev)
-    if ids_kind == "random":
+    emb = torch.nn.Embedding(vocab, d, padding_idx=0 if ids_kind == "padding" else None).to(dev)
+    if ids_kind == "padding":   # HF BERT's word table: padding_idx = 0, sequences padded with it; that row gets no gradient
+        ids = torch.randint(1, vocab, (B, L), device=dev)
+        ids[:, 50:] = 0
+    elif ids_kind == "random":
         ids = torch.randint(0, vocab, (B, L), device=dev)
     elif ids_kind == "constant":
         ids = torch.zeros((B, L), dtype=torch.long, device=dev)
@@ -385,6 +388,8 @@ def test_embedding_backward_matches_torch(ids_kind):
         grads.append((out.detach().clone(), emb.weight.grad.clone()))
     assert torch.equal(grads[0][0], grads[1][0])
     assert (grads[0][1] - grads[1][1]).abs().max() <= 1e-3 * max(1.0, grads[0][1].abs().max().item())
+    if ids_kind == "padding":
+        assert grads[1][1][0].abs().max().item() == 0.0
 
 
 def test_causal_text_towers_keep_their_causality_under_the_fused_qkv_patch():

@@ -43,3 +43,24 @@ def test_selected_library_kernels_compute_the_same_products():
             assert err <= 2e-2 * scale, (tuple(x.shape), tuple(w.shape), err, scale)
     finally:
         tuned.disable()
+
+
+def test_a_selections_file_from_another_library_build_is_refused(tmp_path):
+    """TunableOp's validators (PyTorch / hipBLASLt / rocBLAS versions, architecture) guard the solution indices: a file recorded
+    elsewhere must leave every GEMM on the library's default instead of picking kernels by a stale index."""
+    import torch.cuda.tunable as tunable
+
+    from mmlearn_amd import tuned
+
+    text = open(tuned.DEFAULT_FILE).read().splitlines()
+    bad = [ln if not ln.startswith("Validator,HIPBLASLT_VERSION") else "Validator,HIPBLASLT_VERSION,0-other-build" for ln in text]
+    p = tmp_path / "other_build.csv"
+    p.write_text("\n".join(bad) + "\n")
+    try:
+        assert tuned.enable(str(p)) is False
+        assert not tunable.is_enabled()
+        x = torch.randn(512, 768, device="cuda").bfloat16()
+        w = torch.randn(768, 768, device="cuda").bfloat16()
+        assert torch.isfinite(F.linear(x, w).float()).all()
+    finally:
+        tuned.disable()

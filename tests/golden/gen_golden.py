@@ -135,10 +135,14 @@ def _dist_worker(rank, world, port, cfg, q):
     B = cfg["B"][rank]
     D = cfg["D"]
     mods = cfg["mods"][rank]
-    embs = {m: F.normalize(torch.randn(B, D), dim=-1) for m in mods}
-    ids = {m: _ids(range(cfg["off"][rank], cfg["off"][rank] + B)) for m in mods}
+    if "rows" in cfg:   # N-way cases: rows per modality, explicit id columns per (rank, modality)
+        embs = {m: F.normalize(torch.randn(cfg["rows"][rank][m], D), dim=-1) for m in mods}
+        ids = {m: _ids(cfg["ids"][rank][m]) for m in mods}
+    else:
+        embs = {m: F.normalize(torch.randn(B, D), dim=-1) for m in mods}
+        ids = {m: _ids(range(cfg["off"][rank], cfg["off"][rank] + B)) for m in mods}
     out = _run_loss(
-        R, embs, ids, cfg["scale"], [((("rgb", "text")), 1.0)],
+        R, embs, ids, cfg["scale"], cfg.get("pairs", [((("rgb", "text")), 1.0)]),
         local_loss=cfg["local_loss"], gather_with_grad=cfg["gather_with_grad"],
     )
     rec = {f"in_{k}": _np(v) for k, v in embs.items()}
@@ -147,6 +151,46 @@ def _dist_worker(rank, world, port, cfg, q):
     q.put((rank, rec))
     dist.barrier()
     dist.destroy_process_group()
+
+
+N3_PAIRS = [(("rgb", "text"), 1.0), (("rgb", "audio"), 0.5), (("text", "audio"), 0.25)]
+
+
+def _nway_cfgs():
+    """3 modalities / 3 weighted pairs across ranks (BASELINE configs[3] shape of the loss: the reference loops
+    modality_loss_pairs over the GATHERED embeddings, contrastive.py:92-144).  Every rank: 8 rgb + 8 text rows with the
+    same ids, 6 audio rows that match a subset of them (partial pairing inside the rank, unequal rows per modality)."""
+    cfgs = []
+    for world in (2, 4):
+        rows = [{"rgb": 8, "text": 8, "audio": 6}] * world
+        ids = [{"rgb": list(range(8 * r, 8 * r + 8)), "text": list(range(8 * r, 8 * r + 8)),
+                "audio": [8 * r + 1, 8 * r + 2, 8 * r + 4, 8 * r + 5, 8 * r + 7, 1000 + r]} for r in range(world)]
+        for ll in (False, True):
+            for gwg in (False, True):
+                cfgs.append(dict(name=f"n3w{world}_local{int(ll)}_gwg{int(gwg)}", world=world, B=[8] * world, D=16,
+                                 mods=[["rgb", "text", "audio"]] * world, rows=rows, ids=ids, pairs=N3_PAIRS, scale=1 / 0.07,
+                                 local_loss=ll, gather_with_grad=gwg))
+    # audio rows matched ACROSS ranks (a global permutation of the example ids): owned rows of the audio side are
+    # scattered over the matched list.  Full-batch cells only (with local_loss the reference slices arange labels by
+    # local match counts, which presumes in-rank pairing).
+    world = 2
+    perm = [5, 12, 0, 9, 14, 3, 7, 10, 1, 15, 6, 11, 2, 13, 4, 8]
+    rows = [{"rgb": 8, "text": 8, "audio": 8}] * world
+    ids = [{"rgb": list(range(8 * r, 8 * r + 8)), "text": list(range(8 * r, 8 * r + 8)), "audio": perm[8 * r: 8 * r + 8]}
+           for r in range(world)]
+    for gwg in (False, True):
+        cfgs.append(dict(name=f"n3w2_scatter_local0_gwg{int(gwg)}", world=world, B=[8] * world, D=16,
+                         mods=[["rgb", "text", "audio"]] * world, rows=rows, ids=ids, pairs=N3_PAIRS, scale=1 / 0.07,
+                         local_loss=False, gather_with_grad=gwg))
+    # rank 1 has no audio at all (placeholder path of _gather_dicts, contrastive.py:471-480); local_loss=False only (Q3)
+    rows = [{"rgb": 8, "text": 8, "audio": 6}, {"rgb": 8, "text": 8}]
+    ids = [{"rgb": list(range(8)), "text": list(range(8)), "audio": [1, 2, 4, 5, 7, 1000]},
+           {"rgb": list(range(8, 16)), "text": list(range(8, 16))}]
+    for gwg in (False, True):
+        cfgs.append(dict(name=f"n3w2_missing_audio_local0_gwg{int(gwg)}", world=2, B=[8, 8], D=16,
+                         mods=[["rgb", "text", "audio"], ["rgb", "text"]], rows=rows, ids=ids, pairs=N3_PAIRS, scale=1 / 0.07,
+                         local_loss=False, gather_with_grad=gwg))
+    return cfgs
 
 
 def gen_dist():
@@ -170,22 +214,34 @@ def gen_dist():
     for gwg in (False,):
         cfgs.append(dict(name=f"w2_missing_local0_gwg{int(gwg)}", world=2, B=[8, 8], D=16,
                          mods=[["rgb", "text"], ["rgb"]], off=[0, 8], scale=1 / 0.07, local_loss=False, gather_with_grad=gwg))
+    # W = 8 (eight gloo processes, B = 8, D = 16, the four flag cells)
+    for ll in (False, True):
+        for gwg in (False, True):
+            cfgs.append(dict(name=f"w8_local{int(ll)}_gwg{int(gwg)}", world=8, B=[8] * 8, D=16,
+                             mods=[["rgb", "text"]] * 8, off=[8 * r for r in range(8)], scale=1 / 0.07,
+                             local_loss=ll, gather_with_grad=gwg))
+    cfgs += _nway_cfgs()
+    only = os.environ.get("GEN_DIST_ONLY")   # debugging aid: regenerate a subset (do not save a partial file)
     for cfg in cfgs:
+        if only and only not in cfg["name"]:
+            continue
         port += 1
         q = ctx.Queue()
         procs = [ctx.Process(target=_dist_worker, args=(r, cfg["world"], port, cfg, q)) for r in range(cfg["world"])]
         for p in procs:
             p.start()
-        res = dict(q.get(timeout=180) for _ in procs)
+        res = dict(q.get(timeout=300) for _ in procs)
         for p in procs:
             p.join(timeout=60)
         rec = {"world": np.array(cfg["world"]), "local_loss": np.array(cfg["local_loss"]),
                "gather_with_grad": np.array(cfg["gather_with_grad"]), "scale": np.array(cfg["scale"])}
+        if "pairs" in cfg:
+            rec["pairs"] = np.array([f"{p[0][0]}|{p[0][1]}|{p[1]}" for p in cfg["pairs"]])
         for r, d in res.items():
             for k, v in d.items():
                 rec[f"r{r}_{k}"] = v
         cases[cfg["name"]] = rec
-        print("  dist", cfg["name"], [float(res[r]["out_loss"]) for r in sorted(res)])
+        print("  dist", cfg["name"], [float(res[r]["out_loss"]) for r in sorted(res)], flush=True)
     return cases
 
 

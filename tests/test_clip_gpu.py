@@ -68,8 +68,25 @@ def test_golden_clip(name):
     # against the reference's own output
     orc = co.contrastive_loss(embs, ids, float(c["scale"]), parse_pairs(c["pairs"]), l2norm=flags.get("l2_normalize", False))
     _check(res, orc["loss"], orc["grads"], orc["dscale"], TOL[dtype], name + ":oracle")
-    ref_tol = TOL[dtype] if dtype == "float32" else 3e-2
-    _check(res, float(c["out_loss"]), {m: c[f"out_grad_{m}"] for m in mods}, float(c["out_grad_scale"]), ref_tol, name + ":golden")
+    if dtype == "float32":
+        _check(res, float(c["out_loss"]), {m: c[f"out_grad_{m}"] for m in mods}, float(c["out_grad_scale"]), TOL[dtype], name + ":golden")
+        return
+    # bf16 / fp16 cases: the reference evaluated logits AND cross-entropy in the 8- / 11-bit type, so its own output
+    # sits up to 3e-2 (bf16) from the exact value of the same inputs (tests/test_oracle_golden.py), while this path keeps f32
+    # accumulators throughout.  north_star's 1e-2 is therefore asserted against the exact value above, and against the
+    # reference's rounded output with the reference's own measured distance from exact added (triangle inequality) -- no
+    # blanket 3e-2.
+    def slack(ref, exact):
+        return float(np.abs(np.asarray(ref, np.float64) - np.asarray(exact, np.float64)).max())
+
+    tol = TOL[dtype]
+    ref_loss, ref_ds = float(c["out_loss"]), float(c["out_grad_scale"])
+    assert abs(res["loss"] - ref_loss) <= tol * max(1.0, abs(ref_loss)) + slack(ref_loss, orc["loss"]), (name, res["loss"], ref_loss)
+    for m in mods:
+        g = c[f"out_grad_{m}"]
+        err = np.abs(res["grads"][m] - g).max()
+        assert err <= tol * max(np.abs(g).max(), 1e-6) + slack(g, orc["grads"][m]), (name, m, err)
+    assert abs(res["dscale"] - ref_ds) <= tol * max(1.0, abs(ref_ds)) + slack(ref_ds, orc["dscale"]), (name, res["dscale"], ref_ds)
 
 
 @pytest.mark.parametrize("n,d,dtype", [(1024, 512, "bfloat16"), (1024, 512, "float32"), (333, 200, "float32"), (777, 136, "bfloat16"),

@@ -43,6 +43,8 @@ def _worker(rank, world, port, case_names, q):
             embs = {f"{m}_embedding": torch.tensor(c[f"r{rank}_in_{m}"]).requires_grad_(True) for m in mods}
             ids = {m: torch.tensor(c[f"r{rank}_ids_{m}"]) for m in mods}
             s = torch.tensor(float(c["scale"]), requires_grad=True)
+            from conftest import parse_pairs
+            specs = [L.LossPairSpec(m, w) for m, w in (parse_pairs(c["pairs"]) if "pairs" in c else [(("rgb", "text"), 1.0)])]
             from mmlearn_amd.wire import pairing_summary
             hint, _ = pairing_summary(ids)   # what the collator would put into batch["fully_paired"] on this rank
             said = [None] * world
@@ -56,7 +58,7 @@ def _worker(rank, world, port, case_names, q):
                                        static_shapes=static is True)
                 if static == "paired":   # wire-format hint: identity pairing only when EVERY rank's batch is paired
                     before = fake_kernels.CALLS["match_ids"]
-                    loss = fn(embs, ids, s, [L.LossPairSpec(("rgb", "text"))], fully_paired=hint)
+                    loss = fn(embs, ids, s, specs, fully_paired=hint)
                     if all(flags):
                         assert fake_kernels.CALLS["match_ids"] == before, "paired batch must not run the matcher"
                     else:
@@ -74,7 +76,7 @@ def _worker(rank, world, port, case_names, q):
                     for m in mods:
                         fn.prefetch_gather(m, embs[f"{m}_embedding"], ids[m])
                     assert set(fn._pending) == set(mods)
-                loss = fn(embs, ids, s, [L.LossPairSpec(("rgb", "text"))])
+                loss = fn(embs, ids, s, specs)
                 assert not fn._pending
                 rec = {"loss": float(loss.detach()), "requires_grad": loss.requires_grad}
                 if loss.requires_grad:
@@ -260,6 +262,34 @@ def _static_worker(rank, world, port, q):
         dist.destroy_process_group()
     except Exception:
         q.put((rank, None, traceback.format_exc()))
+
+
+@pytest.mark.timeout(300)
+def test_world2_three_modalities_three_weighted_pairs():
+    """the multi-pair exchange buffer (``exch_off`` with > 1 pair) and per-pair row ownership across ranks,
+    against the reference's own per-rank outputs: 3 modalities / 3 weighted pairs, unequal rows per modality, partial pairing,
+    audio rows matched across ranks (scattered ownership) and a rank without audio."""
+    names = [n for n in DIST.names() if n.startswith("n3w2_")]
+    assert len(names) == 8
+    out = _run(2, names, 29715)
+    _check(2, names, out)
+
+
+@pytest.mark.timeout(300)
+def test_world4_three_modalities_three_weighted_pairs():
+    names = [n for n in DIST.names() if n.startswith("n3w4_")]
+    assert len(names) == 4
+    out = _run(4, names, 29716)
+    _check(4, names, out)
+
+
+@pytest.mark.timeout(600)
+def test_world8_all_flag_cells():
+    """SURVEY 8(c) G3 asks for W in {2, 4, 8}: eight gloo processes against the reference's eight per-rank outputs."""
+    names = [n for n in DIST.names() if n.startswith("w8_")]
+    assert len(names) == 4
+    out = _run(8, names, 29717)
+    _check(8, names, out)
 
 
 @pytest.mark.timeout(300)

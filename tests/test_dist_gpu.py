@@ -47,6 +47,48 @@ def _stage_collectives_through_host():
     dist.all_reduce = all_reduce
 
 
+def _golden_rank(rank, world, prefixes=None):
+    """Every golden case of this world size on rank `rank`: g3 (one pair `w{W}_*`, three weighted pairs over three modalities
+    `n3w{W}_*`) and the alignment cells of g9.  Collectives are whatever `dist` currently provides."""
+    import mmlearn_amd.losses as L
+    from conftest import Golden as G
+    from conftest import parse_pairs
+
+    dev = torch.device("cuda", 0)
+    results = {}
+    for gname, prefix, align in (("g3_clip_dist", f"w{world}_", False), ("g3_clip_dist", f"n3w{world}_", False), ("g9_align", f"w{world}_", True)):
+        gold = G(gname)
+        for name in [n for n in gold.names() if n.startswith(prefix)]:
+            c = gold[name]
+            mods = sorted(k[len(f"r{rank}_in_"):] for k in c if k.startswith(f"r{rank}_in_"))
+            embs = {f"{m}_embedding": torch.tensor(c[f"r{rank}_in_{m}"], device=dev).requires_grad_(True) for m in mods}
+            ids = {m: torch.tensor(c[f"r{rank}_ids_{m}"], device=dev) for m in mods}
+            s = torch.tensor(float(c["scale"]), device=dev, requires_grad=True)
+            specs = [L.LossPairSpec(m, w) for m, w in (parse_pairs(c["pairs"]) if "pairs" in c else [(("rgb", "text"), 1.0)])]
+            plain = "uneven" not in name and "missing" not in name
+            for static in ((False, True) if plain else (False,)):
+                for t in embs.values():
+                    t.grad = None
+                s.grad = None
+                fn = L.ContrastiveLoss(local_loss=bool(c["local_loss"]), gather_with_grad=bool(c["gather_with_grad"]),
+                                       static_shapes=static, modality_alignment=align)
+                if static:   # what the task does: ids gathered + matched ahead of the encoders, then one gather per tower
+                    fn.prefetch_match(ids, specs)
+                    for m in mods:
+                        fn.prefetch_gather(m, embs[f"{m}_embedding"], ids[m])
+                loss = fn(embs, ids, s, specs)
+                if static and len(mods) >= 2:
+                    assert fn.prefetched_matches_used >= len(specs) and not fn._pending_match and not fn._early_ids
+                rec = {"loss": float(loss.detach()), "requires_grad": loss.requires_grad, "local": bool(c["local_loss"]), "align": align}
+                if loss.requires_grad:
+                    loss.backward()
+                rec["grads"] = {m: (embs[f"{m}_embedding"].grad.cpu().numpy() if embs[f"{m}_embedding"].grad is not None
+                                    else np.zeros_like(c[f"r{rank}_in_{m}"])) for m in mods}
+                rec["dscale"] = float(s.grad) if s.grad is not None else 0.0
+                results[(gname, name, static)] = rec
+    return results
+
+
 def _worker(rank, world, port, q):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -56,63 +98,73 @@ def _worker(rank, world, port, q):
                 sys.path.insert(0, p)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         _stage_collectives_through_host()
-        import mmlearn_amd.losses as L
-        from conftest import Golden as G
-
-        dev = torch.device("cuda", 0)
-        results = {}
-        for gname, prefix, align in (("g3_clip_dist", f"w{world}_", False), ("g9_align", f"w{world}_", True)):
-            gold = G(gname)
-            for name in [n for n in gold.names() if n.startswith(prefix)]:
-                c = gold[name]
-                mods = sorted(k[len(f"r{rank}_in_"):] for k in c if k.startswith(f"r{rank}_in_"))
-                embs = {f"{m}_embedding": torch.tensor(c[f"r{rank}_in_{m}"], device=dev).requires_grad_(True) for m in mods}
-                ids = {m: torch.tensor(c[f"r{rank}_ids_{m}"], device=dev) for m in mods}
-                s = torch.tensor(float(c["scale"]), device=dev, requires_grad=True)
-                plain = "uneven" not in name and "missing" not in name
-                for static in ((False, True) if plain else (False,)):
-                    for t in embs.values():
-                        t.grad = None
-                    s.grad = None
-                    fn = L.ContrastiveLoss(local_loss=bool(c["local_loss"]), gather_with_grad=bool(c["gather_with_grad"]),
-                                           static_shapes=static, modality_alignment=align)
-                    if static:   # what the task does: ids gathered + matched ahead of the encoders, then one gather per tower
-                        fn.prefetch_match(ids, [L.LossPairSpec(("rgb", "text"))])
-                        for m in mods:
-                            fn.prefetch_gather(m, embs[f"{m}_embedding"], ids[m])
-                    loss = fn(embs, ids, s, [L.LossPairSpec(("rgb", "text"))])
-                    if static and len(mods) == 2:
-                        assert fn.prefetched_matches_used >= 1 and not fn._pending_match and not fn._early_ids
-                    rec = {"loss": float(loss.detach()), "requires_grad": loss.requires_grad}
-                    if loss.requires_grad:
-                        loss.backward()
-                    rec["grads"] = {m: (embs[f"{m}_embedding"].grad.cpu().numpy() if embs[f"{m}_embedding"].grad is not None
-                                        else np.zeros_like(c[f"r{rank}_in_{m}"])) for m in mods}
-                    rec["dscale"] = float(s.grad) if s.grad is not None else 0.0
-                    results[(gname, name, static)] = rec
-        q.put((rank, results, None))
+        q.put((rank, _golden_rank(rank, world), None))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
         q.put((rank, None, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+def _golden_threads_worker(world, q):
+    """The golden cases of `world` ranks with the ranks as threads of one process (see _ThreadRanks)."""
+    try:
+        import threading
+
+        for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        tr = _ThreadRanks(world)
+        tr.install()
+        torch.cuda.init()
+        out, errs = {}, {}
+
+        def run(rank):
+            tr.tl.rank = rank
+            try:
+                torch.cuda.set_device(0)
+                out[rank] = _golden_rank(rank, world)
+            except Exception:
+                errs[rank] = traceback.format_exc()
+                tr.bar.abort()
+
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if not errs:
+            # the deferred collective (d loss / d scale is all-reduced in backward except in the local-loss cells)
+            for key in out[0]:
+                if not out[0][key]["local"]:
+                    total = sum(out[r][key]["dscale"] for r in range(world))
+                    for r in range(world):
+                        out[r][key]["dscale"] = total
+        for r in range(world):
+            q.put((r, out.get(r), errs.get(r)))
+    except Exception:
+        for r in range(world):
+            q.put((r, None, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.timeout(600)
 def test_multi_rank_hip_path_vs_reference(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, 29720 + world, q)) for r in range(world)]
+    if world > 4:   # process guard of the GPU box: ranks become threads of one child
+        procs = [ctx.Process(target=_golden_threads_worker, args=(world, q))]
+    else:
+        procs = [ctx.Process(target=_worker, args=(r, world, 29720 + world, q)) for r in range(world)]
     for p in procs:
         p.start()
     out = {}
-    for _ in procs:
+    for _ in range(world):
         rank, res, err = q.get(timeout=500)
         assert err is None, f"rank {rank} failed:\n{err}"
         out[rank] = res
     for p in procs:
         p.join(timeout=60)
-    n_checked = 0
+    n_checked, n_multi_pair = 0, 0
     for rank in range(world):
         for (gname, name, static), got in out[rank].items():
             c = Golden(gname)[name]
@@ -126,41 +178,52 @@ def test_multi_rank_hip_path_vs_reference(world):
             ref_ds = float(c[f"r{rank}_out_grad_scale"]) if has_graph else 0.0
             assert abs(got["dscale"] - ref_ds) <= 1e-3 * max(1.0, abs(ref_ds)), (tag, got["dscale"], ref_ds)
             n_checked += 1
-    assert n_checked >= (13 if world == 2 else 8) * world // 2
+            n_multi_pair += name.startswith("n3")
+    # per rank: W = 2: 13 one-pair + 8 alignment + 14 three-pair runs; W = 4: 8 + 8 three-pair; W = 8: 8 one-pair runs
+    assert n_checked == {2: 35, 4: 16, 8: 8}[world] * world, n_checked
+    assert n_multi_pair == {2: 14, 4: 8, 8: 0}[world] * world, n_multi_pair
 
 
-def _seeded_inputs(rank, b, d, dtype):
+N3_PAIRS = [(("rgb", "text"), 1.0), (("rgb", "audio"), 0.5), (("text", "audio"), 0.25)]
+
+
+def _seeded_inputs(rank, b, d, dtype, n_mods=2):
+    """-> [rgb, text(, audio)] unit rows correlated with rgb, and the id column shared by all modalities"""
     g = torch.Generator().manual_seed(500 + rank)
     a = torch.nn.functional.normalize(torch.randn(b, d, generator=g), dim=-1)
-    t = torch.nn.functional.normalize(0.5 * a + 0.5 * torch.nn.functional.normalize(torch.randn(b, d, generator=g), dim=-1), dim=-1)
+    mats = [a]
+    for _ in range(n_mods - 1):
+        mats.append(torch.nn.functional.normalize(0.5 * a + 0.5 * torch.nn.functional.normalize(torch.randn(b, d, generator=g), dim=-1), dim=-1))
     ids = torch.stack([torch.zeros(b, dtype=torch.long), torch.arange(rank * b, (rank + 1) * b)], 1)
     if dtype == "bfloat16":
-        a, t = a.bfloat16().float(), t.bfloat16().float()
-    return a, t, ids
+        mats = [m.bfloat16().float() for m in mats]
+    return mats, ids
 
 
-def _seeded_rank(rank, b, d, dtype):
+def _seeded_rank(rank, b, d, dtype, n_mods=2):
     """Both flag cells of one rank of the seeded case; collectives are whatever `dist` currently provides."""
     import mmlearn_amd.losses as L
 
     dev = torch.device("cuda", 0)
     tdt = torch.bfloat16 if dtype == "bfloat16" else torch.float32
-    a, t, ids = _seeded_inputs(rank, b, d, dtype)
+    mats, ids = _seeded_inputs(rank, b, d, dtype, n_mods)
+    names = ["rgb", "text", "audio"][:n_mods]
+    specs = [L.LossPairSpec(m, w) for m, w in (N3_PAIRS if n_mods == 3 else N3_PAIRS[:1])]
     res = {}
     for ll, gwg in ((False, False), (True, True)):
-        ea, et = a.to(dev, tdt).requires_grad_(True), t.to(dev, tdt).requires_grad_(True)
+        e = [m.to(dev, tdt).requires_grad_(True) for m in mats]
         s = torch.tensor(1 / 0.07, device=dev, requires_grad=True)
         fn = L.ContrastiveLoss(local_loss=ll, gather_with_grad=gwg, static_shapes=True)
-        fn.prefetch_gather("rgb", ea, ids.to(dev))
-        fn.prefetch_gather("text", et, ids.to(dev))
-        loss = fn({"rgb_embedding": ea, "text_embedding": et}, {"rgb": ids.to(dev), "text": ids.to(dev)}, s, [L.LossPairSpec(("rgb", "text"))])
+        for n, t in zip(names, e):
+            fn.prefetch_gather(n, t, ids.to(dev))
+        loss = fn({f"{n}_embedding": t for n, t in zip(names, e)}, {n: ids.to(dev) for n in names}, s, specs)
         loss.float().backward()
-        res[(ll, gwg)] = {"loss": float(loss.detach().float()), "ga": ea.grad.float().cpu().numpy(), "gt": et.grad.float().cpu().numpy(),
+        res[(ll, gwg)] = {"loss": float(loss.detach().float()), "grads": {n: t.grad.float().cpu().numpy() for n, t in zip(names, e)},
                           "ds": float(s.grad)}
     return res
 
 
-def _seeded_worker(rank, world, port, b, d, dtype, q):
+def _seeded_worker(rank, world, port, b, d, dtype, n_mods, q):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -169,7 +232,7 @@ def _seeded_worker(rank, world, port, b, d, dtype, q):
                 sys.path.insert(0, p)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         _stage_collectives_through_host()
-        q.put((rank, _seeded_rank(rank, b, d, dtype), None))
+        q.put((rank, _seeded_rank(rank, b, d, dtype, n_mods), None))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
@@ -225,7 +288,7 @@ class _ThreadRanks:
         dist.get_backend = lambda group=None: "gloo"
 
 
-def _seeded_threads_worker(world, b, d, dtype, q):
+def _seeded_threads_worker(world, b, d, dtype, n_mods, q):
     try:
         import threading
 
@@ -241,7 +304,7 @@ def _seeded_threads_worker(world, b, d, dtype, q):
             tr.tl.rank = rank
             try:
                 torch.cuda.set_device(0)
-                out[rank] = _seeded_rank(rank, b, d, dtype)
+                out[rank] = _seeded_rank(rank, b, d, dtype, n_mods)
             except Exception:
                 errs[rank] = traceback.format_exc()
                 tr.bar.abort()
@@ -265,20 +328,22 @@ def _seeded_threads_worker(world, b, d, dtype, q):
             q.put((r, None, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,b,d,dtype", [(2, 1024, 512, "bfloat16"), (4, 333, 200, "float32"), (8, 1024, 512, "bfloat16")])
-@pytest.mark.timeout(900)
-def test_multi_rank_hip_path_seeded_vs_oracle(world, b, d, dtype):
+@pytest.mark.parametrize("world,b,d,dtype,n_mods", [(2, 1024, 512, "bfloat16", 2), (4, 333, 200, "float32", 2), (8, 1024, 512, "bfloat16", 2),
+                                                    (2, 200, 96, "float32", 3), (8, 1024, 512, "bfloat16", 3)])
+@pytest.mark.timeout(1200)
+def test_multi_rank_hip_path_seeded_vs_oracle(world, b, d, dtype, n_mods):
     """BASELINE-sized shards (per-rank 1024 x 512 bf16: 128x128 tiles, label offsets, r != c) against the oracle.  The
-    world = 8 case IS BASELINE configs[2]: eight ranks (threads of one process sharing this one GPU), per-rank batch 1024, global batch 8192, every
-    rank computing its R = 1024 x C = 8192 row shard with label_off = 1024 r, cells (F,F) and (T,T)."""
+    world = 8 cases ARE BASELINE configs[2] / configs[3]: eight ranks (threads of one process sharing this one GPU), per-rank
+    batch 1024, global batch 8192, every rank computing its R = 1024 x C = 8192 row shards with label_off = 1024 r, cells
+    (F,F) and (T,T); with n_mods = 3 three modalities and three weighted pairs (the multi-pair exchange buffer)."""
     from oracle import clip_oracle as co
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     if world > 4:   # process guard of the GPU box: ranks become threads of one child
-        procs = [ctx.Process(target=_seeded_threads_worker, args=(world, b, d, dtype, q))]
+        procs = [ctx.Process(target=_seeded_threads_worker, args=(world, b, d, dtype, n_mods, q))]
     else:
-        procs = [ctx.Process(target=_seeded_worker, args=(r, world, 29730 + world, b, d, dtype, q)) for r in range(world)]
+        procs = [ctx.Process(target=_seeded_worker, args=(r, world, 29730 + world + 10 * n_mods, b, d, dtype, n_mods, q)) for r in range(world)]
     for p in procs:
         p.start()
     out = {}
@@ -288,16 +353,18 @@ def test_multi_rank_hip_path_seeded_vs_oracle(world, b, d, dtype):
         out[rank] = res
     for p in procs:
         p.join(timeout=60)
-    ins = [_seeded_inputs(r, b, d, dtype) for r in range(world)]
-    embs = [{"rgb": i[0].numpy(), "text": i[1].numpy()} for i in ins]
-    ids = [{"rgb": i[2].numpy(), "text": i[2].numpy()} for i in ins]
+    names = ["rgb", "text", "audio"][:n_mods]
+    ins = [_seeded_inputs(r, b, d, dtype, n_mods) for r in range(world)]
+    embs = [{n: m.numpy() for n, m in zip(names, i[0])} for i in ins]
+    ids = [{n: i[1].numpy() for n in names} for i in ins]
     tol = 1e-2 if dtype == "bfloat16" else 1e-3
+    pairs = N3_PAIRS if n_mods == 3 else N3_PAIRS[:1]
     for ll, gwg in ((False, False), (True, True)):
-        orc = co.contrastive_loss_dist(embs, ids, 1 / 0.07, [(("rgb", "text"), 1.0)], ll, gwg)
+        orc = co.contrastive_loss_dist(embs, ids, 1 / 0.07, pairs, ll, gwg)
         for r in range(world):
             got = out[r][(ll, gwg)]
             assert abs(got["loss"] - orc[r]["loss"]) <= tol * max(1.0, abs(orc[r]["loss"])), (ll, gwg, r)
-            for k, m in (("ga", "rgb"), ("gt", "text")):
+            for m in names:
                 ref = orc[r]["grads"][m]
-                assert np.abs(got[k] - ref).max() <= tol * np.abs(ref).max(), (ll, gwg, r, m)
+                assert np.abs(got["grads"][m] - ref).max() <= tol * np.abs(ref).max(), (ll, gwg, r, m)
             assert abs(got["ds"] - orc[r]["dscale"]) <= tol * max(1.0, abs(orc[r]["dscale"])), (ll, gwg, r)

@@ -70,7 +70,8 @@ def test_clip_dist_oracle_vs_reference(name):
         mods = sorted(k[len(f"r{r}_in_"):] for k in c if k.startswith(f"r{r}_in_"))
         embs.append({m: c[f"r{r}_in_{m}"] for m in mods})
         ids.append({m: c[f"r{r}_ids_{m}"] for m in mods})
-    res = co.contrastive_loss_dist(embs, ids, float(c["scale"]), [(("rgb", "text"), 1.0)], bool(c["local_loss"]), bool(c["gather_with_grad"]))
+    pairs = parse_pairs(c["pairs"]) if "pairs" in c else [(("rgb", "text"), 1.0)]   # n3*: three weighted pairs
+    res = co.contrastive_loss_dist(embs, ids, float(c["scale"]), pairs, bool(c["local_loss"]), bool(c["gather_with_grad"]))
     for r in range(W):
         assert abs(res[r]["loss"] - float(c[f"r{r}_out_loss"])) <= 2e-5 * max(1.0, abs(res[r]["loss"])), (name, r)
         assert bool(c[f"r{r}_out_loss_requires_grad"]) == res[r]["has_graph"]

@@ -980,7 +980,7 @@ static unsigned long long* attn_stamp_buffer() {
   static bool tried = false;
   if (!tried) {
     tried = true;
-    if (getenv("MMK_ATTN_STAMPS") != nullptr && hipMalloc(reinterpret_cast<void**>(&buf), 32 * 16 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
+    if (MMK_DBG_ENV("MMK_ATTN_STAMPS") != nullptr && hipMalloc(reinterpret_cast<void**>(&buf), 32 * 16 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
   }
   return buf;
 }
@@ -995,7 +995,7 @@ extern "C" int mmk_attn_debug_stamps(unsigned long long* out, int n) {
 // 1 when mmk_attn_bwd can fill colsum_part for sequences of L rows (the five-product kernel serves them: every tile count
 // with a spare wave, i.e. all but 97..128 and 225..256 rows), 0 otherwise.
 extern "C" int mmk_attn_bwd_has_colsum(int L) {
-  static const bool seven = getenv("MMK_ATTN_BWD7") != nullptr;
+  static const bool seven = MMK_DBG_ENV("MMK_ATTN_BWD7") != nullptr;
   const int nt = (L + 31) / 32;
   return !seven && L > 0 && nt != 4 && nt < 8;
 }
@@ -1026,7 +1026,7 @@ extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const v
   a.B = B; a.H = H; a.L = L; a.scale = scale;
   const bool drop = drop_params(dropout_p, seed, &a.seed_lo, &a.seed_hi, &a.drop_thr, &a.drop_scale);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static const bool seven = getenv("MMK_ATTN_BWD7") != nullptr;  // force the seven-product kernel (A/B runs)
+  static const bool seven = MMK_DBG_ENV("MMK_ATTN_BWD7") != nullptr;  // force the seven-product kernel (A/B runs)
   MMK_REQUIRE(!colsum_part || mmk_attn_bwd_has_colsum(L), "attn_bwd: column sums are not available for this sequence length");
 #define MMK_ATTN_BWD_CASE(NT, NW) \
   case NT: return drop ? launch_attn_bwd<NT, NW, true>(a, st) : launch_attn_bwd<NT, NW, false>(a, st);

@@ -100,8 +100,9 @@ struct ProbBatch {
   Prob p[MAX_PROBS];
   int n_split;
   int n_probs;
-  int dbg;                // timing ablations (MMK_SIM_DBG, wrong results): 1 = no row statistics, 2 = no column statistics,
-                          // 4 = no MFMAs, 16 = no main loop, 32 = return at once; 8 = never take the bounded fast path (results stay right)
+  int dbg;                // -DMMK_DEBUG_SWITCHES builds only (MMK_SIM_DBG; wrong results): 1 = no row statistics, 2 = no column
+                          // statistics, 4 = no MFMAs, 16 = no main loop, 32 = return at once; 8 = never take the bounded fast path.
+                          // The shipped build ignores the field; the exact path is selected by passing no row norms.
 };
 
 // device-coherent accesses for data that one workgroup writes and another reads within the same launch (block sums of
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_kernel(cons
   const Prob& p = batch.p[zprob];
   const int n_tiles = p.tiles_m * p.tiles_n;
   if ((int)blockIdx.x >= n_tiles) return;
+  const int dbg = kDebugSwitches ? batch.dbg : 0;   // folded to 0 in the shipped build: no ablation branch survives
   // XCD-aware tile order (speed only, any placement is correct): workgroups are dealt round-robin over the 8 XCDs,
   // so XCD x can be given the contiguous tile range [base_x, base_x + cnt_x): neighbours in (tn, tm) order then share
   // the Q row tile in one L2 instead of it being fetched by all eight (rocprofv3 FETCH_SIZE, N = 8192: 1082 -> 392 MB).
@@ -199,8 +201,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_kernel(cons
     k_begin = zsplit * p.k_per_split;
     k_end = min(p.K, k_begin + p.k_per_split);
   }
-  if (batch.dbg & 32) return;                                        // timing: launch + dispatch only
-  const int nk = (batch.dbg & 16) ? 0 : (k_end - k_begin) / A::BK;   // timing: no main loop (launch + epilogue)
+  if (dbg & 32) return;                                        // timing: launch + dispatch only
+  const int nk = (dbg & 16) ? 0 : (k_end - k_begin) / A::BK;   // timing: no main loop (launch + epilogue)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM, r = lane & 31, h = lane >> 5;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_kernel(cons
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();  // every wave's share of stage kt is in LDS; stage kt-1 fully consumed
       if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1);  // refill the buffer that stage kt-1 just released
-      if (!(batch.dbg & 4)) compute_stage(smem + (kt % NSTAGE) * STAGE_BYTES);
+      if (!(dbg & 4)) compute_stage(smem + (kt % NSTAGE) * STAGE_BYTES);
     }
     wait_vmcnt<0>();
     __syncthreads();
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_kernel(cons
     float2* red = reinterpret_cast<float2*>(smem);                    // [2][BN]
     bool fast = false;
     float R = 0.f;
-    if (p.qn != nullptr && interior && (n0 + BN <= p.N) && !(batch.dbg & 8)) {
+    if (p.qn != nullptr && interior && (n0 + BN <= p.N) && !(dbg & 8)) {
       R = tile_bound(s2);
       fast = (2.f * R <= 96.f);
     }
@@ -386,13 +388,13 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_kernel(cons
           }
       }
     }
-    const bool want_col = p.mpart != nullptr && !(batch.dbg & 2);
+    const bool want_col = p.mpart != nullptr && !(dbg & 2);
     constexpr int CNT = 16 * MT;
     if (fast) {
       float csum[CNT];
 #pragma unroll
       for (int c = 0; c < CNT; ++c) csum[c] = 0.f;
-      if (!(batch.dbg & 1)) {
+      if (!(dbg & 1)) {
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
           float rs = 0.f;
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_kernel(cons
         if (CNT == 32 || (lane & 16) == 0) p.mpart[(size_t)(tn * 2 + wn) * p.mpart_ld + j] = make_float2(R, cs);
       }
     } else {
-      if (!(batch.dbg & 1))
+      if (!(dbg & 1))
 #pragma unroll
       for (int b = 0; b < NT; ++b) {
         const int nl = wn * (BN / 2) + b * 32 + r;
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_kernel(cons
     // factors are per row / per column.  Both lse are >= -R, so the factors stay below 2^96.
     bool fast = false;
     float R = 0.f;
-    if (p.qn != nullptr && interior && !(batch.dbg & 8)) {
+    if (p.qn != nullptr && interior && !(dbg & 8)) {
       R = tile_bound(s2);
       fast = (2.f * R <= 96.f);
     }
@@ -885,6 +887,16 @@ __global__ __launch_bounds__(256) void lse_merge_kernel(const MergeBatch batch) 
     ticket_s = __hip_atomic_fetch_add(batch.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
+  // A count left behind by an aborted launch (or a workspace bound to a recycled stream handle) shows up as a ticket beyond
+  // the grid: fail loudly -- a NaN loss -- instead of returning a stale or never-written value, and leave the counter
+  // re-armed once the last workgroup of this launch has drawn.
+  if (ticket_s >= n_blocks) {
+    if (tid == 0) {
+      *batch.loss_out = __builtin_nanf("");
+      if ((ticket_s + 1) % n_blocks == 0) __hip_atomic_store(batch.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   if (ticket_s != n_blocks - 1) return;
   if (tid < 64) {   // last arriver: fixed-order sum over all block sums
     float t = 0.f;
@@ -1233,7 +1245,7 @@ struct Plan {
 // 128x128 when that gives >= `want` tiles, else 64x64 (small problems are latency-bound: more, smaller blocks win;
 // 128x64 is kept as an experiment override).
 static void pick_tile(long rows_p, long rows_q, int n_probs, long want, int* bm, int* bn) {
-  if (const char* e = getenv("MMK_TILE")) {  // experiment override: 64 | 12864 | 128
+  if (const char* e = MMK_DBG_ENV("MMK_TILE")) {  // experiment override: 64 | 12864 | 128
     const int v = atoi(e);
     *bm = v == 64 ? 64 : 128;
     *bn = v == 128 ? 128 : 64;
@@ -1268,8 +1280,8 @@ struct LoaderCfg {
 static LoaderCfg loader_cfg() {
   static LoaderCfg cfg = [] {
     LoaderCfg c{LOADER_DMA, 2};
-    if (const char* e = getenv("MMK_LOADER")) c.loader = (e[0] == 'r') ? LOADER_REG : LOADER_DMA;
-    if (const char* e = getenv("MMK_STAGES")) c.stages = atoi(e);
+    if (const char* e = MMK_DBG_ENV("MMK_LOADER")) c.loader = (e[0] == 'r') ? LOADER_REG : LOADER_DMA;
+    if (const char* e = MMK_DBG_ENV("MMK_STAGES")) c.stages = atoi(e);
     if (c.loader == LOADER_REG) c.stages = 2;
     if (c.stages < 2 || c.stages > 4) c.stages = 2;
     return c;
@@ -1332,8 +1344,8 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
   // the bytes into LDS per output, 96 KiB of them in flight per CU instead of 64.  Measured at N = 8192: loads alone 62 us (as
   // with two 128 x 128 workgroups per CU), main loop 106 us instead of 77, whole kernel 121 instead of 109: one workgroup's
   // eight waves in barrier lock-step hide the MFMAs worse than two independent four-wave workgroups do.
-  if (dirs[0].mode == 0 && loader_cfg().loader == LOADER_DMA && getenv("MMK_TILE") == nullptr &&
-      getenv("MMK_STATS_TILE") && atoi(getenv("MMK_STATS_TILE")) == 256 &&
+  if (dirs[0].mode == 0 && loader_cfg().loader == LOADER_DMA && MMK_DBG_ENV("MMK_TILE") == nullptr &&
+      MMK_DBG_ENV("MMK_STATS_TILE") && atoi(MMK_DBG_ENV("MMK_STATS_TILE")) == 256 &&
       (long)cdiv(c_max, 256) * cdiv(r_max, 128) * n_dirs >= 256) {
     pl.bm = 256;
     pl.bn = 128;
@@ -1382,7 +1394,7 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
   }
   b.n_split = 1;
   b.n_probs = n_dirs;
-  b.dbg = getenv("MMK_SIM_DBG") ? atoi(getenv("MMK_SIM_DBG")) : 0;
+  b.dbg = MMK_DBG_ENV("MMK_SIM_DBG") ? atoi(MMK_DBG_ENV("MMK_SIM_DBG")) : 0;
   {
     int rc = align ? launch_gemm<T, EPI_ALIGN_STATS>(b, n_dirs, pl.bm, pl.bn, max_tiles, scale, st)
                    : launch_gemm<T, EPI_STATS>(b, n_dirs, pl.bm, pl.bn, max_tiles, scale, st);
@@ -1498,7 +1510,7 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
   gb.n_split = 1;
   gb.n_probs = n_tile_probs;
   xb.n_probs = n_x;
-  gb.dbg = getenv("MMK_SIM_DBG") ? (atoi(getenv("MMK_SIM_DBG")) & 8) : 0;   // 8 = never take the bounded fast path
+  gb.dbg = MMK_DBG_ENV("MMK_SIM_DBG") ? (atoi(MMK_DBG_ENV("MMK_SIM_DBG")) & 8) : 0;   // 8 = never take the bounded fast path
   xb.dbg = 0;
   xb.n_split = pl.n_split;
   fb.d = d_user;

@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <string>
 
@@ -60,6 +61,18 @@ struct ProfEvents {
       return -3;                                                                           \
     }                                                                                      \
   } while (0)
+
+// Experiment / ablation switches read from the environment exist only in builds made with -DMMK_DEBUG_SWITCHES
+// (`make EXTRA=-DMMK_DEBUG_SWITCHES`): the shipped library reads none of them, so a stray variable cannot change results
+// or kernel selection (tests/test_abi_cpu.py greps the .so for their names).  Deployment knobs that keep results right and are
+// documented in README.md (MMK_ATTN_GRID_FACTOR, MMK_WGRAD_RESERVE_CUS) are ordinary getenv reads, taken once.
+#ifdef MMK_DEBUG_SWITCHES
+#define MMK_DBG_ENV(name) getenv(name)
+constexpr bool kDebugSwitches = true;
+#else
+#define MMK_DBG_ENV(name) (static_cast<const char*>(nullptr))
+constexpr bool kDebugSwitches = false;
+#endif
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }

@@ -302,7 +302,7 @@ static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int
   const int grid = T <= 32 ? 8 * cdiv(a.splits, 8) * T : 8 * cdiv(a.splits * T, 8);
   static bool attr = false;
   const int bytes = 4 * WG_STAGE;
-  static const bool pair = !(getenv("MMK_WGRAD_PAIR") && atoi(getenv("MMK_WGRAD_PAIR")) == 0);
+  static const bool pair = !(MMK_DBG_ENV("MMK_WGRAD_PAIR") && atoi(MMK_DBG_ENV("MMK_WGRAD_PAIR")) == 0);
   if (!attr) {
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));

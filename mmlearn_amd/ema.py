@@ -108,8 +108,9 @@ class ExponentialMovingAverage:
         if self.decay < 1:
             # keyed on the storages themselves: ``.to()`` / ``.half()`` / re-wrapping re-allocates parameters, and a table
             # built for the old storages would keep updating tensors nobody reads
-            key = (id(new_model), tuple(t.data_ptr() for t in self.model.state_dict().values()),
-                   tuple(t.data_ptr() for t in new_model.state_dict().values()))
+            # (parameters() / buffers() walks, not state_dict(): no OrderedDict build, no prefix strings, no state-dict hooks
+            # on the critical path of every step -- ADVICE r2)
+            key = (id(new_model), tuple(t.data_ptr() for m in (self.model, new_model) for it in (m.parameters(), m.buffers()) for t in it))
             if key not in self._tables:
                 self._tables = {key: self._build_tables(new_model)}
             tables, slow, _ = self._tables[key]

@@ -18,6 +18,12 @@ from ._lib import COMPUTE_BF16, COMPUTE_F32, ClipDir, check, dtype_tag, ptr, req
 
 MAX_DIRS_PER_CALL = 8
 
+# Test / measurement seams (module attributes, not environment variables: nothing outside this process can flip them).
+# All three keep results right to rounding.
+BOUNDED_SOFTMAX = True    # False: never hand the row norms to the tile kernels -> per-row / per-column maxima everywhere
+PAIR_MIRRORS = True       # False: the two directions of a pair on one rank as two tile passes (round-1 behaviour)
+TN_MIN_ROWS = 2048        # from this many rows a mirrored pair stores G once; the mirror's dX uses the transposed-read kernel
+
 
 def round_up(a: int, b: int) -> int:
     return (a + b - 1) // b * b
@@ -228,10 +234,9 @@ def _mirror_of(a: Direction, b: Direction, backward: bool = False) -> bool:
 
 
 def _pair_up(dirs: Sequence[Direction], backward: bool = False) -> list:
-    """[(direction, mirror or None)]: consecutive mirrored directions share one tile pass (MMK_NO_MIRROR=1: A/B switch)."""
-    import os
+    """[(direction, mirror or None)]: consecutive mirrored directions share one tile pass (``PAIR_MIRRORS = False``: A/B switch)."""
     out, k = [], 0
-    no = os.environ.get("MMK_NO_MIRROR") is not None
+    no = not PAIR_MIRRORS
     while k < len(dirs):
         if not no and k + 1 < len(dirs) and _mirror_of(dirs[k], dirs[k + 1], backward):
             out.append((dirs[k], dirs[k + 1]))
@@ -247,9 +252,8 @@ _TICKETS: dict = {}
 
 def _tn_min_rows() -> int:
     """Mirrored pairs with at least this many rows store G once and form the second direction's gradient with the
-    transposed-read kernel; smaller ones store G and G^T from the tile pass (one launch fewer).  MMK_TN_MIN_ROWS overrides."""
-    import os
-    return int(os.environ.get("MMK_TN_MIN_ROWS", "2048"))
+    transposed-read kernel; smaller ones store G and G^T from the tile pass (one launch fewer)."""
+    return int(TN_MIN_ROWS)
 
 
 def _tickets(dev: torch.device, n: int) -> torch.Tensor:
@@ -295,7 +299,7 @@ def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.T
             e.x, e.y, e.r, e.c, e.label_off = ptr(dr.x), ptr(dr.y), dr.r, dr.c, dr.label_off
             e.part, e.diag, e.lse, e.loss_part = ptr(part), ptr(dr.diag), ptr(dr.lse), ptr(dr.loss_part)
             e.mode, e.hmax = dr.mode, ptr(dr.hmax)
-            xn, yn = row_norms(dr.x), row_norms(dr.y)
+            xn, yn = (row_norms(dr.x), row_norms(dr.y)) if BOUNDED_SOFTMAX else (None, None)
             if xn is not None and yn is not None and dr.mode == 0:
                 assert xn.numel() >= dr.r and yn.numel() >= dr.c
                 e.x_norm, e.y_norm = ptr(xn), ptr(yn)
@@ -389,7 +393,7 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.
             e.dx_accumulate = int(dr.dx_accumulate)
             e.src, e.normalize = ptr(dr.src), int(dr.normalize)
             e.mode, e.hmax = dr.mode, ptr(dr.hmax)
-            xn, yn = row_norms(dr.x), row_norms(dr.y)
+            xn, yn = (row_norms(dr.x), row_norms(dr.y)) if BOUNDED_SOFTMAX else (None, None)
             if xn is not None and yn is not None and dr.mode == 0:
                 e.x_norm, e.y_norm = ptr(xn), ptr(yn)
                 keep += [xn, yn]

@@ -643,7 +643,9 @@ class ContrastiveLoss(nn.Module):
         f32 otherwise.
     static_shapes : bool
         Multi-rank only: promise that every rank holds the same modalities with the same batch
-        size, which removes the per-step header exchange (one collective + host sync).
+        size, which removes the per-step header exchange (one collective + host sync).  Checked on the
+        first step and whenever this rank's shapes change (see ``_check_static_shapes`` for the one case
+        the check cannot see: samplers that shorten the batch on some ranks only).
     """
 
     def __init__(self, l2_normalize: bool = False, local_loss: bool = False, gather_with_grad: bool = False,
@@ -674,8 +676,12 @@ class ContrastiveLoss(nn.Module):
         promise would otherwise show up as mismatched collectives (a hang or corrupted rows).  Whenever THIS rank sees a
         (modality, rows) it has not validated yet -- the first step, or a shorter last batch, which ``DistributedSampler``
         hands to every rank at the same step -- the ranks exchange a small header and compare (one collective + one host
-        read, only on those steps).  ``MMK_CHECK_STATIC_SHAPES=1`` validates on every call (debug: it also catches ranks
-        whose shapes change at different steps, which the on-change trigger cannot see)."""
+        read, only on those steps).  LIMITATION: the trigger is this rank's own shapes, so it is only rank-symmetric when every
+        rank's shapes change at the same step (what ``DistributedSampler`` and the reference's padded samplers give).  A
+        sampler that hands a shorter batch to SOME ranks only makes the triggering ranks issue the header collective while the
+        others go straight to the embedding gather -- mismatched collectives, i.e. the hang this check exists to prevent.  Use
+        ``static_shapes=False`` with such samplers; ``MMK_CHECK_STATIC_SHAPES=1`` validates on every call (every rank always
+        joins the header collective, at the price of one small collective + host read per step)."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         import os

@@ -11,7 +11,11 @@ raises ``GPU_MAX_HW_QUEUES`` before the first HIP call so that the towers' strea
       strategy: tower_ddp            # registered in Lightning's StrategyRegistry on import of mmlearn_amd
       # or, explicitly:  strategy: {_target_: mmlearn_amd.strategy.TowerDDPStrategy, gradient_as_bucket_view: true}
 
-Tasks without ``wrap_towers_in_ddp`` (or with ``concurrent_encoders`` off) get stock DDP behaviour.  Lightning is not
+Choosing this strategy IS the request for the per-tower schedule: it switches ``task.concurrent_encoders`` on (the task's
+constructor also takes ``concurrent_encoders`` / ``max_side_streams`` / ``match_ahead`` from YAML); pass
+``concurrent_encoders: false`` to the strategy to keep a task's own setting.  Tasks without ``wrap_towers_in_ddp`` (or with
+``concurrent_encoders`` off) get stock DDP behaviour.  The DDP instances are kept outside the task's module tree, so
+checkpoints keep the reference's ``encoders.<m>.*`` keys.  Lightning is not
 installed in the build image: the class is import-guarded, and the part that does not depend on Lightning
 (``setup_towers``) is what the tests drive against a stand-in base class.
 """
@@ -64,10 +68,13 @@ def _unwrap(model: Any) -> Any:
 class TowerDDPStrategy(DDPStrategy):
     strategy_name = "tower_ddp"
 
-    def __init__(self, *args: Any, **kwargs: Any) -> None:
-        # must precede the first HIP call of the process (HIP multiplexes streams onto this many hardware queues; with the
-        # default 4, two of {tower 1, tower 2, RCCL} can share one and the towers' overlap is lost: 216 vs 207.6 ms/step)
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    def __init__(self, *args: Any, concurrent_encoders: bool = True, **kwargs: Any) -> None:
+        self._want_towers = bool(concurrent_encoders)
+        if self._want_towers:
+            # must precede the first HIP call of the process (HIP multiplexes streams onto this many hardware queues; with
+            # the default 4, two of {tower 1, tower 2, RCCL} can share one and the towers' overlap is lost: 216 vs 207.6
+            # ms/step).  Only set when towers will actually be wrapped.
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         kwargs.setdefault("gradient_as_bucket_view", True)
         super().__init__(*args, **kwargs)
         self._towers_wrapped = False
@@ -75,7 +82,11 @@ class TowerDDPStrategy(DDPStrategy):
     def setup_towers(self, model: Any) -> bool:
         """Wrap the task's towers if it can and wants to; True when done (then no outer DDP must be built)."""
         task = _unwrap(model)
-        if not (hasattr(task, "wrap_towers_in_ddp") and getattr(task, "concurrent_encoders", False)):
+        if not hasattr(task, "wrap_towers_in_ddp"):
+            return False
+        if self._want_towers:
+            task.concurrent_encoders = True
+        if not getattr(task, "concurrent_encoders", False):
             return False
         kw = {k: v for k, v in dict(getattr(self, "_ddp_kwargs", {}) or {}).items() if k != "device_ids"}
         task.wrap_towers_in_ddp(**kw)

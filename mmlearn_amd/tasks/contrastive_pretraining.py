@@ -95,11 +95,21 @@ class ContrastivePretraining(TrainingTask):
         compute_validation_loss: bool = True,
         compute_test_loss: bool = True,
         evaluation_tasks: Optional[dict[str, EvaluationSpec]] = None,
+        concurrent_encoders: bool = False,
+        max_side_streams: int = 1,
+        match_ahead: bool = True,
     ) -> None:
+        """The last three parameters are additions to the reference signature (defaults = reference behaviour), settable
+        from YAML under ``mmlearn_run``: ``concurrent_encoders`` runs every tower after the first on a side HIP stream
+        (DESIGN.md 5.9), ``max_side_streams`` caps the number of such streams, ``match_ahead`` launches the id matcher before
+        the encoders."""
         super().__init__(optimizer=optimizer, lr_scheduler=lr_scheduler, loss_fn=loss,
                          compute_validation_loss=compute_validation_loss, compute_test_loss=compute_test_loss)
         self.save_hyperparameters(ignore=["encoders", "heads", "postprocessors", "modality_module_mapping", "loss",
                                           "auxiliary_tasks", "evaluation_tasks", "modality_loss_pairs"])
+        self.concurrent_encoders = bool(concurrent_encoders)
+        self.max_side_streams = int(max_side_streams)
+        self.match_ahead = bool(match_ahead)
 
         if modality_module_mapping is None:  # all module dicts are keyed by modality
             modality_module_mapping = {k: ModuleKeySpec(encoder_key=k, head_key=k, postprocessor_key=k) for k in encoders}
@@ -187,21 +197,29 @@ class ContrastivePretraining(TrainingTask):
         backward passes run one after the other (measured: 152 vs 140 ms), and a gradient bucket can mix gradients written
         on two streams while its all-reduce only waits for one.  Per-tower instances keep each tower's accumulation,
         buckets and collectives on that tower's stream.  Parameters outside the towers (``log_logit_scale``) get a
-        hook that all-reduces their gradient directly.  Call once, after ``.to(device)`` and before the first step."""
+        hook that all-reduces their gradient directly.  Call once, after ``.to(device)`` and before the first step.
+
+        The DDP instances live OUTSIDE the registered module tree (``self._tower_ddp``, looked up by ``encode``): the
+        ModuleDicts keep the plain modules, so ``state_dict()`` / checkpoints keep the reference's key space
+        (``encoders.<m>.*``, no ``.module.`` segment) and a checkpoint written by a per-tower run loads into an unwrapped task
+        with ``strict=True`` and vice versa."""
         import torch.distributed as dist
         from torch.nn.parallel import DistributedDataParallel as DDP
 
         world = dist.get_world_size()
         mods = list(self._available_modalities)
-        side = self._encoder_streams(len(mods) - 1) if getattr(self, "concurrent_encoders", False) else []
+        side = self._encoder_streams(len(mods) - 1) if self.concurrent_encoders else []
         dev = next(self.parameters()).device
-        kw = dict(device_ids=[dev.index], gradient_as_bucket_view=True)
+        kw: dict = dict(gradient_as_bucket_view=True)
+        if dev.type == "cuda":
+            kw["device_ids"] = [dev.index]
         kw.update(ddp_kwargs)
         owned: set[int] = set()   # parameters that already belong to a DDP instance (modules can be shared between towers)
+        wrapped: dict = self.__dict__.setdefault("_tower_ddp", {})   # (group name, modality) -> DDP; not a registered submodule
         for k, m in enumerate(mods):
             ctx = torch.cuda.stream(side[k - 1]) if (side and k) else contextlib.nullcontext()
             with ctx:
-                for group in (self.encoders, self.postprocessors, self.heads):
+                for gname, group in (("encoders", self.encoders), ("postprocessors", self.postprocessors), ("heads", self.heads)):
                     if not (group and m.name in group):
                         continue
                     mine = {id(p) for p in group[m.name].parameters() if p.requires_grad}
@@ -209,7 +227,7 @@ class ContrastivePretraining(TrainingTask):
                         continue   # nothing to reduce, or a module shared with an earlier tower: that tower's instance reduces it
                     if mine & owned:
                         raise NotImplementedError(f"{m.name}: module shares only part of its parameters with another tower")
-                    group[m.name] = DDP(group[m.name], **kw)
+                    wrapped[(gname, m.name)] = DDP(group[m.name], **kw)
                     owned |= mine
         tower_params = {id(p) for g in (self.encoders, self.postprocessors, self.heads) if g for p in g.parameters()}
 
@@ -220,15 +238,17 @@ class ContrastivePretraining(TrainingTask):
         for p in self.parameters():
             if p.requires_grad and id(p) not in tower_params:
                 p.register_post_accumulate_grad_hook(_reduce)
-        torch.cuda.synchronize(dev)   # the constructors broadcast rank 0's weights on the towers' streams
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)   # the constructors broadcast rank 0's weights on the towers' streams
 
     def encode(self, inputs: dict[str, Any], modality: Any, normalize: bool = False) -> torch.Tensor:
         """encoder -> postprocessor -> head -> (optional) L2 normalisation (reference :400-431)."""
-        output = self.encoders[modality.name](inputs)[0]
+        ddp = self.__dict__.get("_tower_ddp") or {}   # per-tower DistributedDataParallel instances (wrap_towers_in_ddp)
+        output = (ddp.get(("encoders", modality.name)) or self.encoders[modality.name])(inputs)[0]
         if self.postprocessors and modality.name in self.postprocessors:
-            output = self.postprocessors[modality.name](output)
+            output = (ddp.get(("postprocessors", modality.name)) or self.postprocessors[modality.name])(output)
         if self.heads and modality.name in self.heads:
-            output = self.heads[modality.name](output)
+            output = (ddp.get(("heads", modality.name)) or self.heads[modality.name])(output)
         if normalize:
             output = l2_normalize(output)
         return output
@@ -240,7 +260,7 @@ class ContrastivePretraining(TrainingTask):
         hardware queues -- a five-stream experiment stalled in the backward pass, and the three-stream
         three-tower step was the one benchmark leg that ever hung."""
         have = self.__dict__.setdefault("_side_streams", [])
-        cap = max(1, int(getattr(self, "max_side_streams", 1)))
+        cap = max(1, int(self.max_side_streams))
         while len(have) < min(n, cap):
             have.append(torch.cuda.Stream())
         return [have[k % len(have)] for k in range(n)] if have else []
@@ -252,10 +272,10 @@ class ContrastivePretraining(TrainingTask):
         # opt-in (``task.concurrent_encoders = True``): the encoders are independent until the loss, so every modality
         # after the first gets its own HIP stream; forward AND backward kernels of the towers then overlap (autograd
         # replays each node on the stream its forward ran on), which fills the tails of kernels that do not cover 256 CUs.
-        side = self._encoder_streams(len(mods) - 1) if getattr(self, "concurrent_encoders", False) and len(mods) > 1 else None
+        side = self._encoder_streams(len(mods) - 1) if self.concurrent_encoders and len(mods) > 1 else None
         main = torch.cuda.current_stream() if side else None
         early_match = getattr(self.loss_fn, "prefetch_match", None) if "example_ids" in inputs and self.loss_fn is not None else None
-        if early_match is not None and inputs.get("fully_paired") is not True and getattr(self, "match_ahead", True):
+        if early_match is not None and inputs.get("fully_paired") is not True and self.match_ahead:
             # matcher + status read-back overlap the encoders; on the second tower's stream when there is one
             early_match(inputs["example_ids"], self.modality_loss_pairs, **({"stream": side[0]} if side else {}))
         for k, m in enumerate(mods):

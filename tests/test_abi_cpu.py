@@ -37,6 +37,15 @@ def test_header_symbols_are_exported(built):
     assert sorted(built.EXPORTED_SYMBOLS) == declared
 
 
+def test_shipped_library_reads_no_experiment_switches(built):
+    """ablation / A-B switches (some of which give wrong results by design) exist only in
+    -DMMK_DEBUG_SWITCHES builds; the shipped library does not even contain their names."""
+    blob = open(built.LIB_PATH, "rb").read()
+    for name in (b"MMK_SIM_DBG", b"MMK_TILE", b"MMK_LOADER", b"MMK_STAGES", b"MMK_STATS_TILE", b"MMK_ATTN_BWD7", b"MMK_WGRAD_PAIR",
+                 b"MMK_ATTN_STAMPS", b"MMK_GEMM_DBG", b"MMK_GEMM_VAR", b"MMK_GEMM_DESYNC", b"MMK_GEMM4_DBG", b"MMK_GEMM_GRID"):
+        assert name not in blob, name
+
+
 def test_library_loads_without_gpu(built):
     lib = built.lib()
     assert lib.mmk_abi_version() == 2

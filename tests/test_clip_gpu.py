@@ -191,10 +191,11 @@ def test_cpu_tensors_raise():
 @pytest.mark.parametrize("n,d,scale", [(700, 512, 1 / 0.07), (1024, 200, 10.0), (640, 512, 100.0), (8192, 512, 1 / 0.07)])
 def test_bounded_fast_path_equals_exact_path(n, d, scale, monkeypatch):
     """The one-exponential path of the similarity-tile kernels (interior tiles whose logits the operand norms bound) against
-    the per-row / per-column maximum path of the same kernels (MMK_SIM_DBG=8): same loss, LSE-derived gradients and d/dscale
+    the per-row / per-column maximum path of the same kernels (no row norms handed over: ``kernels.BOUNDED_SOFTMAX = False``): same loss, LSE-derived gradients and d/dscale
     to f32 rounding, at sizes with interior AND edge tiles, and at scale 100 where the bound is too loose and the kernel
     must fall back by itself (identical results)."""
     from mmlearn_amd import ContrastiveLoss, LossPairSpec
+    from mmlearn_amd import kernels as K
 
     dev = _dev()
     g = torch.Generator().manual_seed(n + d)
@@ -203,16 +204,13 @@ def test_bounded_fast_path_equals_exact_path(n, d, scale, monkeypatch):
     ids = torch.stack([torch.zeros(n, dtype=torch.long), torch.arange(n)], 1).to(dev)
     out = {}
     for mode in ("fast", "exact"):
-        if mode == "exact":
-            monkeypatch.setenv("MMK_SIM_DBG", "8")
-        else:
-            monkeypatch.delenv("MMK_SIM_DBG", raising=False)
+        monkeypatch.setattr(K, "BOUNDED_SOFTMAX", mode == "fast")
         ea, eb = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
         s = torch.tensor(scale, device=dev, requires_grad=True)
         loss = ContrastiveLoss()({"rgb_embedding": ea, "text_embedding": eb}, {"rgb": ids, "text": ids}, s, [LossPairSpec(("rgb", "text"))])
         loss.float().backward()
         out[mode] = (float(loss.detach().float()), ea.grad.float().cpu(), eb.grad.float().cpu(), float(s.grad))
-    monkeypatch.delenv("MMK_SIM_DBG", raising=False)
+    monkeypatch.setattr(K, "BOUNDED_SOFTMAX", True)
     lf, gaf, gbf, dsf = out["fast"]
     le, gae, gbe, dse = out["exact"]
     assert abs(lf - le) <= 2e-6 * max(1.0, abs(le)), (lf, le)
@@ -230,6 +228,7 @@ def test_transposed_read_gradient_equals_stored_transpose(n, d, monkeypatch):
     kernel; smaller ones store G^T from the tile pass.  Same gradients either way (f32 sums in another order), sizes off the
     256 grid included."""
     from mmlearn_amd import ContrastiveLoss, LossPairSpec
+    from mmlearn_amd import kernels as K
 
     dev = _dev()
     g = torch.Generator().manual_seed(n)
@@ -237,14 +236,14 @@ def test_transposed_read_gradient_equals_stored_transpose(n, d, monkeypatch):
     b = torch.nn.functional.normalize(0.5 * a.float() + torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1), dim=-1).bfloat16()
     ids = torch.stack([torch.zeros(n, dtype=torch.long), torch.arange(n)], 1).to(dev)
     out = {}
-    for mode, rows in (("tn", "1024"), ("gt", "1000000000")):
-        monkeypatch.setenv("MMK_TN_MIN_ROWS", rows)
+    for mode, rows in (("tn", 1024), ("gt", 1000000000)):
+        monkeypatch.setattr(K, "TN_MIN_ROWS", rows)
         ea, eb = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
         s = torch.tensor(1 / 0.07, device=dev, requires_grad=True)
         loss = ContrastiveLoss()({"rgb_embedding": ea, "text_embedding": eb}, {"rgb": ids, "text": ids}, s, [LossPairSpec(("rgb", "text"))])
         loss.float().backward()
         out[mode] = (float(loss.detach().float()), ea.grad.float().cpu(), eb.grad.float().cpu(), float(s.grad))
-    monkeypatch.delenv("MMK_TN_MIN_ROWS", raising=False)
+    monkeypatch.setattr(K, "TN_MIN_ROWS", 2048)
     assert out["tn"][0] == out["gt"][0] and out["tn"][3] == out["gt"][3]
     assert torch.equal(out["tn"][1], out["gt"][1])          # first direction: same launches
     x, y = out["tn"][2], out["gt"][2]                       # second direction: other kernel, other summation order

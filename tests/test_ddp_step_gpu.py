@@ -187,10 +187,12 @@ def _three_tower_worker(port, q):
             task.concurrent_encoders = True
             if ddp:
                 task.wrap_towers_in_ddp(bucket_cap_mb=1)
-                kinds = {k: type(v).__name__ for k, v in task.encoders.items()}
-                assert set(kinds.values()) == {"DistributedDataParallel"}, kinds
-                # the shared head is wrapped once (by the first tower); the other towers call the same module unwrapped
-                assert sum(type(h).__name__ == "DistributedDataParallel" for h in task.heads.values()) == 1
+                # the wrappers live outside the module tree (checkpoint keys stay the reference's): one per encoder, and the
+                # shared head is wrapped once (by the first tower); the other towers call the same module unwrapped
+                assert all(type(v).__name__ != "DistributedDataParallel" for v in list(task.encoders.values()) + list(task.heads.values()))
+                assert sorted(k for k in task._tower_ddp if k[0] == "encoders") == [("encoders", m) for m in ("audio", "rgb", "text")]
+                assert sum(k[0] == "heads" for k in task._tower_ddp) == 1
+                assert not any(".module." in k for k in task.state_dict())
             rec = []
             opt = task.configure_optimizers()
             for _ in range(2):

@@ -172,10 +172,66 @@ def test_tower_ddp_strategy_hands_the_wrapping_to_the_task():
     try:
         t2 = Task()
         t2.concurrent_encoders = False
-        assert S.TowerDDPStrategy()._setup_model(t2) == "ddp" and S.TowerDDPStrategy()._setup_model(torch.nn.Linear(2, 2)) == "ddp"
+        os.environ.pop("GPU_MAX_HW_QUEUES", None)
+        keep = S.TowerDDPStrategy(concurrent_encoders=False)          # keeps the task's own setting ...
+        assert "GPU_MAX_HW_QUEUES" not in os.environ                  # ... and leaves the process environment alone
+        assert keep._setup_model(t2) == "ddp" and S.TowerDDPStrategy()._setup_model(torch.nn.Linear(2, 2)) == "ddp"
     finally:
         S.DDPStrategy._setup_model = orig
     assert len(base_calls) == 2 and len(calls) == 2
+    # choosing the strategy IS the request: a task built by hydra with the default concurrent_encoders=False is switched on
+    t3 = Task()
+    t3.concurrent_encoders = False
+    assert S.TowerDDPStrategy()._setup_model(t3) is t3 and t3.concurrent_encoders is True and len(calls) == 3
+
+
+def test_per_tower_ddp_keeps_the_reference_checkpoint_keys():
+    """``wrap_towers_in_ddp`` used to put the DistributedDataParallel instances INTO ``encoders`` / ``heads``, so
+    ``state_dict()`` grew ``encoders.<m>.module.*`` keys -- not the reference's format, and a checkpoint written by such a run
+    did not load back (Lightning restores before the strategy wraps).  The wrappers now live outside the module tree."""
+    import os
+
+    import torch.distributed as dist
+
+    import tiny_models
+    from mmlearn_amd import ContrastiveLoss
+    from mmlearn_amd.tasks import ContrastivePretraining
+
+    def build():
+        torch.manual_seed(3)
+        enc = {"rgb": tiny_models.FlatMLPEncoder("rgb", 3 * 4 * 4, 8, 6), "text": tiny_models.TokenMLPEncoder("text", 20, 5, 6)}
+        heads = {"rgb": torch.nn.Linear(6, 6), "text": torch.nn.Linear(6, 6)}
+        return ContrastivePretraining(encoders=enc, heads=heads, loss=ContrastiveLoss(), concurrent_encoders=False, max_side_streams=2)
+
+    plain = build()
+    assert plain.max_side_streams == 2 and plain.match_ahead is True          # constructor keywords (YAML-reachable)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29800 + os.getpid() % 100)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        task = build()
+        keys_before = list(task.state_dict().keys())
+        task.wrap_towers_in_ddp()
+        assert len(task._tower_ddp) == 4 and list(task.state_dict().keys()) == keys_before
+        assert not any(".module." in k for k in task.state_dict())
+        with torch.no_grad():
+            for p_ in task.parameters():
+                p_.add_(1.0)
+        sd = task.state_dict()
+        missing, unexpected = plain.load_state_dict(sd, strict=True)            # wrapped -> unwrapped
+        assert not missing and not unexpected
+        task2 = build()
+        task2.wrap_towers_in_ddp()
+        task2.load_state_dict(plain.state_dict(), strict=True)                   # unwrapped -> wrapped
+        from mmlearn_amd.modalities import Modalities
+        x = {"rgb": torch.rand(2, 3, 4, 4)}
+        out_w = task2.encode(x, Modalities.get_modality("rgb"))                  # runs through the DDP instance
+        out_p = plain.encode(x, Modalities.get_modality("rgb"))
+        assert torch.allclose(out_w, out_p)
+        out_w.sum().backward()                                                   # DDP's reducer sees the backward
+        assert all(p_.grad is not None for p_ in task2.encoders["rgb"].parameters())
+    finally:
+        dist.destroy_process_group()
 
 
 def test_tuned_gemm_selection_file_is_well_formed():

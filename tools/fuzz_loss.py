@@ -1,13 +1,17 @@
 """Randomised sweep of the contrastive loss against the numpy oracle (run by hand on the GPU; the oracle is test infrastructure).
 Random row counts off and on the tile grid, widths, dtypes, scales on both sides of the one-exponential bound, 2-3 modalities,
-partial / shuffled / duplicated ids, l2_normalize; MMK_TN_MIN_ROWS=256 in the environment also sends mid-size mirrored pairs
+partial / shuffled / duplicated ids, l2_normalize; TN_MIN_ROWS=256 in the environment also sends mid-size mirrored pairs
 through the transposed-read backward.    N=40 SEED=0 python tools/fuzz_loss.py"""
 import os, random, sys
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmlearn_amd import ContrastiveLoss, LossPairSpec
+from mmlearn_amd import kernels as K
 from oracle import clip_oracle as co
+
+if os.environ.get("TN_MIN_ROWS"):
+    K.TN_MIN_ROWS = int(os.environ["TN_MIN_ROWS"])
 
 dev = torch.device("cuda", 0)
 rng = random.Random(int(os.environ.get("SEED", 0)))

@@ -974,7 +974,7 @@ extern "C" int mmk_attn_fwd(const void* q, const void* k, const void* v, void* o
   }
 }
 
-// MMK_ATTN_STAMPS=1: a 4-KiB device buffer that workgroup 0 of the five-product backward stamps (see AttnBwdArgs.stamps)
+// debug builds, MMK_ATTN_STAMPS=1: a 4-KiB device buffer that workgroup 0 of the five-product backward stamps (see AttnBwdArgs.stamps)
 static unsigned long long* attn_stamp_buffer() {
   static unsigned long long* buf = nullptr;
   static bool tried = false;
@@ -986,7 +986,7 @@ static unsigned long long* attn_stamp_buffer() {
 }
 extern "C" int mmk_attn_debug_stamps(unsigned long long* out, int n) {
   unsigned long long* buf = attn_stamp_buffer();
-  MMK_REQUIRE(buf != nullptr && out != nullptr && n > 0 && n <= 32 * 16, "no stamp buffer (set MMK_ATTN_STAMPS=1 before the first call)");
+  MMK_REQUIRE(buf != nullptr && out != nullptr && n > 0 && n <= 32 * 16, "no stamp buffer (a -DMMK_DEBUG_SWITCHES -DMMK_ATTN_STAMPS_BUILD library with the stamps variable set before the first call)");
   MMK_HIP(hipDeviceSynchronize());
   MMK_HIP(hipMemcpy(out, buf, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
   return 0;

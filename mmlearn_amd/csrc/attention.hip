@@ -986,7 +986,7 @@ static unsigned long long* attn_stamp_buffer() {
 }
 extern "C" int mmk_attn_debug_stamps(unsigned long long* out, int n) {
   unsigned long long* buf = attn_stamp_buffer();
-  MMK_REQUIRE(buf != nullptr && out != nullptr && n > 0 && n <= 32 * 16, "no stamp buffer (a -DMMK_DEBUG_SWITCHES -DMMK_ATTN_STAMPS_BUILD library with the stamps variable set before the first call)");
+  MMK_REQUIRE(buf != nullptr && out != nullptr && n > 0 && n <= 32 * 16, "no stamp buffer (needs a debug-switch + attention-stamps build of the library, see tools/attn_bwd_phases.py)");
   MMK_HIP(hipDeviceSynchronize());
   MMK_HIP(hipMemcpy(out, buf, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
   return 0;

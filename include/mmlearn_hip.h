@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMK_ABI_VERSION 2
+#define MMK_ABI_VERSION 3
 
 /* element types of user tensors */
 enum { MMK_F32 = 0, MMK_BF16 = 1, MMK_F16 = 2 };
@@ -47,7 +47,7 @@ enum {
   MMK_K_SIM_GRAD, MMK_K_GRAD_GEMM, MMK_K_GRAD_FINALIZE, MMK_K_L2NORM, MMK_K_IJEPA_LOSS_FWD,
   MMK_K_IJEPA_LOSS_BWD, MMK_K_GATHER_ROWS, MMK_K_SCATTER_ROWS, MMK_K_PRED_ASSEMBLE, MMK_K_PRED_ASSEMBLE_BWD,
   MMK_K_EMA, MMK_K_MASK_INDEX, MMK_K_LAYERNORM_FWD, MMK_K_LAYERNORM_BWD, MMK_K_ACT, MMK_K_ATTN_FWD,
-  MMK_K_ATTN_BWD, MMK_K_WGRAD, MMK_K_RECALL, MMK_K_GEMM, MMK_K_COUNT
+  MMK_K_ATTN_BWD, MMK_K_WGRAD, MMK_K_RECALL, MMK_K_GEMM, MMK_K_CLIP_FUSED, MMK_K_COUNT
 };
 int mmk_profile_enable(int on);          /* on=1 start recording (clears), on=0 stop */
 /* resolve recorded events (synchronises on them); fills count[k] and total_ms[k] for k < MMK_K_COUNT */
@@ -191,6 +191,42 @@ int mmk_reduce_sums(const float* const* ptrs, const int32_t* counts, const float
  * dscale_out (float[1], pre-zeroed by the caller); upstream is the device scalar dL/dloss. */
 int mmk_clip_backward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale,
                       const float* upstream, float* dscale_out, void* stream);
+
+/* ------------------------------------------------------------------ CLIP loss, one resident-grid launch (small batches)
+ * The whole of ContrastiveLoss.forward for up to four LossPairSpecs on ONE rank -- emb[indices] (contrastive.py:290-291),
+ * logit_scale * _safe_matmul (:339-340), both F.cross_entropy terms / 2 * weight (:134-144), torch.stack().sum() (:160) --
+ * AND the gradients of that loss, in one launch (csrc/clip_fused.hip): similarity tiles in registers, tile statistics handed
+ * over through L2, G = P_row + P_col - 2 delta from the same accumulators, dA = G B and dB = G^T A as raw f32 sums in the
+ * workspace.  mmk_clip_fused_backward is one more launch: x weight / (2 n) * scale * upstream, cast, scatter through idx.
+ * Conditions: 1..1024 matched rows per pair, f32 or bf16 rows of whole 16-byte pieces (d % 4 / d % 8 == 0), bf16 MFMA
+ * arithmetic with f32 accumulation (what the reference computes under Lightning's bf16-mixed), and a grid that is
+ * co-resident: `grid` <= `capacity` of mmk_clip_fused_plan (the workgroups of a launch wait for each other).
+ *   a / b      : the embedding matrices [*, d] of the pair's two modalities (src_dtype), untouched
+ *   idx_a/idx_b: int32[n] matched-row lists of find_matching_indices, or NULL (identity: pair p = rows (p, p))
+ *   ws         : workspace of mmk_clip_fused_plan's ws_bytes; all ZERO before the first call, then reusable call after call
+ *                on one stream (its counters are zero again when a launch has completed); it holds the raw gradient sums
+ *                until mmk_clip_fused_backward has run
+ *   loss_out   : float[1];  ds_out: float[2] = {raw d loss / d scale, 0} (NULL when want_grad == 0); the zero is a ready-made
+ *                accumulator for mmk_clip_fused_backward's dscale_out (which ADDS upstream * ds_raw)
+ * A spin that exceeds its bound (a workgroup of the launch never became resident) ends with NaN in loss_out / ds_out. */
+typedef struct mmk_fused_pair {
+  const void* a;
+  const void* b;
+  const int32_t* idx_a;
+  const int32_t* idx_b;
+  int32_t n;              /* matched pairs */
+  float weight;           /* LossPairSpec.weight */
+  /* backward only */
+  void* da;               /* [rows of a, d] gradient buffer (dx_dtype; f32 and pre-zeroed when da_accumulate) */
+  void* db;
+  int32_t da_accumulate;  /* 1: idx_a repeats rows, or another pair writes the same buffer -> atomic adds */
+  int32_t db_accumulate;
+} mmk_fused_pair;
+int mmk_clip_fused_plan(const int32_t* n, int n_pairs, int d, int src_dtype, int64_t* ws_bytes, int32_t* grid, int32_t* capacity);
+int mmk_clip_fused_forward(const mmk_fused_pair* pairs, int n_pairs, int d, int src_dtype, const float* scale, void* ws, int64_t ws_bytes,
+                           int want_grad, float* loss_out, float* ds_out, void* stream);
+int mmk_clip_fused_backward(const mmk_fused_pair* pairs, int n_pairs, int d, int dx_dtype, const float* scale, const float* upstream,
+                            void* ws, int64_t ws_bytes, const float* ds_raw, float* dscale_out, void* stream);
 
 /* ------------------------------------------------------------------ row ops
  * F.normalize(x, p=2, dim=-1, eps=1e-12) forward / backward

@@ -20,14 +20,14 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 F32, BF16, F16 = 0, 1, 2
 COMPUTE_BF16, COMPUTE_F32 = 1, 0
-ABI_VERSION = 2   # include/mmlearn_hip.h MMK_ABI_VERSION this ctypes mirror was written against
+ABI_VERSION = 3   # include/mmlearn_hip.h MMK_ABI_VERSION this ctypes mirror was written against
 
 _DTYPE_TAG = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 KERNEL_NAMES = [
     "match_ids", "pack_rows", "transpose", "sim_stats", "lse_reduce", "loss_combine", "sim_grad", "grad_gemm",
     "grad_finalize", "l2norm", "ijepa_loss_fwd", "ijepa_loss_bwd", "gather_rows", "scatter_rows", "pred_assemble",
-    "pred_assemble_bwd", "ema_update", "mask_to_index", "layernorm_fwd", "layernorm_bwd", "activation", "attn_fwd", "attn_bwd", "wgrad", "recall_ranks", "gemm_nt",
+    "pred_assemble_bwd", "ema_update", "mask_to_index", "layernorm_fwd", "layernorm_bwd", "activation", "attn_fwd", "attn_bwd", "wgrad", "recall_ranks", "gemm_nt", "clip_fused",
 ]
 
 
@@ -60,6 +60,14 @@ class PackReq(C.Structure):
                 ("r", C.c_int32), ("r_pad", C.c_int32), ("normalize", C.c_int32), ("ldt", C.c_int32), ("norm", C.c_void_p)]
 
 
+class FusedPair(C.Structure):
+    """mirror of ``mmk_fused_pair``"""
+
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("idx_a", C.c_void_p), ("idx_b", C.c_void_p),
+                ("n", C.c_int32), ("weight", C.c_float), ("da", C.c_void_p), ("db", C.c_void_p),
+                ("da_accumulate", C.c_int32), ("db_accumulate", C.c_int32)]
+
+
 class EmaEntry(C.Structure):
     """mirror of ``mmk_ema_entry``"""
 
@@ -83,6 +91,9 @@ _SIGNATURES = {
     "mmk_clip_plan": [_i, _i, _i, _i, _vp, _vp, _vp],
     "mmk_clip_forward": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "mmk_reduce_sums": [_vp, _vp, _vp, _i, _i, _vp, _vp],
+    "mmk_clip_fused_plan": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "mmk_clip_fused_forward": [_vp, _i, _i, _i, _vp, _vp, C.c_int64, _i, _vp, _vp, _vp],
+    "mmk_clip_fused_backward": [_vp, _i, _i, _i, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp],
     "mmk_match_workspace_ints": [_i, _i],
     "mmk_clip_backward": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "mmk_l2norm_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "clip_internal.h"
 
 extern "C" int mmk_wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* ws_floats_out);
 extern "C" int mmk_wgrad_partial(const void* dy, const void* x, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx, int32_t* splits_out,
@@ -30,9 +31,6 @@ extern "C" int mmk_wgrad_partial(const void* dy, const void* x, float* ws, int64
 
 namespace mmk {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------- MMA atoms
 // One "macro k-step" consumes 32 bytes of K per operand row: lane (r = lane&31, h = lane>>5)
@@ -61,7 +59,6 @@ struct Atom<float> {
 };
 
 enum { EPI_STATS = 0, EPI_GRAD = 1, EPI_PLAIN = 2, EPI_ALIGN_STATS = 3, EPI_ALIGN_GRAD = 4 };
-constexpr int MAX_PROBS = 8;
 
 struct Prob {
   const char* P;  // rows -> accumulator registers (MFMA A)
@@ -105,17 +102,6 @@ struct ProbBatch {
                           // The shipped build ignores the field; the exact path is selected by passing no row norms.
 };
 
-// device-coherent accesses for data that one workgroup writes and another reads within the same launch (block sums of
-// the merge kernel): sc1 stores / loads that do not linger in a non-coherent XCD L2
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(float2* p, float2 v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float2 ld_agent(const float2* p) {
-  return __builtin_bit_cast(float2, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
 // ------------------------------------------------------------------ main loop
 // LOADER 0: global -> VGPR -> ds_write_b128 staging (2 LDS stages).
 // LOADER 1: LDS-DMA (global_load_lds_dwordx4): each wave-instruction lands 1 KiB = 8 tile rows linearly in
@@ -128,37 +114,9 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// raw v_exp_f32 (2^x); arguments here are <= 0 up to rounding, tiny results may flush -- harmless in a softmax sum
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// Transpose-reduce over the 32 lanes of a half-wave: every lane holds CNT values (one per "column"), on return lane L holds
-// in v[0] the reduction over the 32 lanes (same lane >> 5) of column L & (CNT - 1)  (CNT = 32: 31 shuffles instead of 160;
-// CNT = 16: the xor-16 partner pairs are combined at the end, both lanes of a pair hold the same column).
-template <int CNT, bool IS_MAX>
-__device__ __forceinline__ float half_wave_transpose_reduce(float (&v)[CNT], int lane) {
-  static_assert(CNT == 32 || CNT == 16, "16 or 32 columns");
-  constexpr int STEPS = CNT == 32 ? 5 : 4;
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    const bool bit = (lane >> s) & 1;
-#pragma unroll
-    for (int i = 0; i < (CNT >> (s + 1)); ++i) {
-      const float keep = bit ? v[2 * i + 1] : v[2 * i];
-      const float send = bit ? v[2 * i] : v[2 * i + 1];
-      const float recv = __shfl_xor(send, 1 << s);
-      v[i] = IS_MAX ? fmaxf(keep, recv) : keep + recv;
-    }
-  }
-  if (CNT == 16) {
-    const float o = __shfl_xor(v[0], 16);
-    v[0] = IS_MAX ? fmaxf(v[0], o) : v[0] + o;
-  }
-  return v[0];
 }
 
 // WM = waves along the P rows (m); two waves along the Q rows (n).  WM = 2: four waves, two workgroups per CU (128 x 128 / 64 x 64
@@ -1130,29 +1088,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in
 
 // ------------------------------------------------------------------ finalize
 // one wave per owned row: dy = coef * sum_splits slab ; optional F.normalize backward ; scatter to user grad
-struct FinProb {
-  const float* slab;
-  long split_stride;
-  int slab_ld;
-  int r;
-  float kappa;
-  void* dx;
-  const int32_t* dx_rows;
-  int accumulate;
-  const void* src;  // original rows (normalize backward)
-  int normalize;
-  int n_split;      // slabs to sum
-};
-struct FinBatch {
-  FinProb p[MAX_PROBS];
-  int d;
-};
-struct DsBatch {
-  const float* part[MAX_PROBS];
-  int n[MAX_PROBS];
-  float kappa[MAX_PROBS];
-  int n_probs;
-};
 template <typename U>
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinBatch batch, const float* __restrict__ scale_ptr,
                                                             const float* __restrict__ upstream, const DsBatch ds, float* ds_out, int n_dirs) {
@@ -1540,12 +1475,22 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
     ld_max = std::max(ld_max, (int)kp);
   }
   {
-    ProfScope ps(MMK_K_GRAD_FINALIZE, st);
-    // one launch: a grid row per direction, plus one for the d/dscale reduction
+    int rc = launch_grad_finalize(fb, n_dirs, max_r, ld_max, scale, upstream, db, dscale_out, dirs[0].dx_dtype, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int launch_grad_finalize(const FinBatch& fb, int n_dirs, int max_r, int ld_max, const float* scale, const float* upstream, const DsBatch& db,
+                         float* dscale_out, int dx_dtype, hipStream_t st) {
+  ProfScope ps(MMK_K_GRAD_FINALIZE, st);
+  int rc = MMK_DISPATCH_DTYPE(dx_dtype, U, [&]() -> int {
     hipLaunchKernelGGL((grad_finalize_kernel<U>), dim3(cdiv(max_r, 4), n_dirs + (dscale_out ? 1 : 0)), dim3(256), 4 * ld_max * sizeof(float), st, fb,
                        scale, upstream, db, dscale_out, n_dirs);
-    MMK_LAUNCH_CHECK();
-  }
+    return 0;
+  });
+  if (rc) return rc;
+  MMK_LAUNCH_CHECK();
   return 0;
 }
 

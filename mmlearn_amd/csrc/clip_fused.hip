@@ -1,0 +1,692 @@
+// One-launch CLIP / InfoNCE loss WITH its gradients for small batches (every pair <= 1024 matched rows, one rank).
+//
+// Replaces, per LossPairSpec, the whole ATen sequence of mmlearn/modules/losses/contrastive.py:279-291 (emb[indices]),
+// :327-340 (_safe_matmul, logit_scale *), :134-144 (F.cross_entropy x2, /2 * weight) and its autograd.  At N = 1024 the tiled
+// multi-launch path (clip.hip) is launch-bound: seven launches of 4.5-11 us for 3.2 GFLOP of work.  Here ONE resident grid
+// does all of it; workgroups hand data to each other through L2 with the write-through (sc1) store / agent-scope counter /
+// sc1 load protocol of the CDNA4 guide (Guideline 16, table row "one lane of each storing workgroup adds to a counter"):
+//
+//   phase 1  workgroup (ti, tj): the 64 x 64 tile  S = B[tj] A[ti]^T  (bf16 MFMA 32x32x16, f32 accumulate) straight from the
+//            user's rows (f32 or bf16, gathered through the match index, converted while staging -- no pack launch), per-row
+//            and per-column (max, sum 2^(u - max)) of the tile -> L2; counters c1_row[ti], c1_col[tj].
+//   phase 2  waits for its row strip's and column strip's 2 * nt partials, merges them to the row / column log-sum-exps, forms
+//            G = P_row + P_col - 2 delta from the accumulators it still holds (no recompute), stores the tile of G and of G^T
+//            (bf16, 2 MB each at N = 1024: they never leave the caches), the tile's share of d loss / d scale; the diagonal
+//            workgroups add the loss terms; counters c2_row[ti], c2_col[tj].
+//   phase 3  workgroup w takes output tiles of  dA = G B  and  dB = G^T A  (64 rows x 64 of the D columns, contraction over
+//            all N): both are  out[n][k] = sum_m U[m][n] V[m][k]  with U = G^T or G and V = B or A, i.e. both operands have the
+//            contraction along their rows -> LDS images read with ds_read_b64_tr_b16.  Raw f32 sums go to the workspace.
+//   tail     the workgroup that draws the last ticket adds the loss / d-scale partials in a fixed order and re-arms every
+//            counter (all zero on entry, all zero on exit).
+// The backward call is one launch of the existing finalize kernel (x kappa * scale * upstream, cast, scatter).
+//
+// Why G goes through L2 instead of f32 atomics into the gradients: every (ti, tj) tile contributes a 64 x D partial to dA[ti]
+// and to dB[tj], 16 adders per element at N = 1024 -- 64 MB of atomic adds against the part's ~1.3 TB/s atomic rate is ~50 us;
+// G itself is 2 MB.
+//
+// Residency: a workgroup spins on counters that other workgroups of the same launch advance, so the whole grid must be
+// co-resident: mmk_clip_fused_plan reports the capacity (occupancy query x CUs, at most 2 workgroups per CU) and the host
+// only takes this path when the grid fits.  Every spin is bounded (s_memrealtime); a timeout poisons the loss with NaN.
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+
+#include "clip_internal.h"
+#include "common.h"
+
+namespace mmk {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+
+constexpr int FT = 64;                 // tile edge
+constexpr int F_NT_MAX = 16;           // <= 1024 matched rows per pair
+constexpr int F_THREADS = 256;
+constexpr int F_MAX_PAIRS = 4;       // two gradient directions per pair, MAX_PROBS directions per finalize launch
+constexpr int F_KS = 128;              // phase 1: K elements per LDS stage (two 64-element sub-images)
+constexpr int F_CM = 128;              // phase 3: contraction rows per LDS stage
+constexpr int F_STAGE = 32 * 1024;     // bytes of one LDS stage (both phases)
+constexpr int F_SCRATCH = 6 * 1024;
+constexpr int F_LDS = 2 * F_STAGE + F_SCRATCH;
+constexpr int F_CNT_STRIDE = 16;       // counters on lines of their own (64 B)
+constexpr unsigned long long F_SPIN_LIMIT = 400000000ull;   // 4 s of the 100 MHz realtime clock
+
+struct FusedPair {
+  const char* a;          // raw rows of modality a [*, d] (src dtype)
+  const char* b;
+  const int32_t* idx_a;   // matched-row index lists (null: identity)
+  const int32_t* idx_b;
+  int n, nt, n_pad;
+  int tile0, job0;        // first tile / first phase-3 job of this pair
+  float w;                // weight / (2 n): factor of the pair's loss sums and of d/dscale
+  float2* part_row;       // [nt][n_pad]  (tile column tj, row i)
+  float2* part_col;       // [nt][n_pad]  (tile row ti, column j)
+  bf16_t* G;              // [n_pad][n_pad]  G[i][j]
+  bf16_t* GT;             // [n_pad][n_pad]  G[i][j] at [j][i]
+  unsigned* cnt;          // [4][nt] counters, stride F_CNT_STRIDE: c1_row, c1_col, c2_row, c2_col
+  float* loss_part;       // [2 nt]
+  float* ds_part;         // [nt * nt]
+  float* dA;              // [n_pad][k_pad] raw gradient sums
+  float* dB;
+};
+struct FusedArgs {
+  FusedPair p[MAX_PROBS];
+  int n_pairs, n_tiles, n_jobs;
+  int d, k_pad, nkc;
+  int want_grad;
+  const float* scale;
+  unsigned* done;         // [0] ticket, [F_CNT_STRIDE] error flag
+  float* loss_out;
+  float* ds_out;
+};
+
+__device__ __forceinline__ unsigned ld_cnt(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void add_cnt(unsigned* p) { __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// one lane: wait until both counters have reached `target`; false on timeout (error word set)
+__device__ __forceinline__ bool spin_until(const unsigned* c0, const unsigned* c1, unsigned target, unsigned* err) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    const unsigned v0 = ld_cnt(c0), v1 = ld_cnt(c1);
+    if (v0 >= target && v1 >= target) return true;
+    __builtin_amdgcn_s_sleep(4);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > F_SPIN_LIMIT) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+  }
+}
+
+template <typename S>
+struct SrcT;
+template <>
+struct SrcT<float> {
+  static constexpr int EPP = 4;   // elements per 16-byte piece
+  // 4 floats -> 4 bf16 in 8 bytes
+  static __device__ __forceinline__ uint2 to_bf16(const uint4& v) {
+    typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
+    bf2 lo, hi;
+    lo[0] = (bf16_t)__uint_as_float(v.x); lo[1] = (bf16_t)__uint_as_float(v.y);
+    hi[0] = (bf16_t)__uint_as_float(v.z); hi[1] = (bf16_t)__uint_as_float(v.w);
+    return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+  }
+};
+template <>
+struct SrcT<bf16_t> {
+  static constexpr int EPP = 8;
+};
+
+__device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }   // row of accumulator register e
+
+template <typename S>
+__global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int EPP = SrcT<S>::EPP;
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  // ---- scratch carve (behind the two stages)
+  char* scr = smem + 2 * F_STAGE;
+  float2* red_row = reinterpret_cast<float2*>(scr);             // [2][64]
+  float2* red_col = reinterpret_cast<float2*>(scr + 1024);      // [2][64]
+  float* cmax_w = reinterpret_cast<float*>(scr + 2048) + wave * 32;   // [4][2][16]
+  float* lr2_s = reinterpret_cast<float*>(scr + 2560);          // [64]
+  float* lc2_s = reinterpret_cast<float*>(scr + 2816);          // [64]
+  float* diag_s = reinterpret_cast<float*>(scr + 3072);         // [64]
+  float* misc = reinterpret_cast<float*>(scr + 3328);           // [16]
+  int* flag_s = reinterpret_cast<int*>(scr + 3392);             // [4]
+
+  unsigned* err = a.done + F_CNT_STRIDE;
+
+  // ---- which pair / tile
+  int pi = 0;
+#pragma unroll 1
+  while (pi + 1 < a.n_pairs && (int)blockIdx.x >= a.p[pi + 1].tile0) ++pi;
+  const FusedPair& p = a.p[pi];
+  const int tile = (int)blockIdx.x - p.tile0;
+  const int nt = p.nt, n = p.n, n_pad = p.n_pad;
+  const int ti = tile / nt, tj = tile % nt;
+  const float s = *a.scale;
+  const float s2 = s * LOG2E;
+  unsigned* c1_row = p.cnt + (0 * nt + ti) * F_CNT_STRIDE;
+  unsigned* c1_col = p.cnt + (1 * nt + tj) * F_CNT_STRIDE;
+  unsigned* c2_row = p.cnt + (2 * nt + ti) * F_CNT_STRIDE;
+  unsigned* c2_col = p.cnt + (3 * nt + tj) * F_CNT_STRIDE;
+
+  // =============================================================== phase 1: S tile
+  // stage image: two sub-images (k halves) of [128 rows][128 B]; rows 0..63 = B[tj] (-> accumulator registers: columns j of S),
+  // rows 64..127 = A[ti] (-> lanes: rows i of S); 16-byte chunk ^= (row >> 1) & 7 (conflict-free ds_read_b128 fragments)
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  {
+    constexpr int PPR = F_KS / EPP;                 // 16-byte pieces per row and stage
+    constexpr int NP = 128 * PPR / F_THREADS;       // pieces per thread and stage (16 / 8)
+    constexpr int RPS = F_THREADS / PPR;            // rows covered by one piece slot (8 / 16)
+    const int c = tid % PPR;                        // piece within the row: K elements c*EPP ..
+    long srow[NP];                                  // byte offset of the source row, -1: row beyond n (zeros)
+    int lds_off[NP];
+    const char* base[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int row = u * RPS + tid / PPR;
+      const bool isb = row < 64;
+      const int pp = (isb ? tj : ti) * 64 + (row & 63);
+      const int32_t* idx = isb ? p.idx_b : p.idx_a;
+      base[u] = isb ? p.b : p.a;
+      srow[u] = pp < n ? (long)(idx ? idx[pp] : pp) * a.d * (long)sizeof(S) : -1;
+      const int e0 = (c * EPP) & 63, kh = (c * EPP) >> 6;
+      lds_off[u] = kh * 16384 + row * 128 + ((((e0 >> 3) ^ ((row >> 1) & 7))) << 4) + (e0 & 7) * 2;
+    }
+    const int ns = (a.k_pad + F_KS - 1) / F_KS;
+    uint4 stg[NP];
+    auto load = [&](int st) {
+      const int col = st * F_KS + c * EPP;
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        stg[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (srow[u] >= 0 && col < a.d) stg[u] = *reinterpret_cast<const uint4*>(base[u] + srow[u] + (long)col * (long)sizeof(S));
+      }
+    };
+    auto store = [&](char* buf) {
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        if constexpr (EPP == 4) *reinterpret_cast<uint2*>(buf + lds_off[u]) = SrcT<float>::to_bf16(stg[u]);
+        else *reinterpret_cast<uint4*>(buf + lds_off[u]) = stg[u];
+      }
+    };
+    const int p_off = (wm * 32 + r) * 128, p_sw = ((wm * 32 + r) >> 1) & 7;
+    const int q_off = (64 + wn * 32 + r) * 128, q_sw = ((64 + wn * 32 + r) >> 1) & 7;
+    auto compute = [&](const char* buf, int st) {
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        if (st * F_KS + kh * 64 >= a.k_pad) break;
+        const char* img = buf + kh * 16384;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int ch = 2 * kk + h;
+          const bf16x8 fa = *reinterpret_cast<const bf16x8*>(img + p_off + ((ch ^ p_sw) << 4));
+          const bf16x8 fb = *reinterpret_cast<const bf16x8*>(img + q_off + ((ch ^ q_sw) << 4));
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+        }
+      }
+    };
+    load(0);
+    store(smem);
+    __syncthreads();
+#pragma unroll 1
+    for (int st = 0; st < ns; ++st) {
+      const bool more = st + 1 < ns;
+      if (more) load(st + 1);
+      compute(smem + (st & 1) * F_STAGE, st);
+      if (more) store(smem + ((st + 1) & 1) * F_STAGE);
+      __syncthreads();
+    }
+  }
+
+  // ---- tile statistics, both directions (log2 domain: u = s2 * t)
+  const int i_loc = wn * 32 + r, i_glob = ti * 64 + i_loc;
+  const bool iv = i_glob < n;
+  const int j_base = tj * 64 + wm * 32;
+  {
+    float umax = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float u = (j_base + acc_row(e, h) < n) ? acc[e] * s2 : -INFINITY;
+      umax = fmaxf(umax, u);
+    }
+    umax = fmaxf(umax, __shfl_xor(umax, 32));
+    float sum = 0.f;
+    if (umax > -INFINITY) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sum += (j_base + acc_row(e, h) < n) ? fast_exp2(fmaf(acc[e], s2, -umax)) : 0.f;
+    }
+    sum += __shfl_xor(sum, 32);
+    if (h == 0) red_row[wm * 64 + i_loc] = make_float2(umax, sum);
+    // columns: per accumulator register over the 32 lanes (rows i) of the half-wave
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = iv ? acc[e] * s2 : -INFINITY;
+    const float cm = half_wave_transpose_reduce<16, true>(v, lane);   // lane L: column L & 15 of half h
+    cmax_w[h * 16 + (lane & 15)] = cm;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float mref = cmax_w[h * 16 + e];
+      v[e] = (iv && mref > -INFINITY) ? fast_exp2(fmaf(acc[e], s2, -mref)) : 0.f;
+    }
+    const float cs = half_wave_transpose_reduce<16, false>(v, lane);
+    const int cidx = lane & 15;
+    if ((lane & 16) == 0) red_col[wn * 64 + wm * 32 + acc_row(cidx, h)] = make_float2(cm, cs);
+    if (ti == tj && wm == wn && iv) {   // positive logits of the diagonal tile
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (acc_row(e, h) == r) diag_s[i_loc] = s * acc[e];
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const bool is_row = tid < 64;
+    const int t = tid & 63;
+    const float2* red = is_row ? red_row : red_col;
+    const float2 x0 = red[t], x1 = red[64 + t];
+    const float mx = fmaxf(x0.x, x1.x);
+    float l = 0.f;
+    if (x0.x > -INFINITY) l += x0.y * fast_exp2(x0.x - mx);
+    if (x1.x > -INFINITY) l += x1.y * fast_exp2(x1.x - mx);
+    const int g = (is_row ? ti : tj) * 64 + t;
+    if (g < n) st_agent((is_row ? p.part_row + (size_t)tj * n_pad : p.part_col + (size_t)ti * n_pad) + g, make_float2(mx, l));
+  }
+  drain_vm();
+  __syncthreads();
+  if (tid == 0) {
+    add_cnt(c1_row);
+    add_cnt(c1_col);
+    flag_s[0] = spin_until(c1_row, c1_col, (unsigned)nt, err) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool ok1 = flag_s[0] != 0;
+
+  // =============================================================== phase 2: LSEs, loss terms, G
+  if (ok1) {
+    if (tid < 128) {
+      const bool is_row = tid < 64;
+      const int t = tid & 63;
+      const int g = (is_row ? ti : tj) * 64 + t;
+      float l2 = 0.f, term = 0.f;
+      if (g < n) {
+        const float2* part = (is_row ? p.part_row : p.part_col) + g;
+        float mx = -INFINITY, l = 0.f;
+        float2 pv[F_NT_MAX];
+#pragma unroll
+        for (int q = 0; q < F_NT_MAX; ++q) pv[q] = q < nt ? ld_agent(part + (size_t)q * n_pad) : make_float2(-INFINITY, 0.f);
+#pragma unroll
+        for (int q = 0; q < F_NT_MAX; ++q)
+          if (pv[q].x > -INFINITY) {
+            const float nm = fmaxf(mx, pv[q].x);
+            l = l * fast_exp2(mx - nm) + pv[q].y * fast_exp2(pv[q].x - nm);
+            mx = nm;
+          }
+        l2 = mx + log2f(l);
+        if (ti == tj) term = l2 * LN2 - diag_s[t];
+      }
+      (is_row ? lr2_s : lc2_s)[t] = l2;
+      if (ti == tj) {   // waves 0 and 1: the row / column direction's sum over this strip (fixed order: deterministic)
+        term = wave_sum(term);
+        if (t == 0) st_agent(p.loss_part + (is_row ? ti : nt + tj), term);
+      }
+    }
+    __syncthreads();
+    if (a.want_grad) {
+      const float lr2 = lr2_s[i_loc];
+      float ds_acc = 0.f;
+      char* gs = smem;                 // G tile  [64 i][64 j] bf16, row stride 144 B
+      char* gts = smem + 16384;        // G^T tile [64 j][64 i]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float g4[4];
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int e = 4 * q + e4;
+          const int j_loc = wm * 32 + acc_row(e, h);
+          const float t = acc[e];
+          const float u = t * s2;
+          float g = fast_exp2(u - lr2) + fast_exp2(u - lc2_s[j_loc]);
+          if (ti == tj && j_loc == i_loc) g -= 2.f;
+          if (!(iv && (tj * 64 + j_loc < n))) g = 0.f;
+          ds_acc = fmaf(g, t, ds_acc);
+          g4[e4] = g;
+          *reinterpret_cast<bf16_t*>(gts + j_loc * 144 + i_loc * 2) = (bf16_t)g;
+        }
+        Vec4<bf16_t>::store(reinterpret_cast<bf16_t*>(gs + i_loc * 144) + wm * 32 + 8 * q + 4 * h, make_float4(g4[0], g4[1], g4[2], g4[3]));
+      }
+      ds_acc = wave_sum(ds_acc);
+      if (lane == 0) misc[wave] = ds_acc;
+      __syncthreads();
+      {
+        const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.G), 0, n_pad * n_pad * 2, 0x00020000);
+        const auto rgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.GT), 0, n_pad * n_pad * 2, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int pid = tid + F_THREADS * u, row = pid >> 3, cc = pid & 7;
+          const u32x4 v0 = *reinterpret_cast<const u32x4*>(gs + row * 144 + cc * 16);
+          const u32x4 v1 = *reinterpret_cast<const u32x4*>(gts + row * 144 + cc * 16);
+          __builtin_amdgcn_raw_buffer_store_b128(v0, rg, ((ti * 64 + row) * n_pad + tj * 64 + cc * 8) * 2, 0, 16);    // sc1: write-through
+          __builtin_amdgcn_raw_buffer_store_b128(v1, rgt, ((tj * 64 + row) * n_pad + ti * 64 + cc * 8) * 2, 0, 16);
+        }
+      }
+      if (tid == 0) st_agent(p.ds_part + tile, misc[0] + misc[1] + misc[2] + misc[3]);
+      drain_vm();
+      __syncthreads();
+      if (tid == 0) {
+        add_cnt(c2_row);
+        add_cnt(c2_col);
+      }
+    }
+  }
+
+  // =============================================================== phase 3: dA = G B, dB = G^T A
+  if (a.want_grad) {
+    // stage image: U [128 m][64 n] bf16 (16 KiB) then V [128 m][64 k] (16 KiB); 128-byte rows, 16-byte chunk ^= ((row >> 1) & 1) << 2
+    // (the four rows of a transposed-read block on four different 64-byte groups of the 256-byte bank window)
+    constexpr int VPR = 64 / EPP;                       // V pieces per row (16 / 8)
+    constexpr int NV = F_CM * VPR / F_THREADS;          // V pieces per thread and stage (8 / 4)
+    constexpr int VRS = F_THREADS / VPR;                // rows per V piece slot (16 / 32)
+    const int li = lane & 15, q4 = li >> 2, p4 = li & 3, g1 = (lane >> 4) & 1;
+    const int tr_a = (8 * h + q4) * 128 + ((((wm ^ (q4 >> 1)) * 4 + 2 * g1 + (p4 >> 1))) << 4) + 8 * (p4 & 1);
+    const int tr_b = 16384 + (8 * h + q4) * 128 + ((((wn ^ (q4 >> 1)) * 4 + 2 * g1 + (p4 >> 1))) << 4) + 8 * (p4 & 1);
+    auto tr8 = [&](const char* ptr) {
+      const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ptr));
+      const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ptr + 512));
+      s8v f;
+      f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+      f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+      return __builtin_bit_cast(bf16x8, f);
+    };
+#pragma unroll 1
+    for (int job = blockIdx.x; job < a.n_jobs; job += gridDim.x) {
+      int pj = 0;
+#pragma unroll 1
+      while (pj + 1 < a.n_pairs && job >= a.p[pj + 1].job0) ++pj;
+      const FusedPair& pp = a.p[pj];
+      const int jl = job - pp.job0;
+      const int per_dir = pp.nt * a.nkc;
+      const int dir = jl / per_dir, strip = (jl % per_dir) / a.nkc, kc = (jl % per_dir) % a.nkc;
+      const bf16_t* U = dir == 0 ? pp.GT : pp.G;          // dA: U[m = j][n = i] = G^T ; dB: U[m = i][n = j] = G
+      const char* Vsrc = dir == 0 ? pp.b : pp.a;
+      const int32_t* Vidx = dir == 0 ? pp.idx_b : pp.idx_a;
+      float* out = dir == 0 ? pp.dA : pp.dB;
+      const unsigned* cw = pp.cnt + ((2 + dir) * pp.nt + strip) * F_CNT_STRIDE;
+      const int npad = pp.n_pad, nn = pp.n;
+      const int nst = npad / F_CM + ((npad % F_CM) ? 1 : 0);
+      const auto ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(U), 0, npad * npad * 2, 0x00020000);
+
+      u32x4 ust[4];
+      uint4 vst[NV];
+      const int vc = tid % VPR;
+      const int vcol = kc * 64 + vc * EPP;
+      auto load_v = [&](int st) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+          const int m = st * F_CM + u * VRS + tid / VPR;
+          vst[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (m < nn && vcol < a.d) {
+            const long srow = (long)(Vidx ? Vidx[m] : m) * a.d;
+            vst[u] = *reinterpret_cast<const uint4*>(Vsrc + (srow + vcol) * (long)sizeof(S));
+          }
+        }
+      };
+      auto load_u = [&](int st) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int m = st * F_CM + u * 32 + (tid >> 3);
+          ust[u] = (u32x4){0u, 0u, 0u, 0u};
+          if (m < npad) ust[u] = __builtin_amdgcn_raw_buffer_load_b128(ru, (m * npad + strip * 64 + (tid & 7) * 8) * 2, 0, 16);   // sc1
+        }
+      };
+      auto store_uv = [&](char* buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int row = u * 32 + (tid >> 3), cc = tid & 7;
+          *reinterpret_cast<u32x4*>(buf + row * 128 + ((cc ^ (((row >> 1) & 1) << 2)) << 4)) = ust[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+          const int row = u * VRS + tid / VPR;
+          const int e0 = vc * EPP;
+          char* dst = buf + 16384 + row * 128 + (((e0 >> 3) ^ (((row >> 1) & 1) << 2)) << 4) + (e0 & 7) * 2;
+          if constexpr (EPP == 4) *reinterpret_cast<uint2*>(dst) = SrcT<float>::to_bf16(vst[u]);
+          else *reinterpret_cast<uint4*>(dst) = vst[u];
+        }
+      };
+      f32x16 o;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[e] = 0.f;
+      load_v(0);                       // does not depend on the hand-off: in flight while the strip's G tiles arrive
+      __syncthreads();                 // flag_s / stage buffers of the previous job (or of phase 2) are free
+      if (tid == 0) flag_s[1] = spin_until(cw, cw, (unsigned)pp.nt, err) ? 1 : 0;
+      __syncthreads();
+      const bool ok = flag_s[1] != 0;   // workgroup-uniform
+      if (ok) {
+        load_u(0);
+        store_uv(smem);
+        __syncthreads();
+#pragma unroll 1
+        for (int st = 0; st < nst; ++st) {
+          const bool more = st + 1 < nst;
+          if (more) {
+            load_u(st + 1);
+            load_v(st + 1);
+          }
+          const char* buf = smem + (st & 1) * F_STAGE;
+#pragma unroll
+          for (int ks = 0; ks < F_CM / 16; ++ks) {
+            const bf16x8 fa = tr8(buf + tr_a + ks * 2048);
+            const bf16x8 fb = tr8(buf + tr_b + ks * 2048);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, o, 0, 0, 0);
+          }
+          if (more) store_uv(smem + ((st + 1) & 1) * F_STAGE);
+          __syncthreads();
+        }
+        // out[n = strip*64 + wm*32 + row(e)][k = kc*64 + wn*32 + r]
+        float* ob = out + (size_t)(strip * 64 + wm * 32) * a.k_pad + kc * 64 + wn * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ob[(size_t)acc_row(e, h) * a.k_pad] = o[e];
+      }
+    }
+  }
+
+  // =============================================================== tail: last arriver
+  drain_vm();
+  __syncthreads();
+  if (tid == 0) flag_s[2] = (int)__hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if ((unsigned)flag_s[2] != gridDim.x - 1) return;
+  if (wave == 0) {
+    float loss = 0.f, ds = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < a.n_pairs; ++k) {
+      const FusedPair& q = a.p[k];
+      float lp = 0.f, dp = 0.f;
+      for (int x = lane; x < 2 * q.nt; x += 64) lp += ld_agent(q.loss_part + x);
+      if (a.want_grad)
+        for (int x = lane; x < q.nt * q.nt; x += 64) dp += ld_agent(q.ds_part + x);
+      loss += q.w * wave_sum(lp);
+      ds += q.w * wave_sum(dp);
+      for (int x = lane; x < 4 * q.nt; x += 64) __hip_atomic_store(q.cnt + x * F_CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) {
+      const bool bad = ld_cnt(err) != 0;
+      *a.loss_out = bad ? __builtin_nanf("") : loss;
+      if (a.ds_out) {
+        a.ds_out[0] = bad ? __builtin_nanf("") : ds;
+        a.ds_out[1] = 0.f;   // the accumulator mmk_clip_fused_backward adds upstream * ds to (saves the caller a fill launch)
+      }
+      __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(err, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ host side
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct FusedLayout {
+  size_t part_row, part_col, G, GT, cnt, loss_part, ds_part, dA, dB, end;
+};
+// workspace: [0, 256): ticket + error words; then per pair the regions below
+static FusedLayout pair_layout(size_t off, int n, int k_pad) {
+  const int nt = cdiv(n, FT), n_pad = nt * FT;
+  FusedLayout L;
+  auto take = [&](size_t bytes) {
+    const size_t at = off;
+    off = align_up(off + bytes, 256);
+    return at;
+  };
+  L.cnt = take((size_t)4 * nt * F_CNT_STRIDE * 4);
+  L.loss_part = take((size_t)2 * nt * 4);
+  L.ds_part = take((size_t)nt * nt * 4);
+  L.part_row = take((size_t)nt * n_pad * 8);
+  L.part_col = take((size_t)nt * n_pad * 8);
+  L.G = take((size_t)n_pad * n_pad * 2);
+  L.GT = take((size_t)n_pad * n_pad * 2);
+  L.dA = take((size_t)n_pad * k_pad * 4);
+  L.dB = take((size_t)n_pad * k_pad * 4);
+  L.end = off;
+  return L;
+}
+
+template <typename S>
+static int fused_capacity(int* out) {
+  static int cached = -1;
+  if (cached < 0) {
+    auto kern = clip_fused_kernel<S>;
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
+    int per_cu = 0, dev = 0;
+    MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, F_THREADS, F_LDS));
+    MMK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    MMK_HIP(hipGetDeviceProperties(&prop, dev));
+    cached = std::min(per_cu, 2) * prop.multiProcessorCount;   // LDS admits two workgroups per CU; never count on more
+  }
+  *out = cached;
+  return 0;
+}
+
+}  // namespace mmk
+
+using namespace mmk;
+
+extern "C" {
+
+int mmk_clip_fused_plan(const int32_t* n, int n_pairs, int d, int src_dtype, int64_t* ws_bytes, int32_t* grid, int32_t* capacity) {
+  MMK_REQUIRE(n && n_pairs > 0 && n_pairs <= F_MAX_PAIRS && d > 0, "fused loss: 1..4 pairs per call");
+  MMK_REQUIRE(src_dtype == MMK_F32 || src_dtype == MMK_BF16, "fused loss: f32 or bf16 embeddings");
+  MMK_REQUIRE(d % (src_dtype == MMK_F32 ? 4 : 8) == 0, "fused loss: rows must be whole 16-byte pieces");
+  const int k_pad = round_up(d, 64);
+  size_t off = 256;
+  int tiles = 0;
+  for (int k = 0; k < n_pairs; ++k) {
+    MMK_REQUIRE(n[k] > 0 && n[k] <= FT * F_NT_MAX, "fused loss: 1..1024 matched rows per pair");
+    off = pair_layout(off, n[k], k_pad).end;
+    const int nt = cdiv(n[k], FT);
+    tiles += nt * nt;
+  }
+  if (ws_bytes) *ws_bytes = (int64_t)off;
+  if (grid) *grid = tiles;
+  if (capacity) {
+    int cap = 0;
+    int rc = src_dtype == MMK_F32 ? fused_capacity<float>(&cap) : fused_capacity<bf16_t>(&cap);
+    if (rc) return rc;
+    *capacity = cap;
+  }
+  return 0;
+}
+
+static int fused_fill(const mmk_fused_pair* pairs, int n_pairs, int d, void* ws, int64_t ws_bytes, FusedArgs* a) {
+  const int k_pad = round_up(d, 64);
+  char* base = static_cast<char*>(ws);
+  size_t off = 256;
+  int tiles = 0, jobs = 0;
+  a->n_pairs = n_pairs;
+  a->d = d;
+  a->k_pad = k_pad;
+  a->nkc = k_pad / 64;
+  for (int k = 0; k < n_pairs; ++k) {
+    const mmk_fused_pair& q = pairs[k];
+    MMK_REQUIRE(q.a && q.b && q.n > 0 && q.n <= FT * F_NT_MAX, "fused loss: bad pair");
+    const FusedLayout L = pair_layout(off, q.n, k_pad);
+    off = L.end;
+    FusedPair& p = a->p[k];
+    p.a = static_cast<const char*>(q.a);
+    p.b = static_cast<const char*>(q.b);
+    p.idx_a = q.idx_a;
+    p.idx_b = q.idx_b;
+    p.n = q.n;
+    p.nt = cdiv(q.n, FT);
+    p.n_pad = p.nt * FT;
+    p.tile0 = tiles;
+    p.job0 = jobs;
+    p.w = q.weight / (2.f * (float)q.n);
+    p.part_row = reinterpret_cast<float2*>(base + L.part_row);
+    p.part_col = reinterpret_cast<float2*>(base + L.part_col);
+    p.G = reinterpret_cast<bf16_t*>(base + L.G);
+    p.GT = reinterpret_cast<bf16_t*>(base + L.GT);
+    p.cnt = reinterpret_cast<unsigned*>(base + L.cnt);
+    p.loss_part = reinterpret_cast<float*>(base + L.loss_part);
+    p.ds_part = reinterpret_cast<float*>(base + L.ds_part);
+    p.dA = reinterpret_cast<float*>(base + L.dA);
+    p.dB = reinterpret_cast<float*>(base + L.dB);
+    tiles += p.nt * p.nt;
+    jobs += 2 * p.nt * a->nkc;
+  }
+  MMK_REQUIRE((int64_t)off <= ws_bytes, "fused loss: workspace too small (mmk_clip_fused_plan)");
+  a->n_tiles = tiles;
+  a->n_jobs = jobs;
+  a->done = reinterpret_cast<unsigned*>(base);
+  return 0;
+}
+
+int mmk_clip_fused_forward(const mmk_fused_pair* pairs, int n_pairs, int d, int src_dtype, const float* scale, void* ws, int64_t ws_bytes,
+                           int want_grad, float* loss_out, float* ds_out, void* stream) {
+  MMK_REQUIRE(pairs && n_pairs > 0 && n_pairs <= F_MAX_PAIRS && scale && ws && loss_out, "fused loss: bad arguments (1..4 pairs per call)");
+  MMK_REQUIRE(src_dtype == MMK_F32 || src_dtype == MMK_BF16, "fused loss: f32 or bf16 embeddings");
+  MMK_REQUIRE(d > 0 && d % (src_dtype == MMK_F32 ? 4 : 8) == 0, "fused loss: rows must be whole 16-byte pieces");
+  FusedArgs a;
+  int rc = fused_fill(pairs, n_pairs, d, ws, ws_bytes, &a);
+  if (rc) return rc;
+  a.want_grad = want_grad;
+  a.scale = scale;
+  a.loss_out = loss_out;
+  a.ds_out = ds_out;
+  int cap = 0;
+  rc = src_dtype == MMK_F32 ? fused_capacity<float>(&cap) : fused_capacity<bf16_t>(&cap);
+  if (rc) return rc;
+  MMK_REQUIRE(a.n_tiles <= cap, "fused loss: the grid would not be co-resident (more tiles than mmk_clip_fused_plan's capacity)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  {
+    ProfEvents pe(MMK_K_CLIP_FUSED);
+    if (src_dtype == MMK_F32)
+      hipExtLaunchKernelGGL(clip_fused_kernel<float>, dim3(a.n_tiles), dim3(F_THREADS), F_LDS, st, pe.start, pe.stop, 0, a);
+    else
+      hipExtLaunchKernelGGL(clip_fused_kernel<bf16_t>, dim3(a.n_tiles), dim3(F_THREADS), F_LDS, st, pe.start, pe.stop, 0, a);
+  }
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+int mmk_clip_fused_backward(const mmk_fused_pair* pairs, int n_pairs, int d, int dx_dtype, const float* scale, const float* upstream,
+                            void* ws, int64_t ws_bytes, const float* ds_raw, float* dscale_out, void* stream) {
+  MMK_REQUIRE(pairs && n_pairs > 0 && n_pairs <= F_MAX_PAIRS && scale && upstream && ws, "fused loss: bad arguments (1..4 pairs per call)");
+  FusedArgs a;
+  int rc = fused_fill(pairs, n_pairs, d, ws, ws_bytes, &a);
+  if (rc) return rc;
+  FinBatch fb;
+  DsBatch db;
+  fb.d = d;
+  int max_r = 0, n_dirs = 0;
+  for (int k = 0; k < n_pairs; ++k) {
+    const mmk_fused_pair& q = pairs[k];
+    const float kappa = q.weight / (2.f * (float)q.n);
+    MMK_REQUIRE(q.da && q.db, "fused loss: null gradient buffer");
+    MMK_REQUIRE((!q.da_accumulate && !q.db_accumulate) || dx_dtype == MMK_F32, "accumulating scatter needs f32 gradient buffers");
+    fb.p[n_dirs++] = FinProb{a.p[k].dA, 0, a.k_pad, q.n, kappa, q.da, q.idx_a, q.da_accumulate, nullptr, 0, 1};
+    fb.p[n_dirs++] = FinProb{a.p[k].dB, 0, a.k_pad, q.n, kappa, q.db, q.idx_b, q.db_accumulate, nullptr, 0, 1};
+    max_r = std::max(max_r, (int)q.n);
+  }
+  db.n_probs = 0;
+  if (dscale_out) {
+    MMK_REQUIRE(ds_raw, "fused loss: ds_raw required with dscale_out");
+    db.part[0] = ds_raw;
+    db.n[0] = 1;
+    db.kappa[0] = 1.f;
+    db.n_probs = 1;
+  }
+  return launch_grad_finalize(fb, n_dirs, max_r, a.k_pad, scale, upstream, db, dscale_out, dx_dtype, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

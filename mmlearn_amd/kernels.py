@@ -421,6 +421,104 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.
         del keep  # the caching allocator keeps the blocks alive until the stream has consumed them
 
 
+# ------------------------------------------------------------------ CLIP loss: one resident-grid launch (small batches)
+FUSED_MAX_ROWS = 1024     # matched rows per pair
+FUSED_MAX_PAIRS = 4
+FUSED_LOSS = True         # measurement seam: False sends every call down the tiled multi-launch path
+
+
+class _FusedPlan:
+    """Per (device, rows per pair, d, dtype): workspace size, grid and the co-residency verdict of ``mmk_clip_fused_plan`` (one
+    ctypes call, once), plus a pool of zero-initialised workspaces.  A workspace is checked out by a forward call and returns
+    to the pool when its backward has run (or the forward's handle is dropped), so two losses alive at once never share
+    raw-gradient storage; the counters inside are zero again whenever a launch has completed, so reuse needs no memset."""
+
+    __slots__ = ("ws_bytes", "grid", "capacity", "pool", "device")
+
+    def __init__(self, device: torch.device, ns: tuple, d: int, dtype: torch.dtype):
+        n_arr = (C.c_int32 * len(ns))(*ns)
+        wsb, grid, cap = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        check(_lib.lib().mmk_clip_fused_plan(C.cast(n_arr, C.c_void_p), len(ns), d, dtype_tag(dtype), C.addressof(wsb), C.addressof(grid),
+                                             C.addressof(cap)))
+        self.ws_bytes, self.grid, self.capacity = wsb.value, grid.value, cap.value
+        self.pool: list = []
+        self.device = device
+
+    def take(self) -> torch.Tensor:
+        return self.pool.pop() if self.pool else torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
+
+
+_FUSED_PLANS: dict = {}
+
+
+def clip_fused_plan(device: torch.device, ns: Sequence[int], d: int, dtype: torch.dtype) -> Optional[_FusedPlan]:
+    """The plan if the one-launch path serves these shapes (and its grid is co-resident on this device), else None."""
+    if not FUSED_LOSS or not (0 < len(ns) <= FUSED_MAX_PAIRS) or dtype not in (torch.float32, torch.bfloat16):
+        return None
+    if d % (4 if dtype == torch.float32 else 8) or any(not (0 < n <= FUSED_MAX_ROWS) for n in ns):
+        return None
+    key = (device.index, tuple(ns), d, dtype)
+    plan = _FUSED_PLANS.get(key)
+    if plan is None:
+        plan = _FUSED_PLANS[key] = _FusedPlan(device, tuple(ns), d, dtype)
+    return plan if plan.grid <= plan.capacity else None
+
+
+class FusedRun:
+    """Forward state of one fused call: keeps the workspace (raw gradient sums) until ``backward`` or deletion."""
+
+    __slots__ = ("plan", "ws", "arr", "n_pairs", "d", "dtype", "ds_raw", "ds_acc", "keep", "stream")
+
+    def release(self) -> None:
+        ws, self.ws = self.ws, None
+        if ws is not None and self.plan is not None:
+            self.plan.pool.append(ws)
+
+    def __del__(self):
+        # forward without backward (evaluation, a dropped graph): the launches that use the workspace are already queued
+        # on the stream the next user will launch on, so handing it back is safe
+        try:
+            if self.stream == stream():
+                self.release()
+        except Exception:
+            pass
+
+
+def clip_fused_forward(plan: _FusedPlan, pairs: Sequence[tuple], d: int, scale: torch.Tensor, want_grad: bool):
+    """``pairs``: [(a, b, idx_a, idx_b, n, weight)] with a / b the contiguous embedding matrices and idx int32 match lists or
+    None.  ONE launch: returns (0-dim f32 loss, FusedRun)."""
+    dev = scale.device
+    arr = (_lib.FusedPair * len(pairs))()
+    keep = []
+    for k, (a, b, ia, ib, n, w) in enumerate(pairs):
+        e = arr[k]
+        e.a, e.b, e.idx_a, e.idx_b, e.n, e.weight = ptr(a), ptr(b), ptr(ia), ptr(ib), n, float(w)
+        keep += [a, b, ia, ib]
+    run = FusedRun()
+    run.plan, run.arr, run.n_pairs, run.d, run.dtype, run.keep = plan, arr, len(pairs), d, pairs[0][0].dtype, keep
+    run.stream = stream()
+    run.ws = plan.take()
+    out = torch.empty(3, dtype=torch.float32, device=dev)   # [loss, raw d loss / d scale, 0 = accumulator for backward's dscale]
+    run.ds_raw, run.ds_acc = out[1:], out[2:]
+    check(_lib.lib().mmk_clip_fused_forward(C.cast(arr, C.c_void_p), len(pairs), d, dtype_tag(run.dtype), ptr(scale), ptr(run.ws), plan.ws_bytes,
+                                            int(want_grad), ptr(out), ptr(run.ds_raw) if want_grad else None, run.stream))
+    return out[0], run
+
+
+def clip_fused_backward(run: FusedRun, grads: Sequence[tuple], scale: torch.Tensor, upstream: torch.Tensor, dscale: Optional[torch.Tensor]) -> None:
+    """``grads``: [(da, db, accumulate_a, accumulate_b)] per pair (user-dtype buffers, or zeroed f32 ones when accumulating).
+    ONE launch; the workspace goes back to the pool."""
+    assert run.ws is not None, "fused loss: backward called twice (retain_graph is not supported by the one-launch path)"
+    for k, (da, db, acc_a, acc_b) in enumerate(grads):
+        e = run.arr[k]
+        e.da, e.db, e.da_accumulate, e.db_accumulate = ptr(da), ptr(db), int(acc_a), int(acc_b)
+    dt = grads[0][0].dtype
+    assert all(g[0].dtype == dt and g[1].dtype == dt for g in grads)
+    check(_lib.lib().mmk_clip_fused_backward(C.cast(run.arr, C.c_void_p), run.n_pairs, run.d, dtype_tag(dt), ptr(scale), ptr(upstream), ptr(run.ws),
+                                             run.plan.ws_bytes, ptr(run.ds_raw), ptr(dscale), stream()))
+    run.release()
+
+
 # ------------------------------------------------------------------ row ops
 def l2norm_fwd(x: torch.Tensor):
     require_gpu(x)

@@ -263,7 +263,7 @@ class _Run:
         self.d = next(iter(self.embeddings.values())).shape[1]
         dev = scale.device
 
-        # ---- matching + operand packing per pair
+        # ---- matching per pair
         local_counts_needed = []
         for spec in self.pair_specs:
             ma, mb = (Modalities.get_modality(m).name if Modalities.has_modality(m) else m for m in spec.modalities)
@@ -275,6 +275,17 @@ class _Run:
                 continue  # :283-287 / :314-316
             p = _Pair(spec=spec, r_global=mg.n)
             p.ma, p.mb, p.mg = ma, mb, mg
+            self.pairs.append(p)
+
+        # ---- small batches on one rank: the whole loss AND its gradients in one resident-grid launch (csrc/clip_fused.hip)
+        self.fused = None
+        if self.pairs and self._try_fused(views):
+            return self.fused_loss
+
+        # ---- operand packing per pair
+        for p in self.pairs:
+            ma, mb, mg = p.ma, p.mb, p.mg
+            va, vb = views[ma], views[mb]
             (p.a_g, p.a_gt), (p.b_g, p.b_gt) = K.pack_rows_many(
                 [(va.src, _compose(va.rows, mg.idx_a), mg.n, o.l2_normalize, self.needs_grad),
                  (vb.src, _compose(vb.rows, mg.idx_b), mg.n, o.l2_normalize, self.needs_grad)], self.compute)
@@ -287,7 +298,6 @@ class _Run:
                 else:
                     p.ml = o._matched(self.example_ids[ma].to(torch.int64), self.example_ids[mb].to(torch.int64))
                 local_counts_needed.append(p)
-            self.pairs.append(p)
 
         if local_mode and self.pairs:
             # per-rank row counts of every pair (the reference all-gathers them per pair, contrastive.py:196-206).  When the
@@ -329,6 +339,63 @@ class _Run:
                 dist.all_reduce(al)
             loss = al if loss is None else loss + al
         return loss
+
+    def _try_fused(self, views: dict) -> bool:
+        """One rank, no alignment term, no in-loss normalisation, bf16 arithmetic, <= 4 pairs of <= 1024 matched rows whose
+        tile grid is co-resident: ONE launch computes the loss value and leaves the raw gradient sums in a pooled workspace
+        (``kernels.clip_fused_forward``); ``backward`` is one more launch.  Anything else takes the tiled multi-launch path."""
+        o = self.o
+        fused_plan = getattr(K, "clip_fused_plan", None)   # absent from the CPU test double
+        if (fused_plan is None or self.world != 1 or o.modality_alignment or o.l2_normalize or self.compute != COMPUTE_BF16
+                or any(v.rows is not None for v in views.values())):
+            return False
+        first = views[self.pairs[0].ma].src
+        if any(views[m].src.dtype != first.dtype or views[m].src.shape[1] != self.d for p in self.pairs for m in (p.ma, p.mb)):
+            return False
+        plan = fused_plan(first.device, [p.mg.n for p in self.pairs], self.d, first.dtype)
+        if plan is None:
+            return False
+        loss, run = K.clip_fused_forward(plan, [(views[p.ma].src, views[p.mb].src, p.mg.idx_a, p.mg.idx_b, p.mg.n, float(p.spec.weight))
+                                                for p in self.pairs], self.d, self.scale32, self.needs_grad)
+        self.fused, self.fused_loss = run, loss
+        return True
+
+    def _fused_backward(self, grad_out: torch.Tensor):
+        dev = self.scale32.device
+        upstream = grad_out.detach().to(torch.float32).reshape(1)
+        key_of, name_of = {}, {}
+        for key in self.embeddings:
+            name = key[: -len("_embedding")] if key.endswith("_embedding") else key
+            name = Modalities.get_modality(name).name if Modalities.has_modality(name) else name
+            key_of[name], name_of[key] = key, name
+        writers: dict[str, int] = {}
+        for p in self.pairs:
+            for n in (p.ma, p.mb):
+                writers[n] = writers.get(n, 0) + 1
+        acc, covered = {}, {}
+        for p in self.pairs:
+            for n, rep in ((p.ma, p.mg.repeats_a), (p.mb, p.mg.repeats_b)):
+                acc[n] = acc.get(n, False) or writers[n] > 1 or (rep and not p.mg.identity)
+                covered[n] = p.mg.identity and p.mg.n == self.embeddings[key_of[n]].shape[0]   # every row written exactly once
+        mixed = len({self.embeddings[key_of[n]].dtype for n in acc}) > 1 or (any(acc.values()) and not all(acc.values()))
+        grads = {}
+        for n, a_ in acc.items():
+            t = self.embeddings[key_of[n]]
+            dt = _ACCUM_DTYPE if (a_ or mixed) else t.dtype
+            grads[n] = (torch.empty if (covered[n] and not a_) else torch.zeros)(t.shape, dtype=dt, device=dev)
+        run, self.fused = self.fused, None
+        want_ds = self.logit_scale.requires_grad
+        K.clip_fused_backward(run, [(grads[p.ma], grads[p.mb], acc[p.ma], acc[p.mb]) for p in self.pairs], self.scale32, upstream,
+                              run.ds_acc if want_ds else None)
+        out = []
+        for key, t in self.embeddings.items():
+            g = grads.get(name_of[key])
+            if g is None:
+                out.append(torch.zeros_like(t) if t.requires_grad else None)
+            else:
+                out.append(g if g.dtype == t.dtype else g.to(t.dtype))
+        ds = run.ds_acc.reshape(self.logit_scale.shape).to(self.logit_scale.dtype) if want_ds else None
+        return ds, out
 
     def _build_alignment(self, views: dict, dev) -> None:
         """Rows of the modality-alignment BCE (contrastive.py:344-413) owned by this rank: one problem per modality.
@@ -509,6 +576,8 @@ class _Run:
 
     # ------------------------------------------------------------------ backward
     def backward(self, grad_out: torch.Tensor):
+        if getattr(self, "fused", None) is not None:
+            return self._fused_backward(grad_out)
         o, W = self.o, self.world
         dev = self.scale32.device
         upstream = grad_out.detach().to(torch.float32).reshape(1).contiguous()

@@ -22,6 +22,16 @@ def _dev():
     return torch.device("cuda", 0)
 
 
+@pytest.fixture(params=["one_launch", "tiled"])
+def loss_path(request, monkeypatch):
+    """Small one-rank bf16 problems take the resident-grid launch (csrc/clip_fused.hip) by default; the tiled multi-launch
+    kernels (csrc/clip.hip: what every larger, f32 or multi-rank problem runs) must give the same answers."""
+    from mmlearn_amd import kernels as K
+
+    monkeypatch.setattr(K, "FUSED_LOSS", request.param == "one_launch")
+    return request.param
+
+
 def _run_hip(embs, ids, scale, pairs, dtype="float32", **flags):
     from mmlearn_amd import ContrastiveLoss, LossPairSpec
 
@@ -51,7 +61,7 @@ CLIP = Golden("g1_g2_clip")
 
 
 @pytest.mark.parametrize("name", CLIP.names())
-def test_golden_clip(name):
+def test_golden_clip(name, loss_path):
     c = CLIP[name]
     dtype = str(c["dtype"])
     mods = sorted(k[3:] for k in c if k.startswith("in_"))
@@ -91,7 +101,7 @@ def test_golden_clip(name):
 
 @pytest.mark.parametrize("n,d,dtype", [(1024, 512, "bfloat16"), (1024, 512, "float32"), (333, 200, "float32"), (777, 136, "bfloat16"),
                                        (2048, 512, "bfloat16")])
-def test_seeded_vs_oracle(n, d, dtype):
+def test_seeded_vs_oracle(n, d, dtype, loss_path):
     g = np.random.default_rng(n + d)
     a = g.standard_normal((n, d)).astype(np.float32)
     b = g.standard_normal((n, d)).astype(np.float32)
@@ -109,7 +119,8 @@ def test_seeded_vs_oracle(n, d, dtype):
     _check(res, orc["loss"], orc["grads"], orc["dscale"], TOL[dtype], f"{n}x{d}:{dtype}")
 
 
-def test_three_modalities_shared_rows_and_weights():
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
+def test_three_modalities_shared_rows_and_weights(dtype, loss_path):
     g = np.random.default_rng(5)
     embs = {m: (lambda x: x / np.linalg.norm(x, axis=1, keepdims=True))(g.standard_normal((n, 96)).astype(np.float32))
             for m, n in (("rgb", 300), ("text", 300), ("audio", 180))}
@@ -117,9 +128,11 @@ def test_three_modalities_shared_rows_and_weights():
            "text": np.stack([np.zeros(300, np.int64), g.permutation(300)], 1),
            "audio": np.stack([np.zeros(180, np.int64), g.choice(400, 180, replace=False)], 1)}
     pairs = [(("rgb", "text"), 1.0), (("rgb", "audio"), 0.5), (("text", "audio"), 0.25)]
-    res = _run_hip(embs, ids, 20.0, pairs)
+    if dtype == "bfloat16":
+        embs = {m: torch.tensor(v).bfloat16().float().numpy() for m, v in embs.items()}
+    res = _run_hip(embs, ids, 20.0, pairs, dtype=dtype)
     orc = co.contrastive_loss(embs, ids, 20.0, pairs)
-    _check(res, orc["loss"], orc["grads"], orc["dscale"], 1e-3, "n3")
+    _check(res, orc["loss"], orc["grads"], orc["dscale"], TOL[dtype], "n3")
 
 
 def test_full_size_properties():

@@ -1,0 +1,177 @@
+"""GPU: the one-launch resident-grid loss (csrc/clip_fused.hip) through its C ABI, against the numpy oracle.
+
+The kernel's workgroups hand tile statistics and gradient tiles to each other inside one launch; the cases below cover
+the arithmetic (edges off the 64 grid, gathered / partial / duplicated pairings, several weighted pairs, negative and
+large scales, unnormalised rows), the hand-off protocol's re-arming (many calls on one workspace, bit-identical results)
+and the host plumbing (workspace pool, forward without backward).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_oracle as co
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "needs a MI355X"
+    return torch.device("cuda", 0)
+
+
+def _bf16_round(x: np.ndarray) -> np.ndarray:
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).bfloat16().float().numpy()
+
+
+def _run_fused(mats, pairs, scale, dtype, want_grad=True, upstream=1.0):
+    """mats: {name: np [rows, d]}; pairs: [(ma, mb, idx_a|None, idx_b|None, n, weight)] -> loss, grads per modality, dscale."""
+    from mmlearn_amd import kernels as K
+
+    dev = _dev()
+    tdt = torch.bfloat16 if dtype == "bfloat16" else torch.float32
+    t = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev, tdt).contiguous() for k, v in mats.items()}
+    d = next(iter(t.values())).shape[1]
+    plan = K.clip_fused_plan(dev, [p[4] for p in pairs], d, tdt)
+    assert plan is not None, "fused path refused the shape"
+    s = torch.tensor([scale], dtype=torch.float32, device=dev)
+    fp = []
+    for ma, mb, ia, ib, n, w in pairs:
+        ia_t = None if ia is None else torch.from_numpy(np.asarray(ia, np.int32)).to(dev)
+        ib_t = None if ib is None else torch.from_numpy(np.asarray(ib, np.int32)).to(dev)
+        fp.append((t[ma], t[mb], ia_t, ib_t, n, w))
+    loss, run = K.clip_fused_forward(plan, fp, d, s, want_grad)
+    out = {"loss": float(loss)}
+    if not want_grad:
+        del run
+        return out
+    grads = {k: torch.zeros(v.shape, dtype=torch.float32, device=dev) for k, v in t.items()}   # accumulate everywhere: simplest
+    up = torch.tensor([upstream], dtype=torch.float32, device=dev)
+    ds = torch.zeros(1, dtype=torch.float32, device=dev)
+    K.clip_fused_backward(run, [(grads[p[0]], grads[p[1]], True, True) for p in pairs], s, up, ds)
+    out["grads"] = {k: g.cpu().numpy() for k, g in grads.items()}
+    out["dscale"] = float(ds)
+    out["plan"] = plan
+    return out
+
+
+def _oracle(mats, ids, pairs_spec, scale, dtype):
+    embs = {k: (_bf16_round(v) if True else v) for k, v in mats.items()}   # the kernel multiplies bf16-rounded rows
+    return co.contrastive_loss(embs, ids, scale, pairs_spec)
+
+
+def _ids(idx):
+    idx = np.asarray(idx, np.int64)
+    return np.stack([np.zeros_like(idx), idx], 1)
+
+
+def _check(got, ref, tol, tag=""):
+    assert abs(got["loss"] - ref["loss"]) <= tol * max(1.0, abs(ref["loss"])), (tag, got["loss"], ref["loss"])
+    for m, g in ref["grads"].items():
+        err = np.abs(got["grads"][m] - g).max()
+        assert err <= tol * max(np.abs(g).max(), 1e-6), (tag, m, err, np.abs(g).max())
+    assert abs(got["dscale"] - ref["dscale"]) <= tol * max(1.0, abs(ref["dscale"])), (tag, got["dscale"], ref["dscale"])
+
+
+def _unit(g, n, d):
+    x = g.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("n,d,dtype,scale", [(1024, 512, "float32", 1 / 0.07), (1024, 512, "bfloat16", 1 / 0.07), (200, 96, "float32", 1 / 0.07),
+                                             (37, 24, "float32", 10.0), (64, 64, "bfloat16", 30.0), (65, 72, "float32", 1 / 0.07),
+                                             (1000, 768, "bfloat16", 100.0), (513, 128, "float32", -5.0), (1, 8, "float32", 3.0)])
+def test_identity_pairing_vs_oracle(n, d, dtype, scale):
+    g = np.random.default_rng(n * 7 + d)
+    a = _unit(g, n, d)
+    b = 0.6 * a + 0.8 * _unit(g, n, d)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    got = _run_fused({"rgb": a, "text": b}, [("rgb", "text", None, None, n, 1.0)], scale, dtype, upstream=0.75)
+    ref = _oracle({"rgb": a, "text": b}, {"rgb": _ids(range(n)), "text": _ids(range(n))}, [(("rgb", "text"), 1.0)], scale, dtype)
+    ref = {"loss": ref["loss"], "grads": {k: 0.75 * v for k, v in ref["grads"].items()}, "dscale": 0.75 * ref["dscale"]}
+    _check(got, ref, 1e-2, (n, d, dtype))
+
+
+def test_unnormalised_rows_and_tiny_scale():
+    g = np.random.default_rng(5)
+    a = 3.0 * g.standard_normal((300, 40)).astype(np.float32)
+    b = 0.5 * g.standard_normal((300, 40)).astype(np.float32)
+    got = _run_fused({"rgb": a, "text": b}, [("rgb", "text", None, None, 300, 0.35)], 2.0, "float32")
+    ref = _oracle({"rgb": a, "text": b}, {"rgb": _ids(range(300)), "text": _ids(range(300))}, [(("rgb", "text"), 0.35)], 2.0, "float32")
+    _check(got, ref, 1e-2)
+
+
+@pytest.mark.parametrize("kind", ["shuffled", "partial", "duplicates"])
+def test_gathered_pairings_vs_oracle(kind):
+    g = np.random.default_rng(11)
+    n, d = 333, 200
+    a, b = _unit(g, n, d), _unit(g, n, d)
+    ia = np.arange(n)
+    if kind == "shuffled":
+        ib = g.permutation(n)
+    elif kind == "partial":
+        ib = np.arange(n)
+        ib[::3] += 10000
+    else:
+        ia = np.sort(g.integers(0, 150, n))
+        ib = np.sort(g.integers(0, 150, n))
+    ids = {"rgb": _ids(ia), "text": _ids(ib)}
+    ma, mb = co.find_matching_indices(ids["rgb"], ids["text"])
+    if len(ma) > 1024:   # heavy duplication: keep it inside the one-launch limit
+        pytest.skip("too many matches for the fused path")
+    got = _run_fused({"rgb": a, "text": b}, [("rgb", "text", ma, mb, len(ma), 1.0)], 1 / 0.07, "float32")
+    ref = _oracle({"rgb": a, "text": b}, ids, [(("rgb", "text"), 1.0)], 1 / 0.07, "float32")
+    _check(got, ref, 1e-2, kind)
+
+
+def test_three_weighted_pairs_in_one_launch():
+    g = np.random.default_rng(3)
+    n, d = 256, 512
+    r, t, au = _unit(g, n, d), _unit(g, n, d), _unit(g, 192, d)
+    ids = {"rgb": _ids(range(n)), "text": _ids(g.permutation(n)), "audio": _ids(np.arange(192) * 2 % 300)}
+    spec = [(("rgb", "text"), 1.0), (("rgb", "audio"), 0.5), (("text", "audio"), 0.25)]
+    mats = {"rgb": r, "text": t, "audio": au}
+    pairs = []
+    for (ma, mb), w in spec:
+        ia, ib = co.find_matching_indices(ids[ma], ids[mb])
+        pairs.append((ma, mb, ia, ib, len(ia), w))
+    got = _run_fused(mats, pairs, 1 / 0.07, "bfloat16")
+    ref = _oracle(mats, ids, spec, 1 / 0.07, "bfloat16")
+    _check(got, ref, 1e-2)
+
+
+def test_many_calls_on_one_workspace_are_bit_identical_and_forward_only_works():
+    """The counters of the hand-off protocol are zero again after every launch: 30 calls on one pooled workspace give the same
+    bits; a forward-only call (evaluation) in between neither disturbs it nor leaks the workspace."""
+    from mmlearn_amd import kernels as K
+
+    g = np.random.default_rng(9)
+    n, d = 1024, 512
+    a, b = _unit(g, n, d), _unit(g, n, d)
+    first = None
+    for it in range(30):
+        got = _run_fused({"rgb": a, "text": b}, [("rgb", "text", None, None, n, 1.0)], 1 / 0.07, "float32")
+        if it % 7 == 3:
+            ev = _run_fused({"rgb": a, "text": b}, [("rgb", "text", None, None, n, 1.0)], 1 / 0.07, "float32", want_grad=False)
+            assert ev["loss"] == got["loss"]
+        if first is None:
+            first = got
+        else:
+            assert got["loss"] == first["loss"] and got["dscale"] == first["dscale"]
+            assert np.array_equal(got["grads"]["rgb"], first["grads"]["rgb"]) and np.array_equal(got["grads"]["text"], first["grads"]["text"])
+    assert len(first["plan"].pool) == 1   # one workspace served every call
+
+
+def test_shapes_outside_the_one_launch_path_are_refused():
+    from mmlearn_amd import kernels as K
+
+    dev = _dev()
+    assert K.clip_fused_plan(dev, [1025], 512, torch.float32) is None
+    assert K.clip_fused_plan(dev, [512], 510, torch.float32) is None         # rows are not whole 16-byte pieces
+    assert K.clip_fused_plan(dev, [512], 516, torch.bfloat16) is None
+    assert K.clip_fused_plan(dev, [512], 512, torch.float16) is None
+    assert K.clip_fused_plan(dev, [256] * 5, 512, torch.float32) is None
+    big = K.clip_fused_plan(dev, [1024, 1024, 1024], 512, torch.float32)     # 768 tiles: not co-resident on 256 CUs x 2
+    assert big is None
+    ok = K.clip_fused_plan(dev, [1024, 1024], 512, torch.float32)
+    assert ok is not None and ok.grid == 512 <= ok.capacity

@@ -1,6 +1,6 @@
 """Where one workgroup of the attention backward spends an item (shader-clock stamps).  Needs a DEBUG build of the library --
 the stamp checks cost the kernel 6 %, so the default build compiles them out:
-    make -C mmlearn_amd/csrc clean && make -C mmlearn_amd/csrc EXTRA=-DMMK_ATTN_STAMPS_BUILD
+    make -C mmlearn_amd/csrc clean && make -C mmlearn_amd/csrc EXTRA="-DMMK_DEBUG_SWITCHES -DMMK_ATTN_STAMPS_BUILD"
     MMK_ATTN_STAMPS=1 python tools/attn_bwd_phases.py        (B=1024 H=12 L=197 by default; env B, L, P)
     make -C mmlearn_amd/csrc clean && make -C mmlearn_amd/csrc"""
 import ctypes as C, json, os, sys

@@ -19,7 +19,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmlearn_amd import ContrastiveLoss, LossPairSpec, _lib  # noqa: E402
 
 
-def run(n, d, dtype, iters, warmup=5, mods=2):
+def run(n, d, dtype, iters, warmup=5, mods=2, path="auto", autocast=False):
+    from mmlearn_amd import kernels as K
+
+    K.FUSED_LOSS = path != "tiled"
     dev = torch.device("cuda", 0)
     tdt = {"bf16": torch.bfloat16, "fp32": torch.float32}[dtype]
     torch.manual_seed(0)
@@ -33,7 +36,8 @@ def run(n, d, dtype, iters, warmup=5, mods=2):
     def step():
         for t in embs.values():
             t.grad = None
-        loss = fn(embs, ids, s, pairs)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            loss = fn(embs, ids, s, pairs)
         loss.float().backward()
         return loss
 
@@ -57,7 +61,7 @@ def run(n, d, dtype, iters, warmup=5, mods=2):
     n_pairs = len(pairs)
     per = {k: round(ms / cnt * 1e3, 2) for k, (cnt, ms) in prof.items()}  # us per launch
     gemm = 2.0 * n * n * d * n_pairs  # one [N,N,D] product per pair
-    out = {"n": n, "d": d, "dtype": dtype, "pairs": n_pairs, "wall_ms_profiled": round(wall_ms, 3), "wall_ms": round(wall_ms_np, 3),
+    out = {"n": n, "d": d, "dtype": dtype + ("+autocast" if autocast else ""), "path": path, "pairs": n_pairs, "wall_ms_profiled": round(wall_ms, 3), "wall_ms": round(wall_ms_np, 3),
            "kernel_us": per, "device_us_total": round(sum(ms for _, ms in prof.values()) / iters * 1e3, 1)}
     for k, executed in (("sim_stats", 2 * gemm), ("sim_grad", 2 * gemm), ("grad_gemm", 2 * gemm)):
         if k in per:
@@ -73,6 +77,9 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--mods", type=int, default=2)
+    ap.add_argument("--path", nargs="*", default=["auto"], help="auto (one resident-grid launch where it applies) | tiled")
+    ap.add_argument("--autocast", action="store_true", help="f32 embeddings under bf16 autocast (what the task hands the loss)")
     a = ap.parse_args()
     for n in a.n:
-        run(n, a.d, a.dtype, a.iters, mods=a.mods)
+        for path in a.path:
+            run(n, a.d, a.dtype, a.iters, mods=a.mods, path=path, autocast=a.autocast)

@@ -419,7 +419,10 @@ def _loss_roofline(prof: dict, n_rows: int, n_cols: int, d: int, n_pairs: int, s
     single = n_rows == n_cols
     fwd = (2.0 if single else 4.0) * n_rows * n_cols * d * n_pairs
     bwd = 4.0 * n_rows * n_cols * d * n_pairs
-    algo = {"clip_fwd": fwd, "clip_bwd": bwd, "sim_stats": fwd, "grad_gemm": bwd, "sim_grad": 0.0}
+    algo = {"clip_fwd": fwd, "clip_bwd": bwd, "sim_stats": fwd, "grad_gemm": bwd, "sim_grad": 0.0,
+            # one rank, <= 1024 matched rows per pair: ONE launch computes S, its statistics, G and both gradient products
+            # (csrc/clip_fused.hip): all 6 N^2 D algorithmic FLOPs of the pair belong to it
+            "clip_fused": fwd + bwd}
     if loss_only and prof.get("wgrad", (0, 0.0))[0] > 0:
         # large mirrored pair: dA = G B by the NT gradient GEMM, dB = G^T A by the transposed-read kernel, half of the
         # backward's algorithmic work each (in a whole-step profile "wgrad" is the encoders' weight gradient: not counted)

@@ -227,6 +227,9 @@ int mmk_clip_fused_forward(const mmk_fused_pair* pairs, int n_pairs, int d, int 
                            int want_grad, float* loss_out, float* ds_out, void* stream);
 int mmk_clip_fused_backward(const mmk_fused_pair* pairs, int n_pairs, int d, int dx_dtype, const float* scale, const float* upstream,
                             void* ws, int64_t ws_bytes, const float* ds_raw, float* dscale_out, void* stream);
+/* measurement hook: in a -DMMK_DEBUG_SWITCHES build, later launches write [grid][8] realtime-clock stamps (100 MHz) of every
+ * workgroup's phases to device_buf (NULL switches it off); the product build accepts NULL only (tools/fused_phases.py) */
+int mmk_clip_fused_debug_stamps(unsigned long long* device_buf);
 
 /* ------------------------------------------------------------------ row ops
  * F.normalize(x, p=2, dim=-1, eps=1e-12) forward / backward

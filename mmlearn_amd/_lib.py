@@ -15,7 +15,9 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmmlearn_hip.so")
+# MMK_LIB_VARIANT=_dbg: the -DMMK_DEBUG_SWITCHES build (`make -C mmlearn_amd/csrc VARIANT=_dbg EXTRA=-DMMK_DEBUG_SWITCHES`), for
+# measurement tools only; the product library itself reads no experiment switches
+LIB_PATH = os.path.join(_HERE, "lib", f"libmmlearn_hip{os.environ.get('MMK_LIB_VARIANT', '')}.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 F32, BF16, F16 = 0, 1, 2
@@ -94,6 +96,7 @@ _SIGNATURES = {
     "mmk_clip_fused_plan": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "mmk_clip_fused_forward": [_vp, _i, _i, _i, _vp, _vp, C.c_int64, _i, _vp, _vp, _vp],
     "mmk_clip_fused_backward": [_vp, _i, _i, _i, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp],
+    "mmk_clip_fused_debug_stamps": [_vp],
     "mmk_match_workspace_ints": [_i, _i],
     "mmk_clip_backward": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "mmk_l2norm_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],

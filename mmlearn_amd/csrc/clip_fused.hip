@@ -45,7 +45,6 @@ constexpr int F_NT_MAX = 16;           // <= 1024 matched rows per pair
 constexpr int F_THREADS = 256;
 constexpr int F_MAX_PAIRS = 4;       // two gradient directions per pair, MAX_PROBS directions per finalize launch
 constexpr int F_KS = 128;              // phase 1: K elements per LDS stage (two 64-element sub-images)
-constexpr int F_CM = 128;              // phase 3: contraction rows per LDS stage
 constexpr int F_STAGE = 32 * 1024;     // bytes of one LDS stage (both phases)
 constexpr int F_SCRATCH = 6 * 1024;
 constexpr int F_LDS = 2 * F_STAGE + F_SCRATCH;
@@ -79,7 +78,15 @@ struct FusedArgs {
   unsigned* done;         // [0] ticket, [F_CNT_STRIDE] error flag
   float* loss_out;
   float* ds_out;
+  int dbg;                      // -DMMK_DEBUG_SWITCHES builds (MMK_FUSED_DBG; WRONG results, timing only): 1 no U loads, 2 no V loads, 4 no
+                                // transposed reads / MFMAs, 8 no LDS stores in the gradient loop
+  unsigned long long* stamps;   // -DMMK_DEBUG_SWITCHES builds: [grid][16] realtime-clock stamps of every workgroup's phases, or null
 };
+// phase stamps (100 MHz clock): compiled out of the product build
+#define F_STAMP(k)                                                                                                          \
+  do {                                                                                                                      \
+    if (kDebugSwitches && a.stamps != nullptr && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 
 __device__ __forceinline__ unsigned ld_cnt(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void add_cnt(unsigned* p) { __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -142,6 +149,8 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
 
   unsigned* err = a.done + F_CNT_STRIDE;
 
+  const int dbg = kDebugSwitches ? a.dbg : 0;
+  F_STAMP(0);
   // ---- which pair / tile
   int pi = 0;
 #pragma unroll 1
@@ -183,20 +192,23 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
       lds_off[u] = kh * 16384 + row * 128 + ((((e0 >> 3) ^ ((row >> 1) & 7))) << 4) + (e0 & 7) * 2;
     }
     const int ns = (a.k_pad + F_KS - 1) / F_KS;
-    uint4 stg[NP];
-    auto load = [&](int st) {
+    // The loop is latency-bound (128 KiB per workgroup, L2-resident): keep PD stages of loads in flight in registers
+    // (bf16 rows: all of D = 512 at once), one barrier per stage.
+    constexpr int PD = EPP == 8 ? 4 : 2;
+    uint4 stg[PD][NP];
+    auto load = [&](int st, uint4 (&v)[NP]) {
       const int col = st * F_KS + c * EPP;
 #pragma unroll
       for (int u = 0; u < NP; ++u) {
-        stg[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (srow[u] >= 0 && col < a.d) stg[u] = *reinterpret_cast<const uint4*>(base[u] + srow[u] + (long)col * (long)sizeof(S));
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (srow[u] >= 0 && col < a.d) v[u] = *reinterpret_cast<const uint4*>(base[u] + srow[u] + (long)col * (long)sizeof(S));
       }
     };
-    auto store = [&](char* buf) {
+    auto store = [&](char* buf, const uint4 (&v)[NP]) {
 #pragma unroll
       for (int u = 0; u < NP; ++u) {
-        if constexpr (EPP == 4) *reinterpret_cast<uint2*>(buf + lds_off[u]) = SrcT<float>::to_bf16(stg[u]);
-        else *reinterpret_cast<uint4*>(buf + lds_off[u]) = stg[u];
+        if constexpr (EPP == 4) *reinterpret_cast<uint2*>(buf + lds_off[u]) = SrcT<float>::to_bf16(v[u]);
+        else *reinterpret_cast<uint4*>(buf + lds_off[u]) = v[u];
       }
     };
     const int p_off = (wm * 32 + r) * 128, p_sw = ((wm * 32 + r) >> 1) & 7;
@@ -215,19 +227,30 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
         }
       }
     };
-    load(0);
-    store(smem);
-    __syncthreads();
+    F_STAMP(8);
+#pragma unroll
+    for (int q = 0; q < PD; ++q)
+      if (q < ns) load(q, stg[q]);
+    F_STAMP(9);
 #pragma unroll 1
-    for (int st = 0; st < ns; ++st) {
-      const bool more = st + 1 < ns;
-      if (more) load(st + 1);
-      compute(smem + (st & 1) * F_STAGE, st);
-      if (more) store(smem + ((st + 1) & 1) * F_STAGE);
-      __syncthreads();
+    for (int st0 = 0; st0 < ns; st0 += PD) {
+#pragma unroll
+      for (int q = 0; q < PD; ++q) {
+        const int st = st0 + q;
+        if (st < ns) {
+          // stage st -> buffer st & 1 (last read by compute(st - 2), which every thread finished before the barrier of stage st - 1)
+          store(smem + (st & 1) * F_STAGE, stg[q]);
+          if (st == 0) F_STAMP(10);
+          if (st + PD < ns) load(st + PD, stg[q]);
+          __syncthreads();
+          compute(smem + (st & 1) * F_STAGE, st);
+        }
+      }
     }
+    __syncthreads();   // the stage buffers are reused below
   }
 
+  F_STAMP(1);
   // ---- tile statistics, both directions (log2 domain: u = s2 * t)
   const int i_loc = wn * 32 + r, i_glob = ti * 64 + i_loc;
   const bool iv = i_glob < n;
@@ -286,9 +309,11 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
   if (tid == 0) {
     add_cnt(c1_row);
     add_cnt(c1_col);
+    F_STAMP(2);
     flag_s[0] = spin_until(c1_row, c1_col, (unsigned)nt, err) ? 1 : 0;
   }
   __syncthreads();
+  F_STAMP(3);
   const bool ok1 = flag_s[0] != 0;
 
   // =============================================================== phase 2: LSEs, loss terms, G
@@ -315,6 +340,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
         if (ti == tj) term = l2 * LN2 - diag_s[t];
       }
       (is_row ? lr2_s : lc2_s)[t] = l2;
+      F_STAMP(11);
       if (ti == tj) {   // waves 0 and 1: the row / column direction's sum over this strip (fixed order: deterministic)
         term = wave_sum(term);
         if (t == 0) st_agent(p.loss_part + (is_row ? ti : nt + tj), term);
@@ -360,6 +386,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
         }
       }
       if (tid == 0) st_agent(p.ds_part + tile, misc[0] + misc[1] + misc[2] + misc[3]);
+      F_STAMP(12);
       drain_vm();
       __syncthreads();
       if (tid == 0) {
@@ -369,16 +396,24 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
     }
   }
 
+  F_STAMP(4);
   // =============================================================== phase 3: dA = G B, dB = G^T A
   if (a.want_grad) {
-    // stage image: U [128 m][64 n] bf16 (16 KiB) then V [128 m][64 k] (16 KiB); 128-byte rows, 16-byte chunk ^= ((row >> 1) & 1) << 2
+    // Every wave takes a quarter of the contraction rows m for the whole 64 x 64 output tile and streams its own U / V rows
+    // through a wave-private LDS image (no workgroup barrier inside the loop, D3 chunks of loads in flight in registers: the
+    // loop is latency-bound); the four partial tiles are summed through LDS at the end.
+    // chunk image: U [32 m][64 n] bf16 (4 KiB) then V [32 m][64 k] (4 KiB); 128-byte rows, 16-byte chunk ^= ((row >> 1) & 1) << 2
     // (the four rows of a transposed-read block on four different 64-byte groups of the 256-byte bank window)
+    constexpr int CR = 32;
     constexpr int VPR = 64 / EPP;                       // V pieces per row (16 / 8)
-    constexpr int NV = F_CM * VPR / F_THREADS;          // V pieces per thread and stage (8 / 4)
-    constexpr int VRS = F_THREADS / VPR;                // rows per V piece slot (16 / 32)
+    constexpr int NVL = CR * VPR / 64;                  // V loads per lane and chunk (8 / 4)
+    constexpr int VRS = 64 / VPR;                       // rows per V load slot (4 / 8)
+    constexpr int D3 = EPP == 8 ? 3 : 2;                // chunks in flight
+    char* wbuf = smem + wave * 16384;                   // 2 x 8 KiB chunk images, later this wave's partial output tile
     const int li = lane & 15, q4 = li >> 2, p4 = li & 3, g1 = (lane >> 4) & 1;
-    const int tr_a = (8 * h + q4) * 128 + ((((wm ^ (q4 >> 1)) * 4 + 2 * g1 + (p4 >> 1))) << 4) + 8 * (p4 & 1);
-    const int tr_b = 16384 + (8 * h + q4) * 128 + ((((wn ^ (q4 >> 1)) * 4 + 2 * g1 + (p4 >> 1))) << 4) + 8 * (p4 & 1);
+    int tr_off[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) tr_off[t] = (8 * h + q4) * 128 + ((((t ^ (q4 >> 1)) * 4 + 2 * g1 + (p4 >> 1))) << 4) + 8 * (p4 & 1);
     auto tr8 = [&](const char* ptr) {
       const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ptr));
       const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(ptr + 512));
@@ -387,8 +422,19 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
       f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
       return __builtin_bit_cast(bf16x8, f);
     };
+    // XCD-aware job order (speed only: any placement is correct).  Workgroups are dealt round-robin over the 8 XCDs, and every
+    // XCD's L2 has to pull what its workgroups read through the fabric -- which is what bounds this phase (every XCD pulling
+    // all of G and G^T: 32 MB at N = 1024).  The jobs are ordered (pair, direction, strip, k chunk); XCD x takes the contiguous
+    // range [x, x + 1) * n_jobs / 8 = all k chunks of a few strips of one direction: their G strips reach that L2 once.
+    const int ngrp = min(8, (int)gridDim.x);
+    const int grp = (int)blockIdx.x % ngrp, slot = (int)blockIdx.x / ngrp;
+    const int per_grp = (a.n_jobs + ngrp - 1) / ngrp;
+    const int spg = ((int)gridDim.x - grp + ngrp - 1) / ngrp;      // workgroups of this group
+    bool first_job = true;
 #pragma unroll 1
-    for (int job = blockIdx.x; job < a.n_jobs; job += gridDim.x) {
+    for (int jt = slot; jt < per_grp; jt += spg) {
+      const int job = grp * per_grp + jt;
+      if (job >= a.n_jobs) break;
       int pj = 0;
 #pragma unroll 1
       while (pj + 1 < a.n_pairs && job >= a.p[pj + 1].job0) ++pj;
@@ -402,89 +448,161 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
       float* out = dir == 0 ? pp.dA : pp.dB;
       const unsigned* cw = pp.cnt + ((2 + dir) * pp.nt + strip) * F_CNT_STRIDE;
       const int npad = pp.n_pad, nn = pp.n;
-      const int nst = npad / F_CM + ((npad % F_CM) ? 1 : 0);
+      const int mw = npad / 4;                            // contraction rows of this wave (a multiple of 16)
+      const int m_lo = wave * mw, m_hi = m_lo + mw;
+      const int nch = (mw + CR - 1) / CR;
       const auto ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(U), 0, npad * npad * 2, 0x00020000);
 
-      u32x4 ust[4];
-      uint4 vst[NV];
-      const int vc = tid % VPR;
+      u32x4 ust[D3][4];
+      uint4 vst[D3][NVL];
+      const int vc = lane % VPR;
       const int vcol = kc * 64 + vc * EPP;
-      auto load_v = [&](int st) {
+      // Addresses are formed once per job: one wave per SIMD runs this loop alone, so every instruction in it is exposed.
+      // A chunk whose 32 rows all exist (the usual case) loads without per-row checks; the row list of a gathered operand is
+      // the only per-row lookup left.
+      const int m_stop = min(m_hi, nn);                                   // V rows beyond are zero (padding of the pair)
+      const int u_voff = ((m_lo + (lane >> 3)) * npad + strip * 64 + (lane & 7) * 8) * 2;
+      const char* v_ptr = Vsrc + ((long)(m_lo + lane / VPR) * a.d + vcol) * (long)sizeof(S);
+      const bool v_col_ok = vcol < a.d;
+      auto load_v = [&](int ch, uint4 (&v)[NVL]) {
+        const int m0 = m_lo + ch * CR;
+        if (Vidx == nullptr && m0 + CR <= m_stop) {                       // wave-uniform
+          const char* q = v_ptr + (long)ch * CR * a.d * (long)sizeof(S);
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
-          const int m = st * F_CM + u * VRS + tid / VPR;
-          vst[u] = make_uint4(0u, 0u, 0u, 0u);
-          if (m < nn && vcol < a.d) {
+          for (int u = 0; u < NVL; ++u) {
+            v[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (v_col_ok && !(dbg & 2)) v[u] = *reinterpret_cast<const uint4*>(q + (long)u * VRS * a.d * (long)sizeof(S));
+          }
+          return;
+        }
+#pragma unroll
+        for (int u = 0; u < NVL; ++u) {
+          const int m = m0 + u * VRS + lane / VPR;
+          v[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (m < m_stop && v_col_ok && !(dbg & 2)) {
             const long srow = (long)(Vidx ? Vidx[m] : m) * a.d;
-            vst[u] = *reinterpret_cast<const uint4*>(Vsrc + (srow + vcol) * (long)sizeof(S));
+            v[u] = *reinterpret_cast<const uint4*>(Vsrc + (srow + vcol) * (long)sizeof(S));
           }
         }
       };
-      auto load_u = [&](int st) {
+      auto load_u = [&](int ch, u32x4 (&w)[4]) {
+        const int m0 = m_lo + ch * CR;
+        const int off = u_voff + ch * CR * npad * 2;
+        if (m0 + CR <= m_hi) {                                             // wave-uniform
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            w[u] = (u32x4){0u, 0u, 0u, 0u};
+            if (!(dbg & 1)) w[u] = __builtin_amdgcn_raw_buffer_load_b128(ru, off + u * 8 * npad * 2, 0, 16);   // sc1
+          }
+          return;
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int m = st * F_CM + u * 32 + (tid >> 3);
-          ust[u] = (u32x4){0u, 0u, 0u, 0u};
-          if (m < npad) ust[u] = __builtin_amdgcn_raw_buffer_load_b128(ru, (m * npad + strip * 64 + (tid & 7) * 8) * 2, 0, 16);   // sc1
+          w[u] = (u32x4){0u, 0u, 0u, 0u};
+          if (m0 + u * 8 + (lane >> 3) < m_hi && !(dbg & 1)) w[u] = __builtin_amdgcn_raw_buffer_load_b128(ru, off + u * 8 * npad * 2, 0, 16);
         }
       };
-      auto store_uv = [&](char* buf) {
+      auto store_uv = [&](char* buf, const u32x4 (&w)[4], const uint4 (&v)[NVL]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int row = u * 32 + (tid >> 3), cc = tid & 7;
-          *reinterpret_cast<u32x4*>(buf + row * 128 + ((cc ^ (((row >> 1) & 1) << 2)) << 4)) = ust[u];
+          const int row = u * 8 + (lane >> 3), cc = lane & 7;
+          *reinterpret_cast<u32x4*>(buf + row * 128 + ((cc ^ (((row >> 1) & 1) << 2)) << 4)) = w[u];
         }
 #pragma unroll
-        for (int u = 0; u < NV; ++u) {
-          const int row = u * VRS + tid / VPR;
+        for (int u = 0; u < NVL; ++u) {
+          const int row = u * VRS + lane / VPR;
           const int e0 = vc * EPP;
-          char* dst = buf + 16384 + row * 128 + (((e0 >> 3) ^ (((row >> 1) & 1) << 2)) << 4) + (e0 & 7) * 2;
-          if constexpr (EPP == 4) *reinterpret_cast<uint2*>(dst) = SrcT<float>::to_bf16(vst[u]);
-          else *reinterpret_cast<uint4*>(dst) = vst[u];
+          char* dst = buf + 4096 + row * 128 + (((e0 >> 3) ^ (((row >> 1) & 1) << 2)) << 4) + (e0 & 7) * 2;
+          if constexpr (EPP == 4) *reinterpret_cast<uint2*>(dst) = SrcT<float>::to_bf16(v[u]);
+          else *reinterpret_cast<uint4*>(dst) = v[u];
         }
       };
-      f32x16 o;
+      f32x16 o[2][2];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) o[e] = 0.f;
-      load_v(0);                       // does not depend on the hand-off: in flight while the strip's G tiles arrive
-      __syncthreads();                 // flag_s / stage buffers of the previous job (or of phase 2) are free
-      if (tid == 0) flag_s[1] = spin_until(cw, cw, (unsigned)pp.nt, err) ? 1 : 0;
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[i][j][e] = 0.f;
+      // V does not depend on the hand-off: in flight while the strip's G tiles arrive
+#pragma unroll
+      for (int q = 0; q < D3; ++q)
+        if (q < nch) load_v(q, vst[q]);
+      __syncthreads();                 // flag_s / the LDS of the previous job (or of phase 2) are free
+      if (tid == 0) {
+        flag_s[1] = spin_until(cw, cw, (unsigned)pp.nt, err) ? 1 : 0;
+      }
       __syncthreads();
       const bool ok = flag_s[1] != 0;   // workgroup-uniform
+      if (first_job) F_STAMP(5);
       if (ok) {
-        load_u(0);
-        store_uv(smem);
-        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < D3; ++q)
+          if (q < nch) load_u(q, ust[q]);
 #pragma unroll 1
-        for (int st = 0; st < nst; ++st) {
-          const bool more = st + 1 < nst;
-          if (more) {
-            load_u(st + 1);
-            load_v(st + 1);
-          }
-          const char* buf = smem + (st & 1) * F_STAGE;
+        for (int c0 = 0; c0 < nch; c0 += D3) {
 #pragma unroll
-          for (int ks = 0; ks < F_CM / 16; ++ks) {
-            const bf16x8 fa = tr8(buf + tr_a + ks * 2048);
-            const bf16x8 fb = tr8(buf + tr_b + ks * 2048);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, o, 0, 0, 0);
+          for (int q = 0; q < D3; ++q) {
+            const int ch = c0 + q;
+            if (ch < nch) {
+              // LDS operations of one wave execute in issue order: the image of chunk ch - 2 has been read when this lands
+              char* buf = wbuf + (ch & 1) * 8192;
+              if (!(dbg & 8)) store_uv(buf, ust[q], vst[q]);
+              if (ch == 0 && first_job) F_STAMP(13);
+              if (ch + D3 < nch) {
+                load_u(ch + D3, ust[q]);
+                load_v(ch + D3, vst[q]);
+              }
+              if (!(dbg & 4))
+#pragma unroll
+              for (int ks = 0; ks < CR / 16; ++ks) {
+                const bf16x8 fa0 = tr8(buf + tr_off[0] + ks * 2048), fa1 = tr8(buf + tr_off[1] + ks * 2048);
+                const bf16x8 fb0 = tr8(buf + 4096 + tr_off[0] + ks * 2048), fb1 = tr8(buf + 4096 + tr_off[1] + ks * 2048);
+                o[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, o[0][0], 0, 0, 0);
+                o[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, o[0][1], 0, 0, 0);
+                o[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, o[1][0], 0, 0, 0);
+                o[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, o[1][1], 0, 0, 0);
+              }
+            }
           }
-          if (more) store_uv(smem + ((st + 1) & 1) * F_STAGE);
-          __syncthreads();
         }
-        // out[n = strip*64 + wm*32 + row(e)][k = kc*64 + wn*32 + r]
-        float* ob = out + (size_t)(strip * 64 + wm * 32) * a.k_pad + kc * 64 + wn * 32 + r;
+        // partial tile of this wave -> its own 16 KiB as [64 n][64 k] f32; then every thread sums the four partials of 16
+        // consecutive k of one row and stores them
+        if (first_job) F_STAMP(14);
+        float* part = reinterpret_cast<float*>(wbuf);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) ob[(size_t)acc_row(e, h) * a.k_pad] = o[e];
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) part[(32 * i + acc_row(e, h)) * 64 + 32 * j + r] = o[i][j][e];
+        __syncthreads();
+        {
+          const int row = tid >> 2, c0 = (tid & 3) * 16;
+          float* ob = out + (size_t)(strip * 64 + row) * a.k_pad + kc * 64 + c0;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            float4 t = *reinterpret_cast<const float4*>(smem + (row * 64 + c0 + 4 * v) * 4);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+              const float4 x = *reinterpret_cast<const float4*>(smem + w * 16384 + (row * 64 + c0 + 4 * v) * 4);
+              t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
+            }
+            *reinterpret_cast<float4*>(ob + 4 * v) = t;
+          }
+        }
       }
+      first_job = false;
     }
   }
 
+  F_STAMP(6);
   // =============================================================== tail: last arriver
   drain_vm();
   __syncthreads();
   if (tid == 0) flag_s[2] = (int)__hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
+  F_STAMP(7);
   if ((unsigned)flag_s[2] != gridDim.x - 1) return;
   if (wave == 0) {
     float loss = 0.f, ds = 0.f;
@@ -557,11 +675,20 @@ static int fused_capacity(int* out) {
   return 0;
 }
 
+static unsigned long long* g_fused_stamps = nullptr;
+
 }  // namespace mmk
 
 using namespace mmk;
 
 extern "C" {
+
+// measurement hook (debug-switch builds only): device buffer of [grid][8] 64-bit stamps the next launches fill
+int mmk_clip_fused_debug_stamps(unsigned long long* device_buf) {
+  MMK_REQUIRE(kDebugSwitches || device_buf == nullptr, "phase stamps need a -DMMK_DEBUG_SWITCHES build of the library");
+  g_fused_stamps = device_buf;
+  return 0;
+}
 
 int mmk_clip_fused_plan(const int32_t* n, int n_pairs, int d, int src_dtype, int64_t* ws_bytes, int32_t* grid, int32_t* capacity) {
   MMK_REQUIRE(n && n_pairs > 0 && n_pairs <= F_MAX_PAIRS && d > 0, "fused loss: 1..4 pairs per call");
@@ -643,6 +770,8 @@ int mmk_clip_fused_forward(const mmk_fused_pair* pairs, int n_pairs, int d, int 
   a.scale = scale;
   a.loss_out = loss_out;
   a.ds_out = ds_out;
+  a.stamps = kDebugSwitches ? g_fused_stamps : nullptr;
+  a.dbg = MMK_DBG_ENV("MMK_FUSED_DBG") ? atoi(MMK_DBG_ENV("MMK_FUSED_DBG")) : 0;
   int cap = 0;
   rc = src_dtype == MMK_F32 ? fused_capacity<float>(&cap) : fused_capacity<bf16_t>(&cap);
   if (rc) return rc;

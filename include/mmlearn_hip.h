@@ -47,7 +47,7 @@ enum {
   MMK_K_SIM_GRAD, MMK_K_GRAD_GEMM, MMK_K_GRAD_FINALIZE, MMK_K_L2NORM, MMK_K_IJEPA_LOSS_FWD,
   MMK_K_IJEPA_LOSS_BWD, MMK_K_GATHER_ROWS, MMK_K_SCATTER_ROWS, MMK_K_PRED_ASSEMBLE, MMK_K_PRED_ASSEMBLE_BWD,
   MMK_K_EMA, MMK_K_MASK_INDEX, MMK_K_LAYERNORM_FWD, MMK_K_LAYERNORM_BWD, MMK_K_ACT, MMK_K_ATTN_FWD,
-  MMK_K_ATTN_BWD, MMK_K_WGRAD, MMK_K_RECALL, MMK_K_GEMM, MMK_K_CLIP_FUSED, MMK_K_COUNT
+  MMK_K_ATTN_BWD, MMK_K_WGRAD, MMK_K_RECALL, MMK_K_CLIP_FUSED, MMK_K_COUNT
 };
 int mmk_profile_enable(int on);          /* on=1 start recording (clears), on=0 stop */
 /* resolve recorded events (synchronises on them); fills count[k] and total_ms[k] for k < MMK_K_COUNT */
@@ -354,20 +354,6 @@ int mmk_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, in
 int mmk_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx, float* part, float* part2, float* dbias, int64_t rows,
                      int d, int act, int dtype, void* stream);
 
-/* Forward / input-gradient GEMM of a Linear layer: C[M, N] = A[M, K] . B[N, K]^T (+ bias[N]) (-> act), bf16 operands with
- * the contraction along their rows, f32 accumulation, C in out_dtype (MMK_BF16 / MMK_F32), row strides in elements.
- * Replaces the hipBLASLt call behind F.linear in the encoders (mmlearn/modules/encoders/clip.py:29-470, text.py:20-178,
- * modules/layers/mlp.py) -- y = x W^T + b with A = x, B = W; dX = dY W with A = dY, B = W^T.  act: 0 none, 1 quick-GELU
- * (x sigmoid(1.702 x)), 2 erf-GELU; C2 (optional, only with act != 0) also receives the pre-activation values x W^T + b.
- * mmk_gemm_nt_supported: 1 when the shape is served (M >= 256, N % 8 == 0, K % 64 == 0, strides % 8 == 0). */
-int mmk_gemm_nt_supported(int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc);
-int mmk_gemm_nt(const void* A, const void* B, void* C, void* C2, const float* bias, int64_t M, int N, int K, int64_t lda, int64_t ldb,
-                int64_t ldc, int out_dtype, int act, void* stream);
-/* Second design of the same GEMM (csrc/gemm4.hip): four waves, one per SIMD, 128 x 128 register tile each (256 accumulator
- * registers), one barrier per K step; same arguments, same results up to the f32 summation order (identical: k order kept). */
-int mmk_gemm4_nt_supported(int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc);
-int mmk_gemm4_nt(const void* A, const void* B, void* C, void* C2, const float* bias, int64_t M, int N, int K, int64_t lda, int64_t ldb,
-                int64_t ldc, int out_dtype, int act, void* stream);
 
 /* Weight gradient of a Linear, dW[N, K] = dY^T x for dY [M, N], x [M, K] (bf16, row strides ldy / ldx in elements):
  * replaces the dY.t() @ x GEMM of autograd's linear backward where its output is too small to fill the chip

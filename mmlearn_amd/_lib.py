@@ -29,7 +29,7 @@ _DTYPE_TAG = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 KERNEL_NAMES = [
     "match_ids", "pack_rows", "transpose", "sim_stats", "lse_reduce", "loss_combine", "sim_grad", "grad_gemm",
     "grad_finalize", "l2norm", "ijepa_loss_fwd", "ijepa_loss_bwd", "gather_rows", "scatter_rows", "pred_assemble",
-    "pred_assemble_bwd", "ema_update", "mask_to_index", "layernorm_fwd", "layernorm_bwd", "activation", "attn_fwd", "attn_bwd", "wgrad", "recall_ranks", "gemm_nt", "clip_fused",
+    "pred_assemble_bwd", "ema_update", "mask_to_index", "layernorm_fwd", "layernorm_bwd", "activation", "attn_fwd", "attn_bwd", "wgrad", "recall_ranks", "clip_fused",
 ]
 
 
@@ -123,10 +123,6 @@ _SIGNATURES = {
     "mmk_adamw_chunk_elems": [],
     "mmk_adamw_update": [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, C.c_int64, _vp],
     "mmk_embedding_bwd": [_vp, _vp, _vp, C.c_int64, _i, C.c_int64, _i, _vp],
-    "mmk_gemm_nt_supported": [C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64],
-    "mmk_gemm_nt": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _i, _vp],
-    "mmk_gemm4_nt_supported": [C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64],
-    "mmk_gemm4_nt": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _i, _vp],
     "mmk_wgrad_plan": [C.c_int64, _i, _i, _vp, _vp],
     "mmk_wgrad_partial": [_vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp],
     "mmk_wgrad": [_vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _vp],

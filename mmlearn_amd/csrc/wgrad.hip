@@ -52,6 +52,7 @@ __device__ __forceinline__ int wg_opaque(int x) {
 // LDS stage image: 64 rows x 512 B, 16-byte chunk index (0..31) ^= (row & 3) << 2: the four rows of a transposed-read
 // block land in four different 64-byte groups of a 256-byte bank window (conflict-free ds_read_b64_tr_b16).
 // Fill: piece p (0..31) = rows 2p, 2p+1; lane l writes chunk position l & 31 of row 2p + (l >> 5).
+template <bool SW16 = false>
 __device__ __forceinline__ void wg_fill(char* stage, const bf16_t* base, long ld, int col0, int ncols, long row0, long row_end, int wave,
                                         int lane) {
   const uint32_t saddr = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)stage);
@@ -60,7 +61,9 @@ __device__ __forceinline__ void wg_fill(char* stage, const bf16_t* base, long ld
   for (int i = 0; i < 2; ++i) {
     const int p = wave_s * 2 + i;
     const int rr = 2 * p + (lane >> 5);
-    const int ch = (lane & 31) ^ ((rr & 3) << 2);
+    // SW16 (16x16x32 MFMA reads): a 32-lane half reads two blocks 8 rows apart in the same columns, so bit 3 of the row also
+    // moves the chunk (by 32 bytes)
+    const int ch = (lane & 31) ^ ((rr & 3) << 2) ^ (SW16 ? ((rr >> 3) & 1) << 1 : 0);
     // rows past the split's end and columns past the operand's width read a valid address (row / column clamped); the
     // main loop zeroes the fragments of out-of-range rows, out-of-range columns only reach workspace padding
     const long srow = min(row0 + 2 * p, row_end - 1);                  // wave-uniform part of the address
@@ -84,6 +87,125 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
   Vec4<OUT>::store(dw + (long)n * ldw + k, acc);
 }
+
+#ifdef MMK_DEBUG_SWITCHES
+// EXPERIMENT (debug-switch builds only, MMK_WGRAD_MFMA=16; measured, not kept: 1-11 % SLOWER than 32x32x16 on all eight encoder
+// shapes in an interleaved same-process A/B, profiles/r03_wgrad_mfma_shape_ab.json -- this kernel is fed by L2 -> LDS, not bound
+// by the matrix pipe's clock).  The same kernel on v_mfma_f32_16x16x32_bf16 (/opt/skills/guides/MI355X_MICROARCH.md, DVFS item 7: on random
+// data the part holds a higher clock on this shape than on 32x32x16 at equal cycles per FLOP).  A wave still owns 64 x 64 of the
+// output: 4 x 4 tiles of 16 x 16 (64 accumulator registers, as before), one 32-row step = 4 + 4 operand fragments (two transposed
+// reads each, 16 reads) and 16 MFMAs.  Lane l of a fragment holds rows 8 (l >> 4) .. + 7 of the step for column l & 15: each
+// 16-lane group reads its own 4-row block, the two groups of a half 8 rows apart -- hence the extra swizzle bit of the fill.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024, 1) void wgrad_kernel16(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = a.tiles_n * a.tiles_k;
+  int split, tn, tk;
+  if (T <= 32) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    split = (slot / T) * 8 + xcd;
+    const int tile = slot % T;
+    tn = tile / a.tiles_k;
+    tk = tile % a.tiles_k;
+  } else {
+    const int per_xcd = (a.splits * T + 7) >> 3;
+    const int pos = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    split = pos / T;
+    const int q = pos % T;
+    const bool n_short = a.tiles_n <= a.tiles_k;
+    const int ts = n_short ? a.tiles_n : a.tiles_k, tl = n_short ? a.tiles_k : a.tiles_n;
+    const int full = tl / 4, bsz = ts * 4;
+    int s_idx, l_idx;
+    if (q < full * bsz) {
+      const int inner = q % bsz;
+      s_idx = inner / 4;
+      l_idx = (q / bsz) * 4 + inner % 4;
+    } else {
+      const int rem = tl - full * 4, inner = q - full * bsz;
+      s_idx = inner / rem;
+      l_idx = full * 4 + inner % rem;
+    }
+    tn = n_short ? s_idx : l_idx;
+    tk = n_short ? l_idx : s_idx;
+  }
+  if (split >= a.splits) return;
+  const long row0 = (long)split * a.rows_per_split;
+  const long row_end = min((long)a.M, row0 + a.rows_per_split);
+  const int nstages = (int)((row_end - row0 + WG_BM - 1) / WG_BM);
+
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x4v acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+  const int li = lane & 15, q = li >> 2, p = li & 3, g = lane >> 4;
+  const int row_off = (8 * g + q) * 512 + 8 * (p & 1);
+  int ca[4], cb[4];   // swizzled 16-byte chunk offsets of the four 16-column sub-tiles
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ca[i] = (((8 * wm + 2 * i + (p >> 1)) ^ (q << 2) ^ ((g & 1) << 1)) << 4);
+    cb[i] = (((8 * wn + 2 * i + (p >> 1)) ^ (q << 2) ^ ((g & 1) << 1)) << 4);
+  }
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  auto tr8 = [&](const char* base) {
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base + 2048));   // rows + 4
+    s8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, f);
+  };
+  auto issue = [&](int st) {
+    char* sa = smem + (st & 1) * 2 * WG_STAGE;
+    const int lo = wg_opaque(lane);
+    wg_fill<true>(sa, a.dy, a.ldy, tn * WG_TILE, a.N, row0 + (long)st * WG_BM, row_end, wave, lo);
+    wg_fill<true>(sa + WG_STAGE, a.x, a.ldx, tk * WG_TILE, a.K, row0 + (long)st * WG_BM, row_end, wave, lo);
+  };
+  issue(0);
+  for (int st = 0; st < nstages; ++st) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of stage st
+    __syncthreads();
+    if (st + 1 < nstages) issue(st + 1);
+    char* sa = smem + wg_opaque((st & 1) * 2 * WG_STAGE) + row_off;
+    char* sb = sa + WG_STAGE;
+    const int valid = (int)min((long)WG_BM, row_end - (row0 + (long)st * WG_BM));
+    const int ksteps = (valid + 31) / 32;
+#pragma unroll 1
+    for (int ks = 0; ks < ksteps; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = tr8(sa + ks * 16384 + ca[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = tr8(sb + ks * 16384 + cb[j]);
+      if ((ks + 1) * 32 > valid) {   // last stage of the last split: rows beyond the end repeat a valid row, zero them on the A side
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+          if (ks * 32 + 8 * g + jj >= valid) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i][jj] = (bf16_t)0.f;
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // acc[i][j][r] = C[n = 64 wm + 16 i + 4 (lane >> 4) + r][k = 64 wn + 16 j + (lane & 15)]
+  const int n_pad = a.tiles_n * WG_TILE, k_pad = a.tiles_k * WG_TILE;
+  float* wsb = a.ws + ((size_t)split * n_pad + (size_t)tn * WG_TILE) * k_pad + (size_t)tk * WG_TILE;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wsb[(size_t)(64 * wm + 16 * i + 4 * g + r) * k_pad + 64 * wn + 16 * j + li] = acc[i][j][r];
+}
+#endif  // MMK_DEBUG_SWITCHES
 
 template <bool PAIR>
 __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
@@ -303,6 +425,15 @@ static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int
   static bool attr = false;
   const int bytes = 4 * WG_STAGE;
   static const bool pair = !(MMK_DBG_ENV("MMK_WGRAD_PAIR") && atoi(MMK_DBG_ENV("MMK_WGRAD_PAIR")) == 0);
+#ifdef MMK_DEBUG_SWITCHES
+  // MFMA shape experiment: MMK_WGRAD_MFMA=16 selects the 16x16x32 kernel (read per call: interleaved A/B runs)
+  const bool mfma16 = MMK_DBG_ENV("MMK_WGRAD_MFMA") && atoi(MMK_DBG_ENV("MMK_WGRAD_MFMA")) == 16;
+  static bool attr16 = false;
+  if (!attr16) {
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel16), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr16 = true;
+  }
+#endif
   if (!attr) {
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -310,6 +441,10 @@ static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int
   }
   {
     ProfEvents pe(MMK_K_WGRAD);
+#ifdef MMK_DEBUG_SWITCHES
+    if (mfma16) hipExtLaunchKernelGGL(wgrad_kernel16, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
+    else
+#endif
     if (pair) hipExtLaunchKernelGGL(wgrad_kernel<true>, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
     else hipExtLaunchKernelGGL(wgrad_kernel<false>, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
   }

@@ -738,48 +738,6 @@ def wgrad(dy2: torch.Tensor, x2: torch.Tensor, out_dtype: torch.dtype = torch.fl
     return dw
 
 
-GEMM_ACT = {None: 0, "none": 0, "quick_gelu": 1, "gelu": 2}
-
-
-def gemm_nt_supported(M: int, N: int, K: int, lda: int, ldb: int, ldc: int) -> bool:
-    return bool(_lib.lib().mmk_gemm_nt_supported(M, N, K, lda, ldb, ldc))
-
-
-def gemm_nt(a2: torch.Tensor, b2: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
-            out_dtype: torch.dtype = torch.bfloat16, want_pre: bool = False):
-    """C [M, N] = a2 [M, K] @ b2 [N, K]^T (+ bias f32[N]) (-> act): bf16 operands (rows contiguous), f32 accumulation, one
-    persistent HIP kernel (csrc/gemm.hip).  ``want_pre`` (with an activation) also returns the pre-activation tensor."""
-    require_gpu(a2)
-    assert a2.dtype == torch.bfloat16 and b2.dtype == torch.bfloat16 and a2.dim() == 2 and b2.dim() == 2
-    assert a2.stride(1) == 1 and b2.stride(1) == 1 and a2.shape[1] == b2.shape[1]
-    M, K_ = a2.shape
-    N = b2.shape[0]
-    c = torch.empty((M, N), dtype=out_dtype, device=a2.device)
-    pre = torch.empty((M, N), dtype=out_dtype, device=a2.device) if want_pre else None
-    if bias is not None:
-        assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N
-    check(_lib.lib().mmk_gemm_nt(ptr(a2), ptr(b2), ptr(c), ptr(pre), ptr(bias), M, N, K_, a2.stride(0), b2.stride(0), c.stride(0),
-                                 dtype_tag(out_dtype), GEMM_ACT[act], stream()))
-    return (c, pre) if want_pre else c
-
-
-def gemm4_nt(a2: torch.Tensor, b2: torch.Tensor, bias: Optional[torch.Tensor] = None, act: Optional[str] = None,
-             out_dtype: torch.dtype = torch.bfloat16, want_pre: bool = False):
-    """``gemm_nt`` on the four-wave kernel (csrc/gemm4.hip: 128 x 128 register tile per wave, one barrier per K step)."""
-    require_gpu(a2)
-    assert a2.dtype == torch.bfloat16 and b2.dtype == torch.bfloat16 and a2.dim() == 2 and b2.dim() == 2
-    assert a2.stride(1) == 1 and b2.stride(1) == 1 and a2.shape[1] == b2.shape[1]
-    M, K_ = a2.shape
-    N = b2.shape[0]
-    c = torch.empty((M, N), dtype=out_dtype, device=a2.device)
-    pre = torch.empty((M, N), dtype=out_dtype, device=a2.device) if want_pre else None
-    if bias is not None:
-        assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N
-    check(_lib.lib().mmk_gemm4_nt(ptr(a2), ptr(b2), ptr(c), ptr(pre), ptr(bias), M, N, K_, a2.stride(0), b2.stride(0), c.stride(0),
-                                  dtype_tag(out_dtype), GEMM_ACT[act], stream()))
-    return (c, pre) if want_pre else c
-
-
 def cast_transpose(w: torch.Tensor, want_plain: bool = True):
     """w [n, k] (f32 / bf16 / f16, contiguous) -> (bf16 w [n, k] or None, bf16 w^T [k, n]) in one pass over w."""
     require_gpu(w)

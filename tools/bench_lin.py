@@ -5,6 +5,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmlearn_amd import kernels as K
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes"))
+import gemm_probe as GP  # retired GEMM experiments: `make -C mmlearn_amd/csrc probes`
 
 
 def timeit(fn, iters):
@@ -42,7 +44,7 @@ def main():
             for rnd in range(3):
                 for v in args.desync.split(","):
                     os.environ["MMK_GEMM_DESYNC"] = v
-                    res.setdefault(v, []).append(timeit(lambda: K.gemm_nt(a, b), args.iters))
+                    res.setdefault(v, []).append(timeit(lambda: GP.gemm_nt(a, b), args.iters))
             t_lib = timeit(lambda: torch.nn.functional.linear(a, b), args.iters)
             print(json.dumps({"M": M, "N": N, "K": Kd, "hipblaslt_us": round(t_lib, 1), **{f"desync{v}_us": [round(x, 1) for x in ts] for v, ts in res.items()}}), flush=True)
             continue
@@ -51,7 +53,7 @@ def main():
             for rnd in range(3):
                 for v in args.dbgs.split(","):
                     os.environ["MMK_GEMM_DBG"] = v
-                    res.setdefault(v, []).append(timeit(lambda: K.gemm_nt(a, b), args.iters))
+                    res.setdefault(v, []).append(timeit(lambda: GP.gemm_nt(a, b), args.iters))
             os.environ["MMK_GEMM_DBG"] = "0"
             print(json.dumps({"M": M, "N": N, "K": Kd, **{f"dbg{v}_us": [round(x, 1) for x in ts] for v, ts in res.items()}}), flush=True)
             continue
@@ -60,13 +62,13 @@ def main():
             for rnd in range(3):
                 for v in args.vars.split(","):
                     os.environ["MMK_GEMM_VAR"] = v
-                    res.setdefault(v, []).append(timeit(lambda: K.gemm_nt(a, b), args.iters))
+                    res.setdefault(v, []).append(timeit(lambda: GP.gemm_nt(a, b), args.iters))
             t_lib = timeit(lambda: torch.nn.functional.linear(a, b), args.iters)
             print(json.dumps({"M": M, "N": N, "K": Kd, "hipblaslt_us": round(t_lib, 1), **{f"var{v}_us": [round(x, 1) for x in ts] for v, ts in res.items()}}), flush=True)
             continue
         if os.environ.get("MMK_GEMM_DBG") and int(os.environ["MMK_GEMM_DBG"]) & 16:
             for _ in range(30):
-                c = K.gemm_nt(a, b)
+                c = GP.gemm_nt(a, b)
             torch.cuda.synchronize()
             st = c.view(-1)[:8].view(torch.int64).tolist()
             if int(os.environ["MMK_GEMM_DBG"]) & 32:
@@ -78,13 +80,13 @@ def main():
             print(json.dumps({"M": M, "N": N, "K": Kd, "wg0_cycles": st[0], "wg0_realtime_ticks_100MHz": st[1], "clock_GHz": round(st[0] / st[1] * 0.1, 3),
                               "wg0_us": st[1] / 100.0}), flush=True)
             continue
-        t_hip = timeit(lambda: K.gemm_nt(a, b), args.iters)
+        t_hip = timeit(lambda: GP.gemm_nt(a, b), args.iters)
         t_lib = timeit(lambda: torch.nn.functional.linear(a, b), args.iters)
         fl = 2.0 * M * N * Kd
         out = {"M": M, "N": N, "K": Kd, "hip_us": round(t_hip, 1), "hip_tflops": round(fl / t_hip / 1e6, 1),
                "hipblaslt_us": round(t_lib, 1), "hipblaslt_tflops": round(fl / t_lib / 1e6, 1)}
         if M % 256 == 0 and N % 256 == 0:   # the four-wave kernel (csrc/gemm4.hip); MMK_GEMM4_DBG=4: no C stores (timing only)
-            t4 = timeit(lambda: K.gemm4_nt(a, b), args.iters)
+            t4 = timeit(lambda: GP.gemm4_nt(a, b), args.iters)
             out.update({"hip4_us": round(t4, 1), "hip4_tflops": round(fl / t4 / 1e6, 1)})
         print(json.dumps(out), flush=True)
 

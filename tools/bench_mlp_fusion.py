@@ -5,6 +5,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmlearn_amd import kernels as K
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes"))
+import gemm_probe as GP  # retired GEMM experiments: `make -C mmlearn_amd/csrc probes`
 
 
 def timeit(fn, iters=20):
@@ -35,16 +37,16 @@ def main():
         out = {"M": M, "act": act}
         out["fwd_lib_gemm_us"] = timeit(lambda: torch.nn.functional.linear(x, w1))
         out["fwd_bias_act_us"] = timeit(lambda: K.bias_act_fwd(h, b1, a))
-        out["fwd_fused_pre_us"] = timeit(lambda: K.gemm_nt(x, w1, b1, act, want_pre=True))
-        out["fwd_fused_nopre_us"] = timeit(lambda: K.gemm_nt(x, w1, b1, act))
-        out["fwd_own_plain_us"] = timeit(lambda: K.gemm_nt(x, w1))
+        out["fwd_fused_pre_us"] = timeit(lambda: GP.gemm_nt(x, w1, b1, act, want_pre=True))
+        out["fwd_fused_nopre_us"] = timeit(lambda: GP.gemm_nt(x, w1, b1, act))
+        out["fwd_own_plain_us"] = timeit(lambda: GP.gemm_nt(x, w1))
         dact = torch.nn.functional.linear(dy, w2t)
         out["bwd_lib_gemm_us"] = timeit(lambda: torch.nn.functional.linear(dy, w2t))
         out["bwd_lib_gemm_nn_us"] = timeit(lambda: dy @ w2)
         out["bwd_bias_act_us"] = timeit(lambda: K.bias_act_bwd(h, b1, dact, a))
-        out["bwd_own_plain_us"] = timeit(lambda: K.gemm_nt(dy, w2t))
+        out["bwd_own_plain_us"] = timeit(lambda: GP.gemm_nt(dy, w2t))
         if hasattr(K, "gemm_nt_dact"):
-            out["bwd_fused_us"] = timeit(lambda: K.gemm_nt_dact(dy, w2t, h, b1, act))
+            out["bwd_fused_us"] = timeit(lambda: GP.gemm_nt_dact(dy, w2t, h, b1, act))
         print(json.dumps(out), flush=True)
 
 

@@ -1,0 +1,34 @@
+"""Interleaved same-process A/B of the weight-gradient kernel's MFMA shape (v_mfma_f32_16x16x32_bf16 vs 32x32x16) on the encoder
+shapes, random data, HIP-event durations of the main kernel.  Needs the debug-switch build (the product build has no switch):
+    make -C mmlearn_amd/csrc VARIANT=_dbg EXTRA=-DMMK_DEBUG_SWITCHES -j8 && MMK_LIB_VARIANT=_dbg python tools/bench_wgrad_ab.py"""
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmlearn_amd import kernels as K, _lib
+dev = torch.device("cuda", 0)
+SHAPES = [(M, N, K_) for M in (1024 * 197, 1024 * 77) for N, K_ in ((768, 768), (2304, 768), (768, 3072), (3072, 768))]
+rounds = int(os.environ.get("ROUNDS", 6))
+for M, N, K_ in SHAPES:
+    dy = torch.randn(M, N, device=dev).bfloat16()
+    x = torch.randn(M, K_, device=dev).bfloat16()
+    ref = None
+    times = {"16": [], "32": []}
+    for r in range(rounds):
+        for v in ("16", "32"):
+            os.environ["MMK_WGRAD_MFMA"] = v   # 32 (or unset) = the shipped kernel
+            for _ in range(2): K.wgrad(dy, x)
+            torch.cuda.synchronize()
+            _lib.profile_enable(True); _lib.profile_read()
+            for _ in range(10): out = K.wgrad(dy, x)
+            torch.cuda.synchronize()
+            pr = _lib.profile_read(); _lib.profile_enable(False)
+            times[v].append(pr["wgrad"][1] / pr["wgrad"][0] * 1e3)
+            if ref is None:
+                ref = out.clone()
+            else:
+                assert (out - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+    med = {v: sorted(t)[len(t) // 2] for v, t in times.items()}
+    fl = 2.0 * M * N * K_
+    print(json.dumps({"M": M, "N": N, "K": K_, "us_16x16x32": round(med["16"], 1), "us_32x32x16": round(med["32"], 1),
+                      "min_16": round(min(times["16"]), 1), "min_32": round(min(times["32"]), 1),
+                      "TF_16": round(fl / med["16"] / 1e6, 1), "TF_32": round(fl / med["32"] / 1e6, 1), "ratio": round(med["32"] / med["16"], 3)}), flush=True)

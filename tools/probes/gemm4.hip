@@ -352,7 +352,7 @@ int mmk_gemm4_nt(const void* A, const void* B, void* C, void* C2, const float* b
   MMK_REQUIRE(kern != nullptr, "gemm4_nt: this (dtype, activation, second output) combination is not built");
   MMK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
   {
-    ProfEvents pe(MMK_K_GEMM);
+    ProfEvents pe(MMK_K_WGRAD);
     void* params[] = {&a};
     MMK_HIP(hipExtLaunchKernel(kern, dim3(grid), dim3(512), params, G4_LDS, st, pe.start, pe.stop, 0));
   }

@@ -307,7 +307,7 @@ def cls_only_leg(b: int, dev, small: bool, steps: int = 6, warmup: int = 3):
             "loss": round(float(loss.detach().float()), 4)}
 
 
-def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2):
+def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2, stock: bool = False):
     """BASELINE configs[3] on the driver's clock (bounded, outside the headline region): image + text + audio (HTSAT)
     towers, ONE shared projection head (Linear 768 -> 512), learnable logit scale, three weighted loss pairs -> the
     N-way pairwise similarity path (3 pairs = 6 CE directions in one launch set).  The bioscan_1m recipe shape
@@ -318,6 +318,8 @@ def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2):
 
     torch.manual_seed(0)
     rgb, text, audio = _PooledVision(small), _PooledText(small), _PooledAudio(small)
+    if stock:   # the denominator: the same three towers as PyTorch-ROCm runs them, torch AdamW, the reference's loss op sequence
+        return _three_tower_stock(rgb, text, audio, b, dev, small, steps, warmup)
     accelerate_encoder(rgb, low_precision_ln=("layer_norm1", "layer_norm2"), fuse_qkv=True, fuse_add_ln=True)
     accelerate_encoder(text, fuse_qkv=True, fuse_add_ln=True)
     if os.environ.get("MMK_BENCH_STOCK_AUDIO") is None:
@@ -332,10 +334,7 @@ def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2):
         compute_validation_loss=False, compute_test_loss=False).to(dev)
     task.concurrent_encoders = True
     opt = task.configure_optimizers()
-    g = torch.Generator(device="cpu").manual_seed(77)
-    ids = torch.stack([torch.zeros(b, dtype=torch.long), torch.arange(b)], 1).to(dev)
-    batch = {"rgb": torch.rand(b, 3, 224, 224, generator=g).to(dev), "text": torch.randint(0, 30522, (b, 77), generator=g).to(dev),
-             "audio": torch.randn(b, 1, 1001, 64, generator=g).to(dev), "example_ids": {"rgb": ids, "text": ids, "audio": ids}}
+    batch = _three_tower_batch(b, dev)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -364,13 +363,60 @@ def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2):
     return out
 
 
-def ijepa_leg(b: int, dev, small: bool, steps: int = 4, warmup: int = 3):
+def _three_tower_batch(b: int, dev):
+    g = torch.Generator(device="cpu").manual_seed(77)
+    ids = torch.stack([torch.zeros(b, dtype=torch.long), torch.arange(b)], 1).to(dev)
+    return {"rgb": torch.rand(b, 3, 224, 224, generator=g).to(dev), "text": torch.randint(0, 30522, (b, 77), generator=g).to(dev),
+            "audio": torch.randn(b, 1, 1001, 64, generator=g).to(dev), "example_ids": {"rgb": ids, "text": ids, "audio": ids}}
+
+
+def _three_tower_stock(rgb, text, audio, b: int, dev, small: bool, steps: int, warmup: int):
+    """Baseline leg of configs[3]: stock HF modules (SDPA, hipBLASLt, ATen elementwise), torch.optim.AdamW, F.normalize and the
+    reference's loss op sequence over the three weighted pairs (oracle/eager_torch.py = contrastive.py:113-160), one stream."""
+    from oracle.eager_torch import EagerContrastiveLoss
+
+    import mmlearn_amd.tasks.contrastive_pretraining as cp
+    from mmlearn_amd.tasks import ContrastivePretraining, LossPairSpec, ModuleKeySpec
+
+    width = 128 if small else 768
+    saved = cp.l2_normalize
+    cp.l2_normalize = lambda x: torch.nn.functional.normalize(x, p=2, dim=-1)
+    try:
+        task = ContrastivePretraining(
+            encoders={"rgb": rgb, "text": text, "audio": audio},
+            heads={"shared": {"proj": nn.Linear(width, 512, bias=False)}},
+            modality_module_mapping={m: ModuleKeySpec(encoder_key=m, head_key="shared") for m in ("rgb", "text", "audio")},
+            loss=EagerContrastiveLoss(), optimizer=_adamw(False),
+            modality_loss_pairs=[LossPairSpec(("rgb", "text")), LossPairSpec(("rgb", "audio"), 0.5), LossPairSpec(("text", "audio"), 0.5)],
+            compute_validation_loss=False, compute_test_loss=False).to(dev)
+        opt = task.configure_optimizers()
+        batch = _three_tower_batch(b, dev)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = task.training_step(batch, 0)
+            loss.backward()
+            opt.step()
+            return loss
+
+        sec = _timed_steps(step, warmup, steps)
+        loss = step()
+        torch.cuda.synchronize()
+    finally:
+        cp.l2_normalize = saved
+    return {"ms_per_step": round(sec * 1e3, 2), "samples_s": round(b / sec, 1), "steps": steps, "warmup": warmup, "per_gpu_batch": b,
+            "loss": round(float(loss.detach().float()), 4),
+            "what": "stock HF CLIP ViT-B/16 + BERT-base + HTSAT (CLAP audio), SDPA, hipBLASLt, torch.optim.AdamW, bf16 autocast, reference loss op sequence (eager), one stream"}
+
+
+def ijepa_leg(b: int, dev, small: bool, steps: int = 4, warmup: int = 3, stock: bool = False):
     """BASELINE configs[4] on the driver's clock (bounded): I-JEPA ViT-L/16 224^2, 4 target blocks, EMA target encoder,
     12 x 384 predictor, bf16, AdamW + EMA update -- the step of tools/bench_ijepa_step.py (mmlearn/tasks/ijepa.py:217-263)."""
     from mmlearn_amd import _lib
     from tools.bench_ijepa_step import build
 
-    task = build(small, True, dev)
+    task = build(small, not stock, dev)
     opt = task.configure_optimizers()
     opt = opt["optimizer"] if isinstance(opt, dict) else opt
     imgs = torch.rand(b, 3, 224, 224, generator=torch.Generator().manual_seed(1)).to(dev)
@@ -385,7 +431,15 @@ def ijepa_leg(b: int, dev, small: bool, steps: int = 4, warmup: int = 3):
         return loss
 
     torch.manual_seed(7)
-    sec = _timed_steps(step, warmup, steps)
+    sec = _timed_steps(step, warmup + (2 if stock else 0), steps)   # MIOpen settles its patch-embedding convolution over the first calls
+    if stock:
+        loss = step()
+        torch.cuda.synchronize()
+        return {"ms_per_step": round(sec * 1e3, 2), "images_s": round(b / sec, 1), "steps": steps, "warmup": warmup + 2, "per_gpu_batch": b,
+                "loss": round(float(loss.detach().float()), 4),
+                "what": "the same ViT-L/16 + predictor as stock pre-LN blocks on SDPA / ATen LayerNorm / GELU, hipBLASLt, MIOpen patch convolution, "
+                        "torch.optim.AdamW, bf16 autocast (tools/bench_ijepa_step.py build(fused=False)); mask generation, target / context "
+                        "gathers, loss and EMA are this repo's ops in both legs"}
     _lib.profile_read()
     _lib.profile_enable(True)
     loss = step()
@@ -526,9 +580,18 @@ def _leg_ijepa(args, dev):
     return ijepa_leg(16 if args.small else 128, dev, args.small)
 
 
+def _leg_three_tower_eager(args, dev):
+    return three_tower_leg(64 if args.small else 256, dev, args.small, stock=True)
+
+
+def _leg_ijepa_eager(args, dev):
+    return ijepa_leg(16 if args.small else 128, dev, args.small, stock=True)
+
+
 LEGS = {"eager_gpu": _leg_eager, "loss_n8192": _leg_loss_n8192, "three_tower": _leg_three_tower, "ijepa_vitl": _leg_ijepa,
-        "cls_only_last_layer": _leg_cls_only}
-LEG_TIMEOUT_S = {"eager_gpu": 240, "loss_n8192": 120, "three_tower": 150, "ijepa_vitl": 240, "cls_only_last_layer": 150}
+        "cls_only_last_layer": _leg_cls_only, "three_tower_eager": _leg_three_tower_eager, "ijepa_vitl_eager": _leg_ijepa_eager}
+LEG_TIMEOUT_S = {"eager_gpu": 240, "loss_n8192": 120, "three_tower": 150, "ijepa_vitl": 240, "cls_only_last_layer": 150,
+                 "three_tower_eager": 180, "ijepa_vitl_eager": 240}
 
 
 def leg_main(args) -> int:
@@ -774,6 +837,13 @@ def main():
     if rank == 0 and world == 1 and not force_dist and not args.no_extra_legs:
         for name in ("loss_n8192", "three_tower", "ijepa_vitl", "cls_only_last_layer"):
             extra[name] = run_leg(name, args)
+        # denominators of the configs[3] / configs[4] legs: the same steps on stock modules, each in a child process of its own
+        for name, key in (("three_tower", "samples_s"), ("ijepa_vitl", "images_s")):
+            if isinstance(extra.get(name), dict) and "error" not in extra[name]:
+                base = run_leg(name + "_eager", args)
+                extra[name]["eager"] = base
+                if key in base and key in extra[name]:
+                    extra[name]["vs_baseline"] = round(extra[name][key] / base[key], 3)
 
     if rank == 0 and eager and "pairs_s" in eager and isinstance(extra.get("cls_only_last_layer"), dict) and "pairs_s" in extra["cls_only_last_layer"]:
         extra["cls_only_last_layer"]["vs_baseline"] = round(extra["cls_only_last_layer"]["pairs_s"] / eager["pairs_s"], 3)

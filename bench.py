@@ -519,13 +519,18 @@ def loss_n8192_leg(dev, n: int = 8192, d: int = 512, iters: int = 10):
     torch.cuda.synchronize()
     _lib.profile_read()
     _lib.profile_enable(True)
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    # wall time from a pass of its own: the profiled pass of a fresh process creates every HIP event it records (hipEventCreate,
+    # ~0.1 ms each), which made the r02 line read 4.9 ms of "wall" next to 0.5 ms of device time
     t0 = time.perf_counter()
     for _ in range(iters):
         step()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / iters
-    prof = _lib.profile_read()
-    _lib.profile_enable(False)
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))

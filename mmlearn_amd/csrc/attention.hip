@@ -788,10 +788,25 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
       }
     }
 
+    // The roles run their own loops (the same number of barriers each): their register sets do not overlap, so the dQ wave can
+    // keep the transposed K fragments of the whole item -- the same for every query tile -- in registers (28 x 4 VGPRs at NT = 7)
+    // instead of re-reading them from LDS at every step (two thirds of its LDS reads, and the reads its MFMAs waited for).
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    auto tr8 = [&](const char* p0, const char* p1) {
+      const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p0));
+      const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p1));
+      s8 f;
+      f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+      f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+      return __builtin_bit_cast(bf16x8, f);
+    };
+    if (keyw) {
+    // (r03: issuing the S / dP products of tile it + 1 ahead of the softmax arithmetic of tile it -- a software pipeline over the
+    // query tiles, +32 VGPRs -- saved cycles in the stamps but no time: 1045-1060 us against 1053-1056 at L = 197; not kept)
 #pragma unroll 1
     for (int it = 0; it <= NT; ++it) {
-      if (keyw && it < NT) {
-        // ---------------- pair (query tile it, key tile wave), the key on the lane
+      if (it < NT) {
         f32x16 sc, dp;
 #pragma unroll
         for (int e = 0; e < 16; ++e) sc[e] = dp[e] = 0.f;
@@ -800,6 +815,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
           sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(Qs + it * 4096 + il.row[kk]), kf[kk], sc, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(Gs + it * 4096 + il.row[kk]), vf[kk], dp, 0, 0, 0);
         }
+        // ---------------- pair (query tile it, key tile wave), the key on the lane
+        if (it == 3) stamp(12);
         bf16x8 pf[2], df[2];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -820,6 +837,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
             df[e >> 3][e & 7] = (bf16_t)(p * ((DROP ? dp[e] * keep : dp[e]) - dlv[e4]));
           }
         }
+        if (it == 3) stamp(13);
         // dS tile -> [key][query] image of this step: registers 4g..4g+3 = queries 8g + 4h .. +3 of key j
         {
           char* dsrow = DS + (it & 1) * DSB + j * 64;
@@ -832,6 +850,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
             *reinterpret_cast<bf16x4*>(dsrow + (((2 * g4 + h) ^ sw) << 3)) = w4;
           }
         }
+        if (it == 3) stamp(14);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -839,36 +858,42 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
             acc2[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(Gs, il, it * 4096 + s * 2048, dt), pf[s], acc2[dt], 0, 0, 0);
             acc1[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(Qs, il, it * 4096 + s * 2048, dt), df[s], acc1[dt], 0, 0, 0);
           }
+        if (it == 3) stamp(15);
       }
-      if (dqw && it > 0) {
+      __syncthreads();
+      stamp(3 + it);
+    }
+    } else if (dqw) {
+    constexpr int KH = 2 * NT < 12 ? 2 * NT : 12;   // k steps whose K fragments stay in registers (all but the last two at NT = 7: no spills)
+    bf16x8 kt[KH][2];
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) kt[ks][mt] = tr8(Ks + ks * 2048 + ktr[0][mt], Ks + ks * 2048 + ktr[1][mt]);
+#pragma unroll 1
+    for (int it = 0; it <= NT; ++it) {
+      if (it > 0) {
         // ---------------- dQᵀ of query tile it-1 = Kᵀ dSᵀ over all keys
         const char* dsb = DS + ((it - 1) & 1) * DSB;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc1[dt][e] = 0.f;
-        typedef short s4 __attribute__((ext_vector_type(4)));
-        typedef short s8 __attribute__((ext_vector_type(8)));
-        auto tr8 = [&](const char* p0, const char* p1) {
-          const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p0));
-          const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p1));
-          s8 f;
-          f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-          f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-          return __builtin_bit_cast(bf16x8, f);
-        };
 #pragma unroll
         for (int ks = 0; ks < 2 * NT; ++ks) {
           const bf16x8 bfr = tr8(dsb + ks * 1024 + dtr[0], dsb + ks * 1024 + dtr[1]);
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
-            acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr8(Ks + ks * 2048 + ktr[0][mt], Ks + ks * 2048 + ktr[1][mt]), bfr,
-                                                               acc1[mt], 0, 0, 0);
+            acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks < KH ? kt[ks < KH ? ks : 0][mt] : tr8(Ks + ks * 2048 + ktr[0][mt], Ks + ks * 2048 + ktr[1][mt]),
+                                                               bfr, acc1[mt], 0, 0, 0);
         }
         store_rows_staged_cs(stage, a.dq + gbase, a.g_sl, (it - 1) * 32, a.L, acc1, a.scale, opaque(lane), cs_slot(a, b, hh, it - 1, 0));
       }
       __syncthreads();
-      stamp(3 + it);
+    }
+    } else {
+#pragma unroll 1
+      for (int it = 0; it <= NT; ++it) __syncthreads();
     }
     if (keyw) {
       store_rows_staged_cs(stage, a.dk + gbase, a.g_sl, wave * 32, a.L, acc1, a.scale, opaque(lane), cs_slot(a, b, hh, wave, 1));

@@ -533,7 +533,7 @@ def loss_n8192_leg(dev, n: int = 8192, d: int = 512, iters: int = 10):
     wall = (time.perf_counter() - t0) / iters
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
         traffic = pmc.get("n8192", {}).get("hbm_bytes_per_launch")
     except Exception:
         traffic = None
@@ -856,7 +856,7 @@ def main():
         n_rows, n_cols, d = args.batch, args.batch * world, 512
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes of the same kernel and shape (profiles/)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
             if world == 1 and args.batch == 1024:
                 traffic = pmc.get("n1024", {}).get("hbm_bytes_per_launch")
         except Exception:

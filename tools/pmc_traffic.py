@@ -4,7 +4,7 @@ tallies 128-byte requests at 64 bytes, /opt/skills/guides/MI355X_MICROARCH.md, H
     python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> > profiles/rNN_pmc_traffic.json"""
 import collections, csv, json, sys
 
-NAMES = {"Li0ELi1E": "sim_stats", "Li1ELi1E": "sim_grad", "Li2ELi1E": "grad_gemm", "lse_merge": "lse_merge", "pack_tr": "pack_rows",
+NAMES = {"clip_fused_kernel": "clip_fused", "Li0ELi1E": "sim_stats", "Li1ELi1E": "sim_grad", "Li2ELi1E": "grad_gemm", "lse_merge": "lse_merge", "pack_tr": "pack_rows",
          "grad_finalize": "grad_finalize", "wgrad_kernel": "wgrad (dB = G^T A)", "match_small": "match_ids", "match_kernel": "match_ids", "match_scan": "match_ids"}
 
 
@@ -32,9 +32,13 @@ for key in sorted(fetch):
     w, nw = write.get(key, [0.0, 1])
     out["kernels"].append({"kernel": key[0], "grid_threads": key[1], "symbol": key[2], "launches": nf, "fetch_kib_per_launch": round(f / nf, 1),
                            "write_kib_per_launch": round(w / max(nw, 1), 1), "hbm_bytes_per_launch": int((2 * f / nf + w / max(nw, 1)) * 1024)})
-# the shapes of the bench: the similarity-statistics kernel at N = 1024 (64x64 tiles) and N = 8192 (128x128 tiles)
+# the shapes of the bench: N = 1024 -> the one-launch kernel (256 workgroups x 256 threads), else the similarity-statistics kernel of
+# the tiled path (64x64 tiles); N = 8192 -> the similarity-statistics kernel (128x128 tiles)
+for k in out["kernels"]:
+    if k["kernel"] == "clip_fused" and k["grid_threads"] == 256 * 256:
+        out["n1024"] = {"kernel": "clip_fused", "hbm_bytes_per_launch": k["hbm_bytes_per_launch"]}
 for tag, sym in (("n1024", "Li64ELi64ELi0E"), ("n8192", "Li128ELi128ELi0E")):
     for k in out["kernels"]:
-        if k["kernel"] == "sim_stats" and sym in k["symbol"] + "".join(n for n in [k["symbol"]]):
+        if k["kernel"] == "sim_stats" and sym in k["symbol"] and tag not in out:
             out[tag] = {"kernel": "sim_stats", "hbm_bytes_per_launch": k["hbm_bytes_per_launch"]}
 print(json.dumps(out, indent=1))

@@ -316,6 +316,10 @@ def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2, s
     from mmlearn_amd.fused import accelerate_encoder
     from mmlearn_amd.tasks import ContrastivePretraining, LossPairSpec, ModuleKeySpec
 
+    if os.environ.get("MMK_BENCH_TILED_LOSS") is not None:   # A/B switch: the tiled multi-launch loss instead of the one-launch kernel
+        from mmlearn_amd import kernels as _K
+
+        _K.FUSED_LOSS = False
     torch.manual_seed(0)
     rgb, text, audio = _PooledVision(small), _PooledText(small), _PooledAudio(small)
     if stock:   # the denominator: the same three towers as PyTorch-ROCm runs them, torch AdamW, the reference's loss op sequence
@@ -323,7 +327,14 @@ def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2, s
     accelerate_encoder(rgb, low_precision_ln=("layer_norm1", "layer_norm2"), fuse_qkv=True, fuse_add_ln=True)
     accelerate_encoder(text, fuse_qkv=True, fuse_add_ln=True)
     if os.environ.get("MMK_BENCH_STOCK_AUDIO") is None:
-        accelerate_encoder(audio)   # HTSAT: the LayerNorm swap only (f32 in / f32 out); its windowed attention stays on SDPA / ATen
+        accelerate_encoder(audio)   # HTSAT: the LayerNorm swap (f32 in / f32 out); its windowed attention stays on SDPA / ATen
+        # ... and its 4 x 4 / stride 4 patch embedding as im2col + GEMM.  Besides the time, this takes MIOpen's implicit-GEMM
+        # convolution kernels out of the leg: with AMD_SERIALIZE_KERNEL=3 + AMD_LOG_LEVEL=3 the leg's intermittent `Memory access
+        # fault by GPU` (round 2: unexplained; round 3: reproducible once the allocation pattern changed) is raised by
+        # `igemm_bwd_gtcx35_nhwc_bf16_...`, the library's backward kernel of exactly this convolution.
+        from mmlearn_amd.fused import patch_conv_as_gemm
+
+        patch_conv_as_gemm(audio)
     width = 128 if small else 768
     task = ContrastivePretraining(
         encoders={"rgb": rgb, "text": text, "audio": audio},
@@ -355,7 +366,19 @@ def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2, s
     torch.cuda.synchronize()
     prof = _lib.profile_read()
     _lib.profile_enable(False)
+    # where the step goes: forward + backward of each tower alone (same batch, one stream, 3 passes each after one warm-up)
+    from mmlearn_amd.modalities import Modalities
+
+    tower_ms = {}
+    for m in ("rgb", "text", "audio"):
+        def tower_pass(m=m):
+            task.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                e = task.encode(batch, Modalities.get_modality(m), normalize=True)
+            e.float().sum().backward()
+        tower_ms[m] = round(_timed_steps(tower_pass, 1, 3) * 1e3, 2)
     out = {"workload": f"BASELINE configs[3] on 1 GPU: CLIP ViT-B/16 + BERT-base + HTSAT (HF CLAP audio), shared Linear({width},512) head, 3 weighted pairs, per-GPU batch {b}, bf16",
+           "tower_fwd_bwd_ms": tower_ms,
            "ms_per_step": round(sec * 1e3, 2), "samples_s": round(b / sec, 1), "steps": steps, "warmup": warmup, "loss": round(float(loss.detach().float()), 4),
            "roofline": _loss_roofline(prof, n_rows=b, n_cols=b, d=512, n_pairs=3, steps=1)}
     del task, opt, batch

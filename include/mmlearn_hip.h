@@ -370,6 +370,9 @@ int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int
  * mmlearn/modules/layers/embedding.py PatchEmbed): out[(b, py, px)][(c, i, j)] = in[b][c][py P + i][px P + j] as bf16,
  * so that the convolution runs as one GEMM against weight.view(E, C P P).  in: [B, C, H, W] of `dtype`, contiguous. */
 int mmk_patchify(const void* in, void* out, int B, int C, int H, int W, int P, int dtype, void* stream);
+/* its backward with respect to the image (the inverse permutation; a non-overlapping convolution's col2im has no sums):
+ * din[b][c][py P + i][px P + j] = dcols[(b, py, px)][(c, i, j)].  dtype = dcols dtype (bf16 / f32) | image dtype << 4. */
+int mmk_unpatchify(const void* dcols, void* din, int B, int C, int H, int W, int P, int dtype, void* stream);
 
 /* bf16 operands of an encoder nn.Linear from its master weight w [n, k] of `dtype` (f32 / bf16 / f16), in one pass: w16 [n, k]
  * (may be null) for the forward x w16^T -- what autocast's per-step cast of the weight produces -- and w16t [k, n] = w16^T, so that

@@ -118,6 +118,7 @@ _SIGNATURES = {
     "mmk_add_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _f, C.c_uint64, _vp],
     "mmk_bias_act_part_blocks": [C.c_long],
     "mmk_patchify": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "mmk_unpatchify": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "mmk_cast_transpose": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mmk_recall_ranks": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mmk_adamw_chunk_elems": [],

@@ -79,7 +79,7 @@ struct FusedArgs {
   float* loss_out;
   float* ds_out;
   int dbg;                      // -DMMK_DEBUG_SWITCHES builds (MMK_FUSED_DBG; WRONG results, timing only): 1 no U loads, 2 no V loads, 4 no
-                                // transposed reads / MFMAs, 8 no LDS stores in the gradient loop
+                                // transposed reads / MFMAs, 8 no LDS stores in the gradient loop, 16 no phase-1 loads, 64 no gradient stores
   unsigned long long* stamps;   // -DMMK_DEBUG_SWITCHES builds: [grid][16] realtime-clock stamps of every workgroup's phases, or null
 };
 // phase stamps (100 MHz clock): compiled out of the product build
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
 #pragma unroll
       for (int u = 0; u < NP; ++u) {
         v[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (srow[u] >= 0 && col < a.d) v[u] = *reinterpret_cast<const uint4*>(base[u] + srow[u] + (long)col * (long)sizeof(S));
+        if (srow[u] >= 0 && col < a.d && !(dbg & 16)) v[u] = *reinterpret_cast<const uint4*>(base[u] + srow[u] + (long)col * (long)sizeof(S));
       }
     };
     auto store = [&](char* buf, const uint4 (&v)[NP]) {
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
               const float4 x = *reinterpret_cast<const float4*>(smem + w * 16384 + (row * 64 + c0 + 4 * v) * 4);
               t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
             }
-            *reinterpret_cast<float4*>(ob + 4 * v) = t;
+            if (!(dbg & 64)) *reinterpret_cast<float4*>(ob + 4 * v) = t;
           }
         }
       }

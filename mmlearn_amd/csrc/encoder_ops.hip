@@ -473,6 +473,22 @@ __global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ in,
   }
 }
 
+// backward of patchify with respect to the image: the inverse permutation (col2im of a non-overlapping convolution has no sums).
+// din[b][c][py P + i][px P + j] = dcols[(b, py, px)][(c, i, j)]; dcols bf16 / f32, din in the image's dtype.
+template <typename G, typename T>
+__global__ __launch_bounds__(256) void unpatchify_kernel(const G* __restrict__ dcols, T* __restrict__ din, int B, int C, int H, int W, int P) {
+  const int gh = H / P, gw = W / P, cpp4 = C * P * P / 4, p4 = P / 4;
+  const long n4 = (long)B * gh * gw * cpp4;
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n4; o += (long)gridDim.x * 256) {
+    const int col4 = (int)(o % cpp4);
+    const long row = o / cpp4;
+    const int j4 = col4 % p4, i = (col4 / p4) % P, c = col4 / (p4 * P);
+    const int px = (int)(row % gw), py = (int)((row / gw) % gh);
+    const long b = row / ((long)gw * gh);
+    Vec4<T>::store(din + ((b * C + c) * H + (long)py * P + i) * W + (long)px * P + j4 * 4, Vec4<G>::load(dcols + o * 4));
+  }
+}
+
 // ------------------------------------------------------------------ weight cast + transposed twin
 // W [n, k] (the f32 master weight of an nn.Linear, or bf16 / f16) -> W16 [n, k] bf16, the forward's operand (y = x W16^T), and
 // W16T [k, n] bf16 for the backward: dX = dY W is then F.linear(dY, W16T), the operand layout the library's forward kernels
@@ -801,6 +817,26 @@ int mmk_patchify(const void* in, void* out, int B, int C, int H, int W, int P, i
   const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 256 * 32);
   int rc = MMK_DISPATCH_DTYPE(dtype, T, [&]() -> int {
     hipLaunchKernelGGL((patchify_kernel<T>), dim3(grid), dim3(256), 0, st, static_cast<const T*>(in), static_cast<bf16_t*>(out), B, C, H, W, P);
+    return 0;
+  });
+  if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+int mmk_unpatchify(const void* dcols, void* din, int B, int C, int H, int W, int P, int dtype, void* stream) {
+  MMK_REQUIRE(dcols && din && B > 0 && C > 0 && H > 0 && W > 0 && P > 0, "bad arguments");
+  MMK_REQUIRE(P % 4 == 0 && H % P == 0 && W % P == 0, "unpatchify: patch size must be a multiple of 4 and divide H and W");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long n4 = (long)B * (H / P) * (W / P) * (C * P * P / 4);
+  const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 256 * 32);
+  const int gd = dtype & 15, td = dtype >> 4;   // gradient-columns dtype | image dtype << 4
+  MMK_REQUIRE(gd == MMK_BF16 || gd == MMK_F32, "unpatchify: gradient columns must be bf16 or f32");
+  int rc = MMK_DISPATCH_DTYPE(td, T, [&]() -> int {
+    if (gd == MMK_BF16)
+      hipLaunchKernelGGL((unpatchify_kernel<bf16_t, T>), dim3(grid), dim3(256), 0, st, static_cast<const bf16_t*>(dcols), static_cast<T*>(din), B, C, H, W, P);
+    else
+      hipLaunchKernelGGL((unpatchify_kernel<float, T>), dim3(grid), dim3(256), 0, st, static_cast<const float*>(dcols), static_cast<T*>(din), B, C, H, W, P);
     return 0;
   });
   if (rc) return rc;

@@ -599,16 +599,31 @@ def fuse_qkv_attention(module: nn.Module) -> int:
     return n
 
 
+class _PatchifyFn(torch.autograd.Function):
+    """``kernels.patchify`` for an image that requires grad (HTSAT's patch embedding sits behind a BatchNorm): the backward is the
+    inverse permutation."""
+
+    @staticmethod
+    def forward(ctx, x, patch):
+        ctx.shape, ctx.patch, ctx.dtype = tuple(x.shape), patch, x.dtype
+        return K.patchify(x, patch)
+
+    @staticmethod
+    def backward(ctx, dcols):
+        return K.unpatchify(dcols, ctx.shape, ctx.patch, ctx.dtype), None
+
+
 def _patch_conv_forward(self, x):
     """Replaces the forward of an ``nn.Conv2d`` whose stride equals its kernel (ViT patch embedding): HIP im2col
     (a permutation + cast) and one GEMM; the result is returned as a ``[B, E, gh, gw]`` view of the ``[B, gh gw, E]``
     GEMM output, so the usual ``.flatten(2).transpose(1, 2)`` that follows is free."""
     P = self.kernel_size[0]
     bf16 = x.dtype == torch.bfloat16 or _autocast_bf16()
-    if (x.dim() == 4 and x.is_cuda and bf16 and not x.requires_grad and P % 4 == 0 and x.shape[2] % P == 0 and x.shape[3] % P == 0
+    if (x.dim() == 4 and x.is_cuda and bf16 and P % 4 == 0 and x.shape[2] % P == 0 and x.shape[3] % P == 0
             and x.dtype in (torch.float32, torch.bfloat16, torch.float16)):
         B, _, H, W = x.shape
-        y = linear(K.patchify(x, P), self.weight.view(self.out_channels, -1), self.bias)
+        cols = _PatchifyFn.apply(x.contiguous(), P) if (x.requires_grad and torch.is_grad_enabled()) else K.patchify(x, P)
+        y = linear(cols, self.weight.view(self.out_channels, -1), self.bias)
         return y.view(B, H // P, W // P, self.out_channels).permute(0, 3, 1, 2)
     return self._mmk_stock_forward(x)
 

@@ -759,6 +759,16 @@ def patchify(x: torch.Tensor, patch: int) -> torch.Tensor:
     return out
 
 
+def unpatchify(dcols: torch.Tensor, shape: tuple, patch: int, dtype: torch.dtype) -> torch.Tensor:
+    """Backward of ``patchify`` w.r.t. the image: dcols [B * H/P * W/P, C * P * P] (bf16 / f32) -> [B, C, H, W] of ``dtype``."""
+    require_gpu(dcols)
+    B, Cc, H, W = shape
+    dcols = dcols.contiguous()
+    out = torch.empty((B, Cc, H, W), dtype=dtype, device=dcols.device)
+    check(_lib.lib().mmk_unpatchify(ptr(dcols), ptr(out), B, Cc, H, W, int(patch), dtype_tag(dcols.dtype) | (dtype_tag(dtype) << 4), stream()))
+    return out
+
+
 def embedding_bwd(dout2: torch.Tensor, ids: torch.Tensor, vocab: int) -> torch.Tensor:
     """dW f32 [vocab, d] with dW[ids[r]] += dout2[r] (dout2 [rows, d] f32 / bf16, ids int64 [rows])."""
     require_gpu(dout2)

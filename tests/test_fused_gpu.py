@@ -233,7 +233,8 @@ def test_bias_act_vs_torch(rows, d, dt, act):
     assert e <= (5e-2 if dt != torch.float32 else 1e-3) * max(1.0, br.grad.abs().max().item()), ("dbias", e)
 
 
-@pytest.mark.parametrize("B,C,H,W,P,E,bias", [(3, 3, 224, 224, 16, 768, False), (2, 3, 64, 96, 16, 64, True), (5, 4, 32, 32, 8, 40, True)])
+@pytest.mark.parametrize("B,C,H,W,P,E,bias", [(3, 3, 224, 224, 16, 768, False), (2, 3, 64, 96, 16, 64, True), (5, 4, 32, 32, 8, 40, True),
+                                              (8, 1, 256, 256, 4, 96, True)])   # the last: HTSAT's (HF CLAP audio) patch embedding
 def test_patch_conv_as_gemm_matches_conv2d(B, C, H, W, P, E, bias):
     from mmlearn_amd import fused
 
@@ -241,12 +242,15 @@ def test_patch_conv_as_gemm_matches_conv2d(B, C, H, W, P, E, bias):
     torch.manual_seed(B + P)
     conv = torch.nn.Conv2d(C, E, kernel_size=P, stride=P, bias=bias).to(dev)
     x = torch.rand(B, C, H, W, device=dev)
+    if C == 1:   # HTSAT: the image comes out of a BatchNorm, so it carries a gradient (patchify's backward = the inverse permutation)
+        x.requires_grad_(True)
     w = torch.randn(B, E, H // P, W // P, device=dev)
-    outs = []
+    outs, gx = [], []
     for patched in (False, True):
         if patched:
             assert fused.patch_conv_as_gemm(conv) == 1
         conv.zero_grad(set_to_none=True)
+        x.grad = None
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = conv(x)
         assert y.shape == (B, E, H // P, W // P) and y.dtype == torch.bfloat16
@@ -254,7 +258,10 @@ def test_patch_conv_as_gemm_matches_conv2d(B, C, H, W, P, E, bias):
         assert t.shape == (B, (H // P) * (W // P), E)
         (y.float() * w).sum().backward()
         outs.append((y.float().detach(), conv.weight.grad.clone(), None if not bias else conv.bias.grad.clone()))
+        gx.append(None if x.grad is None else x.grad.clone())
     (y0, gw0, gb0), (y1, gw1, gb1) = outs
+    if x.requires_grad:
+        assert gx[0].shape == gx[1].shape == x.shape and (gx[0] - gx[1]).abs().max() <= 2e-2 * max(1.0, gx[0].abs().max().item())
     assert (y0 - y1).abs().max() <= 2e-2 * max(1.0, y0.abs().max().item())
     assert (gw0 - gw1).abs().max() <= 2e-2 * max(1.0, gw0.abs().max().item())
     if bias:

@@ -324,17 +324,8 @@ def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2, s
     rgb, text, audio = _PooledVision(small), _PooledText(small), _PooledAudio(small)
     if stock:   # the denominator: the same three towers as PyTorch-ROCm runs them, torch AdamW, the reference's loss op sequence
         return _three_tower_stock(rgb, text, audio, b, dev, small, steps, warmup)
-    accelerate_encoder(rgb, low_precision_ln=("layer_norm1", "layer_norm2"), fuse_qkv=True, fuse_add_ln=True)
-    accelerate_encoder(text, fuse_qkv=True, fuse_add_ln=True)
-    if os.environ.get("MMK_BENCH_STOCK_AUDIO") is None:
-        accelerate_encoder(audio)   # HTSAT: the LayerNorm swap (f32 in / f32 out); its windowed attention stays on SDPA / ATen
-        # ... and its 4 x 4 / stride 4 patch embedding as im2col + GEMM.  Besides the time, this takes MIOpen's implicit-GEMM
-        # convolution kernels out of the leg: with AMD_SERIALIZE_KERNEL=3 + AMD_LOG_LEVEL=3 the leg's intermittent `Memory access
-        # fault by GPU` (round 2: unexplained; round 3: reproducible once the allocation pattern changed) is raised by
-        # `igemm_bwd_gtcx35_nhwc_bf16_...`, the library's backward kernel of exactly this convolution.
-        from mmlearn_amd.fused import patch_conv_as_gemm
-
-        patch_conv_as_gemm(audio)
+    for m, tower in (("rgb", rgb), ("text", text), ("audio", audio)):
+        accelerate_tower(tower, m)
     width = 128 if small else 768
     task = ContrastivePretraining(
         encoders={"rgb": rgb, "text": text, "audio": audio},
@@ -384,6 +375,26 @@ def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2, s
     del task, opt, batch
     torch.cuda.empty_cache()
     return out
+
+
+def accelerate_tower(tower, modality: str):
+    """What the HIP leg of configs[3] swaps into each tower (also used by tools/prof_tower.py)."""
+    from mmlearn_amd.fused import accelerate_encoder, patch_conv_as_gemm
+
+    if modality == "rgb":
+        return accelerate_encoder(tower, low_precision_ln=("layer_norm1", "layer_norm2"), fuse_qkv=True, fuse_add_ln=True)
+    if modality == "text":
+        return accelerate_encoder(tower, fuse_qkv=True, fuse_add_ln=True)
+    # HTSAT: the LayerNorm swap (f32 in / f32 out) and every Linear's weight gradient on csrc/wgrad.hip; its windowed attention
+    # stays on ATen ...
+    swapped = accelerate_encoder(tower, wgrad_linear=os.environ.get("MMK_BENCH_NO_AUDIO_WGRAD") is None)
+    # ... and its 4 x 4 / stride 4 patch embedding as im2col + GEMM (the image comes out of a BatchNorm: patchify has a backward).
+    # Besides the time, this takes MIOpen's implicit-GEMM convolution kernels out of the leg: with AMD_SERIALIZE_KERNEL=3 +
+    # AMD_LOG_LEVEL=3 the leg's `Memory access fault by GPU` (round 2: intermittent, unexplained; round 3: reproducible once the
+    # allocation pattern changed) is raised by `igemm_bwd_gtcx35_nhwc_bf16_...`, the library's backward kernel of exactly this
+    # convolution (DESIGN.md 5).
+    swapped["patch_conv"] = patch_conv_as_gemm(tower)
+    return swapped
 
 
 def _three_tower_batch(b: int, dev):

@@ -325,6 +325,23 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return F.linear(x, weight, bias)
 
 
+def _linear_module_forward(self, x):
+    return linear(x, self.weight, self.bias)
+
+
+def linear_wgrad(module: nn.Module) -> int:
+    """Patch every plain ``nn.Linear`` inside ``module`` to run through :func:`linear`: where the layer sees >= 6k rows in bf16
+    its weight gradient comes from ``csrc/wgrad.hip`` (split over the rows), its dX from the transposed twin.  For towers none of
+    the block-level fusions recognise -- HTSAT's Swin stages: ``dW [384 x 96] = dY^T x`` over 1,048,576 rows is 12 output tiles
+    for the library's 64 x 64 x 256 kernel, 0.96 ms a call (profiles/r03_htsat_tower_kernel_stats.csv); 29 such GEMMs per step."""
+    n = 0
+    for m in module.modules():
+        if type(m) is nn.Linear and "forward" not in m.__dict__:
+            m.forward = types.MethodType(_linear_module_forward, m)
+            n += 1
+    return n
+
+
 def linear_nobias(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     """``x @ W^T`` of an ``nn.Linear`` whose bias is added by the consumer kernel (``add_layer_norm`` / ``bias_act``)."""
     return linear(x, lin.weight, None)
@@ -763,7 +780,7 @@ def cls_only_last_layer(module: nn.Module) -> int:
 
 
 def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), fuse_qkv: bool = False, fuse_add_ln: bool = False,
-                       cls_only: bool = False) -> dict:
+                       cls_only: bool = False, wgrad_linear: bool = False) -> dict:
     """Swap ``nn.LayerNorm`` -> :class:`LayerNorm` and quick-GELU activations -> :class:`QuickGELU` inside ``module`` (in place);
     with ``fuse_qkv`` also patch the attention modules (:func:`fuse_qkv_attention`), with ``fuse_add_ln`` the residual
     add + LayerNorm pairs (:func:`fuse_add_layer_norm`).
@@ -773,6 +790,7 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
     for HF CLIP); ``norm1`` / ``norm2`` of timm-style pre-LN blocks (mmlearn's own ViT / predictor) and ``layer_norm1`` /
     ``layer_norm2`` of HF ``CLIPEncoderLayer`` get it automatically -- they feed nothing but that block's Linears.
     ``cls_only``: :func:`cls_only_last_layer` (opt-in; only for encoders pooled at token 0).
+    ``wgrad_linear``: :func:`linear_wgrad` on every ``nn.Linear`` left unpatched (towers without a recognised block structure).
     Returns the number of modules swapped per kind.
     """
     swapped = {"layernorm": 0, "quick_gelu": 0, "fused_qkv": fuse_qkv_attention(module) if fuse_qkv else 0, "fused_add_ln": 0}
@@ -794,6 +812,8 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
         swapped["fused_add_ln"] = fuse_add_layer_norm(module)
         swapped["patch_conv"] = patch_conv_as_gemm(module)
         swapped["embedding"] = patch_embedding_backward(module)
+    if wgrad_linear:
+        swapped["linear_wgrad"] = linear_wgrad(module)
     if cls_only:     # last: it wraps whatever forward the last layer has by now (fused or stock)
         swapped["cls_only_last_layer"] = cls_only_last_layer(module)
     return swapped

@@ -483,3 +483,35 @@ def test_cls_only_last_layer_on_the_fused_towers_keeps_loss_and_gradients():
             # holds there is bf16 noise, so it is compared on the scale of the real gradients, like every other tiny tensor
             scale = max(g_full[k].abs().max().item(), 1e-2 * top)
             assert (g_full[k] - g_cls[k]).abs().max() <= 6e-2 * scale, (k, (g_full[k] - g_cls[k]).abs().max().item(), scale)
+
+
+def test_linear_wgrad_patch_matches_stock_linears_on_a_swin_shaped_mlp():
+    """``accelerate_encoder(wgrad_linear=True)`` (HTSAT's stages: narrow layers over very many rows): output, input gradient and
+    every parameter gradient against the stock modules under the same autocast."""
+    import copy
+
+    from mmlearn_amd import fused
+
+    dev = _dev()
+    torch.manual_seed(4)
+    stock = torch.nn.Sequential(torch.nn.Linear(96, 384), torch.nn.GELU(), torch.nn.Linear(384, 96), torch.nn.Linear(96, 288, bias=False)).to(dev)
+    fast = copy.deepcopy(stock)
+    assert fused.accelerate_encoder(fast, wgrad_linear=True)["linear_wgrad"] == 3
+    x0 = torch.randn(4, 4096, 96, device=dev)      # 16,384 rows: above the 6k-row threshold of the weight-gradient kernel
+    up = torch.randn(4, 4096, 288, device=dev)
+    res = []
+    for mod in (stock, fast):
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = mod(x)
+        assert y.dtype == torch.bfloat16
+        (y.float() * up).sum().backward()
+        res.append((y.float().detach(), x.grad.clone(), [p.grad.clone() for p in mod.parameters()]))
+    (y0, gx0, gp0), (y1, gx1, gp1) = res
+    assert (y0 - y1).abs().max() <= 2e-2 * y0.abs().max()
+    assert (gx0 - gx1).abs().max() <= 2e-2 * gx0.abs().max()
+    for a, b in zip(gp0, gp1):
+        assert a.shape == b.shape and (a - b).abs().max() <= 2e-2 * a.abs().max()
+    # small inputs (below the threshold) and f32 without autocast fall through to F.linear
+    xs = torch.randn(8, 96, device=dev)
+    assert torch.equal(fast(xs), stock(xs))

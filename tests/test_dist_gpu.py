@@ -1,8 +1,10 @@
 """GPU: the REAL multi-rank loss path (HIP kernels + collectives) on one MI355X.
 
-Two worker processes share cuda:0 and talk over gloo (RCCL refuses two ranks on one device); collectives on device
-tensors are staged through the host inside the workers.  Everything else is the product path: gather, ownership,
-row-sharded HIP kernels with label offsets, LSE all-reduce, per-flag gradient recipes.  Checked against the
+Two / four worker processes share cuda:0 and talk over gloo (RCCL refuses two ranks on one device).  The loss's own
+`dist.all_gather_into_tensor` / `dist.all_reduce` call sites run unmodified on DEVICE tensors (gloo moves them through the
+host by itself), async handles included; everything is the product path: gather, ownership, row-sharded HIP kernels with
+label offsets, LSE all-reduce, per-flag gradient recipes.  (Round 2 swapped the collectives for host copies inside the
+workers; only the eight-rank case, whose ranks are threads of one process, still does -- see _ThreadRanks.)  Checked against the
 per-rank outputs of the reference under torch.distributed (golden g3_clip_dist / g9_align).
 """
 
@@ -25,26 +27,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class _Done:
     def wait(self):
         return True
-
-
-def _stage_collectives_through_host():
-    """gloo has no device all-gather: run the collective on host copies, write the result back on the stream."""
-    ag, ar = dist.all_gather_into_tensor, dist.all_reduce
-
-    def all_gather_into_tensor(out, inp, group=None, async_op=False):
-        o = torch.empty(out.shape, dtype=out.dtype)
-        ag(o, inp.detach().cpu().contiguous())
-        out.copy_(o)
-        return _Done() if async_op else None
-
-    def all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
-        h = t.detach().cpu()
-        ar(h, op=op)
-        t.copy_(h)
-        return _Done() if async_op else None
-
-    dist.all_gather_into_tensor = all_gather_into_tensor
-    dist.all_reduce = all_reduce
 
 
 def _golden_rank(rank, world, prefixes=None):
@@ -97,7 +79,6 @@ def _worker(rank, world, port, q):
             if p not in sys.path:
                 sys.path.insert(0, p)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        _stage_collectives_through_host()
         q.put((rank, _golden_rank(rank, world), None))
         dist.barrier()
         dist.destroy_process_group()
@@ -231,7 +212,6 @@ def _seeded_worker(rank, world, port, b, d, dtype, n_mods, q):
             if p not in sys.path:
                 sys.path.insert(0, p)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        _stage_collectives_through_host()
         q.put((rank, _seeded_rank(rank, b, d, dtype, n_mods), None))
         dist.barrier()
         dist.destroy_process_group()
@@ -241,8 +221,8 @@ def _seeded_worker(rank, world, port, b, d, dtype, n_mods, q):
 
 class _ThreadRanks:
     """`world` ranks as threads of ONE process (a GPU box admits at most 6 processes on its card, so eight rank processes
-    plus the test runner cannot share it).  Same seam as _stage_collectives_through_host: all_gather_into_tensor /
-    all_reduce exchange host copies — here through a barrier-guarded slot list, reduced in rank order — and the rank /
+    plus the test runner cannot share it).  all_gather_into_tensor /
+    all_reduce exchange host copies through a barrier-guarded slot list, reduced in rank order — and the rank /
     world queries answer per thread.  The loss code and every HIP launch are the real ones.  Backward passes run on
     autograd's single device thread, one after the other, so a collective issued there cannot meet its peers: the one the
     path has (the SUM of the scalar d loss / d scale) is recorded in `deferred` and applied by the caller afterwards."""

@@ -152,13 +152,24 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
   const int dbg = kDebugSwitches ? a.dbg : 0;
   F_STAMP(0);
   // ---- which pair / tile
+  // XCD-aware: block b runs on XCD b % 8 and every XCD has its own L2, so the blocks of one XCD take CONSECUTIVE positions of
+  // the tile list, and the list walks each pair in super-tiles of 4 x 8 tiles: at nt = 16 an XCD's 32 workgroups need 4 row
+  // strips of A and 8 of B (768 rows through that L2) instead of all 2048 (r03_pmc_traffic.json: FETCH 9.2 -> see DESIGN 5)
+  const int bp = ((int)blockIdx.x & 7) * (a.n_tiles >> 3) + min((int)blockIdx.x & 7, a.n_tiles & 7) + ((int)blockIdx.x >> 3);
   int pi = 0;
 #pragma unroll 1
-  while (pi + 1 < a.n_pairs && (int)blockIdx.x >= a.p[pi + 1].tile0) ++pi;
+  while (pi + 1 < a.n_pairs && bp >= a.p[pi + 1].tile0) ++pi;
   const FusedPair& p = a.p[pi];
-  const int tile = (int)blockIdx.x - p.tile0;
   const int nt = p.nt, n = p.n, n_pad = p.n_pad;
-  const int ti = tile / nt, tj = tile % nt;
+  int ti, tj;
+  {
+    const int t = bp - p.tile0;
+    const int sr = t / (4 * nt), t2 = t - sr * 4 * nt, rh = min(4, nt - 4 * sr);
+    const int sc = t2 / (rh * 8), t3 = t2 - sc * rh * 8, cw = min(8, nt - 8 * sc);
+    ti = 4 * sr + t3 / cw;
+    tj = 8 * sc + t3 % cw;
+  }
+  const int tile = ti * nt + tj;
   const float s = *a.scale;
   const float s2 = s * LOG2E;
   unsigned* c1_row = p.cnt + (0 * nt + ti) * F_CNT_STRIDE;

@@ -187,18 +187,41 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
     constexpr int PPR = F_KS / EPP;                 // 16-byte pieces per row and stage
     constexpr int NP = 128 * PPR / F_THREADS;       // pieces per thread and stage (16 / 8)
     constexpr int RPS = F_THREADS / PPR;            // rows covered by one piece slot (8 / 16)
+    static_assert(64 % RPS == 0, "a piece slot never straddles the B / A halves of the stage image");
     const int c = tid % PPR;                        // piece within the row: K elements c*EPP ..
+    const int trow = (tid & (F_THREADS - 1)) / PPR; // 0 .. RPS-1
     long srow[NP];                                  // byte offset of the source row, -1: row beyond n (zeros)
     int lds_off[NP];
-    const char* base[NP];
+    // Which operand a piece slot belongs to is a compile-time fact (u * RPS < 64): the pointers below stay in scalar registers.
+    // (With a per-thread `row < 64` the compiler fetched p.a / p.b / p.idx_* from the kernarg segment with per-lane global loads
+    // and waited for each -- four dependent round trips before the first operand load, 1.4 us of the launch.)
+    const char* const pa = p.a;
+    const char* const pb = p.b;
+    const int32_t* const ia = p.idx_a;
+    const int32_t* const ib = p.idx_b;
+    int src_row[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) src_row[u] = (u * RPS < 64 ? tj : ti) * 64 + ((u * RPS + trow) & 63);
+    // gathered pairings: all index loads of a half in one batch (clamped, unconditional), one wait
+    if (ib != nullptr) {
+#pragma unroll
+      for (int u = 0; u < NP; ++u)
+        if (u * RPS < 64) src_row[u] = src_row[u] < n ? ib[min(src_row[u], n - 1)] : -1;
+    }
+    if (ia != nullptr) {
+#pragma unroll
+      for (int u = 0; u < NP; ++u)
+        if (u * RPS >= 64) src_row[u] = src_row[u] < n ? ia[min(src_row[u], n - 1)] : -1;
+    }
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
-      const int row = u * RPS + tid / PPR;
-      const bool isb = row < 64;
-      const int pp = (isb ? tj : ti) * 64 + (row & 63);
-      const int32_t* idx = isb ? p.idx_b : p.idx_a;
-      base[u] = isb ? p.b : p.a;
-      srow[u] = pp < n ? (long)(idx ? idx[pp] : pp) * a.d * (long)sizeof(S) : -1;
+      const int pp = (u * RPS < 64 ? tj : ti) * 64 + ((u * RPS + trow) & 63);
+      if (pp >= n) src_row[u] = -1;
+    }
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int row = u * RPS + trow;
+      srow[u] = src_row[u] >= 0 ? (long)src_row[u] * a.d * (long)sizeof(S) : -1;
       const int e0 = (c * EPP) & 63, kh = (c * EPP) >> 6;
       lds_off[u] = kh * 16384 + row * 128 + ((((e0 >> 3) ^ ((row >> 1) & 7))) << 4) + (e0 & 7) * 2;
     }
@@ -212,7 +235,8 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
 #pragma unroll
       for (int u = 0; u < NP; ++u) {
         v[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (srow[u] >= 0 && col < a.d && !(dbg & 16)) v[u] = *reinterpret_cast<const uint4*>(base[u] + srow[u] + (long)col * (long)sizeof(S));
+        if (srow[u] >= 0 && col < a.d && !(dbg & 16))
+          v[u] = *reinterpret_cast<const uint4*>((u * RPS < 64 ? pb : pa) + srow[u] + (long)col * (long)sizeof(S));
       }
     };
     auto store = [&](char* buf, const uint4 (&v)[NP]) {
@@ -419,7 +443,10 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
     constexpr int VPR = 64 / EPP;                       // V pieces per row (16 / 8)
     constexpr int NVL = CR * VPR / 64;                  // V loads per lane and chunk (8 / 4)
     constexpr int VRS = 64 / VPR;                       // rows per V load slot (4 / 8)
-    constexpr int D3 = EPP == 8 ? 3 : 2;                // chunks in flight
+    // chunks in flight.  (r03: a one-workgroup-per-CU build with 512 registers and all 8 chunks of a 1024-row pair in flight ran the
+    // loop in 3.0 us instead of 5.8 but waited 1.7 us longer for its first chunk -- the phase moves 256 KB per CU at ~40 GB/s either
+    // way; not kept)
+    constexpr int D3 = EPP == 8 ? 3 : 2;
     char* wbuf = smem + wave * 16384;                   // 2 x 8 KiB chunk images, later this wave's partial output tile
     const int li = lane & 15, q4 = li >> 2, p4 = li & 3, g1 = (lane >> 4) & 1;
     int tr_off[2];

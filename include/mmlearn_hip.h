@@ -235,6 +235,10 @@ int mmk_clip_fused_debug_stamps(unsigned long long* device_buf);
  * F.normalize(x, p=2, dim=-1, eps=1e-12) forward / backward
  * (mmlearn/tasks/contrastive_pretraining.py:428-429; modules/layers/normalization.py:34). */
 int mmk_l2norm_fwd(const void* x, void* y, float* inv_norm, int rows, int d, int dtype, void* stream);
+/* the same with a second output: y16 [rows, d] bf16 = y rounded (nullable).  The task's embeddings leave F.normalize as f32
+ * (autocast keeps it there) and the bf16 similarity kernels round them again on every read; with the twin written by the
+ * producer the one-launch loss (mmk_clip_fused_forward) reads half the bytes.  Same values bit for bit. */
+int mmk_l2norm_fwd_twin(const void* x, void* y, void* y16, float* inv_norm, int rows, int d, int dtype, void* stream);
 int mmk_l2norm_bwd(const void* x, const void* dy, const float* inv_norm, void* dx, int rows, int d, int dtype,
                    void* stream);
 

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "mmk_match_workspace_ints": [_i, _i],
     "mmk_clip_backward": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "mmk_l2norm_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mmk_l2norm_fwd_twin": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mmk_l2norm_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mmk_mask_to_index": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "mmk_gather_rows": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

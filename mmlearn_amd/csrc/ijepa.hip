@@ -17,8 +17,8 @@ constexpr int ROWS_PER_BLOCK = 4;  // 4 waves of 64
 
 // ------------------------------------------------------------------ L2 normalise
 template <typename T>
-__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, float* __restrict__ inv_norm,
-                                                         int rows, int d) {
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, bf16_t* __restrict__ y16,
+                                                         float* __restrict__ inv_norm, int rows, int d) {
   const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const T* in = x + (size_t)row * d;
@@ -44,9 +44,14 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x
       float4 v = Vec4<T>::load(in + c);
       v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
       Vec4<T>::store(out + c, v);
+      if (y16) Vec4<bf16_t>::store(y16 + (size_t)row * d + c, v);   // the rows as the bf16 similarity kernels will round them
     }
   } else {
-    for (int c = lane; c < d; c += 64) out[c] = from_f32<T>(to_f32(in[c]) * inv);
+    for (int c = lane; c < d; c += 64) {
+      const float v = to_f32(in[c]) * inv;
+      out[c] = from_f32<T>(v);
+      if (y16) y16[(size_t)row * d + c] = from_f32<bf16_t>(v);
+    }
   }
 }
 
@@ -458,19 +463,23 @@ using namespace mmk;
 
 extern "C" {
 
-int mmk_l2norm_fwd(const void* x, void* y, float* inv_norm, int rows, int d, int dtype, void* stream) {
+int mmk_l2norm_fwd_twin(const void* x, void* y, void* y16, float* inv_norm, int rows, int d, int dtype, void* stream) {
   MMK_REQUIRE(x && y && rows >= 0 && d > 0, "bad arguments");
   if (rows == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(MMK_K_L2NORM, st);
   int rc = MMK_DISPATCH_DTYPE(dtype, T, [&]() -> int {
     hipLaunchKernelGGL((l2norm_fwd_kernel<T>), dim3(cdiv(rows, ROWS_PER_BLOCK)), dim3(256), 0, st, static_cast<const T*>(x),
-                       static_cast<T*>(y), inv_norm, rows, d);
+                       static_cast<T*>(y), static_cast<bf16_t*>(y16), inv_norm, rows, d);
     return 0;
   });
   if (rc) return rc;
   MMK_LAUNCH_CHECK();
   return 0;
+}
+
+int mmk_l2norm_fwd(const void* x, void* y, float* inv_norm, int rows, int d, int dtype, void* stream) {
+  return mmk_l2norm_fwd_twin(x, y, nullptr, inv_norm, rows, d, dtype, stream);
 }
 
 int mmk_l2norm_bwd(const void* x, const void* dy, const float* inv_norm, void* dx, int rows, int d, int dtype, void* stream) {

@@ -520,13 +520,18 @@ def clip_fused_backward(run: FusedRun, grads: Sequence[tuple], scale: torch.Tens
 
 
 # ------------------------------------------------------------------ row ops
-def l2norm_fwd(x: torch.Tensor):
+def l2norm_fwd(x: torch.Tensor, twin: bool = False):
+    """-> (y, 1 / norm per row[, y rounded to bf16 when ``twin``])"""
     require_gpu(x)
     x2 = x.contiguous().view(-1, x.shape[-1])
     y = torch.empty_like(x2)
     inv = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
-    check(_lib.lib().mmk_l2norm_fwd(ptr(x2), ptr(y), ptr(inv), x2.shape[0], x2.shape[1], dtype_tag(x.dtype), stream()))
-    return y.view(x.shape), inv
+    if not twin:
+        check(_lib.lib().mmk_l2norm_fwd(ptr(x2), ptr(y), ptr(inv), x2.shape[0], x2.shape[1], dtype_tag(x.dtype), stream()))
+        return y.view(x.shape), inv
+    y16 = torch.empty(x2.shape, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mmk_l2norm_fwd_twin(ptr(x2), ptr(y), ptr(y16), ptr(inv), x2.shape[0], x2.shape[1], dtype_tag(x.dtype), stream()))
+    return y.view(x.shape), inv, y16.view(x.shape)
 
 
 def l2norm_bwd(x: torch.Tensor, dy: torch.Tensor, inv: torch.Tensor) -> torch.Tensor:

@@ -349,13 +349,20 @@ class _Run:
         if (fused_plan is None or self.world != 1 or o.modality_alignment or o.l2_normalize or self.compute != COMPUTE_BF16
                 or any(v.rows is not None for v in views.values())):
             return False
-        first = views[self.pairs[0].ma].src
-        if any(views[m].src.dtype != first.dtype or views[m].src.shape[1] != self.d for p in self.pairs for m in (p.ma, p.mb)):
+        src = {m: views[m].src for p in self.pairs for m in (p.ma, p.mb)}
+        # f32 rows that carry their own rounding to bf16 (``ops.l2_normalize`` under bf16 autocast): read the copy -- the kernel
+        # would round every row to the same bits while staging it
+        twins = {m: getattr(views[m].local, "_mmk_bf16", None) for m in src}
+        if all(t is not None and t.dtype == torch.bfloat16 and t.shape == src[m].shape and t.device == src[m].device and t.is_contiguous()
+               and src[m].dtype == torch.float32 for m, t in twins.items()):
+            src = twins
+        first = next(iter(src.values()))
+        if any(t.dtype != first.dtype or t.shape[1] != self.d for t in src.values()):
             return False
         plan = fused_plan(first.device, [p.mg.n for p in self.pairs], self.d, first.dtype)
         if plan is None:
             return False
-        loss, run = K.clip_fused_forward(plan, [(views[p.ma].src, views[p.mb].src, p.mg.idx_a, p.mg.idx_b, p.mg.n, float(p.spec.weight))
+        loss, run = K.clip_fused_forward(plan, [(src[p.ma], src[p.mb], p.mg.idx_a, p.mg.idx_b, p.mg.n, float(p.spec.weight))
                                                 for p in self.pairs], self.d, self.scale32, self.needs_grad)
         self.fused, self.fused_loss = run, loss
         return True

@@ -27,24 +27,37 @@ MaskList = Union[torch.Tensor, Sequence[torch.Tensor]]
 # ------------------------------------------------------------------ L2 normalise
 class _L2Normalize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: torch.Tensor):
+    def forward(ctx, x: torch.Tensor, twin: bool):
+        if twin:
+            y, inv, y16 = K.l2norm_fwd(x, twin=True)
+            ctx.mark_non_differentiable(y16)
+            ctx.save_for_backward(x, inv)
+            return y, y16
         y, inv = K.l2norm_fwd(x)
         ctx.save_for_backward(x, inv)
         return y
 
     @staticmethod
-    def backward(ctx, dy: torch.Tensor):
+    def backward(ctx, dy: torch.Tensor, *_):
         x, inv = ctx.saved_tensors
-        return K.l2norm_bwd(x, dy.to(x.dtype), inv)
+        return K.l2norm_bwd(x, dy.to(x.dtype), inv), None
 
 
 def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     """``F.normalize(x, p=2, dim=-1, eps=1e-12)`` on MI355X.  Under bf16/fp16 autocast the result is
-    f32, like ``F.normalize`` (an autocast-to-f32 op)."""
+    f32, like ``F.normalize`` (an autocast-to-f32 op).  Under bf16 autocast a 2-D result also carries its own rounding to bf16
+    as ``y._mmk_bf16`` (written by the same kernel): the bf16 similarity kernels of :class:`ContrastiveLoss` would round these
+    rows on every read, and the one-launch loss takes the copy instead -- same bits, half the bytes."""
     K.require_gpu(x)
-    if torch.is_autocast_enabled() and x.dtype != torch.float32:
+    autocast = torch.is_autocast_enabled()
+    if autocast and x.dtype != torch.float32:
         x = x.float()
-    return _L2Normalize.apply(x)
+    if (autocast and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.dtype == torch.float32 and x.dim() == 2
+            and x.shape[1] % 8 == 0):
+        y, y16 = _L2Normalize.apply(x, True)
+        y._mmk_bf16 = y16
+        return y
+    return _L2Normalize.apply(x, False)
 
 
 # ------------------------------------------------------------------ masks -> indices

@@ -162,9 +162,10 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale, upstre
             dr.dx[rows] = dx.to(dr.dx.dtype)
 
 
-def l2norm_fwd(x):
+def l2norm_fwd(x, twin=False):
     inv = 1.0 / x.norm(dim=-1).clamp_min(1e-12)
-    return x * inv[..., None], inv
+    y = x * inv[..., None]
+    return (y, inv, y.bfloat16()) if twin else (y, inv)
 
 
 def l2norm_bwd(x, dy, inv):

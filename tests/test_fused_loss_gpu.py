@@ -175,3 +175,38 @@ def test_shapes_outside_the_one_launch_path_are_refused():
     assert big is None
     ok = K.clip_fused_plan(dev, [1024, 1024], 512, torch.float32)
     assert ok is not None and ok.grid == 512 <= ok.capacity
+
+
+def test_l2_normalize_twin_feeds_the_one_launch_loss_with_the_same_bits(monkeypatch):
+    """Under bf16 autocast ``ops.l2_normalize`` leaves, next to its f32 result, the rows rounded to bf16 (``_mmk_bf16``); the
+    one-launch loss reads that copy instead of rounding the f32 rows itself: same loss, same gradients, bit for bit."""
+    import mmlearn_amd.losses as L
+    from mmlearn_amd import kernels as K
+    from mmlearn_amd import ops
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    raw = {m: torch.randn(1024, 512, generator=g).to(dev).bfloat16() for m in ("rgb", "text")}
+    ids = torch.stack([torch.zeros(1024, dtype=torch.long), torch.arange(1024)], 1).to(dev)
+    seen = []
+    real = K.clip_fused_forward
+    monkeypatch.setattr(K, "clip_fused_forward", lambda plan, pairs, *a, **k: (seen.append(pairs[0][0].dtype), real(plan, pairs, *a, **k))[1])
+    out = []
+    for use_twin in (True, False):
+        leaves = {m: t.clone().requires_grad_(True) for m, t in raw.items()}
+        s = torch.tensor(1 / 0.07, device=dev, requires_grad=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            emb = {m: ops.l2_normalize(t) for m, t in leaves.items()}
+            for m, y in emb.items():
+                assert y.dtype == torch.float32 and torch.equal(y._mmk_bf16, y.detach().bfloat16())
+                if not use_twin:
+                    del y._mmk_bf16
+            loss = L.ContrastiveLoss()({f"{m}_embedding": y for m, y in emb.items()}, {m: ids for m in emb}, s,
+                                       [L.LossPairSpec(("rgb", "text"), 1.0)])
+        loss.backward()
+        out.append((loss.detach().clone(), s.grad.clone(), {m: t.grad.clone() for m, t in leaves.items()}))
+    assert seen == [torch.bfloat16, torch.float32]
+    (l0, d0, g0), (l1, d1, g1) = out
+    assert torch.equal(l0, l1) and torch.equal(d0, d1)
+    for m in g0:
+        assert torch.equal(g0[m], g1[m])

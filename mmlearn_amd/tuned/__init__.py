@@ -16,6 +16,7 @@ candidate kernels)
 """
 
 import os
+import warnings
 
 import torch
 
@@ -37,6 +38,9 @@ def enable(path: str = None) -> bool:
     ok = bool(tunable.read_file(path))
     if not ok:
         tunable.enable(False)
+        # not silent: without the selections the encoder GEMMs run the library's default heuristic (about 3 ms of a 200 ms step)
+        warnings.warn(f"mmlearn_amd.tuned: {path} was refused by TunableOp's validators (recorded with another PyTorch / hipBLASLt / "
+                      "rocBLAS build?); library GEMMs stay on the default heuristic", RuntimeWarning, stacklevel=2)
     return ok
 
 

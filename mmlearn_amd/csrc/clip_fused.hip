@@ -85,7 +85,8 @@ struct FusedArgs {
 // phase stamps (100 MHz clock): compiled out of the product build
 #define F_STAMP(k)                                                                                                          \
   do {                                                                                                                      \
-    if (kDebugSwitches && a.stamps != nullptr && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    if (kDebugSwitches && a.stamps != nullptr && threadIdx.x == 0 && (int)blockIdx.x < a.n_tiles)                                       \
+      a.stamps[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime();                                                        \
   } while (0)
 
 __device__ __forceinline__ unsigned ld_cnt(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -151,6 +152,11 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
 
   const int dbg = kDebugSwitches ? a.dbg : 0;
   F_STAMP(0);
+  // Workgroups beyond the tile count are HELPERS: the host launches max(tiles, gradient jobs) workgroups (within the co-resident
+  // capacity), because several small pairs have many more gradient jobs than tiles -- three pairs of 256 rows: 48 tiles, 192
+  // jobs -- and a grid of 48 ran four jobs back to back per workgroup on a fifth of the chip.  A helper skips phases 1 and 2.
+  const bool helper = (int)blockIdx.x >= a.n_tiles;
+  if (!helper) {
   // ---- which pair / tile
   // XCD-aware: block b runs on XCD b % 8 and every XCD has its own L2, so the blocks of one XCD take CONSECUTIVE positions of
   // the tile list, and the list walks each pair in super-tiles of 4 x 8 tiles: at nt = 16 an XCD's 32 workgroups need 4 row
@@ -431,6 +437,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
     }
   }
 
+  }   // !helper
   F_STAMP(4);
   // =============================================================== phase 3: dA = G B, dB = G^T A
   if (a.want_grad) {
@@ -817,10 +824,12 @@ int mmk_clip_fused_forward(const mmk_fused_pair* pairs, int n_pairs, int d, int 
   hipStream_t st = static_cast<hipStream_t>(stream);
   {
     ProfEvents pe(MMK_K_CLIP_FUSED);
+    // helpers for the gradient phase (see the kernel): as many workgroups as there are jobs, within what is co-resident
+    const int grid = a.want_grad ? std::min(cap, std::max(a.n_tiles, a.n_jobs)) : a.n_tiles;
     if (src_dtype == MMK_F32)
-      hipExtLaunchKernelGGL(clip_fused_kernel<float>, dim3(a.n_tiles), dim3(F_THREADS), F_LDS, st, pe.start, pe.stop, 0, a);
+      hipExtLaunchKernelGGL(clip_fused_kernel<float>, dim3(grid), dim3(F_THREADS), F_LDS, st, pe.start, pe.stop, 0, a);
     else
-      hipExtLaunchKernelGGL(clip_fused_kernel<bf16_t>, dim3(a.n_tiles), dim3(F_THREADS), F_LDS, st, pe.start, pe.stop, 0, a);
+      hipExtLaunchKernelGGL(clip_fused_kernel<bf16_t>, dim3(grid), dim3(F_THREADS), F_LDS, st, pe.start, pe.stop, 0, a);
   }
   MMK_LAUNCH_CHECK();
   return 0;

@@ -26,10 +26,7 @@ def _worker(rank, world, port, q, streams):
         for p in (ROOT, os.path.join(ROOT, "tests")):
             if p not in sys.path:
                 sys.path.insert(0, p)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        from test_dist_gpu import _stage_collectives_through_host
-
-        _stage_collectives_through_host()
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # the loss's collectives run on device tensors as they are
         import bench
         from mmlearn_amd import ContrastiveLoss
 

@@ -146,8 +146,7 @@ def _recall_rank_worker(rank, world, port, q):
             if p not in sys.path:
                 sys.path.insert(0, p)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        from test_dist_gpu import _stage_collectives_through_host
-        _stage_collectives_through_host()   # two ranks share cuda:0: device collectives go through host copies
+        # two ranks share cuda:0; gloo serves the metric's all_reduce / all_gather_into_tensor on device tensors as they are
         from mmlearn_amd.metrics import RetrievalRecallAtK
         g = torch.Generator().manual_seed(5)
         x = torch.randn(2, world, 48, 32, generator=g)                     # [update, rank, rows, D]

@@ -444,8 +444,15 @@ class _FusedPlan:
         self.pool: list = []
         self.device = device
 
-    def take(self) -> torch.Tensor:
-        return self.pool.pop() if self.pool else torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
+    def take(self, stream_handle: int) -> torch.Tensor:
+        """A workspace last used on THIS stream (its previous launches are ordered before ours), else a fresh zeroed one."""
+        for k in range(len(self.pool) - 1, -1, -1):
+            if self.pool[k][0] == stream_handle:
+                return self.pool.pop(k)[1]
+        return torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
+
+    def give(self, stream_handle: int, ws: torch.Tensor) -> None:
+        self.pool.append((stream_handle, ws))
 
 
 _FUSED_PLANS: dict = {}
@@ -469,17 +476,16 @@ class FusedRun:
 
     __slots__ = ("plan", "ws", "arr", "n_pairs", "d", "dtype", "ds_raw", "ds_acc", "keep", "stream")
 
-    def release(self) -> None:
+    def release(self, last_stream: Optional[int] = None) -> None:
+        """Hand the workspace back, tagged with the stream its last launch went to (the pool only reuses it on that stream)."""
         ws, self.ws = self.ws, None
         if ws is not None and self.plan is not None:
-            self.plan.pool.append(ws)
+            self.plan.give(self.stream if last_stream is None else last_stream, ws)
 
     def __del__(self):
-        # forward without backward (evaluation, a dropped graph): the launches that use the workspace are already queued
-        # on the stream the next user will launch on, so handing it back is safe
+        # forward without backward (evaluation, a dropped graph): the launch that used the workspace is queued on self.stream
         try:
-            if self.stream == stream():
-                self.release()
+            self.release()
         except Exception:
             pass
 
@@ -497,7 +503,7 @@ def clip_fused_forward(plan: _FusedPlan, pairs: Sequence[tuple], d: int, scale: 
     run = FusedRun()
     run.plan, run.arr, run.n_pairs, run.d, run.dtype, run.keep = plan, arr, len(pairs), d, pairs[0][0].dtype, keep
     run.stream = stream()
-    run.ws = plan.take()
+    run.ws = plan.take(run.stream)
     out = torch.empty(3, dtype=torch.float32, device=dev)   # [loss, raw d loss / d scale, 0 = accumulator for backward's dscale]
     run.ds_raw, run.ds_acc = out[1:], out[2:]
     check(_lib.lib().mmk_clip_fused_forward(C.cast(arr, C.c_void_p), len(pairs), d, dtype_tag(run.dtype), ptr(scale), ptr(run.ws), plan.ws_bytes,
@@ -508,7 +514,9 @@ def clip_fused_forward(plan: _FusedPlan, pairs: Sequence[tuple], d: int, scale: 
 def clip_fused_backward(run: FusedRun, grads: Sequence[tuple], scale: torch.Tensor, upstream: torch.Tensor, dscale: Optional[torch.Tensor]) -> None:
     """``grads``: [(da, db, accumulate_a, accumulate_b)] per pair (user-dtype buffers, or zeroed f32 ones when accumulating).
     ONE launch; the workspace goes back to the pool."""
-    assert run.ws is not None, "fused loss: backward called twice (retain_graph is not supported by the one-launch path)"
+    if run.ws is None:
+        raise RuntimeError("mmlearn_amd: second backward through the one-launch loss (its raw gradient sums are released after the "
+                           "first; set mmlearn_amd.kernels.FUSED_LOSS = False if retain_graph is needed)")
     for k, (da, db, acc_a, acc_b) in enumerate(grads):
         e = run.arr[k]
         e.da, e.db, e.da_accumulate, e.db_accumulate = ptr(da), ptr(db), int(acc_a), int(acc_b)
@@ -516,7 +524,7 @@ def clip_fused_backward(run: FusedRun, grads: Sequence[tuple], scale: torch.Tens
     assert all(g[0].dtype == dt and g[1].dtype == dt for g in grads)
     check(_lib.lib().mmk_clip_fused_backward(C.cast(run.arr, C.c_void_p), run.n_pairs, run.d, dtype_tag(dt), ptr(scale), ptr(upstream), ptr(run.ws),
                                              run.plan.ws_bytes, ptr(run.ds_raw), ptr(dscale), stream()))
-    run.release()
+    run.release(stream())
 
 
 # ------------------------------------------------------------------ row ops

@@ -364,7 +364,7 @@ class _Run:
             return False
         loss, run = K.clip_fused_forward(plan, [(src[p.ma], src[p.mb], p.mg.idx_a, p.mg.idx_b, p.mg.n, float(p.spec.weight))
                                                 for p in self.pairs], self.d, self.scale32, self.needs_grad)
-        self.fused, self.fused_loss = run, loss
+        self.fused, self.fused_loss, self.fused_taken = run, loss, True
         return True
 
     def _fused_backward(self, grad_out: torch.Tensor):
@@ -585,6 +585,9 @@ class _Run:
     def backward(self, grad_out: torch.Tensor):
         if getattr(self, "fused", None) is not None:
             return self._fused_backward(grad_out)
+        if getattr(self, "fused_taken", False):
+            raise RuntimeError("mmlearn_amd: second backward through the one-launch loss (its raw gradient sums are released after the "
+                               "first; set mmlearn_amd.kernels.FUSED_LOSS = False if retain_graph is needed)")
         o, W = self.o, self.world
         dev = self.scale32.device
         upstream = grad_out.detach().to(torch.float32).reshape(1).contiguous()

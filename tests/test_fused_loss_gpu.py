@@ -210,3 +210,36 @@ def test_l2_normalize_twin_feeds_the_one_launch_loss_with_the_same_bits(monkeypa
     assert torch.equal(l0, l1) and torch.equal(d0, d1)
     for m in g0:
         assert torch.equal(g0[m], g1[m])
+
+
+def test_workspaces_are_per_stream_and_a_second_backward_is_refused():
+    import mmlearn_amd.losses as L
+    from mmlearn_amd import kernels as K
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    a = torch.nn.functional.normalize(torch.randn(320, 64, generator=g), dim=-1).to(dev)
+    b = torch.nn.functional.normalize(torch.randn(320, 64, generator=g), dim=-1).to(dev)
+    s = torch.tensor([10.0], device=dev)
+    plan = K.clip_fused_plan(dev, [320], 64, torch.float32)
+    plan.pool.clear()
+    side = torch.cuda.Stream()
+    loss0, run0 = K.clip_fused_forward(plan, [(a, b, None, None, 320, 1.0)], 64, s, False)
+    run0.release()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        loss1, run1 = K.clip_fused_forward(plan, [(a, b, None, None, 320, 1.0)], 64, s, False)
+        assert len(plan.pool) == 1           # the main stream's workspace stayed in the pool: another stream got its own
+        run1.release()
+    torch.cuda.current_stream().wait_stream(side)
+    assert len(plan.pool) == 2 and {h for h, _ in plan.pool} == {torch.cuda.current_stream().cuda_stream, side.cuda_stream}
+    assert float(loss0) == float(loss1)
+
+    ea, eb = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ids = torch.stack([torch.zeros(320, dtype=torch.long), torch.arange(320)], 1).to(dev)
+    sc = torch.tensor(10.0, device=dev, requires_grad=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = L.ContrastiveLoss()({"rgb_embedding": ea, "text_embedding": eb}, {"rgb": ids, "text": ids}, sc, [L.LossPairSpec(("rgb", "text"))])
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        loss.backward()

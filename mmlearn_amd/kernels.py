@@ -8,6 +8,7 @@ ATen math runs here.  There is deliberately no CPU path: CPU tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Optional, Sequence
 
@@ -433,7 +434,7 @@ class _FusedPlan:
     to the pool when its backward has run (or the forward's handle is dropped), so two losses alive at once never share
     raw-gradient storage; the counters inside are zero again whenever a launch has completed, so reuse needs no memset."""
 
-    __slots__ = ("ws_bytes", "grid", "capacity", "pool", "device")
+    __slots__ = ("ws_bytes", "grid", "capacity", "pool", "device", "allocs")
 
     def __init__(self, device: torch.device, ns: tuple, d: int, dtype: torch.dtype):
         n_arr = (C.c_int32 * len(ns))(*ns)
@@ -443,12 +444,14 @@ class _FusedPlan:
         self.ws_bytes, self.grid, self.capacity = wsb.value, grid.value, cap.value
         self.pool: list = []
         self.device = device
+        self.allocs = 0   # workspaces ever allocated (a steady-state loop needs one or two)
 
     def take(self, stream_handle: int) -> torch.Tensor:
         """A workspace last used on THIS stream (its previous launches are ordered before ours), else a fresh zeroed one."""
         for k in range(len(self.pool) - 1, -1, -1):
             if self.pool[k][0] == stream_handle:
                 return self.pool.pop(k)[1]
+        self.allocs += 1
         return torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
 
     def give(self, stream_handle: int, ws: torch.Tensor) -> None:
@@ -474,7 +477,7 @@ def clip_fused_plan(device: torch.device, ns: Sequence[int], d: int, dtype: torc
 class FusedRun:
     """Forward state of one fused call: keeps the workspace (raw gradient sums) until ``backward`` or deletion."""
 
-    __slots__ = ("plan", "ws", "arr", "n_pairs", "d", "dtype", "ds_raw", "ds_acc", "keep", "stream")
+    __slots__ = ("plan", "ws", "arr", "n_pairs", "d", "dtype", "ds_raw", "ds_acc", "keep", "stream", "n_bwd")
 
     def release(self, last_stream: Optional[int] = None) -> None:
         """Hand the workspace back, tagged with the stream its last launch went to (the pool only reuses it on that stream)."""
@@ -502,7 +505,7 @@ def clip_fused_forward(plan: _FusedPlan, pairs: Sequence[tuple], d: int, scale: 
         keep += [a, b, ia, ib]
     run = FusedRun()
     run.plan, run.arr, run.n_pairs, run.d, run.dtype, run.keep = plan, arr, len(pairs), d, pairs[0][0].dtype, keep
-    run.stream = stream()
+    run.stream, run.n_bwd = stream(), 0
     run.ws = plan.take(run.stream)
     out = torch.empty(3, dtype=torch.float32, device=dev)   # [loss, raw d loss / d scale, 0 = accumulator for backward's dscale]
     run.ds_raw, run.ds_acc = out[1:], out[2:]
@@ -513,10 +516,10 @@ def clip_fused_forward(plan: _FusedPlan, pairs: Sequence[tuple], d: int, scale: 
 
 def clip_fused_backward(run: FusedRun, grads: Sequence[tuple], scale: torch.Tensor, upstream: torch.Tensor, dscale: Optional[torch.Tensor]) -> None:
     """``grads``: [(da, db, accumulate_a, accumulate_b)] per pair (user-dtype buffers, or zeroed f32 ones when accumulating).
-    ONE launch; the workspace goes back to the pool."""
+    ONE launch.  The raw sums are only read, so a second backward (``retain_graph=True``) repeats it; the workspace returns to the
+    pool when the run is dropped."""
     if run.ws is None:
-        raise RuntimeError("mmlearn_amd: second backward through the one-launch loss (its raw gradient sums are released after the "
-                           "first; set mmlearn_amd.kernels.FUSED_LOSS = False if retain_graph is needed)")
+        raise RuntimeError("mmlearn_amd: backward through a one-launch loss whose workspace was already released")
     for k, (da, db, acc_a, acc_b) in enumerate(grads):
         e = run.arr[k]
         e.da, e.db, e.da_accumulate, e.db_accumulate = ptr(da), ptr(db), int(acc_a), int(acc_b)
@@ -524,7 +527,7 @@ def clip_fused_backward(run: FusedRun, grads: Sequence[tuple], scale: torch.Tens
     assert all(g[0].dtype == dt and g[1].dtype == dt for g in grads)
     check(_lib.lib().mmk_clip_fused_backward(C.cast(run.arr, C.c_void_p), run.n_pairs, run.d, dtype_tag(dt), ptr(scale), ptr(upstream), ptr(run.ws),
                                              run.plan.ws_bytes, ptr(run.ds_raw), ptr(dscale), stream()))
-    run.release(stream())
+    run.stream = stream()   # the workspace's last launch; it goes back to the pool when the autograd graph lets go of the run
 
 
 # ------------------------------------------------------------------ row ops

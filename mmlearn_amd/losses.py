@@ -280,7 +280,10 @@ class _Run:
         # ---- small batches on one rank: the whole loss AND its gradients in one resident-grid launch (csrc/clip_fused.hip)
         self.fused = None
         if self.pairs and self._try_fused(views):
-            return self.fused_loss
+            # not kept on self: the returned tensor's grad_fn owns this run, a reference back would make a cycle, and the run's
+            # workspace goes back to the pool when the run is dropped (by reference count, not by a later gc pass)
+            loss, self.fused_loss = self.fused_loss, None
+            return loss
 
         # ---- operand packing per pair
         for p in self.pairs:
@@ -364,7 +367,7 @@ class _Run:
             return False
         loss, run = K.clip_fused_forward(plan, [(src[p.ma], src[p.mb], p.mg.idx_a, p.mg.idx_b, p.mg.n, float(p.spec.weight))
                                                 for p in self.pairs], self.d, self.scale32, self.needs_grad)
-        self.fused, self.fused_loss, self.fused_taken = run, loss, True
+        self.fused, self.fused_loss = run, loss
         return True
 
     def _fused_backward(self, grad_out: torch.Tensor):
@@ -390,10 +393,14 @@ class _Run:
             t = self.embeddings[key_of[n]]
             dt = _ACCUM_DTYPE if (a_ or mixed) else t.dtype
             grads[n] = (torch.empty if (covered[n] and not a_) else torch.zeros)(t.shape, dtype=dt, device=dev)
-        run, self.fused = self.fused, None
+        run = self.fused   # kept: the kernel's raw sums are only read here, a second backward (retain_graph) repeats the launch
         want_ds = self.logit_scale.requires_grad
+        # d loss / d scale accumulates into a word the forward launch left at zero; a repeated backward gets a fresh one (the first
+        # one's may have become the parameter's .grad)
+        ds_acc = run.ds_acc if run.n_bwd == 0 else torch.zeros(1, dtype=torch.float32, device=dev)
+        run.n_bwd += 1
         K.clip_fused_backward(run, [(grads[p.ma], grads[p.mb], acc[p.ma], acc[p.mb]) for p in self.pairs], self.scale32, upstream,
-                              run.ds_acc if want_ds else None)
+                              ds_acc if want_ds else None)
         out = []
         for key, t in self.embeddings.items():
             g = grads.get(name_of[key])
@@ -401,7 +408,7 @@ class _Run:
                 out.append(torch.zeros_like(t) if t.requires_grad else None)
             else:
                 out.append(g if g.dtype == t.dtype else g.to(t.dtype))
-        ds = run.ds_acc.reshape(self.logit_scale.shape).to(self.logit_scale.dtype) if want_ds else None
+        ds = ds_acc.reshape(self.logit_scale.shape).to(self.logit_scale.dtype) if want_ds else None
         return ds, out
 
     def _build_alignment(self, views: dict, dev) -> None:
@@ -574,7 +581,8 @@ class _Run:
         if not terms:  # this rank owns no rows (e.g. it lacks a modality): graph-attached zero
             return torch.zeros((), dtype=torch.float32, device=dev)
         if self.fused_loss is not None and not exchange_sum:
-            return self.fused_loss
+            loss, self.fused_loss = self.fused_loss, None   # (no reference from the run back to its own output: see forward)
+            return loss
         out = None
         for i0 in range(0, len(terms), 2 * K.MAX_DIRS_PER_CALL):
             part = K.reduce_sums(terms[i0:i0 + 2 * K.MAX_DIRS_PER_CALL], weights[i0:i0 + 2 * K.MAX_DIRS_PER_CALL])
@@ -585,9 +593,6 @@ class _Run:
     def backward(self, grad_out: torch.Tensor):
         if getattr(self, "fused", None) is not None:
             return self._fused_backward(grad_out)
-        if getattr(self, "fused_taken", False):
-            raise RuntimeError("mmlearn_amd: second backward through the one-launch loss (its raw gradient sums are released after the "
-                               "first; set mmlearn_amd.kernels.FUSED_LOSS = False if retain_graph is needed)")
         o, W = self.o, self.world
         dev = self.scale32.device
         upstream = grad_out.detach().to(torch.float32).reshape(1).contiguous()

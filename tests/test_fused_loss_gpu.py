@@ -159,7 +159,7 @@ def test_many_calls_on_one_workspace_are_bit_identical_and_forward_only_works():
         else:
             assert got["loss"] == first["loss"] and got["dscale"] == first["dscale"]
             assert np.array_equal(got["grads"]["rgb"], first["grads"]["rgb"]) and np.array_equal(got["grads"]["text"], first["grads"]["text"])
-    assert len(first["plan"].pool) == 1   # one workspace served every call
+    assert len(first["plan"].pool) <= 2   # every call was served from the pool (a run gives its workspace back when it is dropped)
 
 
 def test_shapes_outside_the_one_launch_path_are_refused():
@@ -212,7 +212,7 @@ def test_l2_normalize_twin_feeds_the_one_launch_loss_with_the_same_bits(monkeypa
         assert torch.equal(g0[m], g1[m])
 
 
-def test_workspaces_are_per_stream_and_a_second_backward_is_refused():
+def test_workspaces_are_per_stream_and_a_second_backward_repeats_the_first():
     import mmlearn_amd.losses as L
     from mmlearn_amd import kernels as K
 
@@ -240,6 +240,9 @@ def test_workspaces_are_per_stream_and_a_second_backward_is_refused():
     sc = torch.tensor(10.0, device=dev, requires_grad=True)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         loss = L.ContrastiveLoss()({"rgb_embedding": ea, "text_embedding": eb}, {"rgb": ids, "text": ids}, sc, [L.LossPairSpec(("rgb", "text"))])
+    # retain_graph: the kernel's raw gradient sums stay in the run's workspace until the graph lets go of it, so a second
+    # backward repeats the finalize launch and autograd accumulates it
     loss.backward(retain_graph=True)
-    with pytest.raises(RuntimeError, match="second backward"):
-        loss.backward()
+    g1 = (ea.grad.clone(), eb.grad.clone(), sc.grad.clone())
+    loss.backward()
+    assert torch.equal(ea.grad, 2 * g1[0]) and torch.equal(eb.grad, 2 * g1[1]) and torch.equal(sc.grad, 2 * g1[2])

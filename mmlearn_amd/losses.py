@@ -73,6 +73,9 @@ def _unpack_keys(keys: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------------------------
+_FUSED_MAX_GROUPS = 4   # launches of the one-launch kernel per loss call before the tiled path is the better deal
+
+
 @dataclass
 class _View:
     """One modality as seen by the loss: rows of every rank (compact, rank order)."""
@@ -344,9 +347,10 @@ class _Run:
         return loss
 
     def _try_fused(self, views: dict) -> bool:
-        """One rank, no alignment term, no in-loss normalisation, bf16 arithmetic, <= 4 pairs of <= 1024 matched rows whose
-        tile grid is co-resident: ONE launch computes the loss value and leaves the raw gradient sums in a pooled workspace
-        (``kernels.clip_fused_forward``); ``backward`` is one more launch.  Anything else takes the tiled multi-launch path."""
+        """One rank, no alignment term, no in-loss normalisation, bf16 arithmetic, pairs of <= 1024 matched rows: ONE launch per
+        group of pairs whose tile grid is co-resident (usually one group) computes the loss value and leaves the raw gradient
+        sums in a pooled workspace (``kernels.clip_fused_forward``); ``backward`` is one more launch per group.  Anything else
+        takes the tiled multi-launch path."""
         o = self.o
         fused_plan = getattr(K, "clip_fused_plan", None)   # absent from the CPU test double
         if (fused_plan is None or self.world != 1 or o.modality_alignment or o.l2_normalize or self.compute != COMPUTE_BF16
@@ -362,12 +366,30 @@ class _Run:
         first = next(iter(src.values()))
         if any(t.dtype != first.dtype or t.shape[1] != self.d for t in src.values()):
             return False
-        plan = fused_plan(first.device, [p.mg.n for p in self.pairs], self.d, first.dtype)
-        if plan is None:
+        # Pairs in launch groups: as many consecutive pairs per launch as the kernel takes and the device holds at once (three pairs
+        # of 1024 rows are 768 tiles for 512 resident slots: two launches, 2 + 1).  A pair that does not fit a launch of its own,
+        # or more than _FUSED_MAX_GROUPS launches, sends everything to the tiled path.
+        groups, cur, cur_plan = [], [], None
+        for p in self.pairs:
+            plan = fused_plan(first.device, [q.mg.n for q in cur] + [p.mg.n], self.d, first.dtype) if len(cur) < K.FUSED_MAX_PAIRS else None
+            if plan is None:
+                if cur:
+                    groups.append((cur, cur_plan))
+                cur, cur_plan = [p], fused_plan(first.device, [p.mg.n], self.d, first.dtype)
+                if cur_plan is None:
+                    return False
+            else:
+                cur, cur_plan = cur + [p], plan
+        groups.append((cur, cur_plan))
+        if len(groups) > _FUSED_MAX_GROUPS:
             return False
-        loss, run = K.clip_fused_forward(plan, [(src[p.ma], src[p.mb], p.mg.idx_a, p.mg.idx_b, p.mg.n, float(p.spec.weight))
-                                                for p in self.pairs], self.d, self.scale32, self.needs_grad)
-        self.fused, self.fused_loss = run, loss
+        runs, loss = [], None
+        for members, plan in groups:
+            part, run = K.clip_fused_forward(plan, [(src[p.ma], src[p.mb], p.mg.idx_a, p.mg.idx_b, p.mg.n, float(p.spec.weight))
+                                                    for p in members], self.d, self.scale32, self.needs_grad)
+            runs.append((members, run))
+            loss = part if loss is None else loss + part
+        self.fused, self.fused_loss = runs, loss
         return True
 
     def _fused_backward(self, grad_out: torch.Tensor):
@@ -393,14 +415,16 @@ class _Run:
             t = self.embeddings[key_of[n]]
             dt = _ACCUM_DTYPE if (a_ or mixed) else t.dtype
             grads[n] = (torch.empty if (covered[n] and not a_) else torch.zeros)(t.shape, dtype=dt, device=dev)
-        run = self.fused   # kept: the kernel's raw sums are only read here, a second backward (retain_graph) repeats the launch
+        runs = self.fused   # kept: the kernels' raw sums are only read here, a second backward (retain_graph) repeats the launches
         want_ds = self.logit_scale.requires_grad
-        # d loss / d scale accumulates into a word the forward launch left at zero; a repeated backward gets a fresh one (the first
-        # one's may have become the parameter's .grad)
-        ds_acc = run.ds_acc if run.n_bwd == 0 else torch.zeros(1, dtype=torch.float32, device=dev)
-        run.n_bwd += 1
-        K.clip_fused_backward(run, [(grads[p.ma], grads[p.mb], acc[p.ma], acc[p.mb]) for p in self.pairs], self.scale32, upstream,
-                              ds_acc if want_ds else None)
+        # d loss / d scale accumulates into a word the (first) forward launch left at zero; a repeated backward gets a fresh one
+        # (the first one's may have become the parameter's .grad)
+        head = runs[0][1]
+        ds_acc = head.ds_acc if head.n_bwd == 0 else torch.zeros(1, dtype=torch.float32, device=dev)
+        head.n_bwd += 1
+        for members, run in runs:
+            K.clip_fused_backward(run, [(grads[p.ma], grads[p.mb], acc[p.ma], acc[p.mb]) for p in members], self.scale32, upstream,
+                                  ds_acc if want_ds else None)
         out = []
         for key, t in self.embeddings.items():
             g = grads.get(name_of[key])

@@ -246,3 +246,31 @@ def test_workspaces_are_per_stream_and_a_second_backward_repeats_the_first():
     g1 = (ea.grad.clone(), eb.grad.clone(), sc.grad.clone())
     loss.backward()
     assert torch.equal(ea.grad, 2 * g1[0]) and torch.equal(eb.grad, 2 * g1[1]) and torch.equal(sc.grad, 2 * g1[2])
+
+
+def test_three_pairs_of_1024_rows_run_as_two_launches(monkeypatch):
+    """768 tiles do not fit 512 resident slots: ``ContrastiveLoss`` groups the pairs (2 + 1) and runs the one-launch kernel twice;
+    loss, every embedding gradient (two writers per modality, across the two launches) and d loss / d scale against the oracle."""
+    import mmlearn_amd.losses as L
+    from mmlearn_amd import kernels as K
+
+    dev = _dev()
+    g = np.random.default_rng(17)
+    n, d = 1024, 256
+    mats = {m: _unit(g, n, d) for m in ("rgb", "text", "audio")}
+    perm = g.permutation(n)
+    ids = {"rgb": _ids(range(n)), "text": _ids(perm), "audio": _ids(range(n))}
+    spec = [(("rgb", "text"), 1.0), (("rgb", "audio"), 0.5), (("text", "audio"), 0.25)]
+    calls = []
+    real = K.clip_fused_forward
+    monkeypatch.setattr(K, "clip_fused_forward", lambda plan, pairs, *a, **k: (calls.append(len(pairs)), real(plan, pairs, *a, **k))[1])
+    emb = {m: torch.from_numpy(v).to(dev).requires_grad_(True) for m, v in mats.items()}
+    s = torch.tensor(1 / 0.07, device=dev, requires_grad=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = L.ContrastiveLoss()({f"{m}_embedding": t for m, t in emb.items()}, {m: torch.from_numpy(v).to(dev) for m, v in ids.items()}, s,
+                                   [L.LossPairSpec(m, w) for m, w in spec])
+    loss.backward()
+    assert calls == [2, 1]
+    ref = _oracle(mats, ids, spec, 1 / 0.07, "float32")
+    got = {"loss": float(loss.detach()), "grads": {m: t.grad.cpu().numpy() for m, t in emb.items()}, "dscale": float(s.grad)}
+    _check(got, ref, 1e-2)

@@ -1125,6 +1125,11 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinBatch batch
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;
+    for (int k = 0; k < p.n_extra; ++k) {
+      const float ck = p.kappa_extra[k] * (*scale_ptr) * (*upstream);
+      const float4 t = *reinterpret_cast<const float4*>(p.extra[k] + (size_t)i * p.slab_ld + c);
+      v.x = fmaf(ck, t.x, v.x); v.y = fmaf(ck, t.y, v.y); v.z = fmaf(ck, t.z, v.z); v.w = fmaf(ck, t.w, v.w);
+    }
     *reinterpret_cast<float4*>(buf + c) = v;
     if (p.normalize) {
       float xv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1159,7 +1164,12 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const FinBatch batch
       for (int e = 0; e < 4; ++e)
         if (c + e < d) o[e] = (o[e] - to_f32(x[c + e]) * proj) * inv;
     }
-    if (p.accumulate) {
+    if (p.accumulate && p.exclusive && vec) {   // one writer per element in this launch, earlier launches ordered by the stream
+      float4* q = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.dx) + (size_t)dst_row * d + c);
+      float4 t = *q;
+      t.x += o[0]; t.y += o[1]; t.z += o[2]; t.w += o[3];
+      *q = t;
+    } else if (p.accumulate) {
       for (int e = 0; e < 4; ++e)
         if (c + e < d) atomicAdd(reinterpret_cast<float*>(p.dx) + (size_t)dst_row * d + c + e, o[e]);
     } else if (vec) {

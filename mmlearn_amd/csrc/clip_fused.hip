@@ -850,10 +850,35 @@ int mmk_clip_fused_backward(const mmk_fused_pair* pairs, int n_pairs, int d, int
     const float kappa = q.weight / (2.f * (float)q.n);
     MMK_REQUIRE(q.da && q.db, "fused loss: null gradient buffer");
     MMK_REQUIRE((!q.da_accumulate && !q.db_accumulate) || dx_dtype == MMK_F32, "accumulating scatter needs f32 gradient buffers");
-    fb.p[n_dirs++] = FinProb{a.p[k].dA, 0, a.k_pad, q.n, kappa, q.da, q.idx_a, q.da_accumulate, nullptr, 0, 1};
-    fb.p[n_dirs++] = FinProb{a.p[k].dB, 0, a.k_pad, q.n, kappa, q.db, q.idx_b, q.db_accumulate, nullptr, 0, 1};
+    // Directions of this launch that add into the same identity-paired destination (two pairs sharing a modality) become ONE
+    // problem with several sources: every element then has one writer here, so the accumulation into what earlier launches left
+    // is a plain load + add + store instead of f32 atomics (3 pairs x 256 rows: 15.7 -> see DESIGN 3.1a).
+    const float* raw[2] = {a.p[k].dA, a.p[k].dB};
+    void* dst[2] = {q.da, q.db};
+    const int32_t* rows[2] = {q.idx_a, q.idx_b};
+    const int accf[2] = {q.da_accumulate, q.db_accumulate};
+    for (int side = 0; side < 2; ++side) {
+      int host = -1;
+      if (accf[side] && rows[side] == nullptr)
+        for (int j = 0; j < n_dirs; ++j)
+          if (fb.p[j].dx == dst[side] && fb.p[j].dx_rows == nullptr && fb.p[j].accumulate && fb.p[j].r == q.n && fb.p[j].n_extra < 3) host = j;
+      if (host >= 0) {
+        FinProb& h = fb.p[host];
+        h.extra[h.n_extra] = raw[side];
+        h.kappa_extra[h.n_extra] = kappa;
+        ++h.n_extra;
+      } else {
+        FinProb f{raw[side], 0, a.k_pad, q.n, kappa, dst[side], rows[side], accf[side], nullptr, 0, 1};
+        f.exclusive = accf[side] && rows[side] == nullptr;   // identity pairing: row i is written by this problem's row i only ...
+        fb.p[n_dirs++] = f;
+      }
+    }
     max_r = std::max(max_r, (int)q.n);
   }
+  // ... unless another problem of this launch targets the same buffer with other rows (a gathered pairing): then both keep atomics
+  for (int i = 0; i < n_dirs; ++i)
+    for (int j = 0; j < n_dirs; ++j)
+      if (i != j && fb.p[i].dx == fb.p[j].dx) fb.p[i].exclusive = 0;
   db.n_probs = 0;
   if (dscale_out) {
     MMK_REQUIRE(ds_raw, "fused loss: ds_raw required with dscale_out");

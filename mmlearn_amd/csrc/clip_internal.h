@@ -64,6 +64,12 @@ struct FinProb {
   const void* src;  // original rows (normalize backward)
   int normalize;
   int n_split;      // slabs to sum
+  // further sources with coefficients of their own, summed into the same destination rows (the one-launch loss: two pairs that
+  // share a modality, identity pairing): extra[k] [r][slab_ld], kappa_extra[k]
+  const float* extra[3] = {nullptr, nullptr, nullptr};
+  float kappa_extra[3] = {0.f, 0.f, 0.f};
+  int n_extra = 0;
+  int exclusive = 0;  // with accumulate: every destination element has ONE writer in this launch -> load + add + store, no atomics
 };
 struct FinBatch {
   FinProb p[MAX_PROBS];

@@ -643,9 +643,12 @@ class _Run:
                 m = p.ml if self.local_mode else p.mg
                 rep = (m.repeats_a if role == "a" else m.repeats_b) if not m.identity else False
                 accumulate[n] = accumulate.get(n, False) or rep or writers[n] > 1
+        # one launch takes one gradient dtype: when some modality needs the f32 accumulating scatter (repeated rows, several
+        # writers) and the embeddings are not f32, every buffer of the call is f32 and is cast once at the end
+        mixed = any(accumulate.values()) and any(self.embeddings[key_of[n]].dtype != _ACCUM_DTYPE for n in accumulate)
         for n, acc in accumulate.items():
             t = self.embeddings[key_of[n]]
-            grads[n] = torch.zeros(t.shape, dtype=_ACCUM_DTYPE if acc else t.dtype, device=dev)
+            grads[n] = torch.zeros(t.shape, dtype=_ACCUM_DTYPE if (acc or mixed) else t.dtype, device=dev)
         dirs_all = []
         for p in self.pairs:
             for dr, role in zip(p.dirs, p.roles):

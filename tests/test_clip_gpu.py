@@ -371,3 +371,25 @@ def test_modality_alignment_seeded_three_modalities(dtype):
     res = _run_hip(embs, ids, 6.0, pairs, dtype=dtype, modality_alignment=True, l2_normalize=(dtype == "float32"))
     orc = co.contrastive_loss(embs, ids, 6.0, pairs, modality_alignment=True, l2norm=(dtype == "float32"))
     _check(res, orc["loss"], orc["grads"], orc["dscale"], TOL[dtype], f"align3:{dtype}")
+
+
+@pytest.mark.parametrize("l2", [True, False])
+def test_bf16_rows_with_a_repeated_id_in_one_modality_only(l2, loss_path):
+    """One modality needs the f32 accumulating scatter (a repeated id -> a row matched twice), the other does not: every gradient
+    buffer of the launch is then f32 (found by tools/fuzz_loss.py SEED=31: the tiled backward handed the kernel one bf16 and one
+    f32 buffer and was refused)."""
+    g = np.random.default_rng(34)
+    n, d = 37, 128
+    a = g.standard_normal((n, d)).astype(np.float32)
+    b = (0.5 * a + g.standard_normal((n, d))).astype(np.float32)
+    if not l2:
+        a /= np.linalg.norm(a, axis=1, keepdims=True)
+        b /= np.linalg.norm(b, axis=1, keepdims=True)
+    a, b = (torch.from_numpy(x).bfloat16().float().numpy() for x in (a, b))   # what the bf16 leaves hold
+    ia, ib = np.arange(n), np.arange(n)
+    ib[5] = ib[20]                                   # text rows 5 and 20 carry the same id: rgb row 20 matches both
+    ids = {"rgb": np.stack([np.zeros(n, np.int64), ia], 1), "text": np.stack([np.zeros(n, np.int64), ib], 1)}
+    pairs = [(("rgb", "text"), 1.0)]
+    res = _run_hip({"rgb": a, "text": b}, ids, 1 / 0.07, pairs, dtype="bfloat16", l2_normalize=l2)
+    ref = co.contrastive_loss({"rgb": a, "text": b}, ids, 1 / 0.07, pairs, l2norm=l2)
+    _check(res, ref["loss"], ref["grads"], ref["dscale"], 2e-2, (l2, loss_path))

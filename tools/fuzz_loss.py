@@ -22,6 +22,7 @@ for it in range(int(os.environ.get("N", 40))):
     dt = rng.choice([torch.float32, torch.bfloat16, torch.bfloat16])
     scale = rng.choice([1.0, 1 / 0.07, 30.0, 100.0, -5.0])
     l2 = rng.random() < 0.3
+    align = rng.random() < 0.2
     mods = ["rgb", "text", "audio"][: rng.choice([2, 2, 3])]
     g = torch.Generator().manual_seed(1000 + it)
     embs, ids = {}, {}
@@ -45,14 +46,15 @@ for it in range(int(os.environ.get("N", 40))):
     te = {f"{m}_embedding": embs[m].to(dev).requires_grad_(True) for m in mods}
     s = torch.tensor(scale, device=dev, requires_grad=True)
     try:
-        loss = ContrastiveLoss(l2_normalize=l2)(te, {m: ids[m].to(dev) for m in mods}, s, [LossPairSpec(p, w) for p, w in pairs])
+        loss = ContrastiveLoss(l2_normalize=l2, modality_alignment=align)(te, {m: ids[m].to(dev) for m in mods}, s, [LossPairSpec(p, w) for p, w in pairs])
         loss.float().backward()
     except Exception as e:
         bad += 1
-        print("LOSS RAISED", dict(it=it, n=n, d=d, dt=str(dt), scale=scale, l2=l2, mods=len(mods), kind=kind,
+        print("LOSS RAISED", dict(it=it, n=n, d=d, dt=str(dt), scale=scale, l2=l2, align=align, mods=len(mods), kind=kind,
                                   rows={m: tuple(embs[m].shape) for m in mods}), repr(e)[:300], flush=True)
         continue
-    ref = co.contrastive_loss({m: embs[m].float().numpy() for m in mods}, {m: ids[m].numpy() for m in mods}, scale, pairs, l2norm=l2)
+    ref = co.contrastive_loss({m: embs[m].float().numpy() for m in mods}, {m: ids[m].numpy() for m in mods}, scale, pairs, l2norm=l2,
+                              modality_alignment=align)
     # bf16 operands: the packed (normalised) rows are rounded to bf16 before the MFMA, and a rounding of 2^-8 of a cosine is
     # 0.4 in the logits at scale 100: the sharper the softmax, the more of it shows
     tol = (3e-2 if abs(scale) >= 30 else 1e-2) if dt == torch.bfloat16 else 1e-3
@@ -63,6 +65,6 @@ for it in range(int(os.environ.get("N", 40))):
     errs.append(abs(float(s.grad) - ref["dscale"]) / max(1.0, abs(ref["dscale"])))
     if max(errs) > tol or not np.isfinite(max(errs)):
         bad += 1
-        print("LOSS MISMATCH", dict(n=n, d=d, dt=str(dt), scale=scale, l2=l2, mods=len(mods), kind=kind), [f"{e:.2e}" for e in errs], flush=True)
+        print("LOSS MISMATCH", dict(it=it, n=n, d=d, dt=str(dt), scale=scale, l2=l2, align=align, mods=len(mods), kind=kind), [f"{e:.2e}" for e in errs], flush=True)
 torch.cuda.synchronize()
 print("fuzz_loss done, mismatches:", bad)

@@ -455,7 +455,8 @@ class _FusedPlan:
         return torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
 
     def give(self, stream_handle: int, ws: torch.Tensor) -> None:
-        self.pool.append((stream_handle, ws))
+        if len(self.pool) < 4:   # more than a few idle workspaces per shape are not worth their memory
+            self.pool.append((stream_handle, ws))
 
 
 _FUSED_PLANS: dict = {}
@@ -467,10 +468,13 @@ def clip_fused_plan(device: torch.device, ns: Sequence[int], d: int, dtype: torc
         return None
     if d % (4 if dtype == torch.float32 else 8) or any(not (0 < n <= FUSED_MAX_ROWS) for n in ns):
         return None
-    key = (device.index, tuple(ns), d, dtype)
+    # workspace layout, grid and capacity depend on the rows of a pair only through its tile count: one plan (and one workspace
+    # pool) per tile-count tuple, so a pairing whose matched-row count changes from batch to batch does not grow the cache
+    nts = tuple((int(n) + 63) // 64 for n in ns)
+    key = (device.index, nts, d, dtype)
     plan = _FUSED_PLANS.get(key)
     if plan is None:
-        plan = _FUSED_PLANS[key] = _FusedPlan(device, tuple(ns), d, dtype)
+        plan = _FUSED_PLANS[key] = _FusedPlan(device, tuple(64 * t for t in nts), d, dtype)
     return plan if plan.grid <= plan.capacity else None
 
 

@@ -274,3 +274,24 @@ def test_three_pairs_of_1024_rows_run_as_two_launches(monkeypatch):
     ref = _oracle(mats, ids, spec, 1 / 0.07, "float32")
     got = {"loss": float(loss.detach()), "grads": {m: t.grad.cpu().numpy() for m, t in emb.items()}, "dscale": float(s.grad)}
     _check(got, ref, 1e-2)
+
+
+def test_one_workspace_serves_every_row_count_of_a_tile_count():
+    """Plans (and their workspace pools) are keyed by tile counts, not rows: a pairing whose matched-row count changes from batch
+    to batch reuses one workspace, and whatever an earlier, larger problem left in the padding must not leak into a smaller one."""
+    from mmlearn_amd import kernels as K
+
+    g = np.random.default_rng(23)
+    d = 96
+    plans = set()
+    for n in (1000, 961, 1024, 970, 1000):          # all 16 x 16 tiles
+        a = _unit(g, n, d)
+        b = 0.5 * a + _unit(g, n, d)
+        got = _run_fused({"rgb": a, "text": b}, [("rgb", "text", None, None, n, 1.0)], 1 / 0.07, "float32")
+        ref = _oracle({"rgb": a, "text": b}, {"rgb": _ids(range(n)), "text": _ids(range(n))}, [(("rgb", "text"), 1.0)], 1 / 0.07, "float32")
+        _check(got, ref, 1e-2, n)
+        plans.add(id(got["plan"]))
+        got = None
+    assert len(plans) == 1
+    plan = K.clip_fused_plan(_dev(), [1000], d, torch.float32)
+    assert plan.allocs <= 2, plan.allocs

@@ -119,6 +119,24 @@ __device__ __forceinline__ void img_load(char* img, const bf16_t* base, long sl,
   }
 }
 
+constexpr bool kAttnStagedDefault = true;   // (debug builds: MMK_ATTN_STAGED=0 / 1 selects the other form for A/B runs)
+
+// ONE piece (rows 8 piece .. +7) of an image, for loaders whose piece indices are not congruent mod 16 rows (an odd number of
+// loader waves): the per-lane offset is formed per piece.  Rows >= L repeat row L-1.
+__device__ __forceinline__ void img_load_piece(char* img, const bf16_t* base, long sl, int L, int piece, int lane, int dst_piece = -1) {
+  const int row = 8 * piece + (lane >> 3);
+  const int ch = (lane & 7) ^ img_swz(row);   // (a destination that starts at a multiple of 16 rows keeps the source row's swizzle)
+  const uint32_t voff = (uint32_t)(min(row, L - 1) * (int)sl + ch * 8) * 2u;
+  lds_dma16(base, voff, lds_addr_of(img) + (dst_piece < 0 ? piece : dst_piece) * 1024);
+}
+// s_waitcnt vmcnt(n) for a run-time n in {0, 2, 4, 6} (wave-uniform)
+__device__ __forceinline__ void wait_vmem_upto(int n) {
+  if (n >= 6) __builtin_amdgcn_s_waitcnt(0x0F76);
+  else if (n >= 4) __builtin_amdgcn_s_waitcnt(0x0F74);
+  else if (n >= 2) __builtin_amdgcn_s_waitcnt(0x0F72);
+  else __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
 // MFMA operands out of an image.  k along the 64 COLUMNS: lane (r, h) takes row `row`, elements 16kk + 8h .. +7, one
 // ds_read_b128 at  row * 128 + (((2 kk + h) ^ img_swz(row)) << 4).  k along the ROWS (transposed use of the same image):
 // for the 32x32x16 A operand X^T[c][k] with c = 32 ct + (lane & 31) and the accumulator-as-operand k order, the lane
@@ -700,7 +718,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(cons
 // dQᵀ[it] = Kᵀ dSᵀ over the 32·NT keys (both operands by transposed reads: K image, dS image) while the key waves are
 // already on the next query tile (two dS buffers).  Five MFMA products per tile pair instead of seven and no second
 // set of exponentials; the dQ wave's 2·NT·2 MFMAs per step balance a key wave's 16 MFMAs + softmax arithmetic.
-template <int NT, int NW, bool DROP>
+// STAGED: the key waves are the only loaders (four 8-row pieces of every image each), K first, then the Q / dO pieces in row
+// order, and a step only waits for the pieces of ITS query tile (counted vmcnt): step 0 starts when K, V, the row constants and
+// the first 32 rows of Q / dO are in, the rest of the 84 KiB lands behind the steps.
+template <int NT, int NW, bool DROP, bool STAGED>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(const AttnBwdArgs a) {
   static_assert(NT < NW, "needs a spare wave for dQ");
   constexpr int LP = 32 * NT;
@@ -741,7 +762,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
     stamp(0);
     // ---- load: V_j fragments (compiler-visible, first), then the Q, dO, K images and the row-constant record
     bf16x8 kf[4], vf[4];
-    if (keyw) {
+    if (keyw && !STAGED) {
       const int lo = opaque(lane);
       const uint32_t voff = (uint32_t)(min(wave * 32 + (lo & 31), a.L - 1) * (int)a.v_sl + 8 * (lo >> 5)) * 2u;
       const char* vbase = reinterpret_cast<const char*>(a.v + b * a.v_sb + hh * a.v_sh);
@@ -749,7 +770,30 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
       for (int kk = 0; kk < 4; ++kk) vf[kk] = *reinterpret_cast<const bf16x8*>(vbase + voff + 32 * kk);
     }
     asm volatile("" ::: "memory");
-    {
+    // pieces of tile t are complete once every loader has its pieces g <= (4 t + 3) / NT: that leaves 2 (3 - g) younger DMAs
+    auto allow = [](int t) { return 2 * (3 - (4 * t + 3) / NT); };
+    if (STAGED) {
+      const int lo = opaque(lane);
+      const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+      if (wave_s < NT) {
+        // this wave's 32 V rows -> its own staging tile (free until the item's final stores), read back as row fragments below.
+        // Every load of the item is an LDS-DMA the compiler does not track: a compiler-visible load would make it wait for ALL
+        // of them (vmcnt(0)) at its first use.
+#pragma unroll
+        for (int g = 0; g < 4; ++g) img_load_piece(stage, a.v + b * a.v_sb + hh * a.v_sh, a.v_sl, a.L, 4 * wave_s + g, lo, g);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) img_load_piece(Ks, a.k + b * a.k_sb + hh * a.k_sh, a.k_sl, a.L, wave_s + NT * g, lo);
+        for (int rc = wave_s; rc < 2; rc += NT)   // the two row-constant records (one loader wave: both)
+          lds_dma16(a.delta + ((long)item * 2 + rc) * ROWC, (uint32_t)lo * 16u, lds_addr_of(reinterpret_cast<const char*>(rowc + rc * ROWC)));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          img_load_piece(Qs, a.q + b * a.q_sb + hh * a.q_sh, a.q_sl, a.L, wave_s + NT * g, lo);
+          img_load_piece(Gs, a.dout + obase, osl, a.L, wave_s + NT * g, lo);
+        }
+      }
+      stamp(1);
+      if (wave_s < NT) wait_vmem_upto(allow(0));
+    } else {
       const int lo = opaque(lane);
       img_load(Qs, a.q + b * a.q_sb + hh * a.q_sh, a.q_sl, a.L, LP, wave, NW, lo);
       img_load(Gs, a.dout + obase, osl, a.L, LP, wave, NW, lo);
@@ -758,9 +802,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
       if (wave_s < 2)
         lds_dma16(a.delta + ((long)item * 2 + wave_s) * ROWC, (uint32_t)lo * 16u,
                   lds_addr_of(reinterpret_cast<const char*>(rowc + wave_s * ROWC)));
+      stamp(1);
+      wait_vmem_all();
     }
-    stamp(1);
-    wait_vmem_all();
     __syncthreads();
     stamp(2);
 
@@ -770,6 +814,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
     if (keyw) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) kf[kk] = lds_row_frag(Ks + wave * 4096 + il.row[kk]);
+      if (STAGED) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) vf[kk] = lds_row_frag(stage + il.row[kk]);
+      }
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -860,6 +908,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
           }
         if (it == 3) stamp(15);
       }
+      if (STAGED && it + 1 < NT) wait_vmem_upto(allow(it + 1));   // this wave's pieces of the next query tile
       __syncthreads();
       stamp(3 + it);
     }
@@ -903,12 +952,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
   }
 }
 
-template <int NT, int NW, bool DROP>
+template <int NT, int NW, bool DROP, bool STAGED>
 static int launch_attn_bwd5(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int LP = 32 * NT;
   constexpr int bytes = 3 * LP * 128 + 2 * LP * 64 + 2 * ROWC * 4 + NW * STAGE_BYTES;
   static_assert(bytes <= 160 * 1024, "LDS budget");
-  auto kern = attn_bwd5_kernel<NT, NW, DROP>;
+  auto kern = attn_bwd5_kernel<NT, NW, DROP, STAGED>;
   static int wgs_per_cu = 0, cus = 0;
   if (!wgs_per_cu) {
     if (bytes > 64 * 1024)
@@ -1052,13 +1101,15 @@ extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const v
   const bool drop = drop_params(dropout_p, seed, &a.seed_lo, &a.seed_hi, &a.drop_thr, &a.drop_scale);
   hipStream_t st = static_cast<hipStream_t>(stream);
   static const bool seven = MMK_DBG_ENV("MMK_ATTN_BWD7") != nullptr;  // force the seven-product kernel (A/B runs)
+  static const bool staged = MMK_DBG_ENV("MMK_ATTN_STAGED") ? atoi(MMK_DBG_ENV("MMK_ATTN_STAGED")) != 0 : kAttnStagedDefault;
   MMK_REQUIRE(!colsum_part || mmk_attn_bwd_has_colsum(L), "attn_bwd: column sums are not available for this sequence length");
 #define MMK_ATTN_BWD_CASE(NT, NW) \
   case NT: return drop ? launch_attn_bwd<NT, NW, true>(a, st) : launch_attn_bwd<NT, NW, false>(a, st);
 #define MMK_ATTN_BWD5_CASE(NT, NW)                                                                                   \
   case NT:                                                                                                           \
     if (seven) return drop ? launch_attn_bwd<NT, NW, true>(a, st) : launch_attn_bwd<NT, NW, false>(a, st);           \
-    return drop ? launch_attn_bwd5<NT, NW, true>(a, st) : launch_attn_bwd5<NT, NW, false>(a, st);
+    if (staged) return drop ? launch_attn_bwd5<NT, NW, true, true>(a, st) : launch_attn_bwd5<NT, NW, false, true>(a, st); \
+    return drop ? launch_attn_bwd5<NT, NW, true, false>(a, st) : launch_attn_bwd5<NT, NW, false, false>(a, st);
   switch ((L + 31) / 32) {
     MMK_ATTN_BWD5_CASE(1, 4) MMK_ATTN_BWD5_CASE(2, 4) MMK_ATTN_BWD5_CASE(3, 4) MMK_ATTN_BWD_CASE(4, 4)
     MMK_ATTN_BWD5_CASE(5, 8) MMK_ATTN_BWD5_CASE(6, 8) MMK_ATTN_BWD5_CASE(7, 8)

@@ -623,17 +623,19 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
             for (int e = 0; e < 16; ++e) part[(32 * i + acc_row(e, h)) * 64 + 32 * j + r] = o[i][j][e];
         __syncthreads();
         {
-          const int row = tid >> 2, c0 = (tid & 3) * 16;
-          float* ob = out + (size_t)(strip * 64 + row) * a.k_pad + kc * 64 + c0;
+          // 16 lanes per 256-byte row of the partial tiles (one bank window: conflict-free ds_read_b128, whole-row global stores);
+          // four passes of 16 rows.  (A thread per quarter row made every read 4-way conflicted: profiles/r03_loss_pmc_sq.json.)
+          const int c = (tid & 15) * 4;
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            float4 t = *reinterpret_cast<const float4*>(smem + (row * 64 + c0 + 4 * v) * 4);
+          for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 16 + (tid >> 4);
+            float4 t = *reinterpret_cast<const float4*>(smem + (row * 64 + c) * 4);
 #pragma unroll
             for (int w = 1; w < 4; ++w) {
-              const float4 x = *reinterpret_cast<const float4*>(smem + w * 16384 + (row * 64 + c0 + 4 * v) * 4);
+              const float4 x = *reinterpret_cast<const float4*>(smem + w * 16384 + (row * 64 + c) * 4);
               t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
             }
-            if (!(dbg & 64)) *reinterpret_cast<float4*>(ob + 4 * v) = t;
+            if (!(dbg & 64)) *reinterpret_cast<float4*>(out + (size_t)(strip * 64 + row) * a.k_pad + kc * 64 + c) = t;
           }
         }
       }

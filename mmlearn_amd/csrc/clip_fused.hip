@@ -229,7 +229,9 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
       const int row = u * RPS + trow;
       srow[u] = src_row[u] >= 0 ? (long)src_row[u] * a.d * (long)sizeof(S) : -1;
       const int e0 = (c * EPP) & 63, kh = (c * EPP) >> 6;
-      lds_off[u] = kh * 16384 + row * 128 + ((((e0 >> 3) ^ ((row >> 1) & 7))) << 4) + (e0 & 7) * 2;
+      // the second sub-image keeps row r at row r ^ 1: the 16 lanes that store one row's two k halves then fill BOTH 128-byte halves
+      // of a bank window (the sub-images are 16 KiB apart, i.e. on the same banks: every store was 2-way conflicted)
+      lds_off[u] = kh * 16384 + (row ^ kh) * 128 + ((((e0 >> 3) ^ ((row >> 1) & 7))) << 4) + (e0 & 7) * 2;
     }
     const int ns = (a.k_pad + F_KS - 1) / F_KS;
     // The loop is latency-bound (128 KiB per workgroup, L2-resident): keep PD stages of loads in flight in registers
@@ -262,8 +264,8 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const int ch = 2 * kk + h;
-          const bf16x8 fa = *reinterpret_cast<const bf16x8*>(img + p_off + ((ch ^ p_sw) << 4));
-          const bf16x8 fb = *reinterpret_cast<const bf16x8*>(img + q_off + ((ch ^ q_sw) << 4));
+          const bf16x8 fa = *reinterpret_cast<const bf16x8*>(img + (p_off ^ (kh << 7)) + ((ch ^ p_sw) << 4));
+          const bf16x8 fb = *reinterpret_cast<const bf16x8*>(img + (q_off ^ (kh << 7)) + ((ch ^ q_sw) << 4));
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
         }
       }

@@ -10,12 +10,13 @@
 //            user's rows (f32 or bf16, gathered through the match index, converted while staging -- no pack launch), per-row
 //            and per-column (max, sum 2^(u - max)) of the tile -> L2; counters c1_row[ti], c1_col[tj].
 //   phase 2  waits for its row strip's and column strip's 2 * nt partials, merges them to the row / column log-sum-exps, forms
-//            G = P_row + P_col - 2 delta from the accumulators it still holds (no recompute), stores the tile of G and of G^T
-//            (bf16, 2 MB each at N = 1024: they never leave the caches), the tile's share of d loss / d scale; the diagonal
-//            workgroups add the loss terms; counters c2_row[ti], c2_col[tj].
+//            G = P_row + P_col - 2 delta from the accumulators it still holds (no recompute), stores its tile of G (bf16,
+//            2 MB at N = 1024: it never leaves the caches), the tile's share of d loss / d scale; the diagonal workgroups add
+//            the loss terms; counters c2_row[ti], c2_col[tj].
 //   phase 3  workgroup w takes output tiles of  dA = G B  and  dB = G^T A  (64 rows x 64 of the D columns, contraction over
-//            all N): both are  out[n][k] = sum_m U[m][n] V[m][k]  with U = G^T or G and V = B or A, i.e. both operands have the
-//            contraction along their rows -> LDS images read with ds_read_b64_tr_b16.  Raw f32 sums go to the workspace.
+//            all N).  dB: out[n][k] = sum_m G[m][n] A[m][k], both operands with the contraction along their rows -> LDS images
+//            read with ds_read_b64_tr_b16.  dA: the same G is the MFMA A operand as it lies in memory (its rows are the output
+//            rows), only B is read transposed -- G^T is never stored.  Raw f32 sums go to the workspace.
 //   tail     the workgroup that draws the last ticket adds the loss / d-scale partials in a fixed order and re-arms every
 //            counter (all zero on entry, all zero on exit).
 // The backward call is one launch of the existing finalize kernel (x kappa * scale * upstream, cast, scatter).
@@ -62,7 +63,6 @@ struct FusedPair {
   float2* part_row;       // [nt][n_pad]  (tile column tj, row i)
   float2* part_col;       // [nt][n_pad]  (tile row ti, column j)
   bf16_t* G;              // [n_pad][n_pad]  G[i][j]
-  bf16_t* GT;             // [n_pad][n_pad]  G[i][j] at [j][i]
   unsigned* cnt;          // [4][nt] counters, stride F_CNT_STRIDE: c1_row, c1_col, c2_row, c2_col
   float* loss_part;       // [2 nt]
   float* ds_part;         // [nt * nt]
@@ -394,7 +394,6 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
       const float lr2 = lr2_s[i_loc];
       float ds_acc = 0.f;
       char* gs = smem;                 // G tile  [64 i][64 j] bf16, row stride 144 B
-      char* gts = smem + 16384;        // G^T tile [64 j][64 i]
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float g4[4];
@@ -409,23 +408,20 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
           if (!(iv && (tj * 64 + j_loc < n))) g = 0.f;
           ds_acc = fmaf(g, t, ds_acc);
           g4[e4] = g;
-          *reinterpret_cast<bf16_t*>(gts + j_loc * 144 + i_loc * 2) = (bf16_t)g;
         }
         Vec4<bf16_t>::store(reinterpret_cast<bf16_t*>(gs + i_loc * 144) + wm * 32 + 8 * q + 4 * h, make_float4(g4[0], g4[1], g4[2], g4[3]));
       }
+      F_STAMP(15);
       ds_acc = wave_sum(ds_acc);
       if (lane == 0) misc[wave] = ds_acc;
       __syncthreads();
       {
         const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.G), 0, n_pad * n_pad * 2, 0x00020000);
-        const auto rgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.GT), 0, n_pad * n_pad * 2, 0x00020000);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int pid = tid + F_THREADS * u, row = pid >> 3, cc = pid & 7;
           const u32x4 v0 = *reinterpret_cast<const u32x4*>(gs + row * 144 + cc * 16);
-          const u32x4 v1 = *reinterpret_cast<const u32x4*>(gts + row * 144 + cc * 16);
           __builtin_amdgcn_raw_buffer_store_b128(v0, rg, ((ti * 64 + row) * n_pad + tj * 64 + cc * 8) * 2, 0, 16);    // sc1: write-through
-          __builtin_amdgcn_raw_buffer_store_b128(v1, rgt, ((tj * 64 + row) * n_pad + ti * 64 + cc * 8) * 2, 0, 16);
         }
       }
       if (tid == 0) st_agent(p.ds_part + tile, misc[0] + misc[1] + misc[2] + misc[3]);
@@ -489,7 +485,12 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
       const int jl = job - pp.job0;
       const int per_dir = pp.nt * a.nkc;
       const int dir = jl / per_dir, strip = (jl % per_dir) / a.nkc, kc = (jl % per_dir) % a.nkc;
-      const bf16_t* U = dir == 0 ? pp.GT : pp.G;          // dA: U[m = j][n = i] = G^T ; dB: U[m = i][n = j] = G
+      // dB = G^T A: U[m = i][n = j] = G, both operands with the contraction along their rows (transposed reads).  dA = G B takes
+      // the SAME matrix the other way round: its output rows are G's rows and the contraction runs along them, i.e. G is the MFMA
+      // A operand as it lies in memory (row fragments, no transposed read) -- G^T is never stored (r03: it was, 2 MB of
+      // write-through stores per launch that every tile waited for).
+      const bf16_t* U = pp.G;
+      const bool u_rows = dir == 0;   // workgroup-uniform
       const char* Vsrc = dir == 0 ? pp.b : pp.a;
       const int32_t* Vidx = dir == 0 ? pp.idx_b : pp.idx_a;
       float* out = dir == 0 ? pp.dA : pp.dB;
@@ -508,7 +509,9 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
       // A chunk whose 32 rows all exist (the usual case) loads without per-row checks; the row list of a gathered operand is
       // the only per-row lookup left.
       const int m_stop = min(m_hi, nn);                                   // V rows beyond are zero (padding of the pair)
-      const int u_voff = ((m_lo + (lane >> 3)) * npad + strip * 64 + (lane & 7) * 8) * 2;
+      // dB: rows m of G, 8 rows x 128 B per load;  dA: rows i of the strip, columns m: 16 rows x 64 B per load
+      const int u_voff = u_rows ? ((strip * 64 + (lane >> 2)) * npad + m_lo + (lane & 3) * 8) * 2
+                                : ((m_lo + (lane >> 3)) * npad + strip * 64 + (lane & 7) * 8) * 2;
       const char* v_ptr = Vsrc + ((long)(m_lo + lane / VPR) * a.d + vcol) * (long)sizeof(S);
       const bool v_col_ok = vcol < a.d;
       auto load_v = [&](int ch, uint4 (&v)[NVL]) {
@@ -534,6 +537,16 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
       };
       auto load_u = [&](int ch, u32x4 (&w)[4]) {
         const int m0 = m_lo + ch * CR;
+        if (u_rows) {   // [64 i][32 m]: load u = rows 16 u + (lane >> 2); a chunk's upper 16 columns may belong to the next wave
+          const int off = u_voff + ch * CR * 2;
+          const bool ok = m0 + (lane & 3) * 8 < m_hi;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            w[u] = (u32x4){0u, 0u, 0u, 0u};
+            if (ok && !(dbg & 1)) w[u] = __builtin_amdgcn_raw_buffer_load_b128(ru, off + u * 16 * npad * 2, 0, 16);   // sc1
+          }
+          return;
+        }
         const int off = u_voff + ch * CR * npad * 2;
         if (m0 + CR <= m_hi) {                                             // wave-uniform
 #pragma unroll
@@ -550,10 +563,18 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
         }
       };
       auto store_uv = [&](char* buf, const u32x4 (&w)[4], const uint4 (&v)[NVL]) {
+        if (u_rows) {   // image [64 i][64 B]: chunk ^= (row >> 2) & 3 -- the 16 rows of a ds_read_b128 group on 16 different slots
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int row = u * 8 + (lane >> 3), cc = lane & 7;
-          *reinterpret_cast<u32x4*>(buf + row * 128 + ((cc ^ (((row >> 1) & 1) << 2)) << 4)) = w[u];
+          for (int u = 0; u < 4; ++u) {
+            const int row = u * 16 + (lane >> 2), cc = lane & 3;
+            *reinterpret_cast<u32x4*>(buf + row * 64 + ((cc ^ ((row >> 2) & 3)) << 4)) = w[u];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int row = u * 8 + (lane >> 3), cc = lane & 7;
+            *reinterpret_cast<u32x4*>(buf + row * 128 + ((cc ^ (((row >> 1) & 1) << 2)) << 4)) = w[u];
+          }
         }
 #pragma unroll
         for (int u = 0; u < NVL; ++u) {
@@ -603,7 +624,14 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
               if (!(dbg & 4))
 #pragma unroll
               for (int ks = 0; ks < CR / 16; ++ks) {
-                const bf16x8 fa0 = tr8(buf + tr_off[0] + ks * 2048), fa1 = tr8(buf + tr_off[1] + ks * 2048);
+                bf16x8 fa0, fa1;
+                if (u_rows) {   // A[row i][k = m]: lane (r, h) takes 8 consecutive m of row 32 t + r
+                  fa0 = *reinterpret_cast<const bf16x8*>(buf + r * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) << 4));
+                  fa1 = *reinterpret_cast<const bf16x8*>(buf + (32 + r) * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) << 4));
+                } else {
+                  fa0 = tr8(buf + tr_off[0] + ks * 2048);
+                  fa1 = tr8(buf + tr_off[1] + ks * 2048);
+                }
                 const bf16x8 fb0 = tr8(buf + 4096 + tr_off[0] + ks * 2048), fb1 = tr8(buf + 4096 + tr_off[1] + ks * 2048);
                 o[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, o[0][0], 0, 0, 0);
                 o[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, o[0][1], 0, 0, 0);
@@ -683,7 +711,7 @@ __global__ __launch_bounds__(F_THREADS, 2) void clip_fused_kernel(const FusedArg
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct FusedLayout {
-  size_t part_row, part_col, G, GT, cnt, loss_part, ds_part, dA, dB, end;
+  size_t part_row, part_col, G, cnt, loss_part, ds_part, dA, dB, end;
 };
 // workspace: [0, 256): ticket + error words; then per pair the regions below
 static FusedLayout pair_layout(size_t off, int n, int k_pad) {
@@ -700,7 +728,6 @@ static FusedLayout pair_layout(size_t off, int n, int k_pad) {
   L.part_row = take((size_t)nt * n_pad * 8);
   L.part_col = take((size_t)nt * n_pad * 8);
   L.G = take((size_t)n_pad * n_pad * 2);
-  L.GT = take((size_t)n_pad * n_pad * 2);
   L.dA = take((size_t)n_pad * k_pad * 4);
   L.dB = take((size_t)n_pad * k_pad * 4);
   L.end = off;
@@ -791,7 +818,6 @@ static int fused_fill(const mmk_fused_pair* pairs, int n_pairs, int d, void* ws,
     p.part_row = reinterpret_cast<float2*>(base + L.part_row);
     p.part_col = reinterpret_cast<float2*>(base + L.part_col);
     p.G = reinterpret_cast<bf16_t*>(base + L.G);
-    p.GT = reinterpret_cast<bf16_t*>(base + L.GT);
     p.cnt = reinterpret_cast<unsigned*>(base + L.cnt);
     p.loss_part = reinterpret_cast<float*>(base + L.loss_part);
     p.ds_part = reinterpret_cast<float*>(base + L.ds_part);

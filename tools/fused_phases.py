@@ -43,7 +43,7 @@ out["segments_median_us"] = {f"{names[k]}->{names[k + 1]}": round(float(np.media
 # finer stamps (thread 0 of every workgroup): 8 addresses ready, 9 S-tile loads issued, 10 first stage in LDS, 11 LSEs merged,
 # 12 G stores issued, 13 first gradient chunk in LDS, 14 gradient loop done
 fine = {"setup": (0, 8), "issue S loads": (8, 9), "first S stage landed": (9, 10), "rest of S tile": (10, 1), "spin1 exit -> LSEs merged": (3, 11),
-        "LSEs -> G stores issued": (11, 12), "G stores drained + counters": (12, 4), "G arrived -> first chunk in LDS": (5, 13),
+        "LSEs -> G tile computed": (11, 15), "G computed -> G stores issued": (15, 12), "G stores drained + counters": (12, 4), "G arrived -> first chunk in LDS": (5, 13),
         "gradient loop": (13, 14), "partial-tile sum + stores": (14, 6)}
 out["fine_median_us"] = {k: round(float(np.median(st[:, b] - st[:, a_])), 2) for k, (a_, b) in fine.items()}
 print(json.dumps(out))

@@ -232,4 +232,6 @@ def test_per_tower_ddp_with_three_towers_and_a_shared_head():
     for (l0, n0, g0), (l1, n1, g1) in zip(plain, wrapped):
         assert n0 == n1 and "log_logit_scale" in n0
         assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0))
-        assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()
+        # not bitwise: f32 atomics (embedding backward) and the order in which the three towers' contributions reach the shared
+        # head differ from run to run at the 1e-6 level (see the measured spread in the RCCL test above)
+        assert (g0 - g1).abs().max().item() <= 1e-4 * g0.abs().max().item()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMK_ABI_VERSION 3
+#define MMK_ABI_VERSION 4
 
 /* element types of user tensors */
 enum { MMK_F32 = 0, MMK_BF16 = 1, MMK_F16 = 2 };
@@ -47,7 +47,7 @@ enum {
   MMK_K_SIM_GRAD, MMK_K_GRAD_GEMM, MMK_K_GRAD_FINALIZE, MMK_K_L2NORM, MMK_K_IJEPA_LOSS_FWD,
   MMK_K_IJEPA_LOSS_BWD, MMK_K_GATHER_ROWS, MMK_K_SCATTER_ROWS, MMK_K_PRED_ASSEMBLE, MMK_K_PRED_ASSEMBLE_BWD,
   MMK_K_EMA, MMK_K_MASK_INDEX, MMK_K_LAYERNORM_FWD, MMK_K_LAYERNORM_BWD, MMK_K_ACT, MMK_K_ATTN_FWD,
-  MMK_K_ATTN_BWD, MMK_K_WGRAD, MMK_K_RECALL, MMK_K_CLIP_FUSED, MMK_K_COUNT
+  MMK_K_ATTN_BWD, MMK_K_WGRAD, MMK_K_RECALL, MMK_K_CLIP_FUSED, MMK_K_MLP_GEMM, MMK_K_COUNT
 };
 int mmk_profile_enable(int on);          /* on=1 start recording (clears), on=0 stop */
 /* resolve recorded events (synchronises on them); fills count[k] and total_ms[k] for k < MMK_K_COUNT */
@@ -357,6 +357,25 @@ int mmk_bias_act_part_blocks(long rows);
 int mmk_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, int d, int act, int dtype, void* stream);
 int mmk_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx, float* part, float* part2, float* dbias, int64_t rows,
                      int d, int act, int dtype, void* stream);
+/* column sums of a f32 [n_rows, d] buffer of partial rows (fixed summation order): out f32[d]; part2: f32[256, d] scratch */
+int mmk_colsum_f32(const float* part, int n_rows, int d, float* part2, float* out, void* stream);
+
+/* The two GEMMs of an encoder MLP that sit next to its activation, with the activation pass in the epilogue (csrc/mlp_gemm.hip).
+ * Replaces, in the reference's op sequence (mmlearn/modules/layers/mlp.py; HF CLIPMLP / BertIntermediate+BertOutput under
+ * mmlearn/modules/encoders/clip.py:29-470, text.py:20-178, and their autograd):
+ *   forward   F.linear(x, W1) -> + b1 -> activation                       H = act(X W1^T + b1), pre = X W1^T (bf16, bias-free)
+ *   backward  grad_out @ W2 -> * act'(pre + b1) -> .sum(0) for b1.grad    dPre = (dY Wt^T) * act'(pre + b1), part = column sums
+ * All matrices bf16 with K-contiguous rows (strides in elements, multiples of 8); f32 accumulation; act 0 = x*sigmoid(1.702x),
+ * 1 = erf GELU (numbering of mmk_bias_act_*).  Shapes: M % 256 == 0, N % 256 == 0, K % 64 == 0 (mmk_mlp_gemm_supported);
+ * other shapes stay on library GEMM + mmk_bias_act_*.  Wt = fc2.weight^T as [N = hidden, K = out] (the dX twin of
+ * mmk_cast_transpose).  part (nullable): f32[mmk_mlp_gemm_part_rows(M)][N], reduce with mmk_colsum_f32 -> d b1. */
+int mmk_mlp_gemm_supported(int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc);
+int mmk_mlp_gemm_part_rows(int64_t M);
+int mmk_mlp_gemm_plain(const void* A, const void* B, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, void* stream);
+int mmk_mlp_gemm_fwd_act(const void* X, const void* W, const float* bias, void* H, void* pre, int64_t M, int N, int K, int64_t ldx,
+                         int64_t ldw, int64_t ldc, int act, void* stream);
+int mmk_mlp_gemm_bwd_dact(const void* dY, const void* Wt, const void* pre, const float* bias, void* dPre, float* part, int64_t M, int N,
+                          int K, int64_t ldy, int64_t ldw, int64_t ldp, int64_t ldc, int act, void* stream);
 
 
 /* Weight gradient of a Linear, dW[N, K] = dY^T x for dY [M, N], x [M, K] (bf16, row strides ldy / ldx in elements):

@@ -22,14 +22,14 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 F32, BF16, F16 = 0, 1, 2
 COMPUTE_BF16, COMPUTE_F32 = 1, 0
-ABI_VERSION = 3   # include/mmlearn_hip.h MMK_ABI_VERSION this ctypes mirror was written against
+ABI_VERSION = 4   # include/mmlearn_hip.h MMK_ABI_VERSION this ctypes mirror was written against
 
 _DTYPE_TAG = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 KERNEL_NAMES = [
     "match_ids", "pack_rows", "transpose", "sim_stats", "lse_reduce", "loss_combine", "sim_grad", "grad_gemm",
     "grad_finalize", "l2norm", "ijepa_loss_fwd", "ijepa_loss_bwd", "gather_rows", "scatter_rows", "pred_assemble",
-    "pred_assemble_bwd", "ema_update", "mask_to_index", "layernorm_fwd", "layernorm_bwd", "activation", "attn_fwd", "attn_bwd", "wgrad", "recall_ranks", "clip_fused",
+    "pred_assemble_bwd", "ema_update", "mask_to_index", "layernorm_fwd", "layernorm_bwd", "activation", "attn_fwd", "attn_bwd", "wgrad", "recall_ranks", "clip_fused", "mlp_gemm",
 ]
 
 
@@ -130,6 +130,12 @@ _SIGNATURES = {
     "mmk_wgrad": [_vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _vp],
     "mmk_bias_act_fwd": [_vp, _vp, _vp, C.c_int64, _i, _i, _i, _vp],
     "mmk_bias_act_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _i, _vp],
+    "mmk_colsum_f32": [_vp, _i, _i, _vp, _vp, _vp],
+    "mmk_mlp_gemm_supported": [C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64],
+    "mmk_mlp_gemm_part_rows": [C.c_int64],
+    "mmk_mlp_gemm_plain": [_vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _vp],
+    "mmk_mlp_gemm_fwd_act": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _vp],
+    "mmk_mlp_gemm_bwd_dact": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _vp],
     "mmk_quick_gelu_fwd": [_vp, _vp, C.c_int64, _i, _vp],
     "mmk_quick_gelu_bwd": [_vp, _vp, _vp, C.c_int64, _i, _vp],
     "mmk_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, C.c_uint64, _vp],

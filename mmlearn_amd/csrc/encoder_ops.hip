@@ -722,6 +722,19 @@ int mmk_add_layernorm_bwd(const float* s, const void* dy, const void* dy_twin, c
   return 0;
 }
 
+// column sums of a f32 [n_rows, d] buffer of partial rows, in the two fixed-order stages the row kernels' dgamma / dbeta use
+int mmk_colsum_f32(const float* part, int n_rows, int d, float* part2, float* out, void* stream) {
+  MMK_REQUIRE(part && part2 && out && n_rows > 0 && d > 0 && d % 4 == 0, "colsum: d must be a multiple of 4");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rpb = (n_rows + COLSUM_SLICES - 1) / COLSUM_SLICES;
+  const int slices = (n_rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(colsum_kernel, dim3((d + 1023) / 1024, slices), dim3(256), 0, st, part, n_rows, d, part2, rpb);
+  ColsumOuts outs = {{out, nullptr, nullptr}};
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((d + 63) / 64), dim3(256), 0, st, part2, slices, d, 1, outs);
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
 int mmk_bias_act_part_blocks(long rows) { return (int)((rows + BA_ROWS - 1) / BA_ROWS); }
 
 int mmk_bias_act_fwd(const void* x, const float* bias, void* y, int64_t rows, int d, int act, int dtype, void* stream) {

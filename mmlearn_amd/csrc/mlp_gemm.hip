@@ -1,0 +1,457 @@
+// the two GEMMs of the encoders' MLPs that sit next to an activation, each with the activation pass folded
+// into its epilogue (mmlearn/modules/layers/mlp.py; HF CLIPMLP / BertIntermediate + BertOutput under
+// mmlearn/modules/encoders/clip.py:29-470, text.py:20-178):
+//
+//   forward   H = act(X W1^T + b1), and the pre-activation X W1^T for the backward          (mode MG_FWD_ACT)
+//   backward  dPre = (dY W2) * act'(Pre + b1),  db1 = column sums of dPre                    (mode MG_BWD_DACT)
+//
+//     C[M, N] = A[M, K] . B[N, K]^T       bf16 operands (rows K-contiguous), f32 accumulation, bf16 out
+//
+// The unfused step runs  library GEMM -> bias_act kernel : the backward pair writes dAct [M, 3072] (1.24 GB at M = 201,728),
+// reads it back together with Pre and writes dPre -- 3.7 GB of HBM traffic next to a GEMM whose own operands are 0.3 GB.  Here
+// the tile of Pre is read while the accumulators are still in registers and only dPre is written (2.8 GB in all).
+//
+// Main loop (round 2's second GEMM design, tools/probes/gemm4.hip, kept because it is the simplest loop that reaches 0.9 x the
+// tuned library on these shapes): persistent workgroups walk 256 x 256 output tiles in an XCD-aware order; eight waves as
+// 2 (m) x 4 (n), 128 x 64 per wave = 8 accumulator tiles of v_mfma_f32_32x32x16_bf16; operands arrive by LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a ring of ten 16-KiB sub-slots (128 rows x 64 k), the XOR
+// swizzle chunk ^= (row >> 1) & 7 applied on the per-lane SOURCE address so that ds_read_b128 fragment reads are conflict
+// free; ONE barrier per K step with a counted s_waitcnt vmcnt (the next step's pieces stay in flight across it).
+// The weight rows are the MFMA A operand and the activation rows the B operand, so an accumulator register group holds four
+// CONSECUTIVE output columns of one row: one v_permlane32_swap per dword turns two groups into 16 contiguous bytes per lane
+// for the Pre loads and the C stores.
+#include <hip/hip_ext.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace mmk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int MG_TILE = 256;          // output tile edge
+constexpr int MG_BK = 64;             // K per step
+constexpr int MG_SUB = 128 * 128;     // bytes of one sub-slot: 128 rows x 64 bf16
+constexpr int MG_RING = 10;           // sub-slots in the ring
+constexpr int MG_LDS = MG_RING * MG_SUB;
+
+enum { MG_PLAIN = 0, MG_FWD_ACT = 1, MG_BWD_DACT = 2 };
+enum { MG_ACT_QUICK_GELU = 0, MG_ACT_GELU = 1 };   // numbering of mmk_bias_act_*
+
+struct MlpGemmArgs {
+  const bf16_t* A;    // [M, K] row stride lda
+  const bf16_t* B;    // [N, K] row stride ldb
+  bf16_t* C;          // [M, N] row stride ldc
+  bf16_t* C2;         // MG_FWD_ACT: second output, the pre-activation A B^T without the bias (row stride ldc), or null
+  const bf16_t* P;    // MG_BWD_DACT: pre-activation [M, N], row stride ldp
+  const float* bias;  // [N] or null
+  float* part;        // MG_BWD_DACT: column-sum partials f32[2 * tiles_m][N] (one row per 128 output rows), or null
+  long lda, ldb, ldc, ldp;
+  int M, N, K;
+  int tiles_m, tiles_n;
+  int dbg;            // timing ablations, debug-switch builds only: 4 = no C stores, 8 = no epilogue arithmetic, 64 = hot DMA
+};
+
+__device__ __forceinline__ void mg_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+  const uint64_t pb = reinterpret_cast<uint64_t>(sbase);
+  const uint64_t ps = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pb >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb);
+  lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  // no "memory" clobber: the DMA lands in ring slots nobody reads during this step (the barriers order it), and the compiler
+  // must stay free to move this step's fragment reads across it
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(reinterpret_cast<const void*>(ps)), "s"(lds_addr));
+}
+
+template <int N>
+__device__ __forceinline__ void mg_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// pack two f32 into one dword of two bf16 (RNE, NaN-preserving: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t mg_pk(float lo, float hi) {
+  typedef bf16_t bf2 __attribute__((ext_vector_type(2)));
+  bf2 v;
+  v[0] = (bf16_t)lo;
+  v[1] = (bf16_t)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+// Phi(z) (standard normal CDF) and exp(-z^2 / 2) with ONE exponential: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7,
+// i.e. below f32 rounding of the surrounding arithmetic), whose exp(-x^2) factor at x = z / sqrt(2) is the density's.
+__device__ __forceinline__ float mg_phi(float z, float& e) {
+  const float az = fabsf(z) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(az, 0.3275911f, 1.f));
+  e = __builtin_amdgcn_exp2f(z * z * -0.72134752044448170f);   // exp(-z^2 / 2)
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float half_erf = fmaf(p * t, -0.5f * e, 0.5f);          // erf(|z| / sqrt 2) / 2
+  return 0.5f + copysignf(half_erf, z);
+}
+template <int ACT>
+__device__ __forceinline__ float mg_act(float z) {
+  if (ACT == MG_ACT_QUICK_GELU) return z * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(z * -2.4554669595930156f));
+  float e;
+  return z * mg_phi(z, e);
+}
+template <int ACT>
+__device__ __forceinline__ float mg_act_grad(float z) {
+  if (ACT == MG_ACT_QUICK_GELU) {
+    const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(z * -2.4554669595930156f));   // sigmoid(1.702 z)
+    const float ts = 1.702f * z * sg;
+    return fmaf(ts, 1.f - sg, sg);
+  }
+  float e;
+  const float phi = mg_phi(z, e);
+  return fmaf(z * 0.3989422804014327f, e, phi);
+}
+
+template <int MODE, int ACT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_gemm_kernel(const MlpGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // wave tile: output rows 128 wm .., output columns 64 wn ..
+  const int r = lane & 31, h = lane >> 5;
+  const uint32_t ring = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smem);
+  const int dbg = kDebugSwitches ? a.dbg : 0;
+
+  // ---- this workgroup's tiles: XCD x = blockIdx % 8 takes tiles [(i * 8 + x) * per_xcd, + per_xcd), i = 0, 1, ...
+  const int per_xcd = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int total = a.tiles_m * a.tiles_n;
+  const int nk = a.K / MG_BK;
+  int n_my = 0;
+  for (int i = 0;; ++i) {
+    if ((i * 8 + xcd) * per_xcd + slot >= total) break;
+    ++n_my;
+  }
+  const int G = n_my * nk;
+  if (G == 0) return;
+
+  // ---- loader state.  Piece p = 2 * wave + u (u = 0, 1) of a sub-slot covers its rows 8p .. 8p + 7; lane L lands at LDS
+  // row 8p + (L >> 3), chunk slot L & 7 and therefore fetches source chunk (L & 7) ^ swizzle(row).  M and N are multiples
+  // of the tile (host check), so no row needs clamping and the per-lane byte offsets are loop constants; everything that
+  // changes from step to step (tile, k position, half of the tile, ring slot) is scalar.
+  uint32_t voffA[2], voffB[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int lrow = 8 * (2 * wave + u) + (lane >> 3);
+    const uint32_t lchunk = (uint32_t)(((lane & 7) ^ ((lrow >> 1) & 7)) << 4);
+    voffA[u] = (uint32_t)lrow * (uint32_t)(a.lda * 2) + lchunk;
+    voffB[u] = (uint32_t)lrow * (uint32_t)(a.ldb * 2) + lchunk;
+  }
+  const uint32_t wave_lds = ring + (uint32_t)(2 * wave) * 1024u;
+  // data cursors: the (tile, k position) whose A (B) sub-slots are issued next.  They stop at the last step: the ring schedule
+  // below keeps issuing (the same data again, into slots nobody reads any more) so that the instruction counts the vmcnt
+  // waits rely on never change and the K loop has no branch between its MFMAs.
+  struct Cur {
+    int step, kt, tm, tn;
+  };
+  // this workgroup's tiles are t0, t0 + dt, t0 + 2 dt, ...: (tm, tn) advance by (dm, dn) with a carry
+  const int t0 = xcd * per_xcd + slot, dt = 8 * per_xcd;
+  const int dm = dt / a.tiles_n, dn = dt - dm * a.tiles_n;
+  auto next_tile = [&](int& tm, int& tn) {
+    tm += dm;
+    tn += dn;
+    if (tn >= a.tiles_n) {
+      tn -= a.tiles_n;
+      ++tm;
+    }
+  };
+  auto advance = [&](Cur& c) {
+    if (c.step + 1 >= G) return;
+    ++c.step;
+    if (++c.kt == nk) {
+      c.kt = 0;
+      next_tile(c.tm, c.tn);
+    }
+  };
+  Cur cA{0, 0, t0 / a.tiles_n, t0 % a.tiles_n};
+  Cur cB = cA;
+  int posA = 0, posB = 2;   // ring position of the next A / B pair of sub-slots: (4 s) mod 10, (4 s + 2) mod 10
+  auto bump = [&](int& pos) {
+    pos += 4;
+    if (pos >= MG_RING) pos -= MG_RING;
+  };
+  auto wrap1 = [&](int pos) { return pos >= MG_RING ? pos - MG_RING : pos; };
+  auto issue_sub = [&](const bf16_t* src, const uint32_t (&voff)[2], int pos) {   // src: first row of the 128-row half, k position applied
+    const uint32_t dst = wave_lds + (uint32_t)pos * MG_SUB;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) mg_dma16(src, voff[u], dst + (uint32_t)u * 1024u);
+  };
+  const bool hot = (dbg & 64) != 0;   // ablation: every DMA re-reads the same (cache-resident) 64 KiB
+  auto srcA = [&](const Cur& c, int half) { return a.A + (hot ? 0 : ((long)c.tm * MG_TILE + 128 * half) * a.lda + (long)c.kt * MG_BK); };
+  auto srcB = [&](const Cur& c, int half) { return a.B + (hot ? 0 : ((long)c.tn * MG_TILE + 128 * half) * a.ldb + (long)c.kt * MG_BK); };
+
+  // ---- fragment read offsets inside a sub-slot: row (32 blk + r), chunk (2 kk + h) ^ ((r >> 1) & 7)
+  uint32_t offk[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) offk[kk] = (uint32_t)(r * 128 + (((2 * kk + h) ^ ((r >> 1) & 7)) << 4));
+
+  // ---- prologue: A0 B0 A1.  Step g then issues the B half of step g + 1 and the A half of step g + 2 -- for g = 0 into the
+  // four ring slots the prologue left empty, later into the slots step g - 1 released: the same eight instructions per wave
+  // in every step.
+  issue_sub(srcA(cA, 0), voffA, 0);
+  issue_sub(srcA(cA, 1), voffA, 1);
+  advance(cA);
+  issue_sub(srcB(cB, 0), voffB, 2);
+  issue_sub(srcB(cB, 1), voffB, 3);
+  advance(cB);
+  issue_sub(srcA(cA, 0), voffA, 4);
+  issue_sub(srcA(cA, 1), voffA, 5);
+  advance(cA);
+  posA = 8;   // A of step 2
+  posB = 6;   // B of step 1
+
+  int ctm = t0 / a.tiles_n, ctn = t0 % a.tiles_n;   // compute cursor
+  int p0 = 0;   // ring position of the step being computed: (4 g) mod 10
+  // step 0 has landed when at most the A half of step 1 (4 instructions of this wave) is in flight
+  mg_wait_vmcnt<4>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  for (int ti = 0; ti < n_my; ++ti) {
+    f32x16 acc[2][4];   // [n block][m block]
+    {
+      f32x16 zero;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = zero;
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      const bf16_t* sB0 = srcB(cB, 0);
+      const bf16_t* sB1 = srcB(cB, 1);
+      const bf16_t* sA0 = srcA(cA, 0);
+      const bf16_t* sA1 = srcA(cA, 1);
+      const int pb1 = wrap1(posB + 1), pa1 = wrap1(posA + 1);
+      const char* sa = smem + wrap1(p0 + wm) * MG_SUB;        // activation rows (m): lanes
+      const char* sb = smem + wrap1(p0 + 2 + (wn >> 1)) * MG_SUB + (wn & 1) * 8192;   // weight rows (n): accumulator registers
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 fw[2], fx[4];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) fw[nb] = *reinterpret_cast<const bf16x8*>(sb + nb * 4096 + offk[kk]);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) fx[mb] = *reinterpret_cast<const bf16x8*>(sa + mb * 4096 + offk[kk]);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nb], fx[mb], acc[nb][mb], 0, 0, 0);
+        // this k block's share of the DMA: kk 0, 1 -> the two B sub-slots of step g + 1, kk 2, 3 -> the two A sub-slots of g + 2
+        if (kk == 0) issue_sub(sB0, voffB, posB);
+        if (kk == 1) issue_sub(sB1, voffB, pb1);
+        if (kk == 2) issue_sub(sA0, voffA, posA);
+        if (kk == 3) issue_sub(sA1, voffA, pa1);
+      }
+      advance(cB);
+      bump(posB);
+      advance(cA);
+      bump(posA);
+      bump(p0);
+      // step g + 1 must have landed before its first read; the only younger pieces of this wave are the A half of step g + 2
+      // (4 instructions).  (Loads and stores of an epilogue are older than this step's DMA: they have been given a whole step.)
+      mg_wait_vmcnt<4>();
+      __builtin_amdgcn_s_barrier();   // every wave's pieces of step g + 1 are in LDS; every wave is done reading step g
+      asm volatile("" ::: "memory");
+    }
+    {
+      // ---- epilogue of tile (ctm, ctn): acc[nb][mb][e] = C[m = 128 wm + 32 mb + r][n = 64 wn + 32 nb + (e&3) + 8 (e>>2) + 4 h]
+      // For the register-group pair (q0 = 2j, q1 = 2j + 1) one v_permlane32_swap per value hands the lower lane (h = 0) columns
+      // 16j + 0..7 and the upper lane (h = 1) columns 16j + 8..15 of the SAME row: 16 contiguous bytes of bf16 per lane.
+      const int m_base = ctm * MG_TILE + 128 * wm + r;
+      const int n_base = ctn * MG_TILE + 64 * wn;
+      float bv[2][2][8];   // bias of this lane's 8 columns per (nb, j)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float4 t0v = make_float4(0.f, 0.f, 0.f, 0.f), t1v = t0v;
+          if (MODE != MG_PLAIN && a.bias != nullptr) {
+            const float* bp = a.bias + n_base + 32 * nb + 16 * j + 8 * h;
+            t0v = *reinterpret_cast<const float4*>(bp);
+            t1v = *reinterpret_cast<const float4*>(bp + 4);
+          }
+          bv[nb][j][0] = t0v.x; bv[nb][j][1] = t0v.y; bv[nb][j][2] = t0v.z; bv[nb][j][3] = t0v.w;
+          bv[nb][j][4] = t1v.x; bv[nb][j][5] = t1v.y; bv[nb][j][6] = t1v.z; bv[nb][j][7] = t1v.w;
+        }
+      float cs[2][2][8];   // MG_BWD_DACT: column sums over this wave's 128 rows, per lane
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int c = 0; c < 8; ++c) cs[nb][j][c] = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const size_t m = (size_t)(m_base + 32 * mb);
+        uint4 pv[2][2];
+        if (MODE == MG_BWD_DACT) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pv[nb][j] = *reinterpret_cast<const uint4*>(a.P + m * a.ldp + n_base + 32 * nb + 16 * j + 8 * h);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const f32x16 tile = acc[nb][mb];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            float x[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tile[8 * j + i]), __float_as_uint(tile[8 * j + 4 + i]), false, false);
+              x[i] = __uint_as_float(sw[0]);
+              x[4 + i] = __uint_as_float(sw[1]);
+            }
+            const size_t off = m * a.ldc + n_base + 32 * nb + 16 * j + 8 * h;
+            if (MODE == MG_PLAIN) {
+              if (!(dbg & 4)) *reinterpret_cast<uint4*>(a.C + off) = make_uint4(mg_pk(x[0], x[1]), mg_pk(x[2], x[3]), mg_pk(x[4], x[5]), mg_pk(x[6], x[7]));
+            } else if (MODE == MG_FWD_ACT) {
+              float y[8];
+#pragma unroll
+              for (int c = 0; c < 8; ++c) y[c] = (dbg & 8) ? x[c] : mg_act<ACT>(x[c] + bv[nb][j][c]);
+              if (!(dbg & 4)) {
+                *reinterpret_cast<uint4*>(a.C + off) = make_uint4(mg_pk(y[0], y[1]), mg_pk(y[2], y[3]), mg_pk(y[4], y[5]), mg_pk(y[6], y[7]));
+                if (a.C2 != nullptr)
+                  *reinterpret_cast<uint4*>(a.C2 + off) = make_uint4(mg_pk(x[0], x[1]), mg_pk(x[2], x[3]), mg_pk(x[4], x[5]), mg_pk(x[6], x[7]));
+              }
+            } else {
+              const uint4 p = pv[nb][j];
+              const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+              float y[8];
+#pragma unroll
+              for (int c = 0; c < 8; ++c) {
+                const float z = __uint_as_float((c & 1) ? (pw[c >> 1] & 0xffff0000u) : (pw[c >> 1] << 16)) + bv[nb][j][c];
+                y[c] = (dbg & 8) ? x[c] + z : x[c] * mg_act_grad<ACT>(z);
+                cs[nb][j][c] += y[c];
+              }
+              if (!(dbg & 4)) *reinterpret_cast<uint4*>(a.C + off) = make_uint4(mg_pk(y[0], y[1]), mg_pk(y[2], y[3]), mg_pk(y[4], y[5]), mg_pk(y[6], y[7]));
+            }
+          }
+        }
+      }
+      if (MODE == MG_BWD_DACT && a.part != nullptr) {
+        // column sums over the 32 lanes of a half by a transpose-reduce (31 exchanges): value k = 16 nb + 8 j + c ends on lane r = k
+        float v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = cs[k >> 4][(k >> 3) & 1][k & 7];
+#pragma unroll
+        for (int s = 16; s >= 1; s >>= 1) {
+          const bool up = (r & s) != 0;
+#pragma unroll
+          for (int k = 0; k < s; ++k) {
+            const float send = up ? v[k] : v[k + s];
+            const float keep = up ? v[k + s] : v[k];
+            v[k] = keep + __shfl_xor(send, s);
+          }
+        }
+        const int n = n_base + 32 * (r >> 4) + 16 * ((r >> 3) & 1) + 8 * h + (r & 7);
+        a.part[(size_t)(2 * ctm + wm) * a.N + n] = v[0];
+      }
+    }
+    next_tile(ctm, ctn);
+  }
+  mg_wait_vmcnt<0>();   // the ring schedule's last (unused) pieces must not land in LDS after the workgroup has gone
+}
+
+}  // namespace mmk
+
+using namespace mmk;
+
+extern "C" {
+
+// 1 when the MLP GEMMs serve the shape; otherwise the caller keeps library GEMM + bias_act kernel
+int mmk_mlp_gemm_supported(int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc) {
+  return M >= MG_TILE && M % MG_TILE == 0 && N >= MG_TILE && N % MG_TILE == 0 && K >= 2 * MG_BK && K % MG_BK == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+         ldc % 8 == 0 && M < (1ll << 31) - 512 && (int64_t)127 * std::max(lda, ldb) * 2 + 128 < (1ll << 32);
+}
+
+int mmk_mlp_gemm_part_rows(int64_t M) { return (int)(2 * ((M + MG_TILE - 1) / MG_TILE)); }
+
+static int mlp_gemm_launch(int mode, int act, MlpGemmArgs& a, hipStream_t st) {
+  a.tiles_m = cdiv(a.M, MG_TILE);
+  a.tiles_n = cdiv(a.N, MG_TILE);
+  a.dbg = MMK_DBG_ENV("MMK_MLP_GEMM_DBG") ? atoi(MMK_DBG_ENV("MMK_MLP_GEMM_DBG")) : 0;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    MMK_HIP(hipGetDevice(&dev));
+    MMK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = std::max(8, n_cu / 8 * 8);
+  }
+  const int total = a.tiles_m * a.tiles_n;
+  const int grid = std::min(n_cu, round_up(total, 8));
+  const void* kern = nullptr;
+#define MG_PICK(MODE_, ACT_) \
+  if (mode == MODE_ && act == ACT_) kern = reinterpret_cast<const void*>(mlp_gemm_kernel<MODE_, ACT_>);
+  MG_PICK(MG_PLAIN, 0)
+  MG_PICK(MG_FWD_ACT, MG_ACT_QUICK_GELU) MG_PICK(MG_FWD_ACT, MG_ACT_GELU)
+  MG_PICK(MG_BWD_DACT, MG_ACT_QUICK_GELU) MG_PICK(MG_BWD_DACT, MG_ACT_GELU)
+#undef MG_PICK
+  MMK_REQUIRE(kern != nullptr, "mlp_gemm: unknown (mode, activation)");
+  // opt-in to > 64 KiB of dynamic LDS, once per device and kernel
+  {
+    static bool done[16][5] = {};
+    int dev = 0;
+    MMK_HIP(hipGetDevice(&dev));
+    const int ki = mode == MG_PLAIN ? 0 : 1 + 2 * (mode - 1) + act;
+    if (dev < 0 || dev >= 16 || !done[dev][ki]) {
+      MMK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS));
+      if (dev >= 0 && dev < 16) done[dev][ki] = true;
+    }
+  }
+  {
+    ProfEvents pe(MMK_K_MLP_GEMM);
+    void* params[] = {&a};
+    MMK_HIP(hipExtLaunchKernel(kern, dim3(grid), dim3(512), params, MG_LDS, st, pe.start, pe.stop, 0));
+  }
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+// C = A B^T (bf16 out): the main loop alone, for A/B timings against the library (tools/bench_mlp_fusion.py) and parity tests
+int mmk_mlp_gemm_plain(const void* A, const void* B, void* C, int64_t M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, void* stream) {
+  MMK_REQUIRE(A && B && C, "null pointer");
+  MMK_REQUIRE(mmk_mlp_gemm_supported(M, N, K, lda, ldb, ldc), "mlp_gemm: unsupported shape (need M % 256 == 0, N % 256 == 0, K % 64 == 0, strides % 8 == 0)");
+  MlpGemmArgs a = {};
+  a.A = static_cast<const bf16_t*>(A); a.B = static_cast<const bf16_t*>(B); a.C = static_cast<bf16_t*>(C);
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldp = 0; a.M = (int)M; a.N = N; a.K = K;
+  return mlp_gemm_launch(MG_PLAIN, 0, a, static_cast<hipStream_t>(stream));
+}
+
+// H = act(X W^T + bias) and (pre nullable) the bias-free pre-activation X W^T, both bf16 with row stride ldc
+int mmk_mlp_gemm_fwd_act(const void* X, const void* W, const float* bias, void* H, void* pre, int64_t M, int N, int K, int64_t ldx, int64_t ldw,
+                         int64_t ldc, int act, void* stream) {
+  MMK_REQUIRE(X && W && H, "null pointer");
+  MMK_REQUIRE(act == MG_ACT_QUICK_GELU || act == MG_ACT_GELU, "mlp_gemm: act must be 0 (quick_gelu) or 1 (gelu)");
+  MMK_REQUIRE(mmk_mlp_gemm_supported(M, N, K, ldx, ldw, ldc), "mlp_gemm: unsupported shape (need M % 256 == 0, N % 256 == 0, K % 64 == 0, strides % 8 == 0)");
+  MlpGemmArgs a = {};
+  a.A = static_cast<const bf16_t*>(X); a.B = static_cast<const bf16_t*>(W); a.C = static_cast<bf16_t*>(H); a.C2 = static_cast<bf16_t*>(pre);
+  a.bias = bias;
+  a.lda = ldx; a.ldb = ldw; a.ldc = ldc; a.ldp = 0; a.M = (int)M; a.N = N; a.K = K;
+  return mlp_gemm_launch(MG_FWD_ACT, act, a, static_cast<hipStream_t>(stream));
+}
+
+// dPre = (dY Wt^T) * act'(pre + bias): dY [M, K], Wt [N, K] (= fc2.weight^T, K-contiguous), pre [M, N] row stride ldp.
+// part (nullable): f32[mmk_mlp_gemm_part_rows(M)][N], row i = column sums of dPre over output rows [128 i, 128 i + 128).
+int mmk_mlp_gemm_bwd_dact(const void* dY, const void* Wt, const void* pre, const float* bias, void* dPre, float* part, int64_t M, int N, int K,
+                          int64_t ldy, int64_t ldw, int64_t ldp, int64_t ldc, int act, void* stream) {
+  MMK_REQUIRE(dY && Wt && pre && dPre, "null pointer");
+  MMK_REQUIRE(act == MG_ACT_QUICK_GELU || act == MG_ACT_GELU, "mlp_gemm: act must be 0 (quick_gelu) or 1 (gelu)");
+  MMK_REQUIRE(mmk_mlp_gemm_supported(M, N, K, ldy, ldw, ldc) && ldp % 8 == 0,
+              "mlp_gemm: unsupported shape (need M % 256 == 0, N % 256 == 0, K % 64 == 0, strides % 8 == 0)");
+  MlpGemmArgs a = {};
+  a.A = static_cast<const bf16_t*>(dY); a.B = static_cast<const bf16_t*>(Wt); a.C = static_cast<bf16_t*>(dPre);
+  a.P = static_cast<const bf16_t*>(pre); a.bias = bias; a.part = part;
+  a.lda = ldy; a.ldb = ldw; a.ldc = ldc; a.ldp = ldp; a.M = (int)M; a.N = N; a.K = K;
+  return mlp_gemm_launch(MG_BWD_DACT, act, a, static_cast<hipStream_t>(stream));
+}
+
+}

@@ -347,6 +347,54 @@ def linear_nobias(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     return linear(x, lin.weight, None)
 
 
+class _ActLinearFn(torch.autograd.Function):
+    """``act(h + b1) @ W2^T`` -- the bias + activation kernel and the bias-free fc2 GEMM of an MLP as ONE autograd node, so that
+    the backward can run ``dPre = (dY W2) * act'(h + b1)`` and ``db1 = dPre.sum(0)`` inside the epilogue of the dX GEMM
+    (``csrc/mlp_gemm.hip``): the [rows, hidden] gradient of the activation's output is never written or read back.  Shapes the
+    kernel does not serve (rows not a multiple of 256, ...) run library GEMM + ``bias_act_bwd``, the pair this node replaces."""
+
+    @staticmethod
+    def forward(ctx, h, b1, w2, act):
+        d = h.shape[-1]
+        h2 = h.contiguous().view(-1, d)
+        b32 = b1.detach().float().contiguous()
+        a2 = K.bias_act_fwd(h2, b32, act)
+        w16, w_bwd, ctx.w_twin = _weight_operands(w2)
+        ctx.save_for_backward(h2, b32, a2, w_bwd)
+        ctx.act, ctx.h_shape, ctx.b_dtype, ctx.w_dtype = act, h.shape, b1.dtype, w2.dtype
+        with torch.autocast("cuda", enabled=False):
+            y = a2 @ w16.t()
+        return y.view(*h.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        h2, b32, a2, w_bwd = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16).contiguous()
+        M, E = dy2.shape
+        H = h2.shape[1]
+        dh = db1 = dw2 = None
+        with torch.autocast("cuda", enabled=False):
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+                if (ctx.w_twin and h2.dtype == torch.bfloat16 and not os.environ.get("MMK_NO_MLP_FUSION")   # (A/B switch)
+                        and K.mlp_gemm_supported(M, H, E, dy2.stride(0), w_bwd.stride(0), H)):
+                    dh, db1 = K.mlp_gemm_bwd_dact(dy2, w_bwd, h2, b32, ctx.act, want_dbias=ctx.needs_input_grad[1])
+                else:
+                    dh, db1 = K.bias_act_bwd(h2, b32, _dx_gemm(dy2, w_bwd, ctx.w_twin).to(h2.dtype), ctx.act)
+                dh = dh.view(ctx.h_shape)
+                db1 = None if db1 is None else db1.to(ctx.b_dtype)
+            if ctx.needs_input_grad[2]:
+                dw2 = K.wgrad(dy2, a2, ctx.w_dtype if ctx.w_dtype in (torch.float32, torch.bfloat16) else torch.float32).to(ctx.w_dtype)
+        return dh, db1, dw2, None
+
+
+def act_linear(h: torch.Tensor, bias: torch.Tensor, act: str, fc2: nn.Linear) -> torch.Tensor:
+    """``fc2`` (bias-free) of ``act(h + bias)`` for ``h = linear_nobias(fc1, x)``: one autograd node with the fused backward where
+    the weight-gradient path applies (bf16, >= 6k rows), the two separate nodes otherwise."""
+    if h.dtype == torch.bfloat16 and h.is_cuda and fc2.weight.shape[1] == h.shape[-1] and _wgrad_linear_ok(fc2.weight, h):
+        return _ActLinearFn.apply(h, bias, fc2.weight, {"quick_gelu": K.ACT_QUICK_GELU, "gelu": K.ACT_GELU}[act])
+    return linear_nobias(fc2, bias_act(h, bias, act))
+
+
 def _act_name(fn) -> Optional[str]:
     name = type(fn).__name__
     if name in ("QuickGELUActivation", "QuickGELU"):
@@ -370,7 +418,7 @@ def _clip_mlp_nobias(mlp, x2: torch.Tensor):
     h = linear_nobias(mlp.fc1, x2)
     if h.dtype not in (torch.bfloat16, torch.float16, torch.float32):
         return mlp(x2), None
-    return linear_nobias(mlp.fc2, bias_act(h, mlp.fc1.bias, act)), mlp.fc2.bias
+    return act_linear(h, mlp.fc1.bias, act, mlp.fc2), mlp.fc2.bias
 
 
 def _clip_layer_forward(self, hidden_states, attention_mask=None, **kwargs):
@@ -433,6 +481,22 @@ def _bert_intermediate_forward(self, hidden_states):
     return self.intermediate_act_fn(self.dense(hidden_states))
 
 
+def _bert_ffn_chunk(self, attention_output):
+    """Replaces HF ``BertLayer.feed_forward_chunk`` (``self.output(self.intermediate(x), x)``): intermediate and output are
+    separate modules there, here the GELU kernel and ``output.dense`` share one autograd node (``act_linear``: the GELU's backward
+    runs in the epilogue of that GEMM's dX) and ``output.dense.bias`` + dropout + residual + LayerNorm stay one kernel."""
+    inter, outp = self.intermediate, self.output
+    act = _act_name(inter.intermediate_act_fn)
+    if (act is None or not _bias_deferrable(inter.dense, attention_output) or not _bias_deferrable(outp.dense, attention_output)
+            or not _ln_fusable(outp.LayerNorm, attention_output)):
+        return outp(inter(attention_output), attention_output)
+    h = linear_nobias(inter.dense, attention_output)
+    if h.dtype != torch.bfloat16:
+        return outp(bias_act(h, inter.dense.bias, act), attention_output)
+    y = act_linear(h, inter.dense.bias, act, outp.dense)
+    return add_layer_norm(y, attention_output, outp.LayerNorm, outp.dropout.p if self.training else 0.0, xbias=outp.dense.bias, twin=True)[1]
+
+
 def _is_preln_block(m: nn.Module) -> bool:
     """Duck type of the timm-style pre-LN block mmlearn's own ViT / I-JEPA predictor are built from
     (mmlearn/modules/layers/transformer_block.py: ``norm1, attn(qkv, proj, attn_drop, proj_drop, num_heads, scale),
@@ -464,7 +528,7 @@ def _seq_mlp_nobias(mlp, x2: torch.Tensor, training: bool):
     if not (isinstance(fc1, nn.Linear) and isinstance(fc2, nn.Linear) and name is not None and p1 == 0.0 and p2 is not None
             and _bias_deferrable(fc1, x2) and _bias_deferrable(fc2, x2)):
         return None
-    return linear_nobias(fc2, bias_act(linear_nobias(fc1, x2), fc1.bias, name)), fc2.bias, p2
+    return act_linear(linear_nobias(fc1, x2), fc1.bias, name, fc2), fc2.bias, p2
 
 
 def _preln_block_forward(self, x, return_attention: bool = False):
@@ -522,6 +586,9 @@ def fuse_add_layer_norm(module: nn.Module) -> int:
             m._mmk_stock_layer_forward = m.forward
             m.forward = types.MethodType(fwd, m)
             n += 1
+        if (type(m).__name__ == "BertLayer" and "feed_forward_chunk" not in m.__dict__ and hasattr(m, "intermediate")
+                and hasattr(m, "output") and not getattr(m, "add_cross_attention", False)):
+            m.feed_forward_chunk = types.MethodType(_bert_ffn_chunk, m)
         if isinstance(m, nn.ModuleList) and len(m) > 1:   # consecutive pre-LN layers: see _clip_layer_forward
             if all(type(c).__name__ == "CLIPEncoderLayer" for c in m):
                 for cur, nxt in zip(list(m)[:-1], list(m)[1:]):

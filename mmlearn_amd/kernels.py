@@ -840,6 +840,62 @@ def bias_act_bwd(x2: torch.Tensor, bias: torch.Tensor, dy2: torch.Tensor, act: i
     return dx, dbias
 
 
+def mlp_gemm_supported(M: int, N: int, K: int, lda: int, ldb: int, ldc: int) -> bool:
+    """True when ``csrc/mlp_gemm.hip`` serves ``[M, K] x [N, K]^T`` (M, N multiples of 256, K of 64, strides of 8)."""
+    return bool(_lib.lib().mmk_mlp_gemm_supported(M, N, K, lda, ldb, ldc))
+
+
+def _mlp_gemm_check(a2: torch.Tensor, b2: torch.Tensor) -> None:
+    require_gpu(a2)
+    if not (a2.dtype == torch.bfloat16 and b2.dtype == torch.bfloat16 and a2.dim() == 2 and b2.dim() == 2 and a2.stride(1) == 1
+            and b2.stride(1) == 1 and a2.shape[1] == b2.shape[1]):
+        raise ValueError("mlp_gemm: operands must be 2-D bf16 with contiguous rows and equal inner dimension")
+
+
+def mlp_gemm_plain(a2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """``a2 [M, K] @ b2 [N, K]^T`` in bf16 (f32 accumulation) on the MLP GEMM's main loop alone (A/B timings, parity tests)."""
+    _mlp_gemm_check(a2, b2)
+    M, K_ = a2.shape
+    c = torch.empty((M, b2.shape[0]), dtype=torch.bfloat16, device=a2.device)
+    check(_lib.lib().mmk_mlp_gemm_plain(ptr(a2), ptr(b2), ptr(c), M, b2.shape[0], K_, a2.stride(0), b2.stride(0), c.stride(0), stream()))
+    return c
+
+
+def mlp_gemm_fwd_act(x2: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int, want_pre: bool = True):
+    """-> (``act(x2 @ w^T + bias)``, bias-free pre-activation ``x2 @ w^T`` or None), both bf16: fc1 of an MLP in one kernel."""
+    _mlp_gemm_check(x2, w)
+    M, K_ = x2.shape
+    N = w.shape[0]
+    assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N
+    h = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
+    pre = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device) if want_pre else None
+    check(_lib.lib().mmk_mlp_gemm_fwd_act(ptr(x2), ptr(w), ptr(bias), ptr(h), ptr(pre), M, N, K_, x2.stride(0), w.stride(0), h.stride(0),
+                                          int(act), stream()))
+    return h, pre
+
+
+def mlp_gemm_bwd_dact(dy2: torch.Tensor, wt: torch.Tensor, pre: torch.Tensor, bias: torch.Tensor, act: int, want_dbias: bool = True):
+    """-> (``dPre = (dy2 @ wt^T) * act'(pre + bias)`` bf16, ``dbias`` f32[N] = column sums of dPre or None): the dX GEMM of fc2
+    with the activation's backward in its epilogue.  ``wt`` = fc2.weight^T as [hidden, out] (K-contiguous)."""
+    _mlp_gemm_check(dy2, wt)
+    M, K_ = dy2.shape
+    N = wt.shape[0]
+    assert pre.dtype == torch.bfloat16 and pre.shape == (M, N) and pre.stride(1) == 1
+    assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N
+    dev = dy2.device
+    dpre = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    part = dbias = None
+    if want_dbias:
+        part = torch.empty((_lib.lib().mmk_mlp_gemm_part_rows(M), N), dtype=torch.float32, device=dev)
+    check(_lib.lib().mmk_mlp_gemm_bwd_dact(ptr(dy2), ptr(wt), ptr(pre), ptr(bias), ptr(dpre), ptr(part), M, N, K_, dy2.stride(0),
+                                           wt.stride(0), pre.stride(0), dpre.stride(0), int(act), stream()))
+    if want_dbias:
+        part2 = torch.empty((256, N), dtype=torch.float32, device=dev)
+        dbias = torch.empty(N, dtype=torch.float32, device=dev)
+        check(_lib.lib().mmk_colsum_f32(ptr(part), part.shape[0], N, ptr(part2), ptr(dbias), stream()))
+    return dpre, dbias
+
+
 def quick_gelu_fwd(x: torch.Tensor) -> torch.Tensor:
     require_gpu(x)
     y = torch.empty_like(x)

@@ -1,0 +1,169 @@
+"""GPU parity of the MLP GEMMs with the activation in the epilogue (csrc/mlp_gemm.hip) against plain PyTorch f32 references:
+forward  act(x W1^T + b1)  (+ the bias-free pre-activation), backward  (dY W2) * act'(pre + b1)  with its column sums."""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ACTS = {0: "quick_gelu", 1: "gelu"}
+
+
+def _act(z, act):
+    return z * torch.sigmoid(1.702 * z) if act == 0 else F.gelu(z)
+
+
+def _act_grad(z, act):
+    z = z.detach().clone().requires_grad_(True)
+    _act(z, act).sum().backward()
+    return z.grad
+
+
+def _operands(M, N, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    b = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    return a, b
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 768), (1024, 3072, 768), (768, 512, 3072), (256 * 9, 256 * 5, 192)])
+def test_plain_product_vs_torch(M, N, K):
+    from mmlearn_amd import kernels as Kn
+
+    dev = torch.device("cuda", 0)
+    a, b = _operands(M, N, K, M + N + K)
+    assert Kn.mlp_gemm_supported(M, N, K, K, K, N)
+    c = Kn.mlp_gemm_plain(a.to(dev), b.to(dev))
+    ref = a.float() @ b.float().t()
+    err = (c.float().cpu() - ref).abs().max().item()
+    assert c.dtype == torch.bfloat16 and err <= 1e-2 * max(1.0, ref.abs().max().item()), err
+
+
+def test_product_is_exact_on_integer_data_with_an_asymmetric_operand():
+    """A = [I | 0] against an asymmetric integer B: every output element is exact in bf16, so a swapped row / column map,
+    a wrong k order inside a fragment or a misplaced tile cannot hide behind a tolerance."""
+    from mmlearn_amd import kernels as Kn
+
+    dev = torch.device("cuda", 0)
+    M, N, K = 512, 512, 512
+    a = torch.zeros(M, K)
+    a[torch.arange(M), torch.arange(M) % K] = 1.0
+    a[torch.arange(M), (3 * torch.arange(M) + 7) % K] += 2.0
+    b = ((torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 5) % 31 - 15).float()
+    ref = a @ b.t()
+    c = Kn.mlp_gemm_plain(a.bfloat16().to(dev), b.bfloat16().to(dev))
+    assert torch.equal(c.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (768, 3072, 768), (512, 512, 256)])
+def test_forward_with_activation(M, N, K, act):
+    from mmlearn_amd import kernels as Kn
+
+    dev = torch.device("cuda", 0)
+    x, w = _operands(M, N, K, 11 * M + N + K + act)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(5)) * 0.2
+    h, pre = Kn.mlp_gemm_fwd_act(x.to(dev), w.to(dev), bias.to(dev), act)
+    ref_pre = x.float() @ w.float().t()
+    ref_h = _act(ref_pre + bias, act)
+    assert h.dtype == pre.dtype == torch.bfloat16
+    assert (pre.float().cpu() - ref_pre).abs().max().item() <= 1e-2 * max(1.0, ref_pre.abs().max().item())
+    assert (h.float().cpu() - ref_h).abs().max().item() <= 1e-2 * max(1.0, ref_h.abs().max().item())
+    h2, none = Kn.mlp_gemm_fwd_act(x.to(dev), w.to(dev), bias.to(dev), act, want_pre=False)
+    assert none is None and torch.equal(h2, h)
+    # the same epilogue as the unfused pair (library GEMM -> bias_act kernel), up to the rounding of the pre-activation
+    h_unfused = Kn.bias_act_fwd(F.linear(x.to(dev), w.to(dev)), bias.to(dev), act)
+    assert (h.float() - h_unfused.float()).abs().max().item() <= 2e-2 * max(1.0, ref_h.abs().max().item())
+
+
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1024, 3072, 768), (512, 768, 256), (256 * 5, 512, 768)])
+def test_backward_with_activation_gradient_and_column_sums(M, N, K, act):
+    from mmlearn_amd import kernels as Kn
+
+    dev = torch.device("cuda", 0)
+    dy, wt = _operands(M, N, K, 7 * M + N + K + act)
+    g = torch.Generator().manual_seed(M + act)
+    pre = (torch.randn(M, N, generator=g) * 1.5).bfloat16()
+    bias = torch.randn(N, generator=g) * 0.2
+    dpre, db = Kn.mlp_gemm_bwd_dact(dy.to(dev), wt.to(dev), pre.to(dev), bias.to(dev), act)
+    dact = dy.float() @ wt.float().t()
+    ref = dact * _act_grad(pre.float() + bias, act)
+    scale = max(1.0, ref.abs().max().item())
+    assert dpre.dtype == torch.bfloat16 and dpre.shape == (M, N)
+    assert (dpre.float().cpu() - ref).abs().max().item() <= 1e-2 * scale
+    ref_db = ref.sum(0)
+    assert db.dtype == torch.float32 and db.shape == (N,)
+    assert (db.cpu() - ref_db).abs().max().item() <= 2e-3 * max(1.0, ref.abs().sum(0).max().item())
+    # the unfused pair it replaces
+    dx_u, db_u = Kn.bias_act_bwd(pre.to(dev), bias.to(dev), F.linear(dy.to(dev), wt.to(dev)), act)
+    assert (dpre.float() - dx_u.float()).abs().max().item() <= 2e-2 * scale
+    assert (db - db_u).abs().max().item() <= 5e-3 * max(1.0, ref.abs().sum(0).max().item())
+    dpre2, none = Kn.mlp_gemm_bwd_dact(dy.to(dev), wt.to(dev), pre.to(dev), bias.to(dev), act, want_dbias=False)
+    assert none is None and torch.equal(dpre2, dpre)
+
+
+def test_strided_operands_and_many_tiles_per_workgroup():
+    """Operands that are column slices of wider buffers, and more tiles than workgroups (every workgroup walks several tiles,
+    the ring keeps streaming across tile boundaries)."""
+    from mmlearn_amd import kernels as Kn
+
+    dev = torch.device("cuda", 0)
+    M, N, K = 256 * 24, 256 * 12, 128
+    g = torch.Generator().manual_seed(9)
+    big_a = torch.randn(M, K + 64, generator=g).bfloat16().to(dev)
+    big_b = (torch.randn(N, K + 8, generator=g) / K ** 0.5).bfloat16().to(dev)
+    a, b = big_a[:, 64:], big_b[:, :K]
+    assert Kn.mlp_gemm_supported(M, N, K, a.stride(0), b.stride(0), N)
+    c = Kn.mlp_gemm_plain(a, b)
+    ref = a.float() @ b.float().t()
+    assert (c.float() - ref).abs().max().item() <= 1e-2 * max(1.0, ref.abs().max().item())
+
+
+def test_unsupported_shapes_are_refused():
+    from mmlearn_amd import kernels as Kn
+
+    assert not Kn.mlp_gemm_supported(250, 256, 128, 128, 128, 256)
+    assert not Kn.mlp_gemm_supported(256, 200, 128, 128, 128, 200)
+    assert not Kn.mlp_gemm_supported(256, 256, 96, 96, 96, 256)
+    dev = torch.device("cuda", 0)
+    with pytest.raises(RuntimeError):
+        Kn.mlp_gemm_plain(torch.zeros(250, 128, dtype=torch.bfloat16, device=dev), torch.zeros(256, 128, dtype=torch.bfloat16, device=dev))
+
+
+@pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
+def test_act_linear_node_matches_the_unfused_pair_and_f32_autograd(act, monkeypatch):
+    """``fused.act_linear`` (bias + activation kernel and fc2 as one autograd node, activation backward inside the dX GEMM's
+    epilogue) against (a) the two separate nodes it replaces and (b) plain f32 autograd of the same MLP."""
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    E, H, rows = 256, 512, 8192
+    fc1, fc2 = torch.nn.Linear(E, H).to(dev), torch.nn.Linear(H, E).to(dev)
+    x0 = torch.randn(32, rows // 32, E, device=dev)
+    wgt = torch.randn(32, rows // 32, E, device=dev)
+
+    def run(mode):
+        for p in list(fc1.parameters()) + list(fc2.parameters()):
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        if mode == "f32":
+            z = F.linear(x, fc1.weight, fc1.bias)
+            y = F.linear(_act(z, 0 if act == "quick_gelu" else 1), fc2.weight)
+        else:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = fused.act_linear(fused.linear_nobias(fc1, x), fc1.bias, act, fc2)
+        (y.float() * wgt).sum().backward()
+        return [y.detach().float(), x.grad.float(), fc1.weight.grad.float(), fc1.bias.grad.float(), fc2.weight.grad.float()]
+
+    fused_out = run("fused")
+    monkeypatch.setenv("MMK_NO_MLP_FUSION", "1")
+    unfused_out = run("unfused")
+    monkeypatch.delenv("MMK_NO_MLP_FUSION")
+    ref = run("f32")
+    for name, a, b, c in zip(("y", "dx", "dW1", "db1", "dW2"), fused_out, unfused_out, ref):
+        scale = max(1.0, c.abs().max().item())
+        assert (a - c).abs().max().item() <= 3e-2 * scale, (name, "vs f32", (a - c).abs().max().item(), scale)
+        assert (a - b).abs().max().item() <= 2e-2 * scale, (name, "vs unfused", (a - b).abs().max().item(), scale)

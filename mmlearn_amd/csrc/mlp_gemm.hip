@@ -18,8 +18,8 @@
 // swizzle chunk ^= (row >> 1) & 7 applied on the per-lane SOURCE address so that ds_read_b128 fragment reads are conflict
 // free; ONE barrier per K step with a counted s_waitcnt vmcnt (the next step's pieces stay in flight across it).
 // The weight rows are the MFMA A operand and the activation rows the B operand, so an accumulator register group holds four
-// CONSECUTIVE output columns of one row: one v_permlane32_swap per dword turns two groups into 16 contiguous bytes per lane
-// for the Pre loads and the C stores.
+// CONSECUTIVE output columns of one row (8 bytes of bf16); the epilogue regroups them into whole 128-byte lines through a
+// wave-private LDS image, so that every global access of the tile (C stores, Pre loads) is 8 rows x 128 B per wave-instruction.
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 
@@ -31,6 +31,7 @@ namespace mmk {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MG_TILE = 256;          // output tile edge
 constexpr int MG_BK = 64;             // K per step
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = zero;
     }
-    for (int kt = 0; kt < nk; ++kt) {
+    auto k_step = [&]() {
       const bf16_t* sB0 = srcB(cB, 0);
       const bf16_t* sB1 = srcB(cB, 1);
       const bf16_t* sA0 = srcA(cA, 0);
@@ -260,101 +261,132 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       mg_wait_vmcnt<4>();
       __builtin_amdgcn_s_barrier();   // every wave's pieces of step g + 1 are in LDS; every wave is done reading step g
       asm volatile("" ::: "memory");
+    };
+    for (int kt = 0; kt < nk - 1; ++kt) k_step();
+    u32x4 pr[8];   // MG_BWD_DACT: a 64 x 64 block of P in row layout (piece p: row 8 p + (lane >> 3), 16-byte chunk lane & 7)
+    if (MODE == MG_BWD_DACT) {
+      // the first of the epilogue's two dependent HBM reads, requested one K step ahead: older than the last step's LDS-DMA, so that
+      // step's closing s_waitcnt vmcnt(4) covers it and it travels behind the step's MFMAs
+      const bf16_t* pp = a.P + (size_t)(ctm * MG_TILE + 128 * wm + (lane >> 3)) * a.ldp + ctn * MG_TILE + 64 * wn + 8 * (lane & 7);
+      const long pstep = 8 * a.ldp;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        pr[p] = *reinterpret_cast<const u32x4*>(pp);
+        pp += pstep;
+      }
     }
+    k_step();
     {
-      // ---- epilogue of tile (ctm, ctn): acc[nb][mb][e] = C[m = 128 wm + 32 mb + r][n = 64 wn + 32 nb + (e&3) + 8 (e>>2) + 4 h]
-      // For the register-group pair (q0 = 2j, q1 = 2j + 1) one v_permlane32_swap per value hands the lower lane (h = 0) columns
-      // 16j + 0..7 and the upper lane (h = 1) columns 16j + 8..15 of the SAME row: 16 contiguous bytes of bf16 per lane.
-      const int m_base = ctm * MG_TILE + 128 * wm + r;
+      // ---- epilogue of tile (ctm, ctn): acc[nb][mb][e] = C[m = 128 wm + 32 mb + r][n = 64 wn + 32 nb + 8 (e>>2) + 4 h + (e&3)]
+      // A lane holds pieces of 32 different rows, and row-per-lane global accesses are issue-bound (16 stores of 16 bytes per lane
+      // took 4.7 us per tile and wave pair: the whole difference to the library on the plain product, and as much again for the
+      // loads of P).  So every global access of the epilogue is a whole 128-byte line per 8 lanes -- one wave-instruction = 8 rows
+      // x 128 B -- and the tile changes layout through a wave-private LDS image: the four sub-slots of the step just finished are
+      // free until step g + 1 issues its first DMA (the barrier at the end of this block), 8 KiB = 64 rows x 128 B per wave,
+      // 16-byte chunk index ^= row & 7 (both access shapes conflict-free or 2-way).  No workgroup barrier inside: a wave's LDS
+      // operations execute in order.
+      const int pfree = p0 >= 4 ? p0 - 4 : p0 + 6;
+      char* stg = smem + wrap1(pfree + (wave >> 1)) * MG_SUB + (wave & 1) * 8192;
+      const int m0 = ctm * MG_TILE + 128 * wm;
       const int n_base = ctn * MG_TILE + 64 * wn;
-      float bv[2][2][8];   // bias of this lane's 8 columns per (nb, j)
+      const int sw = r & 7, L3 = lane >> 3, L7 = lane & 7;
+      char* acc_ptr = stg + r * 128 + 8 * h;                     // + mb' * 4096 + (((4 nb + q) ^ sw) << 4): 4 columns of row 32 mb' + r
+      char* row_ptr = stg + L3 * 128 + ((L7 ^ L3) << 4);          // + p * 1024: chunk L7 of row 8 p + L3
+      // Every load of the epilogue is issued before its first store: vmcnt retires in order, so waiting for a load that was issued
+      // behind stores waits for those stores to drain as well (the bias read piecemeal between the two halves' stores cost 60 us of
+      // a 1190 us launch).
+      const bool has_bias = MODE != MG_PLAIN && a.bias != nullptr;
+      float bv[2][4][4];   // bias of this lane's columns 32 nb + 8 q + 4 h + i
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          float4 t0v = make_float4(0.f, 0.f, 0.f, 0.f), t1v = t0v;
-          if (MODE != MG_PLAIN && a.bias != nullptr) {
-            const float* bp = a.bias + n_base + 32 * nb + 16 * j + 8 * h;
-            t0v = *reinterpret_cast<const float4*>(bp);
-            t1v = *reinterpret_cast<const float4*>(bp + 4);
-          }
-          bv[nb][j][0] = t0v.x; bv[nb][j][1] = t0v.y; bv[nb][j][2] = t0v.z; bv[nb][j][3] = t0v.w;
-          bv[nb][j][4] = t1v.x; bv[nb][j][5] = t1v.y; bv[nb][j][6] = t1v.z; bv[nb][j][7] = t1v.w;
+        for (int q = 0; q < 4; ++q) {
+          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (has_bias) t = *reinterpret_cast<const float4*>(a.bias + n_base + 32 * nb + 8 * q + 4 * h);
+          bv[nb][q][0] = t.x; bv[nb][q][1] = t.y; bv[nb][q][2] = t.z; bv[nb][q][3] = t.w;
         }
-      float cs[2][2][8];   // MG_BWD_DACT: column sums over this wave's 128 rows, per lane
+      float csr[8];   // MG_BWD_DACT: sums of this lane's 8 columns (chunk L7) over the rows it stores, taken from the ROUNDED values
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+      for (int c = 0; c < 8; ++c) csr[c] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int c = 0; c < 8; ++c) cs[nb][j][c] = 0.f;
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        const size_t m = (size_t)(m_base + 32 * mb);
-        uint4 pv[2][2];
+      for (int hb = 0; hb < 2; ++hb) {
         if (MODE == MG_BWD_DACT) {
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb)
+          for (int p = 0; p < 8; ++p) *reinterpret_cast<u32x4*>(row_ptr + p * 1024) = pr[p];
+          if (hb == 0) {   // the second half's block: requested now, needed after the first half's arithmetic and stores
+            const bf16_t* pp = a.P + (size_t)(m0 + 64 + L3) * a.ldp + n_base + 8 * L7;
+            const long pstep = 8 * a.ldp;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) pv[nb][j] = *reinterpret_cast<const uint4*>(a.P + m * a.ldp + n_base + 32 * nb + 16 * j + 8 * h);
+            for (int p = 0; p < 8; ++p) {
+              pr[p] = *reinterpret_cast<const u32x4*>(pp);
+              pp += pstep;
+            }
+          }
         }
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          const f32x16 tile = acc[nb][mb];
+        for (int pass = 0; pass < (MODE == MG_FWD_ACT ? 2 : 1); ++pass) {
+          if (pass == 1 && a.C2 == nullptr) break;
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            float x[8];
+          for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tile[8 * j + i]), __float_as_uint(tile[8 * j + 4 + i]), false, false);
-              x[i] = __uint_as_float(sw[0]);
-              x[4 + i] = __uint_as_float(sw[1]);
+            for (int q = 0; q < 4; ++q) {
+              const float bvq[4] = {bv[nb][q][0], bv[nb][q][1], bv[nb][q][2], bv[nb][q][3]};
+#pragma unroll
+              for (int mbl = 0; mbl < 2; ++mbl) {
+                const f32x16 tile = acc[nb][2 * hb + mbl];
+                char* ap = acc_ptr + mbl * 4096 + (((4 * nb + q) ^ sw) << 4);
+                float y[4];
+                if (MODE == MG_PLAIN || pass == 1) {
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) y[i] = tile[4 * q + i];
+                } else if (MODE == MG_FWD_ACT) {
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) y[i] = (dbg & 8) ? tile[4 * q + i] : mg_act<ACT>(tile[4 * q + i] + bvq[i]);
+                } else {
+                  const uint2 pz = *reinterpret_cast<const uint2*>(ap);
+                  const float z[4] = {__uint_as_float(pz.x << 16), __uint_as_float(pz.x & 0xffff0000u), __uint_as_float(pz.y << 16),
+                                      __uint_as_float(pz.y & 0xffff0000u)};
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) y[i] = (dbg & 8) ? tile[4 * q + i] + z[i] : tile[4 * q + i] * mg_act_grad<ACT>(z[i] + bvq[i]);
+                }
+                *reinterpret_cast<uint2*>(ap) = make_uint2(mg_pk(y[0], y[1]), mg_pk(y[2], y[3]));
+              }
             }
-            const size_t off = m * a.ldc + n_base + 32 * nb + 16 * j + 8 * h;
-            if (MODE == MG_PLAIN) {
-              if (!(dbg & 4)) *reinterpret_cast<uint4*>(a.C + off) = make_uint4(mg_pk(x[0], x[1]), mg_pk(x[2], x[3]), mg_pk(x[4], x[5]), mg_pk(x[6], x[7]));
-            } else if (MODE == MG_FWD_ACT) {
-              float y[8];
+          }
+          bf16_t* out = (pass == 1 ? a.C2 : a.C) + (size_t)(m0 + 64 * hb + L3) * a.ldc + n_base + 8 * L7;
+          const long ostep = 8 * a.ldc;
 #pragma unroll
-              for (int c = 0; c < 8; ++c) y[c] = (dbg & 8) ? x[c] : mg_act<ACT>(x[c] + bv[nb][j][c]);
-              if (!(dbg & 4)) {
-                *reinterpret_cast<uint4*>(a.C + off) = make_uint4(mg_pk(y[0], y[1]), mg_pk(y[2], y[3]), mg_pk(y[4], y[5]), mg_pk(y[6], y[7]));
-                if (a.C2 != nullptr)
-                  *reinterpret_cast<uint4*>(a.C2 + off) = make_uint4(mg_pk(x[0], x[1]), mg_pk(x[2], x[3]), mg_pk(x[4], x[5]), mg_pk(x[6], x[7]));
-              }
-            } else {
-              const uint4 p = pv[nb][j];
-              const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
-              float y[8];
-#pragma unroll
-              for (int c = 0; c < 8; ++c) {
-                const float z = __uint_as_float((c & 1) ? (pw[c >> 1] & 0xffff0000u) : (pw[c >> 1] << 16)) + bv[nb][j][c];
-                y[c] = (dbg & 8) ? x[c] + z : x[c] * mg_act_grad<ACT>(z);
-                cs[nb][j][c] += y[c];
-              }
-              if (!(dbg & 4)) *reinterpret_cast<uint4*>(a.C + off) = make_uint4(mg_pk(y[0], y[1]), mg_pk(y[2], y[3]), mg_pk(y[4], y[5]), mg_pk(y[6], y[7]));
+          for (int p = 0; p < 8; ++p) {
+            const uint4 v = *reinterpret_cast<const uint4*>(row_ptr + p * 1024);
+            if (!(dbg & 4)) *reinterpret_cast<uint4*>(out) = v;
+            out += ostep;
+            if (MODE == MG_BWD_DACT) {
+              csr[0] += __uint_as_float(v.x << 16); csr[1] += __uint_as_float(v.x & 0xffff0000u);
+              csr[2] += __uint_as_float(v.y << 16); csr[3] += __uint_as_float(v.y & 0xffff0000u);
+              csr[4] += __uint_as_float(v.z << 16); csr[5] += __uint_as_float(v.z & 0xffff0000u);
+              csr[6] += __uint_as_float(v.w << 16); csr[7] += __uint_as_float(v.w & 0xffff0000u);
             }
           }
         }
       }
       if (MODE == MG_BWD_DACT && a.part != nullptr) {
-        // column sums over the 32 lanes of a half by a transpose-reduce (31 exchanges): value k = 16 nb + 8 j + c ends on lane r = k
-        float v[32];
+        // lanes L7 + 8 k (k = lane >> 3) hold partial sums of the same 8 columns: transpose-reduce over k (7 exchanges), column
+        // index c ends on the lane whose k has bit pattern c
 #pragma unroll
-        for (int k = 0; k < 32; ++k) v[k] = cs[k >> 4][(k >> 3) & 1][k & 7];
+        for (int s2 = 4; s2 >= 1; s2 >>= 1) {
+          const bool up = (L3 & s2) != 0;
 #pragma unroll
-        for (int s = 16; s >= 1; s >>= 1) {
-          const bool up = (r & s) != 0;
-#pragma unroll
-          for (int k = 0; k < s; ++k) {
-            const float send = up ? v[k] : v[k + s];
-            const float keep = up ? v[k + s] : v[k];
-            v[k] = keep + __shfl_xor(send, s);
+          for (int k = 0; k < s2; ++k) {
+            const float send = up ? csr[k] : csr[k + s2];
+            const float keep = up ? csr[k + s2] : csr[k];
+            csr[k] = keep + __shfl_xor(send, 8 * s2);
           }
         }
-        const int n = n_base + 32 * (r >> 4) + 16 * ((r >> 3) & 1) + 8 * h + (r & 7);
-        a.part[(size_t)(2 * ctm + wm) * a.N + n] = v[0];
+        a.part[(size_t)(2 * ctm + wm) * a.N + n_base + 8 * L7 + L3] = csr[0];
       }
+      // every wave is done with its staging image before any wave lets step g + 1's DMA into these sub-slots
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
     next_tile(ctm, ctn);
   }

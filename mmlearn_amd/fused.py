@@ -347,52 +347,76 @@ def linear_nobias(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     return linear(x, lin.weight, None)
 
 
-class _ActLinearFn(torch.autograd.Function):
-    """``act(h + b1) @ W2^T`` -- the bias + activation kernel and the bias-free fc2 GEMM of an MLP as ONE autograd node, so that
-    the backward can run ``dPre = (dY W2) * act'(h + b1)`` and ``db1 = dPre.sum(0)`` inside the epilogue of the dX GEMM
-    (``csrc/mlp_gemm.hip``): the [rows, hidden] gradient of the activation's output is never written or read back.  Shapes the
-    kernel does not serve (rows not a multiple of 256, ...) run library GEMM + ``bias_act_bwd``, the pair this node replaces."""
+class _MLPFn(torch.autograd.Function):
+    """``act(x W1^T + b1) W2^T`` -- a two-layer MLP without fc2's bias (the consumer kernel adds it) as ONE autograd node around
+    the two GEMMs of ``csrc/mlp_gemm.hip`` that carry the activation pass in their epilogue:
+
+    * forward: ``fc1`` + bias + activation in one kernel that writes the activation and the bias-free pre-activation (the unfused
+      step runs library GEMM -> ``bias_act_fwd``: one read of the [rows, hidden] tensor more);
+    * backward: ``dPre = (dY W2) * act'(pre + b1)`` and ``db1 = dPre.sum(0)`` inside fc2's dX GEMM (the unfused step writes
+      ``dY W2``, reads it back with ``pre`` and writes ``dPre``: two passes over [rows, hidden] more).
+
+    fc2's forward and fc1's dX stay library GEMMs, both weight gradients run on ``csrc/wgrad.hip``.  Shapes the kernels do not serve
+    (rows not a multiple of 256, ...) take the library GEMM + ``bias_act`` kernels inside the same node."""
 
     @staticmethod
-    def forward(ctx, h, b1, w2, act):
-        d = h.shape[-1]
-        h2 = h.contiguous().view(-1, d)
+    def forward(ctx, x, w1, b1, w2, act):
+        k = x.shape[-1]
+        x2 = x.reshape(-1, k).to(torch.bfloat16)
+        if x2.stride(1) != 1 or x2.stride(0) % 8:
+            x2 = x2.contiguous()
+        w1_16, w1_bwd, ctx.w1_twin = _weight_operands(w1)
+        w2_16, w2_bwd, ctx.w2_twin = _weight_operands(w2)
         b32 = b1.detach().float().contiguous()
-        a2 = K.bias_act_fwd(h2, b32, act)
-        w16, w_bwd, ctx.w_twin = _weight_operands(w2)
-        ctx.save_for_backward(h2, b32, a2, w_bwd)
-        ctx.act, ctx.h_shape, ctx.b_dtype, ctx.w_dtype = act, h.shape, b1.dtype, w2.dtype
+        M, H = x2.shape[0], w1.shape[0]
+        ctx.fused = not os.environ.get("MMK_NO_MLP_FUSION")   # (A/B switch)
         with torch.autocast("cuda", enabled=False):
-            y = a2 @ w16.t()
-        return y.view(*h.shape[:-1], w2.shape[0])
+            if ctx.fused and K.mlp_gemm_supported(M, H, k, x2.stride(0), w1_16.stride(0), H):
+                a2, h2 = K.mlp_gemm_fwd_act(x2, w1_16, b32, act)
+            else:
+                h2 = x2 @ w1_16.t()
+                a2 = K.bias_act_fwd(h2, b32, act)
+            y = a2 @ w2_16.t()
+        ctx.save_for_backward(x2, h2, a2, b32, w1_bwd, w2_bwd)
+        ctx.meta = (x.shape, x.dtype, w1.dtype, b1.dtype, w2.dtype, act)
+        return y.view(*x.shape[:-1], w2.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        h2, b32, a2, w_bwd = ctx.saved_tensors
+        x2, h2, a2, b32, w1_bwd, w2_bwd = ctx.saved_tensors
+        x_shape, x_dtype, w1_dtype, b_dtype, w2_dtype, act = ctx.meta
         dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16).contiguous()
         M, E = dy2.shape
         H = h2.shape[1]
-        dh = db1 = dw2 = None
+        wdt = lambda t: t if t in (torch.float32, torch.bfloat16) else torch.float32
+        dx = dw1 = db1 = dw2 = None
         with torch.autocast("cuda", enabled=False):
-            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-                if (ctx.w_twin and h2.dtype == torch.bfloat16 and not os.environ.get("MMK_NO_MLP_FUSION")   # (A/B switch)
-                        and K.mlp_gemm_supported(M, H, E, dy2.stride(0), w_bwd.stride(0), H)):
-                    dh, db1 = K.mlp_gemm_bwd_dact(dy2, w_bwd, h2, b32, ctx.act, want_dbias=ctx.needs_input_grad[1])
+            if ctx.needs_input_grad[3]:
+                dw2 = K.wgrad(dy2, a2, wdt(w2_dtype)).to(w2_dtype)
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                if ctx.fused and ctx.w2_twin and K.mlp_gemm_supported(M, H, E, dy2.stride(0), w2_bwd.stride(0), H):
+                    dpre, db1 = K.mlp_gemm_bwd_dact(dy2, w2_bwd, h2, b32, act, want_dbias=ctx.needs_input_grad[2])
                 else:
-                    dh, db1 = K.bias_act_bwd(h2, b32, _dx_gemm(dy2, w_bwd, ctx.w_twin).to(h2.dtype), ctx.act)
-                dh = dh.view(ctx.h_shape)
-                db1 = None if db1 is None else db1.to(ctx.b_dtype)
-            if ctx.needs_input_grad[2]:
-                dw2 = K.wgrad(dy2, a2, ctx.w_dtype if ctx.w_dtype in (torch.float32, torch.bfloat16) else torch.float32).to(ctx.w_dtype)
-        return dh, db1, dw2, None
+                    dpre, db1 = K.bias_act_bwd(h2, b32, _dx_gemm(dy2, w2_bwd, ctx.w2_twin), act)
+                if ctx.needs_input_grad[0]:
+                    dx = _dx_gemm(dpre, w1_bwd, ctx.w1_twin).view(x_shape).to(x_dtype)
+                if ctx.needs_input_grad[1]:
+                    dw1 = K.wgrad(dpre, x2, wdt(w1_dtype)).to(w1_dtype)
+                db1 = db1.to(b_dtype) if (db1 is not None and ctx.needs_input_grad[2]) else None
+        return dx, dw1, db1, dw2, None
 
 
-def act_linear(h: torch.Tensor, bias: torch.Tensor, act: str, fc2: nn.Linear) -> torch.Tensor:
-    """``fc2`` (bias-free) of ``act(h + bias)`` for ``h = linear_nobias(fc1, x)``: one autograd node with the fused backward where
-    the weight-gradient path applies (bf16, >= 6k rows), the two separate nodes otherwise."""
-    if h.dtype == torch.bfloat16 and h.is_cuda and fc2.weight.shape[1] == h.shape[-1] and _wgrad_linear_ok(fc2.weight, h):
-        return _ActLinearFn.apply(h, bias, fc2.weight, {"quick_gelu": K.ACT_QUICK_GELU, "gelu": K.ACT_GELU}[act])
-    return linear_nobias(fc2, bias_act(h, bias, act))
+def mlp_fc1_act_fc2(x: torch.Tensor, fc1: nn.Linear, act: str, fc2: nn.Linear) -> torch.Tensor:
+    """``fc2.weight`` applied to ``act(fc1(x))`` -- everything of a two-layer MLP except fc2's bias, which the consumer kernel adds.
+    Where the weight-gradient path applies (bf16, >= 6k rows, gradients on) the whole thing is one autograd node on the fused
+    GEMMs (``_MLPFn``); otherwise the three separate ops: bias-free fc1, bias + activation kernel, bias-free fc2."""
+    x16 = getattr(x, "_mmk_bf16", None)   # bf16 twin attached by add_layer_norm(twin=True)
+    if x16 is not None and x16.shape == x.shape and _autocast_bf16():
+        x = x16
+    if (_wgrad_linear_ok(fc1.weight, x) and fc2.weight.requires_grad and fc1.bias is not None and fc2.weight.dim() == 2
+            and fc2.weight.shape[1] == fc1.weight.shape[0] and fc2.weight.shape[0] % 8 == 0 and fc2.weight.shape[1] % 8 == 0):
+        return _MLPFn.apply(x, fc1.weight, fc1.bias, fc2.weight, {"quick_gelu": K.ACT_QUICK_GELU, "gelu": K.ACT_GELU}[act])
+    return linear_nobias(fc2, bias_act(linear_nobias(fc1, x), fc1.bias, act))
 
 
 def _act_name(fn) -> Optional[str]:
@@ -415,10 +439,7 @@ def _clip_mlp_nobias(mlp, x2: torch.Tensor):
     act = _act_name(mlp.activation_fn)
     if act is None or not (_bias_deferrable(mlp.fc1, x2) and _bias_deferrable(mlp.fc2, x2)):
         return mlp(x2), None
-    h = linear_nobias(mlp.fc1, x2)
-    if h.dtype not in (torch.bfloat16, torch.float16, torch.float32):
-        return mlp(x2), None
-    return act_linear(h, mlp.fc1.bias, act, mlp.fc2), mlp.fc2.bias
+    return mlp_fc1_act_fc2(x2, mlp.fc1, act, mlp.fc2), mlp.fc2.bias
 
 
 def _clip_layer_forward(self, hidden_states, attention_mask=None, **kwargs):
@@ -483,17 +504,14 @@ def _bert_intermediate_forward(self, hidden_states):
 
 def _bert_ffn_chunk(self, attention_output):
     """Replaces HF ``BertLayer.feed_forward_chunk`` (``self.output(self.intermediate(x), x)``): intermediate and output are
-    separate modules there, here the GELU kernel and ``output.dense`` share one autograd node (``act_linear``: the GELU's backward
-    runs in the epilogue of that GEMM's dX) and ``output.dense.bias`` + dropout + residual + LayerNorm stay one kernel."""
+    separate modules there, here the GELU kernel and ``output.dense`` share one autograd node (``mlp_fc1_act_fc2``: the GELU's
+    backward runs inside that GEMM's dX kernel) and ``output.dense.bias`` + dropout + residual + LayerNorm stay one kernel."""
     inter, outp = self.intermediate, self.output
     act = _act_name(inter.intermediate_act_fn)
     if (act is None or not _bias_deferrable(inter.dense, attention_output) or not _bias_deferrable(outp.dense, attention_output)
             or not _ln_fusable(outp.LayerNorm, attention_output)):
         return outp(inter(attention_output), attention_output)
-    h = linear_nobias(inter.dense, attention_output)
-    if h.dtype != torch.bfloat16:
-        return outp(bias_act(h, inter.dense.bias, act), attention_output)
-    y = act_linear(h, inter.dense.bias, act, outp.dense)
+    y = mlp_fc1_act_fc2(attention_output, inter.dense, act, outp.dense)
     return add_layer_norm(y, attention_output, outp.LayerNorm, outp.dropout.p if self.training else 0.0, xbias=outp.dense.bias, twin=True)[1]
 
 
@@ -528,7 +546,7 @@ def _seq_mlp_nobias(mlp, x2: torch.Tensor, training: bool):
     if not (isinstance(fc1, nn.Linear) and isinstance(fc2, nn.Linear) and name is not None and p1 == 0.0 and p2 is not None
             and _bias_deferrable(fc1, x2) and _bias_deferrable(fc2, x2)):
         return None
-    return act_linear(linear_nobias(fc1, x2), fc1.bias, name, fc2), fc2.bias, p2
+    return mlp_fc1_act_fc2(x2, fc1, name, fc2), fc2.bias, p2
 
 
 def _preln_block_forward(self, x, return_attention: bool = False):

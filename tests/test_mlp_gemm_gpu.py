@@ -133,14 +133,15 @@ def test_unsupported_shapes_are_refused():
 
 
 @pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
-def test_act_linear_node_matches_the_unfused_pair_and_f32_autograd(act, monkeypatch):
-    """``fused.act_linear`` (bias + activation kernel and fc2 as one autograd node, activation backward inside the dX GEMM's
-    epilogue) against (a) the two separate nodes it replaces and (b) plain f32 autograd of the same MLP."""
+@pytest.mark.parametrize("E,H", [(256, 512), (768, 1024)])
+def test_mlp_node_matches_the_unfused_ops_and_f32_autograd(E, H, act, monkeypatch):
+    """``fused.mlp_fc1_act_fc2`` (bias-free fc1, then activation + fc2 as one autograd node whose backward is the fused dX GEMM)
+    against (a) the same node on library GEMM + ``bias_act_bwd`` and (b) plain f32 autograd of the same MLP."""
     from mmlearn_amd import fused
 
     dev = torch.device("cuda", 0)
     torch.manual_seed(3)
-    E, H, rows = 256, 512, 8192
+    rows = 8192
     fc1, fc2 = torch.nn.Linear(E, H).to(dev), torch.nn.Linear(H, E).to(dev)
     x0 = torch.randn(32, rows // 32, E, device=dev)
     wgt = torch.randn(32, rows // 32, E, device=dev)
@@ -154,7 +155,7 @@ def test_act_linear_node_matches_the_unfused_pair_and_f32_autograd(act, monkeypa
             y = F.linear(_act(z, 0 if act == "quick_gelu" else 1), fc2.weight)
         else:
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                y = fused.act_linear(fused.linear_nobias(fc1, x), fc1.bias, act, fc2)
+                y = fused.mlp_fc1_act_fc2(x, fc1, act, fc2)
         (y.float() * wgt).sum().backward()
         return [y.detach().float(), x.grad.float(), fc1.weight.grad.float(), fc1.bias.grad.float(), fc2.weight.grad.float()]
 
@@ -167,3 +168,7 @@ def test_act_linear_node_matches_the_unfused_pair_and_f32_autograd(act, monkeypa
         scale = max(1.0, c.abs().max().item())
         assert (a - c).abs().max().item() <= 3e-2 * scale, (name, "vs f32", (a - c).abs().max().item(), scale)
         assert (a - b).abs().max().item() <= 2e-2 * scale, (name, "vs unfused", (a - b).abs().max().item(), scale)
+    # without gradients (evaluation) the separate ops run and give the same activations
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y_eval = fused.mlp_fc1_act_fc2(x0, fc1, act, fc2)
+    assert (y_eval.float() - ref[0]).abs().max().item() <= 3e-2 * max(1.0, ref[0].abs().max().item())

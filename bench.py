@@ -17,7 +17,8 @@ The JSON line carries, besides the driver contract:
                   inside the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s);
   roofline_widened -- the same for the dominant hand-written kernel of the whole step (the weight-gradient GEMM);
   cpu_baseline -- the same step (same model, torch eager ops, oracle/eager_torch loss = the reference's op
-                  sequence) on the host cores for a bounded sample (rank 0, N = 1 only).
+                  sequence) on rank 0's host cores for a bounded sample (at every N);
+  roofline_shard -- one rank's share of the row-sharded loss at configs[2] (R = 1024 x C = 8192), timed at N = 1.
 """
 
 from __future__ import annotations
@@ -581,6 +582,79 @@ def loss_n8192_leg(dev, n: int = 8192, d: int = 512, iters: int = 10):
     return roof
 
 
+def _shard_traffic(cols: int):
+    """HBM-side bytes of one rank's share at this column count from the committed PMC passes (profiles/r04_pmc_traffic_shard.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/bench_loss_shard.py), or None."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_shard.json")))
+        return pmc.get(f"cols{cols}")
+    except Exception:
+        return None
+
+
+def loss_shard_leg(dev, rows: int = 1024, cols: int = 8192, d: int = 512, rank: int = 3, iters: int = 20):
+    """One rank's share of the row-sharded loss path at BASELINE configs[2] (W = 8: R = 1024 owned rows x C = 8192 gathered columns,
+    both directions S_r = A_r B_all^T and T_r = B_r A_all^T) on one GPU: the launches ``mmlearn_amd.losses`` issues between the
+    all-gather and the LSE all-reduce and after it (pack, similarity statistics, merge, gradient tiles, gradient GEMMs, finalize;
+    the collectives themselves are not in it) -- the shape a rank runs at the BASELINE metric, on the driver's clock.  Algorithmic
+    work per rank = 8 R C D."""
+    from mmlearn_amd import _lib, kernels as K
+
+    R, C, D = rows, cols, d
+    p0 = min(rank, C // R - 1) * R
+    torch.manual_seed(0)
+    A = torch.nn.functional.normalize(torch.randn(C, D, device=dev), dim=-1).bfloat16()
+    B = torch.nn.functional.normalize(torch.randn(C, D, device=dev), dim=-1).bfloat16()
+    scale = torch.tensor([1 / 0.07], device=dev)
+    upstream = torch.ones((), device=dev)
+    comp = _lib.COMPUTE_BF16
+    kg = 1.0 / (2.0 * C)
+
+    def step():
+        (ag, agt), (bg, bgt) = K.pack_rows_many([(A, None, C, False, True), (B, None, C, False, True)], comp)
+        dirs = []
+        for x, y, yt in ((K.slice_packed(ag, p0), bg, bgt), (K.slice_packed(bg, p0), ag, agt)):
+            dirs.append(K.Direction(x=x, y=y, y_t=yt, r=R, c=C, label_off=p0, kappa=kg, ds_kappa=kg))
+        dirs[1].s_row = dirs[1].s_col = dirs[1].s_diag = 0.0
+        K.clip_forward(dirs, D, comp, scale)
+        # stand-in for the all-reduced column LSEs: this rank's own rows are real, the other ranks' entries reuse them
+        for dr, other in ((dirs[0], dirs[1]), (dirs[1], dirs[0])):
+            dr.lse_col = other.lse.repeat(C // R).contiguous()
+            dr.dx = torch.zeros((R, D), dtype=torch.bfloat16, device=dev)
+        ds = torch.zeros(1, device=dev)
+        K.clip_backward(dirs, D, comp, scale, upstream, ds)
+
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    _lib.profile_read()
+    _lib.profile_enable(True)
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / iters
+    pmc = _shard_traffic(C)
+    roof = _loss_roofline(prof, R, C, D, 1, iters, pmc.get("dominant_hbm_bytes_per_launch") if pmc else None, loss_only=True)
+    if roof is not None:
+        dev_us = sum(v[1] for v in prof.values()) / iters * 1e3
+        roof["device_us_per_rank_share"] = round(dev_us, 1)
+        roof["wall_us_per_rank_share"] = round(wall * 1e6, 1)
+        roof["algorithmic_tflops_per_rank_share"] = round(8.0 * R * C * D / (dev_us * 1e-6) / 1e12, 1)
+        roof["hbm_bytes_per_rank_share"] = pmc.get("total_hbm_bytes") if pmc else None
+        roof["operand_bytes_per_rank_share"] = int(2 * (C + R) * D * 2 * 2 + 2 * R * D * 2)
+    return roof
+
+
+def _leg_loss_shard(args, dev):
+    return loss_shard_leg(dev)
+
+
 def _leg_eager(args, dev):
     return eager_gpu_leg(args.batch, int(os.environ.get("RANK", "0")), dev, args.small)
 
@@ -628,9 +702,9 @@ def _leg_ijepa_eager(args, dev):
     return ijepa_leg(16 if args.small else 128, dev, args.small, stock=True)
 
 
-LEGS = {"eager_gpu": _leg_eager, "loss_n8192": _leg_loss_n8192, "three_tower": _leg_three_tower, "ijepa_vitl": _leg_ijepa,
+LEGS = {"eager_gpu": _leg_eager, "loss_n8192": _leg_loss_n8192, "loss_shard": _leg_loss_shard, "three_tower": _leg_three_tower, "ijepa_vitl": _leg_ijepa,
         "cls_only_last_layer": _leg_cls_only, "three_tower_eager": _leg_three_tower_eager, "ijepa_vitl_eager": _leg_ijepa_eager}
-LEG_TIMEOUT_S = {"eager_gpu": 240, "loss_n8192": 120, "three_tower": 150, "ijepa_vitl": 240, "cls_only_last_layer": 150,
+LEG_TIMEOUT_S = {"eager_gpu": 240, "loss_n8192": 120, "loss_shard": 120, "three_tower": 150, "ijepa_vitl": 240, "cls_only_last_layer": 150,
                  "three_tower_eager": 180, "ijepa_vitl_eager": 240}
 
 
@@ -875,7 +949,7 @@ def main():
         eager = run_leg("eager_gpu", args)
     extra = {}
     if rank == 0 and world == 1 and not force_dist and not args.no_extra_legs:
-        for name in ("loss_n8192", "three_tower", "ijepa_vitl", "cls_only_last_layer"):
+        for name in ("loss_n8192", "loss_shard", "three_tower", "ijepa_vitl", "cls_only_last_layer"):
             extra[name] = run_leg(name, args)
         # denominators of the configs[3] / configs[4] legs: the same steps on stock modules, each in a child process of its own
         for name, key in (("three_tower", "samples_s"), ("ijepa_vitl", "images_s")):
@@ -891,9 +965,11 @@ def main():
         n_rows, n_cols, d = args.batch, args.batch * world, 512
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes of the same kernel and shape (profiles/)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
-            if world == 1 and args.batch == 1024:
+            if world == 1 and not force_dist and args.batch == 1024:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
                 traffic = pmc.get("n1024", {}).get("hbm_bytes_per_launch")
+            elif args.batch == 1024:   # N > 1: the rank's sharded shape (R = batch rows x C = batch * world columns)
+                traffic = (_shard_traffic(n_cols) or {}).get("dominant_hbm_bytes_per_launch")
         except Exception:
             traffic = None
         roofline = _loss_roofline(prof, n_rows, n_cols, d, 1, prof_steps, traffic)
@@ -940,9 +1016,12 @@ def main():
             "roofline_widened": roofline_widened,
             "eager_gpu": eager,
             "roofline_n8192": extra.get("loss_n8192"),
-            "extra": {k: v for k, v in extra.items() if k != "loss_n8192"} or None,
+            # one rank's share of configs[2] (R = 1024 x C = 8192, both directions): the shape a rank runs at the BASELINE metric
+            "roofline_shard": extra.get("loss_shard"),
+            "extra": {k: v for k, v in extra.items() if k not in ("loss_n8192", "loss_shard")} or None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # rank 0's host cores, at every N (the other ranks wait at the barrier below): a bounded sample of the same step
             out["cpu_baseline"] = cpu_baseline()
     # RCCL leaves its version banner in the C stdout buffer of a process until exit: every rank pushes its buffer out, then all
     # meet, and only then rank 0 prints the result line -- the last line on stdout

@@ -1346,10 +1346,10 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
     if (rc) return rc;
   }
   {
-    ProfScope ps(MMK_K_LSE_REDUCE, st);
-    if (align)
+    if (align) {
+      ProfScope ps(MMK_K_LSE_REDUCE, st);
       hipLaunchKernelGGL(align_reduce_kernel, dim3(cdiv(r_max, 256), n_dirs), dim3(256), 0, st, ab);
-    else {
+    } else {
       const dim3 grid(cdiv(r_red_max, 64), n_red);
       mb.loss_out = nullptr;
       mb.counter = nullptr;
@@ -1360,7 +1360,8 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
         mb.counter = reinterpret_cast<unsigned*>(tickets);
         mb.scratch = reinterpret_cast<float*>(tickets) + 1;
       }
-      hipLaunchKernelGGL(lse_merge_kernel, grid, dim3(256), 0, st, mb);
+      ProfEvents pe(MMK_K_LSE_REDUCE);   // dispatch-stamped (see launch_grad_finalize)
+      hipExtLaunchKernelGGL(lse_merge_kernel, grid, dim3(256), 0, st, pe.start, pe.stop, 0, mb);
     }
     MMK_LAUNCH_CHECK();
   }
@@ -1493,10 +1494,12 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
 
 int launch_grad_finalize(const FinBatch& fb, int n_dirs, int max_r, int ld_max, const float* scale, const float* upstream, const DsBatch& db,
                          float* dscale_out, int dx_dtype, hipStream_t st) {
-  ProfScope ps(MMK_K_GRAD_FINALIZE, st);
+  // dispatch-stamped events (hipExtLaunchKernelGGL), like the MFMA kernels of the path: a record-before / record-after pair reads
+  // the queue wait of a short kernel behind a long one as its duration (168 us for a 5 us launch in the round-3 driver line)
+  ProfEvents pe(MMK_K_GRAD_FINALIZE);
   int rc = MMK_DISPATCH_DTYPE(dx_dtype, U, [&]() -> int {
-    hipLaunchKernelGGL((grad_finalize_kernel<U>), dim3(cdiv(max_r, 4), n_dirs + (dscale_out ? 1 : 0)), dim3(256), 4 * ld_max * sizeof(float), st, fb,
-                       scale, upstream, db, dscale_out, n_dirs);
+    hipExtLaunchKernelGGL((grad_finalize_kernel<U>), dim3(cdiv(max_r, 4), n_dirs + (dscale_out ? 1 : 0)), dim3(256), 4 * ld_max * sizeof(float), st,
+                          pe.start, pe.stop, 0, fb, scale, upstream, db, dscale_out, n_dirs);
     return 0;
   });
   if (rc) return rc;
@@ -1575,12 +1578,12 @@ int mmk_pack_rows_many(const mmk_pack_req* reqs, int n, int src_dtype, int d, in
     b.e[k] = PackEntry{q.src, q.idx, q.dst, q.dstT, q.r, q.r_pad, q.normalize, q.ldt, q.norm};
     r_pad_max = std::max(r_pad_max, q.r_pad);
   }
-  ProfScope ps(MMK_K_PACK, st);
+  ProfEvents pe(MMK_K_PACK);   // dispatch-stamped (see launch_grad_finalize)
   int rc = MMK_DISPATCH_DTYPE(src_dtype, S, [&]() -> int {
     if (compute == MMK_COMPUTE_BF16)
-      hipLaunchKernelGGL((pack_tr_kernel<S, bf16_t>), dim3(r_pad_max / 16, n), dim3(256), 0, st, b, d, k_pad);
+      hipExtLaunchKernelGGL((pack_tr_kernel<S, bf16_t>), dim3(r_pad_max / 16, n), dim3(256), 0, st, pe.start, pe.stop, 0, b, d, k_pad);
     else
-      hipLaunchKernelGGL((pack_tr_kernel<S, float>), dim3(r_pad_max / 16, n), dim3(256), 0, st, b, d, k_pad);
+      hipExtLaunchKernelGGL((pack_tr_kernel<S, float>), dim3(r_pad_max / 16, n), dim3(256), 0, st, pe.start, pe.stop, 0, b, d, k_pad);
     return 0;
   });
   if (rc) return rc;

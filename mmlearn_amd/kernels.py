@@ -447,7 +447,11 @@ class _FusedPlan:
         self.allocs = 0   # workspaces ever allocated (a steady-state loop needs one or two)
 
     def take(self, stream_handle: int) -> torch.Tensor:
-        """A workspace last used on THIS stream (its previous launches are ordered before ours), else a fresh zeroed one."""
+        """A workspace last used on THIS stream (its previous launches are ordered before ours), else a fresh zeroed one.  Under
+        graph capture always a fresh one, which the run then never returns: the graph bakes the pointer in, so the buffer must be
+        owned by the graph (its private pool) and by nobody else -- not by later eager calls on the same stream."""
+        if torch.cuda.is_current_stream_capturing():
+            return torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
         for k in range(len(self.pool) - 1, -1, -1):
             if self.pool[k][0] == stream_handle:
                 return self.pool.pop(k)[1]
@@ -460,6 +464,8 @@ class _FusedPlan:
 
 
 _FUSED_PLANS: dict = {}
+_FUSED_EVENTS: dict = {}   # (device index, stream handle) -> event recorded behind that stream's latest fused launch
+_FUSED_LAST: dict = {}     # device index -> (event, stream handle) of the device's latest fused launch
 
 
 def clip_fused_plan(device: torch.device, ns: Sequence[int], d: int, dtype: torch.dtype) -> Optional[_FusedPlan]:
@@ -481,12 +487,13 @@ def clip_fused_plan(device: torch.device, ns: Sequence[int], d: int, dtype: torc
 class FusedRun:
     """Forward state of one fused call: keeps the workspace (raw gradient sums) until ``backward`` or deletion."""
 
-    __slots__ = ("plan", "ws", "arr", "n_pairs", "d", "dtype", "ds_raw", "ds_acc", "keep", "stream", "n_bwd")
+    __slots__ = ("plan", "ws", "arr", "n_pairs", "d", "dtype", "ds_raw", "ds_acc", "keep", "stream", "n_bwd", "captured")
 
     def release(self, last_stream: Optional[int] = None) -> None:
-        """Hand the workspace back, tagged with the stream its last launch went to (the pool only reuses it on that stream)."""
+        """Hand the workspace back, tagged with the stream its last launch went to (the pool only reuses it on that stream).  A
+        workspace taken under graph capture belongs to that graph and is simply dropped here."""
         ws, self.ws = self.ws, None
-        if ws is not None and self.plan is not None:
+        if ws is not None and self.plan is not None and not getattr(self, "captured", False):
             self.plan.give(self.stream if last_stream is None else last_stream, ws)
 
     def __del__(self):
@@ -510,11 +517,27 @@ def clip_fused_forward(plan: _FusedPlan, pairs: Sequence[tuple], d: int, scale: 
     run = FusedRun()
     run.plan, run.arr, run.n_pairs, run.d, run.dtype, run.keep = plan, arr, len(pairs), d, pairs[0][0].dtype, keep
     run.stream, run.n_bwd = stream(), 0
+    run.captured = torch.cuda.is_current_stream_capturing()
     run.ws = plan.take(run.stream)
     out = torch.empty(3, dtype=torch.float32, device=dev)   # [loss, raw d loss / d scale, 0 = accumulator for backward's dscale]
     run.ds_raw, run.ds_acc = out[1:], out[2:]
+    # The kernel is a resident grid with in-launch hand-offs: its workgroups must all be on the chip together.  Two such grids
+    # launched from different streams can each hold part of the slots and wait for the rest until the bounded spins give up (NaN
+    # loss), so fused launches of a device are chained: a launch waits for the previous one if that went to another stream.
+    # (Not under capture: a captured launch replays inside its graph, ordered by the graph.)
+    if not run.captured:
+        cur = torch.cuda.current_stream(dev)
+        last = _FUSED_LAST.get(dev.index)
+        if last is not None and last[1] != run.stream:
+            cur.wait_event(last[0])
     check(_lib.lib().mmk_clip_fused_forward(C.cast(arr, C.c_void_p), len(pairs), d, dtype_tag(run.dtype), ptr(scale), ptr(run.ws), plan.ws_bytes,
                                             int(want_grad), ptr(out), ptr(run.ds_raw) if want_grad else None, run.stream))
+    if not run.captured:
+        ev = _FUSED_EVENTS.get((dev.index, run.stream))
+        if ev is None:
+            ev = _FUSED_EVENTS[(dev.index, run.stream)] = torch.cuda.Event()
+        ev.record(cur)
+        _FUSED_LAST[dev.index] = (ev, run.stream)
     return out[0], run
 
 

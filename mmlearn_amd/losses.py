@@ -359,7 +359,11 @@ class _Run:
         src = {m: views[m].src for p in self.pairs for m in (p.ma, p.mb)}
         # f32 rows that carry their own rounding to bf16 (``ops.l2_normalize`` under bf16 autocast): read the copy -- the kernel
         # would round every row to the same bits while staging it
-        twins = {m: getattr(views[m].local, "_mmk_bf16", None) for m in src}
+        def _twin(t):   # (copy, version of t when the copy was written): stale after an in-place edit of t
+            pair = getattr(t, "_mmk_bf16_nograd", None)
+            return pair[0] if pair is not None and pair[1] == t._version else None
+
+        twins = {m: _twin(views[m].local) for m in src}
         if all(t is not None and t.dtype == torch.bfloat16 and t.shape == src[m].shape and t.device == src[m].device and t.is_contiguous()
                and src[m].dtype == torch.float32 for m, t in twins.items()):
             src = twins

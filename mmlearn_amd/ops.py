@@ -46,8 +46,11 @@ class _L2Normalize(torch.autograd.Function):
 def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     """``F.normalize(x, p=2, dim=-1, eps=1e-12)`` on MI355X.  Under bf16/fp16 autocast the result is
     f32, like ``F.normalize`` (an autocast-to-f32 op).  Under bf16 autocast a 2-D result also carries its own rounding to bf16
-    as ``y._mmk_bf16`` (written by the same kernel): the bf16 similarity kernels of :class:`ContrastiveLoss` would round these
-    rows on every read, and the one-launch loss takes the copy instead -- same bits, half the bytes."""
+    as ``y._mmk_bf16_nograd`` = ``(copy, y._version)`` (written by the same kernel): the bf16 similarity kernels of
+    :class:`ContrastiveLoss` would round these rows on every read, and the one-launch loss takes the copy instead -- same bits,
+    half the bytes.  The copy carries NO gradient, hence a name of its own: ``fused.linear`` and friends pick up
+    ``_mmk_bf16`` (``add_layer_norm``'s differentiable twin) and must never see this one; the version stamp lets the loss
+    ignore the copy after an in-place edit of ``y``."""
     K.require_gpu(x)
     autocast = torch.is_autocast_enabled()
     if autocast and x.dtype != torch.float32:
@@ -55,7 +58,7 @@ def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     if (autocast and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.dtype == torch.float32 and x.dim() == 2
             and x.shape[1] % 8 == 0):
         y, y16 = _L2Normalize.apply(x, True)
-        y._mmk_bf16 = y16
+        y._mmk_bf16_nograd = (y16, y._version)
         return y
     return _L2Normalize.apply(x, False)
 

@@ -178,7 +178,7 @@ def test_shapes_outside_the_one_launch_path_are_refused():
 
 
 def test_l2_normalize_twin_feeds_the_one_launch_loss_with_the_same_bits(monkeypatch):
-    """Under bf16 autocast ``ops.l2_normalize`` leaves, next to its f32 result, the rows rounded to bf16 (``_mmk_bf16``); the
+    """Under bf16 autocast ``ops.l2_normalize`` leaves, next to its f32 result, the rows rounded to bf16 (``_mmk_bf16_nograd``); the
     one-launch loss reads that copy instead of rounding the f32 rows itself: same loss, same gradients, bit for bit."""
     import mmlearn_amd.losses as L
     from mmlearn_amd import kernels as K
@@ -198,9 +198,10 @@ def test_l2_normalize_twin_feeds_the_one_launch_loss_with_the_same_bits(monkeypa
         with torch.autocast("cuda", dtype=torch.bfloat16):
             emb = {m: ops.l2_normalize(t) for m, t in leaves.items()}
             for m, y in emb.items():
-                assert y.dtype == torch.float32 and torch.equal(y._mmk_bf16, y.detach().bfloat16())
+                assert y.dtype == torch.float32 and torch.equal(y._mmk_bf16_nograd[0], y.detach().bfloat16())
+                assert not hasattr(y, "_mmk_bf16")   # that name is the DIFFERENTIABLE twin fused.linear picks up (add_layer_norm)
                 if not use_twin:
-                    del y._mmk_bf16
+                    del y._mmk_bf16_nograd
             loss = L.ContrastiveLoss()({f"{m}_embedding": y for m, y in emb.items()}, {m: ids for m in emb}, s,
                                        [L.LossPairSpec(("rgb", "text"), 1.0)])
         loss.backward()
@@ -210,6 +211,81 @@ def test_l2_normalize_twin_feeds_the_one_launch_loss_with_the_same_bits(monkeypa
     assert torch.equal(l0, l1) and torch.equal(d0, d1)
     for m in g0:
         assert torch.equal(g0[m], g1[m])
+
+
+def test_l2_normalize_twin_is_invisible_to_linear_and_ignored_after_an_in_place_edit():
+    """the loss-only copy carries no gradient, so (a) ``fused.linear`` behind ``l2_normalize`` must read the f32 rows
+    (the encoder gets the gradient ``F.linear`` gives it), and (b) after an in-place edit of the normalised rows the loss must not
+    read the stale copy."""
+    import torch.nn.functional as F
+
+    import mmlearn_amd.losses as L
+    from mmlearn_amd import fused, ops
+
+    dev = _dev()
+    torch.manual_seed(4)
+    lin = torch.nn.Linear(512, 256).to(dev)
+    x0 = torch.randn(8192, 512, device=dev)
+    grads = []
+    for custom in (True, False):
+        lin.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = ops.l2_normalize(x)
+            assert fused._wgrad_linear_ok(lin.weight, y)
+            out = fused.linear(y, lin.weight, lin.bias) if custom else F.linear(y, lin.weight, lin.bias)
+        out.float().square().sum().backward()
+        assert x.grad is not None and x.grad.abs().max().item() > 0
+        grads.append(x.grad.clone())
+    assert (grads[0] - grads[1]).abs().max().item() <= 2e-2 * grads[1].abs().max().item()
+
+    ids = torch.stack([torch.zeros(512, dtype=torch.long), torch.arange(512)], 1).to(dev)
+    s = torch.tensor(1 / 0.07, device=dev)
+    g = torch.Generator().manual_seed(5)
+    raw = {m: torch.randn(512, 64, generator=g).to(dev) for m in ("rgb", "text")}
+    losses = []
+    for edit_in_place in (True, False):
+        with torch.autocast("cuda", dtype=torch.bfloat16), torch.no_grad():
+            emb = {m: ops.l2_normalize(t) for m, t in raw.items()}
+            if edit_in_place:
+                emb["rgb"].mul_(-1.0)          # the copy attached to emb["rgb"] is now stale
+            else:
+                emb["rgb"] = -emb["rgb"]       # a new tensor: no copy attached
+            losses.append(L.ContrastiveLoss()({f"{m}_embedding": y for m, y in emb.items()}, {m: ids for m in emb}, s,
+                                              [L.LossPairSpec(("rgb", "text"), 1.0)]).item())
+    assert abs(losses[0] - losses[1]) <= 1e-3 * abs(losses[1]), losses
+
+
+def test_two_streams_launching_the_resident_grid_at_once_both_get_the_right_loss():
+    """The one-launch kernel needs all its workgroups on the chip together; two of them started from different streams at the
+    same moment could starve each other into the spin bound (NaN).  Launches are chained per device: both streams get the
+    single-stream result, every time."""
+    import mmlearn_amd.losses as L
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(8)
+    embs = [{m: torch.nn.functional.normalize(torch.randn(1024, 512, generator=g), dim=-1).to(dev).bfloat16() for m in ("rgb", "text")}
+            for _ in range(2)]
+    ids = torch.stack([torch.zeros(1024, dtype=torch.long), torch.arange(1024)], 1).to(dev)
+    s = torch.tensor(1 / 0.07, device=dev)
+    loss_fn = L.ContrastiveLoss()
+    pairs = [L.LossPairSpec(("rgb", "text"), 1.0)]
+
+    def one(e):
+        return loss_fn({f"{m}_embedding": y for m, y in e.items()}, {m: ids for m in e}, s, pairs, fully_paired=True)
+
+    ref = [one(e).item() for e in embs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for s_ in streams:
+        s_.wait_stream(torch.cuda.current_stream())
+    for _ in range(20):
+        out = []
+        for k in (0, 1, 0, 1):
+            with torch.cuda.stream(streams[k]):
+                out.append((k, one(embs[k])))
+        torch.cuda.synchronize()
+        for k, v in out:
+            assert torch.isfinite(v).item() and abs(v.item() - ref[k]) <= 1e-6 * abs(ref[k]), (k, v.item(), ref[k])
 
 
 def test_workspaces_are_per_stream_and_a_second_backward_repeats_the_first():

@@ -313,6 +313,12 @@ typedef struct {
 int mmk_adamw_chunk_elems(void);
 int mmk_adamw_update(const mmk_adamw_tensor* tensors, const void* const* grads, const int32_t* grad_dtypes, const mmk_adamw_chunk* chunks,
                      int n_chunks, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream);
+/* the same update with the learning rate and the step count (including this step, as f32) read from device memory and the bias
+ * corrections formed in the kernel: no host scalar of the step is baked into the launch, so it can be captured into a HIP graph
+ * (the plumb point of mmlearn/cli/run.py:139 -- whole-step capture / compile) and replayed */
+int mmk_adamw_update_dev(const mmk_adamw_tensor* tensors, const void* const* grads, const int32_t* grad_dtypes, const mmk_adamw_chunk* chunks,
+                         int n_chunks, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, const float* step_dev,
+                         void* stream);
 
 /* ------------------------------------------------------------------ eval-side retrieval metric
  * RetrievalRecallAtK._process_batch + _recall_at_k (mmlearn/modules/metrics/retrieval_recall.py:239-289): for every

@@ -124,6 +124,7 @@ _SIGNATURES = {
     "mmk_recall_ranks": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mmk_adamw_chunk_elems": [],
     "mmk_adamw_update": [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, C.c_int64, _vp],
+    "mmk_adamw_update_dev": [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _vp, _vp],
     "mmk_embedding_bwd": [_vp, _vp, _vp, C.c_int64, _i, C.c_int64, _i, _vp],
     "mmk_wgrad_plan": [C.c_int64, _i, _i, _vp, _vp],
     "mmk_wgrad_partial": [_vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp],

@@ -416,9 +416,20 @@ __global__ __launch_bounds__(256) void ema_kernel(const mmk_ema_entry* __restric
 //   p *= 1 - lr * wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 // The foreach implementation is ~7 passes of 15-25 launches over the parameters (3.7 ms for 172 M parameters); this is one
 // pass: every block takes one 4096-element chunk from a flat (tensor, offset) work list built once on the host.
+// DEV: the learning rate and the step count are read from device words (lr_dev[0], step_dev[0] = the count INCLUDING this step) and
+// the bias corrections are formed here, so that a captured launch replays with whatever the words hold at that time
+// (torch.optim.AdamW(capturable=True) does the same with its foreach ops).
+template <bool DEV>
 __global__ __launch_bounds__(256) void adamw_kernel(const mmk_adamw_tensor* __restrict__ tensors, const void* const* __restrict__ grads,
                                                     const int32_t* __restrict__ grad_dtypes, const mmk_adamw_chunk* __restrict__ chunks,
-                                                    float lr, float b1, float b2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2) {
+                                                    float lr, float b1, float b2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2,
+                                                    const float* __restrict__ lr_dev, const float* __restrict__ step_dev) {
+  if (DEV) {
+    lr = lr_dev[0];
+    const float t = step_dev[0];
+    inv_bc1 = 1.f / (1.f - powf(b1, t));
+    inv_sqrt_bc2 = 1.f / sqrtf(1.f - powf(b2, t));
+  }
   const mmk_adamw_chunk ck = chunks[blockIdx.x];
   const mmk_adamw_tensor t = tensors[ck.tensor];
   const void* g = grads[ck.tensor];
@@ -683,8 +694,20 @@ int mmk_adamw_update(const mmk_adamw_tensor* tensors, const void* const* grads, 
   MMK_REQUIRE(tensors && grads && grad_dtypes && chunks && n_chunks > 0 && step > 0, "bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)n_chunks), dim3(256), 0, st, tensors, grads, grad_dtypes, chunks, lr, beta1, beta2, eps,
-                     weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+  hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)n_chunks), dim3(256), 0, st, tensors, grads, grad_dtypes, chunks, lr, beta1, beta2, eps,
+                     weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), static_cast<const float*>(nullptr),
+                     static_cast<const float*>(nullptr));
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+int mmk_adamw_update_dev(const mmk_adamw_tensor* tensors, const void* const* grads, const int32_t* grad_dtypes, const mmk_adamw_chunk* chunks,
+                         int n_chunks, const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, const float* step_dev,
+                         void* stream) {
+  MMK_REQUIRE(tensors && grads && grad_dtypes && chunks && n_chunks > 0 && lr_dev && step_dev, "bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)n_chunks), dim3(256), 0, st, tensors, grads, grad_dtypes, chunks, 0.f, beta1, beta2, eps,
+                     weight_decay, 0.f, 0.f, lr_dev, step_dev);
   MMK_LAUNCH_CHECK();
   return 0;
 }

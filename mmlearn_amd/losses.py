@@ -784,6 +784,12 @@ class ContrastiveLoss(nn.Module):
         self._early_ids: dict[str, tuple] = {}
         self._match_stream = None
         self._static_validated: dict[str, int] = {}
+        # graph capture with the id matcher in the graph: the pair COUNT (and the identity / repeated-row flags) are host values
+        # that size the loss's launches, so a captured step takes them from the last eager step with the same id-column shapes
+        # and checks on the device that every replayed batch still has them (capture_mismatch, NaN loss otherwise)
+        self._match_seen: dict[tuple, tuple] = {}
+        self._capture_poison: Optional[torch.Tensor] = None
+        self.capture_mismatch: Optional[torch.Tensor] = None   # device bool: some replayed batch matched differently than captured
 
     # ------------------------------------------------------------------ static_shapes: a checked promise
     def _check_static_shapes(self, rows: dict[str, int]) -> None:
@@ -850,6 +856,8 @@ class ContrastiveLoss(nn.Module):
         ``static_shapes=True``) the id columns are all-gathered here as well -- they do not depend on the encoders -- and
         ``prefetch_gather`` then only moves embeddings."""
         self._pending_match, self._early_ids = [], {}
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return   # inside a graph capture there is no read-back to get ahead of: forward() runs the matcher in the graph
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         gathered = world > 1 or (self._force_gather and dist.is_available() and dist.is_initialized())
         if gathered and not self.static_shapes:
@@ -892,8 +900,43 @@ class ContrastiveLoss(nn.Module):
                 pm.side_stream = stream
                 self._pending_match.append(pm)
 
+    def _matched_in_capture(self, ids_a: torch.Tensor, ids_b: torch.Tensor) -> "K.Match":
+        """The matcher inside a HIP-graph capture: its kernels are captured (every replay pairs that batch's ids on the device), its
+        16-byte status is NOT read back -- the counts that size the launches come from the last eager step with these shapes, and
+        a device-side comparison poisons the loss (NaN) and raises ``capture_mismatch`` when a replayed batch pairs differently
+        (another pair count, identity vs. permuted order, repeated ids).  A permutation-paired batch of the captured size always
+        replays correctly: warm up with a representative (shuffled) batch."""
+        key = (tuple(ids_a.shape), tuple(ids_b.shape))
+        seen = self._match_seen.get(key)
+        if seen is None:
+            raise RuntimeError("mmlearn_amd.ContrastiveLoss: the id matcher cannot learn its pair count during graph capture -- run one "
+                               "eager step with a batch of the same shapes first (or pass fully_paired=True)")
+        total, ident, rep_a, rep_b, expect = seen
+        pm = K.match_ids_launch(ids_a, ids_b)
+        if total > pm.idx_a.numel():
+            raise RuntimeError("mmlearn_amd.ContrastiveLoss: heavily duplicated ids need a second matcher pass; not capturable")
+        bad = (pm.status != expect).any()
+        self._capture_poison = bad if self._capture_poison is None else (self._capture_poison | bad)
+        if ident:
+            return K.Match(total, True, None, None)
+        return K.Match(total, False, pm.idx_a[:total], pm.idx_b[:total], bool(rep_a), bool(rep_b))
+
     def _matched(self, ids_a: torch.Tensor, ids_b: torch.Tensor) -> "K.Match":
         """The pairing of two id columns: the prefetched answer if it was computed for exactly these tensors."""
+        if ids_a.is_cuda and torch.cuda.is_current_stream_capturing():
+            return self._matched_in_capture(ids_a, ids_b)
+        m = self._matched_eager(ids_a, ids_b)
+        if ids_a.is_cuda:
+            key = (tuple(ids_a.shape), tuple(ids_b.shape))
+            seen = self._match_seen.get(key)
+            if seen is None or seen[:4] != (m.n, m.identity, m.repeats_a, m.repeats_b):   # (device copy made once per change)
+                expect = torch.tensor([m.n, int(m.identity), int(m.repeats_a), int(m.repeats_b)], dtype=torch.int32, device=ids_a.device)
+                self._match_seen[key] = (m.n, m.identity, m.repeats_a, m.repeats_b, expect)
+            if self.capture_mismatch is None:
+                self.capture_mismatch = torch.zeros((), dtype=torch.bool, device=ids_a.device)
+        return m
+
+    def _matched_eager(self, ids_a: torch.Tensor, ids_b: torch.Tensor) -> "K.Match":
         for k, pm in enumerate(self._pending_match):
             if pm.ids_a.data_ptr() == ids_a.data_ptr() and pm.ids_b.data_ptr() == ids_b.data_ptr() \
                     and pm.ids_a.shape == ids_a.shape and pm.ids_b.shape == ids_b.shape:
@@ -929,10 +972,16 @@ class ContrastiveLoss(nn.Module):
         if not isinstance(logit_scale, torch.Tensor):
             raise TypeError("logit_scale must be a 0-dim tensor")
         run = _Run(self, embeddings, example_ids, logit_scale, list(modality_loss_pairs), fully_paired)
+        self._capture_poison = None
         try:
-            return self._forward(run, embeddings, logit_scale)
+            loss = self._forward(run, embeddings, logit_scale)
+            if self._capture_poison is not None:   # captured matcher: a replayed batch that pairs differently must not train silently
+                self.capture_mismatch.logical_or_(self._capture_poison)   # persistent flag (created by the eager warm-up step)
+                loss = torch.where(self._capture_poison, torch.full_like(loss, float("nan")), loss)
+            return loss
         finally:
             self._pending_match, self._early_ids = [], {}   # answers belong to one batch
+            self._capture_poison = None
 
     def _forward(self, run: "_Run", embeddings, logit_scale) -> torch.Tensor:
         first = next(iter(embeddings.values()))

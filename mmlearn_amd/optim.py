@@ -6,6 +6,12 @@ parameters (3.7 ms for the 172 M parameters of ViT-B/16 + BERT-base), this one r
 Use it wherever an mmlearn task takes ``optimizer=partial(torch.optim.AdamW, ...)``:
 ``optimizer=partial(mmlearn_amd.optim.AdamW, lr=..., weight_decay=...)``.  ``state_dict`` keeps torch's layout
 (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter).
+
+``capturable=True`` (as in ``torch.optim.AdamW``): the step count and the learning rate live in device words per group, the kernel
+forms the bias corrections itself, and ``step()`` neither reads anything back nor bakes a host scalar into the launch -- the whole
+training step can then be captured into a HIP graph (``torch.cuda.graph``) and replayed (tests/test_graph_capture_gpu.py).
+Per-parameter ``step`` entries of the state are then device tensors, as in torch; a scheduler that changes ``group["lr"]`` is
+honoured by eager steps and, between replays of a graph, through ``opt.lr_device(g).fill_(...)`` (a replay reads the word).
 """
 
 from __future__ import annotations
@@ -32,15 +38,19 @@ def _to_device(raw: bytes, device) -> torch.Tensor:
 
 
 class AdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 capturable: bool = False):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameters")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=bool(capturable)))
         self._tables: Dict[int, Any] = {}
+        self._grad_tables: Dict[int, Any] = {}
+        self._dev_words: Dict[int, Any] = {}
 
     def load_state_dict(self, state_dict) -> None:
         super().load_state_dict(state_dict)
         self._tables = {}   # the restored moment tensors are new storages
+        self._dev_words = {}
 
     def _table(self, gi: int, plist: List[torch.Tensor]):
         """Static device tables of one group, rebuilt when the set of parameters with gradients changes or when any of the
@@ -87,13 +97,16 @@ class AdamW(torch.optim.Optimizer):
                     st["exp_avg_sq"] = st["exp_avg_sq"].to(device=p.device, dtype=torch.float32).contiguous()
                 if st and not isinstance(st["step"], torch.Tensor):
                     st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
-                if st and st["step"].is_cuda:
+                if st and st["step"].is_cuda and not group.get("capturable", False):
                     st["step"] = st["step"].cpu()   # load_state_dict moves the state to the parameter's device; the step counter lives on the host
                 if not st:
-                    st["step"] = torch.zeros((), dtype=torch.float32)
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device if group.get("capturable", False) else None)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
             tab = self._table(gi, plist)
+            if group.get("capturable", False):
+                self._step_capturable(gi, group, plist, tab)
+                continue
             steps = {int(self.state[p]["step"].item()) for p in plist}
             if len(steps) != 1:
                 raise RuntimeError("mmlearn_amd.optim.AdamW needs all parameters of a group at the same step")
@@ -109,3 +122,45 @@ class AdamW(torch.optim.Optimizer):
             for p in plist:
                 self.state[p]["step"] += 1
         return loss
+
+    def _step_capturable(self, gi: int, group, plist: List[torch.Tensor], tab) -> None:
+        """One launch with the step count and the learning rate in device words; nothing here depends on a host read, and every
+        host-to-device transfer it needs is made from pinned memory that outlives the launch (the gradient table is rebuilt only
+        when the gradients' addresses change).  All parameters of the group share ONE step word: their ``state[p]["step"]`` are
+        0-dim views of it, so the per-parameter layout of torch's state_dict costs one increment, not one launch per tensor."""
+        dev = plist[0].device
+        capturing = torch.cuda.is_current_stream_capturing()
+        words = self._dev_words.get(gi)
+        if words is None or any(self.state[p]["step"].data_ptr() != words["step"].data_ptr() for p in plist):
+            if capturing:
+                raise RuntimeError("mmlearn_amd.optim.AdamW(capturable=True): run one eager step before capturing")
+            steps = {float(self.state[p]["step"]) for p in plist}      # (host read: first step / after load_state_dict only)
+            if len(steps) != 1:
+                raise RuntimeError("mmlearn_amd.optim.AdamW needs all parameters of a group at the same step")
+            words = {"step": torch.full((1,), steps.pop(), dtype=torch.float32, device=dev),
+                     "lr": torch.full((1,), float(group["lr"]), dtype=torch.float32, device=dev), "lr_seen": float(group["lr"])}
+            self._dev_words[gi] = words
+            for p in plist:
+                self.state[p]["step"] = words["step"].view(())
+        if not capturing and float(group["lr"]) != words["lr_seen"]:   # a scheduler moved the float: follow it (eager steps only)
+            words["lr"].fill_(float(group["lr"]))
+            words["lr_seen"] = float(group["lr"])
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in plist]
+        key = tuple((g.data_ptr(), g.dtype) for g in grads)
+        gt = self._grad_tables.get(gi)
+        if gt is None or gt["key"] != key:
+            # pinned staging that lives as long as the table: a captured copy node re-reads it at every replay
+            pin_p = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64).pin_memory()
+            pin_t = torch.tensor([dtype_tag(g.dtype) for g in grads], dtype=torch.int32).pin_memory()
+            gt = {"key": key, "pin": (pin_p, pin_t), "gptr": pin_p.to(dev, non_blocking=True), "gdt": pin_t.to(dev, non_blocking=True)}
+            self._grad_tables[gi] = gt
+        words["step"].add_(1.0)
+        b1, b2 = group["betas"]
+        check(_lib.lib().mmk_adamw_update_dev(tab["tensors"].data_ptr(), gt["gptr"].data_ptr(), gt["gdt"].data_ptr(), tab["chunks"].data_ptr(),
+                                              tab["n_chunks"], words["lr"].data_ptr(), float(b1), float(b2), float(group["eps"]),
+                                              float(group["weight_decay"]), words["step"].data_ptr(), stream()))
+
+    def lr_device(self, group_index: int = 0) -> torch.Tensor:
+        """The device word a captured step reads its learning rate from (``capturable=True``, after the first eager step):
+        ``opt.lr_device(g).fill_(new_lr)`` between replays is what a scheduler's ``group["lr"] = ...`` is for eager steps."""
+        return self._dev_words[group_index]["lr"]

@@ -48,3 +48,61 @@ def test_small_step_is_graph_capturable_and_replays_bit_identically():
     assert torch.isfinite(loss_g.detach()).all()
     for pe, pg in zip(task_e.parameters(), task_g.parameters()):
         assert torch.equal(pe.detach(), pg.detach())
+
+
+def _copy_batch_(dst, src):
+    """Refill the captured step's input tensors in place (a graph replays on fixed addresses)."""
+    for k in ("rgb", "text"):
+        dst[k].copy_(src[k])
+    for k in ("rgb", "text"):
+        dst["example_ids"][k].copy_(src["example_ids"][k])
+
+
+def test_step_with_the_id_matcher_and_the_repos_own_adamw_is_capturable():
+    """capture beyond ``fully_paired``.  The text rows arrive shuffled, so the loss runs the id matcher -- inside
+    the graph, with its pair count taken from the eager warm-up and verified on the device at every replay -- and the optimizer is
+    ``mmlearn_amd.optim.AdamW(capturable=True)`` (step count and learning rate in device words).  Replays with NEW batches (other
+    pixels, other permutations) give bit-identical parameters to the same steps launched eagerly; a batch that pairs differently
+    than the captured one (a repeated id) raises the device flag and poisons the loss instead of training on a wrong pairing."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import graph_step as G
+
+    dev = torch.device("cuda", 0)
+    batches = [G.make_batch(64, dev, shuffled=True, seed=10 + k) for k in range(7)]
+    # eager reference: 3 warm-up steps + 4 more, each on its own batch
+    task_e, opt_e = G.make(dev, 512, own_adamw=True)
+    for k in range(7):
+        G.step(task_e, opt_e, batches[k])
+    # captured: 3 eager warm-up steps on a side stream, then one capture, replayed on batches 3 .. 6 through a static input buffer
+    task_g, opt_g = G.make(dev, 512, own_adamw=True)
+    static = G.make_batch(64, dev, shuffled=True, seed=99)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for k in range(3):
+            _copy_batch_(static, batches[k])
+            G.step(task_g, opt_g, static)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    _copy_batch_(static, batches[3])
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss_g = G.step(task_g, opt_g, static)
+    losses = []     # capture itself does not execute: the replay for batch 3 comes first
+    for k in range(3, 7):
+        _copy_batch_(static, batches[k])
+        graph.replay()
+        losses.append(float(loss_g.detach()))
+    torch.cuda.synchronize()
+    assert all(l == l for l in losses), losses                      # no NaN: every replayed batch paired like the captured one
+    assert not bool(task_g.loss_fn.capture_mismatch)
+    for pe, pg in zip(task_e.parameters(), task_g.parameters()):
+        assert torch.equal(pe.detach(), pg.detach())
+    assert float(opt_g.state[next(iter(task_g.parameters()))]["step"]) == 7.0
+    # a batch with a repeated id pairs differently (65 pairs, repeated rows): flagged on the device, loss poisoned
+    bad = G.make_batch(64, dev, shuffled=True, seed=5)
+    bad["example_ids"]["text"][7] = bad["example_ids"]["text"][9]
+    _copy_batch_(static, bad)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert bool(task_g.loss_fn.capture_mismatch) and not (float(loss_g.detach()) == float(loss_g.detach()))

@@ -30,31 +30,39 @@ class _MLP(nn.Module):
         return (self.net(inputs[self.key]),)
 
 
-def build(dev, dim):
+def build(dev, dim, own_adamw=False):
     from functools import partial
 
     from mmlearn_amd import ContrastiveLoss
+    from mmlearn_amd.optim import AdamW as OwnAdamW
     from mmlearn_amd.tasks import ContrastivePretraining, LossPairSpec
 
     torch.manual_seed(0)
     task = ContrastivePretraining(
         encoders={"rgb": _MLP("rgb", 3 * 16 * 16, 1024, dim), "text": _MLP("text", 77, 1024, dim)},
-        loss=ContrastiveLoss(), optimizer=partial(torch.optim.AdamW, lr=1e-3, capturable=True),
+        loss=ContrastiveLoss(), optimizer=partial(OwnAdamW if own_adamw else torch.optim.AdamW, lr=1e-3, capturable=True),
         modality_loss_pairs=[LossPairSpec(("rgb", "text"))], compute_validation_loss=False, compute_test_loss=False).to(dev)
     return task
 
 
-def make(dev, dim):
-    task = build(dev, dim)
+def make(dev, dim, own_adamw=False):
+    task = build(dev, dim, own_adamw)
     opt = task.configure_optimizers()
     return task, (opt["optimizer"] if isinstance(opt, dict) else opt)
 
 
-def make_batch(b, dev):
-    g = torch.Generator().manual_seed(3)
+def make_batch(b, dev, shuffled=False, seed=3):
+    """``shuffled``: the text rows arrive in another order than the images (ids permuted, no ``fully_paired`` promise), so the
+    loss has to run the id matcher."""
+    g = torch.Generator().manual_seed(seed)
     ids = torch.stack([torch.zeros(b, dtype=torch.long), torch.arange(b)], 1).to(dev)
-    return {"rgb": torch.rand(b, 3, 16, 16, generator=g).to(dev), "text": torch.rand(b, 77, generator=g).to(dev),
-            "example_ids": {"rgb": ids, "text": ids}, "fully_paired": True}
+    batch = {"rgb": torch.rand(b, 3, 16, 16, generator=g).to(dev), "text": torch.rand(b, 77, generator=g).to(dev),
+             "example_ids": {"rgb": ids, "text": ids}, "fully_paired": True}
+    if shuffled:
+        perm = torch.randperm(b, generator=g).to(dev)
+        batch["example_ids"] = {"rgb": ids, "text": ids[perm]}
+        del batch["fully_paired"]
+    return batch
 
 
 def step(task, opt, batch):

@@ -382,6 +382,12 @@ int mmk_mlp_gemm_fwd_act(const void* X, const void* W, const float* bias, void* 
                          int64_t ldw, int64_t ldc, int act, void* stream);
 int mmk_mlp_gemm_bwd_dact(const void* dY, const void* Wt, const void* pre, const float* bias, void* dPre, float* part, int64_t M, int N,
                           int K, int64_t ldy, int64_t ldw, int64_t ldp, int64_t ldc, int act, void* stream);
+/* The pair the product runs: the forward leaves G = act'(X W^T + bias) behind instead of the pre-activation (same bytes; three more
+ * instructions per element next to the ones act needs), the backward multiplies by it: dPre = (dY Wt^T) * G, part = column sums. */
+int mmk_mlp_gemm_fwd_act_grad(const void* X, const void* W, const float* bias, void* H, void* G, int64_t M, int N, int K, int64_t ldx,
+                              int64_t ldw, int64_t ldc, int act, void* stream);
+int mmk_mlp_gemm_bwd_mul(const void* dY, const void* Wt, const void* G, void* dPre, float* part, int64_t M, int N, int K, int64_t ldy,
+                         int64_t ldw, int64_t ldg, int64_t ldc, void* stream);
 
 
 /* Weight gradient of a Linear, dW[N, K] = dY^T x for dY [M, N], x [M, K] (bf16, row strides ldy / ldx in elements):

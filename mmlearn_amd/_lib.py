@@ -137,6 +137,8 @@ _SIGNATURES = {
     "mmk_mlp_gemm_plain": [_vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _vp],
     "mmk_mlp_gemm_fwd_act": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _vp],
     "mmk_mlp_gemm_bwd_dact": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _i, _vp],
+    "mmk_mlp_gemm_fwd_act_grad": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _vp],
+    "mmk_mlp_gemm_bwd_mul": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp],
     "mmk_quick_gelu_fwd": [_vp, _vp, C.c_int64, _i, _vp],
     "mmk_quick_gelu_bwd": [_vp, _vp, _vp, C.c_int64, _i, _vp],
     "mmk_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, C.c_uint64, _vp],

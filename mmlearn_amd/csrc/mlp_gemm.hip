@@ -5,6 +5,14 @@
 //   forward   H = act(X W1^T + b1), and the pre-activation X W1^T for the backward          (mode MG_FWD_ACT)
 //   backward  dPre = (dY W2) * act'(Pre + b1),  db1 = column sums of dPre                    (mode MG_BWD_DACT)
 //
+// and the pair the product runs, in which the forward leaves the activation's DERIVATIVE behind instead of the pre-activation (the
+// backward needs nothing else of it; same bytes) and the backward's epilogue is a multiply -- the exp / rcp chain of act' costs
+// the forward three more instructions per element next to the ones act needs anyway, and cost the backward 160 us of a 1320 us
+// launch at M = 201,728, exposed (an epilogue cannot hide behind MFMAs when one workgroup owns the CU):
+//
+//   forward   H = act(X W1^T + b1),  G = act'(X W1^T + b1)                                   (mode MG_FWD_ACT_G)
+//   backward  dPre = (dY W2) * G,    db1 = column sums of dPre                               (mode MG_BWD_MUL)
+//
 //     C[M, N] = A[M, K] . B[N, K]^T       bf16 operands (rows K-contiguous), f32 accumulation, bf16 out
 //
 // The unfused step runs  library GEMM -> bias_act kernel : the backward pair writes dAct [M, 3072] (1.24 GB at M = 201,728),
@@ -24,6 +32,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -39,21 +48,21 @@ constexpr int MG_SUB = 128 * 128;     // bytes of one sub-slot: 128 rows x 64 bf
 constexpr int MG_RING = 10;           // sub-slots in the ring
 constexpr int MG_LDS = MG_RING * MG_SUB;
 
-enum { MG_PLAIN = 0, MG_FWD_ACT = 1, MG_BWD_DACT = 2 };
+enum { MG_PLAIN = 0, MG_FWD_ACT = 1, MG_BWD_DACT = 2, MG_FWD_ACT_G = 3, MG_BWD_MUL = 4 };
 enum { MG_ACT_QUICK_GELU = 0, MG_ACT_GELU = 1 };   // numbering of mmk_bias_act_*
 
 struct MlpGemmArgs {
   const bf16_t* A;    // [M, K] row stride lda
   const bf16_t* B;    // [N, K] row stride ldb
   bf16_t* C;          // [M, N] row stride ldc
-  bf16_t* C2;         // MG_FWD_ACT: second output, the pre-activation A B^T without the bias (row stride ldc), or null
-  const bf16_t* P;    // MG_BWD_DACT: pre-activation [M, N], row stride ldp
+  bf16_t* C2;         // MG_FWD_ACT: second output, the pre-activation A B^T without the bias; MG_FWD_ACT_G: act'(A B^T + bias) (stride ldc)
+  const bf16_t* P;    // MG_BWD_DACT: pre-activation [M, N]; MG_BWD_MUL: the factor G [M, N]; row stride ldp
   const float* bias;  // [N] or null
   float* part;        // MG_BWD_DACT: column-sum partials f32[2 * tiles_m][N] (one row per 128 output rows), or null
   long lda, ldb, ldc, ldp;
   int M, N, K;
   int tiles_m, tiles_n;
-  int dbg;            // timing ablations, debug-switch builds only: 4 = no C stores, 8 = no epilogue arithmetic, 64 = hot DMA
+  int dbg;            // timing ablations, debug-switch builds only: 4 = no C stores, 8 = no epilogue arithmetic, 64 = hot DMA, 512 = no PIPE
 };
 
 __device__ __forceinline__ void mg_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
@@ -111,7 +120,28 @@ __device__ __forceinline__ float mg_act_grad(float z) {
   return fmaf(z * 0.3989422804014327f, e, phi);
 }
 
-template <int MODE, int ACT>
+// act(z) and act'(z) from one exponential / reciprocal pair
+template <int ACT>
+__device__ __forceinline__ void mg_act_both(float z, float& y, float& g) {
+  if (ACT == MG_ACT_QUICK_GELU) {
+    const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(z * -2.4554669595930156f));   // sigmoid(1.702 z)
+    y = z * sg;
+    g = fmaf(1.702f * y, 1.f - sg, sg);
+    return;
+  }
+  float e;
+  const float phi = mg_phi(z, e);
+  y = z * phi;
+  g = fmaf(z * 0.3989422804014327f, e, phi);
+}
+
+// PIPE (MG_BWD_MUL, K >= 768): the tile's global I/O is software-pipelined against the K loops.  One CU moves ~10 bytes per cycle
+// to or from HBM, so the 128 KiB of a tile's C stores and as much of G loads take ~5 us each, and vmcnt retires in order: a K
+// step's closing s_waitcnt for its LDS-DMA also waits for every older store, and the loads of G stand in front of the epilogue.
+// Here the epilogue only regroups the tile into 16 row-layout pieces per lane that stay in registers; the NEXT tile's first six K
+// steps store them, two or three pieces per step (a step's closing wait then covers 24 KiB per CU, not 128), and the tile's last
+// six K steps fetch its 16 pieces of G the same way.  Worth 60 us of 1190 at M = 201,728; nothing on the plain product.
+template <int MODE, int ACT, bool PIPE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_gemm_kernel(const MlpGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -215,6 +245,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   mg_wait_vmcnt<4>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  u32x4 oq[16];               // PIPE: the previous tile's output in row layout (piece i: row 8 i + (lane >> 3), chunk lane & 7), not yet stored
+  bf16_t* oq_ptr = nullptr;   // PIPE: this lane's address of piece 0 (piece i: + i * oq_step); null: nothing pending
+  const long oq_step = 8 * a.ldc;
   for (int ti = 0; ti < n_my; ++ti) {
     f32x16 acc[2][4];   // [n block][m block]
     {
@@ -226,7 +259,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = zero;
     }
-    auto k_step = [&]() {
+    constexpr bool HAS_P = MODE == MG_BWD_DACT || MODE == MG_BWD_MUL;
+    u32x4 pr[PIPE ? 16 : 8];   // HAS_P: blocks of P in row layout (piece i: row 8 i + (lane >> 3), 16-byte chunk lane & 7)
+    const bf16_t* pp0 = HAS_P ? a.P + (size_t)(ctm * MG_TILE + 128 * wm + (lane >> 3)) * a.ldp + ctn * MG_TILE + 64 * wn + 8 * (lane & 7) : nullptr;
+    const long pstep = 8 * a.ldp;
+    // One K step.  ST (PIPE): 0..5 = store slice ST of the previous tile's pending pieces first; LD (PIPE, HAS_P): 0..5 = request
+    // slice LD of this tile's pieces of P first; LAST: the tile's last step -- its eight DMA instructions go out in the first two k
+    // blocks and it closes on vmcnt(0) through the BUILTIN, which settles the compiler's own count of the loads of P (it cannot see
+    // the LDS-DMA and would otherwise place vmcnt(15 .. 0) in front of the uses of P, draining that queue each time).
+    auto k_step = [&](auto st_c, auto ld_c, auto last_c) {
+      constexpr int ST = decltype(st_c)::value, LD = decltype(ld_c)::value;
+      constexpr bool LAST = decltype(last_c)::value;
+      constexpr int LO[7] = {0, 3, 6, 9, 12, 14, 16};
+      if (PIPE && ST >= 0) {
+        if (oq_ptr != nullptr) {
+#pragma unroll
+          for (int i = LO[ST >= 0 ? ST : 0]; i < LO[ST >= 0 ? ST + 1 : 0]; ++i)
+            *reinterpret_cast<u32x4*>(oq_ptr + i * oq_step) = oq[i];
+        }
+      }
+      if (PIPE && HAS_P && LD >= 0) {
+#pragma unroll
+        for (int i = LO[LD >= 0 ? LD : 0]; i < LO[LD >= 0 ? LD + 1 : 0]; ++i) pr[i] = *reinterpret_cast<const u32x4*>(pp0 + i * pstep);
+      }
       const bf16_t* sB0 = srcB(cB, 0);
       const bf16_t* sB1 = srcB(cB, 1);
       const bf16_t* sA0 = srcA(cA, 0);
@@ -246,10 +301,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nb], fx[mb], acc[nb][mb], 0, 0, 0);
         // this k block's share of the DMA: kk 0, 1 -> the two B sub-slots of step g + 1, kk 2, 3 -> the two A sub-slots of g + 2
-        if (kk == 0) issue_sub(sB0, voffB, posB);
-        if (kk == 1) issue_sub(sB1, voffB, pb1);
-        if (kk == 2) issue_sub(sA0, voffA, posA);
-        if (kk == 3) issue_sub(sA1, voffA, pa1);
+        if (!(PIPE && LAST)) {
+          if (kk == 0) issue_sub(sB0, voffB, posB);
+          if (kk == 1) issue_sub(sB1, voffB, pb1);
+          if (kk == 2) issue_sub(sA0, voffA, posA);
+          if (kk == 3) issue_sub(sA1, voffA, pa1);
+        } else {
+          if (kk == 0) {
+            issue_sub(sB0, voffB, posB);
+            issue_sub(sB1, voffB, pb1);
+          }
+          if (kk == 1) {
+            issue_sub(sA0, voffA, posA);
+            issue_sub(sA1, voffA, pa1);
+          }
+        }
       }
       advance(cB);
       bump(posB);
@@ -257,25 +323,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       bump(posA);
       bump(p0);
       // step g + 1 must have landed before its first read; the only younger pieces of this wave are the A half of step g + 2
-      // (4 instructions).  (Loads and stores of an epilogue are older than this step's DMA: they have been given a whole step.)
-      mg_wait_vmcnt<4>();
+      // (4 instructions).  (Loads and stores issued before this step's DMA are older: the wait covers them.)
+      if (PIPE && LAST) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+      else mg_wait_vmcnt<4>();
       __builtin_amdgcn_s_barrier();   // every wave's pieces of step g + 1 are in LDS; every wave is done reading step g
       asm volatile("" ::: "memory");
     };
-    for (int kt = 0; kt < nk - 1; ++kt) k_step();
-    u32x4 pr[8];   // MG_BWD_DACT: a 64 x 64 block of P in row layout (piece p: row 8 p + (lane >> 3), 16-byte chunk lane & 7)
-    if (MODE == MG_BWD_DACT) {
-      // the first of the epilogue's two dependent HBM reads, requested one K step ahead: older than the last step's LDS-DMA, so that
-      // step's closing s_waitcnt vmcnt(4) covers it and it travels behind the step's MFMAs
-      const bf16_t* pp = a.P + (size_t)(ctm * MG_TILE + 128 * wm + (lane >> 3)) * a.ldp + ctn * MG_TILE + 64 * wn + 8 * (lane & 7);
-      const long pstep = 8 * a.ldp;
+    typedef std::integral_constant<int, -1> No;
+    if (PIPE) {   // host: nk >= 12
+      k_step(std::integral_constant<int, 0>{}, No{}, std::false_type{});
+      k_step(std::integral_constant<int, 1>{}, No{}, std::false_type{});
+      k_step(std::integral_constant<int, 2>{}, No{}, std::false_type{});
+      k_step(std::integral_constant<int, 3>{}, No{}, std::false_type{});
+      k_step(std::integral_constant<int, 4>{}, No{}, std::false_type{});
+      k_step(std::integral_constant<int, 5>{}, No{}, std::false_type{});
+      for (int kt = 12; kt < nk; ++kt) k_step(No{}, No{}, std::false_type{});
+      k_step(No{}, std::integral_constant<int, 0>{}, std::false_type{});
+      k_step(No{}, std::integral_constant<int, 1>{}, std::false_type{});
+      k_step(No{}, std::integral_constant<int, 2>{}, std::false_type{});
+      k_step(No{}, std::integral_constant<int, 3>{}, std::false_type{});
+      k_step(No{}, std::integral_constant<int, 4>{}, std::false_type{});
+      k_step(No{}, std::integral_constant<int, 5>{}, std::true_type{});
+    } else {
+      for (int kt = 0; kt < nk - 1; ++kt) k_step(No{}, No{}, std::false_type{});
+      if (HAS_P) {
+        // the first of the epilogue's two dependent HBM reads, requested one K step ahead: older than the last step's LDS-DMA, so that
+        // step's closing s_waitcnt vmcnt(4) covers it and it travels behind the step's MFMAs
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        pr[p] = *reinterpret_cast<const u32x4*>(pp);
-        pp += pstep;
+        for (int p = 0; p < 8; ++p) pr[p] = *reinterpret_cast<const u32x4*>(pp0 + p * pstep);
       }
+      k_step(No{}, No{}, std::false_type{});
     }
-    k_step();
     {
       // ---- epilogue of tile (ctm, ctn): acc[nb][mb][e] = C[m = 128 wm + 32 mb + r][n = 64 wn + 32 nb + 8 (e>>2) + 4 h + (e&3)]
       // A lane holds pieces of 32 different rows, and row-per-lane global accesses are issue-bound (16 stores of 16 bytes per lane
@@ -295,7 +373,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // Every load of the epilogue is issued before its first store: vmcnt retires in order, so waiting for a load that was issued
       // behind stores waits for those stores to drain as well (the bias read piecemeal between the two halves' stores cost 60 us of
       // a 1190 us launch).
-      const bool has_bias = MODE != MG_PLAIN && a.bias != nullptr;
+      const bool has_bias = (MODE == MG_FWD_ACT || MODE == MG_FWD_ACT_G || MODE == MG_BWD_DACT) && a.bias != nullptr;
       float bv[2][4][4];   // bias of this lane's columns 32 nb + 8 q + 4 h + i
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
@@ -308,68 +386,80 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       float csr[8];   // MG_BWD_DACT: sums of this lane's 8 columns (chunk L7) over the rows it stores, taken from the ROUNDED values
 #pragma unroll
       for (int c = 0; c < 8; ++c) csr[c] = 0.f;
+      // One pass = RP rows of the wave's 128: 64 (one 8-KiB image) for the one-output modes; 32 for the forward modes with two outputs
+      // (two 4-KiB images side by side), so that act and the second output are computed once and leave together.
+      constexpr bool TWO = MODE == MG_FWD_ACT || MODE == MG_FWD_ACT_G;
+      constexpr int RP = TWO ? 32 : 64, NPASS = 128 / RP, MBL = RP / 32, NPIECE = RP / 8;
+      const bool two = TWO && a.C2 != nullptr;
 #pragma unroll
-      for (int hb = 0; hb < 2; ++hb) {
-        if (MODE == MG_BWD_DACT) {
+      for (int hb = 0; hb < NPASS; ++hb) {
+        if (HAS_P) {
 #pragma unroll
-          for (int p = 0; p < 8; ++p) *reinterpret_cast<u32x4*>(row_ptr + p * 1024) = pr[p];
-          if (hb == 0) {   // the second half's block: requested now, needed after the first half's arithmetic and stores
-            const bf16_t* pp = a.P + (size_t)(m0 + 64 + L3) * a.ldp + n_base + 8 * L7;
-            const long pstep = 8 * a.ldp;
+          for (int p = 0; p < 8; ++p) *reinterpret_cast<u32x4*>(row_ptr + p * 1024) = pr[PIPE ? 8 * hb + p : p];
+          if (!PIPE && hb == 0) {   // the second half's block: requested now, needed after the first half's arithmetic and stores
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-              pr[p] = *reinterpret_cast<const u32x4*>(pp);
-              pp += pstep;
-            }
+            for (int p = 0; p < 8; ++p) pr[p] = *reinterpret_cast<const u32x4*>(pp0 + (8 + p) * pstep);
           }
         }
 #pragma unroll
-        for (int pass = 0; pass < (MODE == MG_FWD_ACT ? 2 : 1); ++pass) {
-          if (pass == 1 && a.C2 == nullptr) break;
+        for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
+          for (int q = 0; q < 4; ++q) {
+            const float bvq[4] = {bv[nb][q][0], bv[nb][q][1], bv[nb][q][2], bv[nb][q][3]};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float bvq[4] = {bv[nb][q][0], bv[nb][q][1], bv[nb][q][2], bv[nb][q][3]};
+            for (int mbl = 0; mbl < MBL; ++mbl) {
+              const f32x16 tile = acc[nb][MBL * hb + mbl];
+              char* ap = acc_ptr + mbl * 4096 + (((4 * nb + q) ^ sw) << 4);
+              float y[4], y2[4];
+              if (MODE == MG_FWD_ACT_G) {
 #pragma unroll
-              for (int mbl = 0; mbl < 2; ++mbl) {
-                const f32x16 tile = acc[nb][2 * hb + mbl];
-                char* ap = acc_ptr + mbl * 4096 + (((4 * nb + q) ^ sw) << 4);
-                float y[4];
-                if (MODE == MG_PLAIN || pass == 1) {
+                for (int i = 0; i < 4; ++i) mg_act_both<ACT>(tile[4 * q + i] + bvq[i], y[i], y2[i]);
+              } else if (MODE == MG_FWD_ACT) {
 #pragma unroll
-                  for (int i = 0; i < 4; ++i) y[i] = tile[4 * q + i];
-                } else if (MODE == MG_FWD_ACT) {
-#pragma unroll
-                  for (int i = 0; i < 4; ++i) y[i] = (dbg & 8) ? tile[4 * q + i] : mg_act<ACT>(tile[4 * q + i] + bvq[i]);
-                } else {
-                  const uint2 pz = *reinterpret_cast<const uint2*>(ap);
-                  const float z[4] = {__uint_as_float(pz.x << 16), __uint_as_float(pz.x & 0xffff0000u), __uint_as_float(pz.y << 16),
-                                      __uint_as_float(pz.y & 0xffff0000u)};
-#pragma unroll
-                  for (int i = 0; i < 4; ++i) y[i] = (dbg & 8) ? tile[4 * q + i] + z[i] : tile[4 * q + i] * mg_act_grad<ACT>(z[i] + bvq[i]);
+                for (int i = 0; i < 4; ++i) {
+                  y2[i] = tile[4 * q + i];
+                  y[i] = (dbg & 8) ? y2[i] : mg_act<ACT>(y2[i] + bvq[i]);
                 }
-                *reinterpret_cast<uint2*>(ap) = make_uint2(mg_pk(y[0], y[1]), mg_pk(y[2], y[3]));
+              } else if (MODE == MG_PLAIN) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] = tile[4 * q + i];
+              } else {
+                const uint2 pz = *reinterpret_cast<const uint2*>(ap);
+                const float z[4] = {__uint_as_float(pz.x << 16), __uint_as_float(pz.x & 0xffff0000u), __uint_as_float(pz.y << 16),
+                                    __uint_as_float(pz.y & 0xffff0000u)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  y[i] = MODE == MG_BWD_MUL ? tile[4 * q + i] * z[i]
+                                            : ((dbg & 8) ? tile[4 * q + i] + z[i] : tile[4 * q + i] * mg_act_grad<ACT>(z[i] + bvq[i]));
               }
+              *reinterpret_cast<uint2*>(ap) = make_uint2(mg_pk(y[0], y[1]), mg_pk(y[2], y[3]));
+              if (TWO && two) *reinterpret_cast<uint2*>(ap + 4096) = make_uint2(mg_pk(y2[0], y2[1]), mg_pk(y2[2], y2[3]));
             }
           }
-          bf16_t* out = (pass == 1 ? a.C2 : a.C) + (size_t)(m0 + 64 * hb + L3) * a.ldc + n_base + 8 * L7;
-          const long ostep = 8 * a.ldc;
+        }
+        bf16_t* out = a.C + (size_t)(m0 + RP * hb + L3) * a.ldc + n_base + 8 * L7;
+        bf16_t* out2 = TWO && two ? a.C2 + (size_t)(m0 + RP * hb + L3) * a.ldc + n_base + 8 * L7 : nullptr;
+        const long ostep = 8 * a.ldc;
 #pragma unroll
-          for (int p = 0; p < 8; ++p) {
-            const uint4 v = *reinterpret_cast<const uint4*>(row_ptr + p * 1024);
-            if (!(dbg & 4)) *reinterpret_cast<uint4*>(out) = v;
-            out += ostep;
-            if (MODE == MG_BWD_DACT) {
-              csr[0] += __uint_as_float(v.x << 16); csr[1] += __uint_as_float(v.x & 0xffff0000u);
-              csr[2] += __uint_as_float(v.y << 16); csr[3] += __uint_as_float(v.y & 0xffff0000u);
-              csr[4] += __uint_as_float(v.z << 16); csr[5] += __uint_as_float(v.z & 0xffff0000u);
-              csr[6] += __uint_as_float(v.w << 16); csr[7] += __uint_as_float(v.w & 0xffff0000u);
-            }
+        for (int p = 0; p < NPIECE; ++p) {
+          const uint4 v = *reinterpret_cast<const uint4*>(row_ptr + p * 1024);
+          if (PIPE) oq[NPIECE * hb + p] = u32x4{v.x, v.y, v.z, v.w};
+          else if (!(dbg & 4)) *reinterpret_cast<uint4*>(out) = v;
+          out += ostep;
+          if (TWO && two) {
+            const uint4 v2 = *reinterpret_cast<const uint4*>(row_ptr + 4096 + p * 1024);
+            if (!(dbg & 4)) *reinterpret_cast<uint4*>(out2) = v2;
+            out2 += ostep;
+          }
+          if (MODE == MG_BWD_DACT || MODE == MG_BWD_MUL) {
+            csr[0] += __uint_as_float(v.x << 16); csr[1] += __uint_as_float(v.x & 0xffff0000u);
+            csr[2] += __uint_as_float(v.y << 16); csr[3] += __uint_as_float(v.y & 0xffff0000u);
+            csr[4] += __uint_as_float(v.z << 16); csr[5] += __uint_as_float(v.z & 0xffff0000u);
+            csr[6] += __uint_as_float(v.w << 16); csr[7] += __uint_as_float(v.w & 0xffff0000u);
           }
         }
       }
-      if (MODE == MG_BWD_DACT && a.part != nullptr) {
+      if ((MODE == MG_BWD_DACT || MODE == MG_BWD_MUL) && a.part != nullptr) {
         // lanes L7 + 8 k (k = lane >> 3) hold partial sums of the same 8 columns: transpose-reduce over k (7 exchanges), column
         // index c ends on the lane whose k has bit pattern c
 #pragma unroll
@@ -384,11 +474,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         a.part[(size_t)(2 * ctm + wm) * a.N + n_base + 8 * L7 + L3] = csr[0];
       }
+      if (PIPE) oq_ptr = (dbg & 4) ? nullptr : a.C + (size_t)(m0 + L3) * a.ldc + n_base + 8 * L7;
       // every wave is done with its staging image before any wave lets step g + 1's DMA into these sub-slots
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
     next_tile(ctm, ctn);
+  }
+  if (PIPE && oq_ptr != nullptr) {   // the last tile's pieces
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *reinterpret_cast<u32x4*>(oq_ptr + i * oq_step) = oq[i];
   }
   mg_wait_vmcnt<0>();   // the ring schedule's last (unused) pieces must not land in LDS after the workgroup has gone
 }
@@ -420,20 +515,26 @@ static int mlp_gemm_launch(int mode, int act, MlpGemmArgs& a, hipStream_t st) {
   }
   const int total = a.tiles_m * a.tiles_n;
   const int grid = std::min(n_cu, round_up(total, 8));
+  // PIPE for the backward only: on the plain product it measured 894 vs 899 us (M = 201,728), i.e. nothing -- the C stores cost
+  // the launch ~130 us whenever they are issued (MMK_MLP_GEMM_DBG=4 removes them: 799 us) -- while with G to fetch it is
+  // 1130 vs 1189 us
+  const bool pipe = (mode == MG_BWD_MUL || (mode == MG_PLAIN && (a.dbg & 1024))) && a.K / MG_BK >= 12 && !(a.dbg & 512);
   const void* kern = nullptr;
-#define MG_PICK(MODE_, ACT_) \
-  if (mode == MODE_ && act == ACT_) kern = reinterpret_cast<const void*>(mlp_gemm_kernel<MODE_, ACT_>);
-  MG_PICK(MG_PLAIN, 0)
-  MG_PICK(MG_FWD_ACT, MG_ACT_QUICK_GELU) MG_PICK(MG_FWD_ACT, MG_ACT_GELU)
-  MG_PICK(MG_BWD_DACT, MG_ACT_QUICK_GELU) MG_PICK(MG_BWD_DACT, MG_ACT_GELU)
+#define MG_PICK(MODE_, ACT_, PIPE_) \
+  if (mode == MODE_ && act == ACT_ && pipe == PIPE_) kern = reinterpret_cast<const void*>(mlp_gemm_kernel<MODE_, ACT_, PIPE_>);
+  MG_PICK(MG_PLAIN, 0, false) MG_PICK(MG_PLAIN, 0, true)
+  MG_PICK(MG_FWD_ACT, MG_ACT_QUICK_GELU, false) MG_PICK(MG_FWD_ACT, MG_ACT_GELU, false)
+  MG_PICK(MG_BWD_DACT, MG_ACT_QUICK_GELU, false) MG_PICK(MG_BWD_DACT, MG_ACT_GELU, false)
+  MG_PICK(MG_FWD_ACT_G, MG_ACT_QUICK_GELU, false) MG_PICK(MG_FWD_ACT_G, MG_ACT_GELU, false)
+  MG_PICK(MG_BWD_MUL, 0, false) MG_PICK(MG_BWD_MUL, 0, true)
 #undef MG_PICK
   MMK_REQUIRE(kern != nullptr, "mlp_gemm: unknown (mode, activation)");
   // opt-in to > 64 KiB of dynamic LDS, once per device and kernel
   {
-    static bool done[16][5] = {};
+    static bool done[16][16] = {};
     int dev = 0;
     MMK_HIP(hipGetDevice(&dev));
-    const int ki = mode == MG_PLAIN ? 0 : 1 + 2 * (mode - 1) + act;
+    const int ki = (mode == MG_PLAIN ? 0 : mode == MG_BWD_MUL ? 7 : mode == MG_FWD_ACT_G ? 5 + act : 1 + 2 * (mode - 1) + act) + (pipe ? 8 : 0);
     if (dev < 0 || dev >= 16 || !done[dev][ki]) {
       MMK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS));
       if (dev >= 0 && dev < 16) done[dev][ki] = true;
@@ -484,6 +585,32 @@ int mmk_mlp_gemm_bwd_dact(const void* dY, const void* Wt, const void* pre, const
   a.P = static_cast<const bf16_t*>(pre); a.bias = bias; a.part = part;
   a.lda = ldy; a.ldb = ldw; a.ldc = ldc; a.ldp = ldp; a.M = (int)M; a.N = N; a.K = K;
   return mlp_gemm_launch(MG_BWD_DACT, act, a, static_cast<hipStream_t>(stream));
+}
+
+// H = act(X W^T + bias), G = act'(X W^T + bias), both bf16 with row stride ldc: the forward of the pair the product runs
+int mmk_mlp_gemm_fwd_act_grad(const void* X, const void* W, const float* bias, void* H, void* G, int64_t M, int N, int K, int64_t ldx, int64_t ldw,
+                              int64_t ldc, int act, void* stream) {
+  MMK_REQUIRE(X && W && H && G, "null pointer");
+  MMK_REQUIRE(act == MG_ACT_QUICK_GELU || act == MG_ACT_GELU, "mlp_gemm: act must be 0 (quick_gelu) or 1 (gelu)");
+  MMK_REQUIRE(mmk_mlp_gemm_supported(M, N, K, ldx, ldw, ldc), "mlp_gemm: unsupported shape (need M % 256 == 0, N % 256 == 0, K % 64 == 0, strides % 8 == 0)");
+  MlpGemmArgs a = {};
+  a.A = static_cast<const bf16_t*>(X); a.B = static_cast<const bf16_t*>(W); a.C = static_cast<bf16_t*>(H); a.C2 = static_cast<bf16_t*>(G);
+  a.bias = bias;
+  a.lda = ldx; a.ldb = ldw; a.ldc = ldc; a.ldp = 0; a.M = (int)M; a.N = N; a.K = K;
+  return mlp_gemm_launch(MG_FWD_ACT_G, act, a, static_cast<hipStream_t>(stream));
+}
+
+// dPre = (dY Wt^T) * G elementwise (G [M, N] bf16, row stride ldg, as mmk_mlp_gemm_fwd_act_grad left it); part as in mmk_mlp_gemm_bwd_dact
+int mmk_mlp_gemm_bwd_mul(const void* dY, const void* Wt, const void* G, void* dPre, float* part, int64_t M, int N, int K, int64_t ldy,
+                         int64_t ldw, int64_t ldg, int64_t ldc, void* stream) {
+  MMK_REQUIRE(dY && Wt && G && dPre, "null pointer");
+  MMK_REQUIRE(mmk_mlp_gemm_supported(M, N, K, ldy, ldw, ldc) && ldg % 8 == 0,
+              "mlp_gemm: unsupported shape (need M % 256 == 0, N % 256 == 0, K % 64 == 0, strides % 8 == 0)");
+  MlpGemmArgs a = {};
+  a.A = static_cast<const bf16_t*>(dY); a.B = static_cast<const bf16_t*>(Wt); a.C = static_cast<bf16_t*>(dPre);
+  a.P = static_cast<const bf16_t*>(G); a.part = part;
+  a.lda = ldy; a.ldb = ldw; a.ldc = ldc; a.ldp = ldg; a.M = (int)M; a.N = N; a.K = K;
+  return mlp_gemm_launch(MG_BWD_MUL, 0, a, static_cast<hipStream_t>(stream));
 }
 
 }

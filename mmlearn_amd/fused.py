@@ -351,10 +351,11 @@ class _MLPFn(torch.autograd.Function):
     """``act(x W1^T + b1) W2^T`` -- a two-layer MLP without fc2's bias (the consumer kernel adds it) as ONE autograd node around
     the two GEMMs of ``csrc/mlp_gemm.hip`` that carry the activation pass in their epilogue:
 
-    * forward: ``fc1`` + bias + activation in one kernel that writes the activation and the bias-free pre-activation (the unfused
-      step runs library GEMM -> ``bias_act_fwd``: one read of the [rows, hidden] tensor more);
-    * backward: ``dPre = (dY W2) * act'(pre + b1)`` and ``db1 = dPre.sum(0)`` inside fc2's dX GEMM (the unfused step writes
-      ``dY W2``, reads it back with ``pre`` and writes ``dPre``: two passes over [rows, hidden] more).
+    * forward: ``fc1`` + bias + activation in one kernel that writes the activation and, in place of the pre-activation, the
+      activation's derivative ``G = act'(x W1^T + b1)`` (the unfused step runs library GEMM -> ``bias_act_fwd``: one read of the
+      [rows, hidden] tensor more);
+    * backward: ``dPre = (dY W2) * G`` and ``db1 = dPre.sum(0)`` inside fc2's dX GEMM (the unfused step writes ``dY W2``, reads it
+      back with the pre-activation and writes ``dPre``: two passes over [rows, hidden] more).
 
     fc2's forward and fc1's dX stay library GEMMs, both weight gradients run on ``csrc/wgrad.hip``.  Shapes the kernels do not serve
     (rows not a multiple of 256, ...) take the library GEMM + ``bias_act`` kernels inside the same node."""
@@ -368,13 +369,17 @@ class _MLPFn(torch.autograd.Function):
         w1_16, w1_bwd, ctx.w1_twin = _weight_operands(w1)
         w2_16, w2_bwd, ctx.w2_twin = _weight_operands(w2)
         b32 = b1.detach().float().contiguous()
-        M, H = x2.shape[0], w1.shape[0]
-        ctx.fused = not os.environ.get("MMK_NO_MLP_FUSION")   # (A/B switch)
+        M, H, E = x2.shape[0], w1.shape[0], w2.shape[0]
+        # both kernels or neither: the forward leaves act'(pre + b1) behind INSTEAD of the pre-activation, which only the fused
+        # backward can use
+        ctx.fused = bool(not os.environ.get("MMK_NO_MLP_FUSION")   # (A/B switch)
+                         and ctx.w2_twin and K.mlp_gemm_supported(M, H, k, x2.stride(0), w1_16.stride(0), H)
+                         and K.mlp_gemm_supported(M, H, E, E, w2_bwd.stride(0), H))
         with torch.autocast("cuda", enabled=False):
-            if ctx.fused and K.mlp_gemm_supported(M, H, k, x2.stride(0), w1_16.stride(0), H):
-                a2, h2 = K.mlp_gemm_fwd_act(x2, w1_16, b32, act)
+            if ctx.fused:
+                a2, h2 = K.mlp_gemm_fwd_act_grad(x2, w1_16, b32, act)     # h2 = act'(x W1^T + b1)
             else:
-                h2 = x2 @ w1_16.t()
+                h2 = x2 @ w1_16.t()                                       # h2 = x W1^T
                 a2 = K.bias_act_fwd(h2, b32, act)
             y = a2 @ w2_16.t()
         ctx.save_for_backward(x2, h2, a2, b32, w1_bwd, w2_bwd)
@@ -386,16 +391,14 @@ class _MLPFn(torch.autograd.Function):
         x2, h2, a2, b32, w1_bwd, w2_bwd = ctx.saved_tensors
         x_shape, x_dtype, w1_dtype, b_dtype, w2_dtype, act = ctx.meta
         dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16).contiguous()
-        M, E = dy2.shape
-        H = h2.shape[1]
         wdt = lambda t: t if t in (torch.float32, torch.bfloat16) else torch.float32
         dx = dw1 = db1 = dw2 = None
         with torch.autocast("cuda", enabled=False):
             if ctx.needs_input_grad[3]:
                 dw2 = K.wgrad(dy2, a2, wdt(w2_dtype)).to(w2_dtype)
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-                if ctx.fused and ctx.w2_twin and K.mlp_gemm_supported(M, H, E, dy2.stride(0), w2_bwd.stride(0), H):
-                    dpre, db1 = K.mlp_gemm_bwd_dact(dy2, w2_bwd, h2, b32, act, want_dbias=ctx.needs_input_grad[2])
+                if ctx.fused:
+                    dpre, db1 = K.mlp_gemm_bwd_mul(dy2, w2_bwd, h2, want_dbias=ctx.needs_input_grad[2])
                 else:
                     dpre, db1 = K.bias_act_bwd(h2, b32, _dx_gemm(dy2, w2_bwd, ctx.w2_twin), act)
                 if ctx.needs_input_grad[0]:

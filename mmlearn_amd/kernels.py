@@ -919,6 +919,41 @@ def mlp_gemm_bwd_dact(dy2: torch.Tensor, wt: torch.Tensor, pre: torch.Tensor, bi
     return dpre, dbias
 
 
+def mlp_gemm_fwd_act_grad(x2: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int):
+    """-> (``act(x2 @ w^T + bias)``, ``act'(x2 @ w^T + bias)``), both bf16: fc1 of an MLP in one kernel that leaves behind what the
+    backward multiplies by (``mlp_gemm_bwd_mul``) instead of the pre-activation."""
+    _mlp_gemm_check(x2, w)
+    M, K_ = x2.shape
+    N = w.shape[0]
+    assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N
+    h = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
+    g = torch.empty((M, N), dtype=torch.bfloat16, device=x2.device)
+    check(_lib.lib().mmk_mlp_gemm_fwd_act_grad(ptr(x2), ptr(w), ptr(bias), ptr(h), ptr(g), M, N, K_, x2.stride(0), w.stride(0), h.stride(0),
+                                               int(act), stream()))
+    return h, g
+
+
+def mlp_gemm_bwd_mul(dy2: torch.Tensor, wt: torch.Tensor, g: torch.Tensor, want_dbias: bool = True):
+    """-> (``dPre = (dy2 @ wt^T) * g`` bf16, ``dbias`` f32[N] = column sums of dPre or None): fc2's dX GEMM with the activation's
+    backward as a multiply in its epilogue; ``g`` = act'(pre + bias) from ``mlp_gemm_fwd_act_grad``, ``wt`` = fc2.weight^T."""
+    _mlp_gemm_check(dy2, wt)
+    M, K_ = dy2.shape
+    N = wt.shape[0]
+    assert g.dtype == torch.bfloat16 and g.shape == (M, N) and g.stride(1) == 1
+    dev = dy2.device
+    dpre = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    part = dbias = None
+    if want_dbias:
+        part = torch.empty((_lib.lib().mmk_mlp_gemm_part_rows(M), N), dtype=torch.float32, device=dev)
+    check(_lib.lib().mmk_mlp_gemm_bwd_mul(ptr(dy2), ptr(wt), ptr(g), ptr(dpre), ptr(part), M, N, K_, dy2.stride(0), wt.stride(0),
+                                          g.stride(0), dpre.stride(0), stream()))
+    if want_dbias:
+        part2 = torch.empty((256, N), dtype=torch.float32, device=dev)
+        dbias = torch.empty(N, dtype=torch.float32, device=dev)
+        check(_lib.lib().mmk_colsum_f32(ptr(part), part.shape[0], N, ptr(part2), ptr(dbias), stream()))
+    return dpre, dbias
+
+
 def quick_gelu_fwd(x: torch.Tensor) -> torch.Tensor:
     require_gpu(x)
     y = torch.empty_like(x)

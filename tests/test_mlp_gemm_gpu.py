@@ -104,6 +104,33 @@ def test_backward_with_activation_gradient_and_column_sums(M, N, K, act):
     assert none is None and torch.equal(dpre2, dpre)
 
 
+@pytest.mark.parametrize("act", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1024, 3072, 768), (512, 768, 256)])
+def test_forward_that_leaves_the_derivative_and_backward_that_multiplies_by_it(M, N, K, act):
+    """The pair the product runs: ``mlp_gemm_fwd_act_grad`` -> (act(z), act'(z)) for z = x W^T + b; ``mlp_gemm_bwd_mul`` ->
+    (dY Wt^T) * act'(z) with its column sums.  Against f32 references and against the epilogue-form kernels."""
+    from mmlearn_amd import kernels as Kn
+
+    dev = torch.device("cuda", 0)
+    x, w = _operands(M, N, K, 3 * M + N + K + act)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(6)) * 0.2
+    h, g = Kn.mlp_gemm_fwd_act_grad(x.to(dev), w.to(dev), bias.to(dev), act)
+    z = x.float() @ w.float().t() + bias
+    assert (h.float().cpu() - _act(z, act)).abs().max().item() <= 1e-2 * max(1.0, _act(z, act).abs().max().item())
+    assert (g.float().cpu() - _act_grad(z, act)).abs().max().item() <= 8e-3          # |act'| <= 1.13, stored in bf16
+    h_e, _ = Kn.mlp_gemm_fwd_act(x.to(dev), w.to(dev), bias.to(dev), act)
+    assert torch.equal(h, h_e)
+    # backward on another product of the same [M, N] shape
+    dy, wt = _operands(M, N, 128 if K < 128 else K, 9 * M + N + act)
+    dpre, db = Kn.mlp_gemm_bwd_mul(dy.to(dev), wt.to(dev), g)
+    ref = (dy.float() @ wt.float().t()) * g.float().cpu()
+    scale = max(1.0, ref.abs().max().item())
+    assert dpre.dtype == torch.bfloat16 and (dpre.float().cpu() - ref).abs().max().item() <= 1e-2 * scale
+    assert (db.cpu() - ref.sum(0)).abs().max().item() <= 3e-3 * max(1.0, ref.abs().sum(0).max().item())
+    dpre2, none = Kn.mlp_gemm_bwd_mul(dy.to(dev), wt.to(dev), g, want_dbias=False)
+    assert none is None and torch.equal(dpre2, dpre)
+
+
 def test_strided_operands_and_many_tiles_per_workgroup():
     """Operands that are column slices of wider buffers, and more tiles than workgroups (every workgroup walks several tiles,
     the ring keeps streaming across tile boundaries)."""

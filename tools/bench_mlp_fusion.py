@@ -58,6 +58,7 @@ def main():
         h = F.linear(x, w1)
         w2t = w2.t().contiguous()    # [H, E]: dAct = dy @ w2 = linear(dy, w2t)
         dact = F.linear(dy, w2t)
+        _, gfac = K.mlp_gemm_fwd_act_grad(x, w1, b1, act)
         arms = {
             "fwd_lib_gemm": lambda: F.linear(x, w1),
             "fwd_bias_act": lambda: K.bias_act_fwd(h, b1, act),
@@ -67,6 +68,8 @@ def main():
             "bwd_bias_act": lambda: K.bias_act_bwd(h, b1, dact, act),
             "bwd_own_plain": lambda: K.mlp_gemm_plain(dy, w2t),
             "bwd_own_fused": lambda: K.mlp_gemm_bwd_dact(dy, w2t, h, b1, act),
+            "fwd_own_fused_grad": lambda: K.mlp_gemm_fwd_act_grad(x, w1, b1, act),
+            "bwd_own_mul": lambda: K.mlp_gemm_bwd_mul(dy, w2t, gfac),
         }
         t = time_arms(arms, args.rounds, args.iters)
         flop = 2.0 * M * E * H
@@ -77,6 +80,9 @@ def main():
                "lib_pflops": round(flop / t["bwd_lib_gemm"]["median_us"] * 1e-9, 3)}
         out["fwd_fused_over_pair"] = round(t["fwd_own_fused"]["median_us"] / out["fwd_pair_us"], 3)
         out["bwd_fused_over_pair"] = round(t["bwd_own_fused"]["median_us"] / out["bwd_pair_us"], 3)
+        # what the product runs: forward that leaves act' behind + backward that multiplies by it
+        out["product_fwd_bwd_us"] = round(t["fwd_own_fused_grad"]["median_us"] + t["bwd_own_mul"]["median_us"], 1)
+        out["unfused_fwd_bwd_us"] = round(out["fwd_pair_us"] + out["bwd_pair_us"], 1)
         print(json.dumps(out), flush=True)
         results.append(out)
     if args.out:

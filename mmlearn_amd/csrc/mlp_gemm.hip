@@ -62,6 +62,7 @@ struct MlpGemmArgs {
   long lda, ldb, ldc, ldp;
   int M, N, K;
   int tiles_m, tiles_n;
+  unsigned long long* stamps;   // debug-switch builds: shader-clock stamps of workgroup 0 (tools/mlp_gemm_stamps.py), else null
   int dbg;            // timing ablations, debug-switch builds only: 4 = no C stores, 8 = no epilogue arithmetic, 64 = hot DMA, 512 = no PIPE
 };
 
@@ -73,6 +74,14 @@ __device__ __forceinline__ void mg_dma16(const void* sbase, uint32_t voff, uint3
   // no "memory" clobber: the DMA lands in ring slots nobody reads during this step (the barriers order it), and the compiler
   // must stay free to move this step's fragment reads across it
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(reinterpret_cast<const void*>(ps)), "s"(lds_addr));
+}
+
+__device__ __forceinline__ unsigned long long mg_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
 }
 
 template <int N>
@@ -259,6 +268,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) acc[nb][mb] = zero;
     }
+    int stamp_step = 0;
     constexpr bool HAS_P = MODE == MG_BWD_DACT || MODE == MG_BWD_MUL;
     u32x4 pr[PIPE ? 16 : 8];   // HAS_P: blocks of P in row layout (piece i: row 8 i + (lane >> 3), 16-byte chunk lane & 7)
     const bf16_t* pp0 = HAS_P ? a.P + (size_t)(ctm * MG_TILE + 128 * wm + (lane >> 3)) * a.ldp + ctn * MG_TILE + 64 * wn + 8 * (lane & 7) : nullptr;
@@ -282,6 +292,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = LO[LD >= 0 ? LD : 0]; i < LO[LD >= 0 ? LD + 1 : 0]; ++i) pr[i] = *reinterpret_cast<const u32x4*>(pp0 + i * pstep);
       }
+      const bool stamping = kDebugSwitches && a.stamps != nullptr && blockIdx.x == 0 && ti == 1;
+      unsigned long long* sp = stamping ? a.stamps + ((size_t)wave * 64 + (size_t)(stamp_step & 15)) * 4 : nullptr;
+      if (stamping && lane == 0) sp[0] = mg_stamp();
       const bf16_t* sB0 = srcB(cB, 0);
       const bf16_t* sB1 = srcB(cB, 1);
       const bf16_t* sA0 = srcA(cA, 0);
@@ -324,10 +337,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       bump(p0);
       // step g + 1 must have landed before its first read; the only younger pieces of this wave are the A half of step g + 2
       // (4 instructions).  (Loads and stores issued before this step's DMA are older: the wait covers them.)
+      if (stamping && lane == 0) sp[1] = mg_stamp();
       if (PIPE && LAST) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
       else mg_wait_vmcnt<4>();
+      if (stamping && lane == 0) sp[2] = mg_stamp();
       __builtin_amdgcn_s_barrier();   // every wave's pieces of step g + 1 are in LDS; every wave is done reading step g
       asm volatile("" ::: "memory");
+      if (stamping && lane == 0) sp[3] = mg_stamp();
+      ++stamp_step;
     };
     typedef std::integral_constant<int, -1> No;
     if (PIPE) {   // host: nk >= 12
@@ -474,10 +491,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         a.part[(size_t)(2 * ctm + wm) * a.N + n_base + 8 * L7 + L3] = csr[0];
       }
+      if (kDebugSwitches && a.stamps != nullptr && blockIdx.x == 0 && ti == 1 && lane == 0) a.stamps[((size_t)wave * 64 + 20) * 4] = mg_stamp();
       if (PIPE) oq_ptr = (dbg & 4) ? nullptr : a.C + (size_t)(m0 + L3) * a.ldc + n_base + 8 * L7;
       // every wave is done with its staging image before any wave lets step g + 1's DMA into these sub-slots
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if (kDebugSwitches && a.stamps != nullptr && blockIdx.x == 0 && ti == 1 && lane == 0) a.stamps[((size_t)wave * 64 + 21) * 4] = mg_stamp();
     }
     next_tile(ctm, ctn);
   }
@@ -506,6 +525,7 @@ static int mlp_gemm_launch(int mode, int act, MlpGemmArgs& a, hipStream_t st) {
   a.tiles_m = cdiv(a.M, MG_TILE);
   a.tiles_n = cdiv(a.N, MG_TILE);
   a.dbg = MMK_DBG_ENV("MMK_MLP_GEMM_DBG") ? atoi(MMK_DBG_ENV("MMK_MLP_GEMM_DBG")) : 0;
+  a.stamps = MMK_DBG_ENV("MMK_MLP_GEMM_STAMPS") ? reinterpret_cast<unsigned long long*>(strtoull(MMK_DBG_ENV("MMK_MLP_GEMM_STAMPS"), nullptr, 0)) : nullptr;
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;

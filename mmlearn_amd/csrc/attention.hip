@@ -710,6 +710,216 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(cons
   }
 }
 
+#ifdef MMK_DEBUG_SWITCHES
+// EXPERIMENT (debug-switch builds only, MMK_ATTN_SPLIT=1; measured, not kept: 18-35 % SLOWER than the five-product kernel at
+// L = 197 / 77 / 169, profiles/r04_attn_bwd.json -- two more exponential passes and twice the operand reads cost more than the step
+// barriers of the one-kernel form).
+// ---- the two-kernel form: the seven-product kernel's two phases as separate launches, so that no wave ever
+// waits at a barrier for a wave in the other role.  PH = 1: dK, dV of an item (a wave owns 32 keys, K_j / V_j fragments in
+// registers, sweeps the query tiles of the Q / dO images).  PH = 2: dQ (a wave owns 32 queries, Q_i / dO_i fragments in registers,
+// sweeps the key tiles of the K / V images).  The two images of a launch are DOUBLE-BUFFERED (4 x 28 KiB at L = 197): the next
+// item's images, row constants and fragments arrive while the current item is computed; the one barrier per item hands the buffers
+// over.  Selected by MMK_ATTN_SPLIT=1 in debug-switch builds (measured against the five-product kernel: DESIGN.md 5.2).
+template <int NT, int NW, bool DROP, int PH>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_split_kernel(const AttnBwdArgs a) {
+  constexpr int LP = 32 * NT;
+  constexpr int IMG = LP * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [2 buffers][X | Y] images: PH 1: X = Q, Y = dO;  PH 2: X = K, Y = V
+  constexpr int SROWS = NT <= 7 ? 32 : 16;
+  float* rowc = reinterpret_cast<float*>(smem + 4 * IMG);  // [2 buffers][lse2 | delta][ROWC]
+  char* stage = reinterpret_cast<char*>(rowc + 4 * ROWC) + (threadIdx.x >> 6) * (SROWS * 128);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const ImgLane il = img_lane(lane);
+  const long osl = (long)a.H * ATT_DH;
+  const float sl2 = a.scale * 1.4426950408889634f;
+  const int nitems = a.B * a.H;
+  const bool active = wave < NT;  // wave-uniform: this wave owns tile `wave`
+
+  bf16x8 xf[4], yf[4];        // this wave's own fragments of the current item (PH 1: K_j, V_j; PH 2: Q_i, dO_i)
+  bf16x8 xn[4], yn[4];        // ... of the next item (second register set: they arrive behind the current item's MFMAs)
+
+  auto obase_of = [&](int bh) { return ((long)(bh / a.H) * a.L * a.H + (bh % a.H)) * ATT_DH; };
+  auto load_regs = [&](int bh, bf16x8 (&xo)[4], bf16x8 (&yo)[4]) {
+    const int b = bh / a.H, hh = bh % a.H;
+    if (active) {
+      const int lo = opaque(lane);
+      const int jc = min(wave * 32 + (lo & 31), a.L - 1);
+      const char* xbase;
+      const char* ybase;
+      uint32_t xoff, yoff;
+      if (PH == 1) {
+        xbase = reinterpret_cast<const char*>(a.k + b * a.k_sb + hh * a.k_sh);
+        ybase = reinterpret_cast<const char*>(a.v + b * a.v_sb + hh * a.v_sh);
+        xoff = (uint32_t)(jc * (int)a.k_sl + 8 * (lo >> 5)) * 2u;
+        yoff = (uint32_t)(jc * (int)a.v_sl + 8 * (lo >> 5)) * 2u;
+      } else {
+        xbase = reinterpret_cast<const char*>(a.q + b * a.q_sb + hh * a.q_sh);
+        ybase = reinterpret_cast<const char*>(a.dout + obase_of(bh));
+        xoff = (uint32_t)(jc * (int)a.q_sl + 8 * (lo >> 5)) * 2u;
+        yoff = (uint32_t)(jc * (int)osl + 8 * (lo >> 5)) * 2u;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        xo[kk] = *reinterpret_cast<const bf16x8*>(xbase + xoff + 32 * kk);
+        yo[kk] = *reinterpret_cast<const bf16x8*>(ybase + yoff + 32 * kk);
+      }
+    }
+    asm volatile("" ::: "memory");  // keep the loads here (not sunk to their first use)
+  };
+  auto issue_imgs = [&](int bh, int buf) {  // the item's two images + its row-constant record (two pieces, waves 0 and 1)
+    const int b = bh / a.H, hh = bh % a.H;
+    const int lo = opaque(lane);
+    char* X = smem + buf * 2 * IMG;
+    char* Y = X + IMG;
+    if (PH == 1) {
+      img_load(X, a.q + b * a.q_sb + hh * a.q_sh, a.q_sl, a.L, LP, wave, NW, lo);
+      img_load(Y, a.dout + obase_of(bh), osl, a.L, LP, wave, NW, lo);
+    } else {
+      img_load(X, a.k + b * a.k_sb + hh * a.k_sh, a.k_sl, a.L, LP, wave, NW, lo);
+      img_load(Y, a.v + b * a.v_sb + hh * a.v_sh, a.v_sl, a.L, LP, wave, NW, lo);
+    }
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    if (wave_s < 2)
+      lds_dma16(a.delta + ((long)bh * 2 + wave_s) * ROWC, (uint32_t)lo * 16u,
+                lds_addr_of(reinterpret_cast<const char*>(rowc + (buf * 2 + wave_s) * ROWC)));
+  };
+
+  int item = blockIdx.x;
+  if (item < nitems) {
+    issue_imgs(item, 0);
+    load_regs(item, xf, yf);
+    wait_vmem_all();
+  }
+  for (int n = 0; item < nitems; item += gridDim.x, ++n) {
+    const int buf = n & 1;
+    const char* X = smem + buf * 2 * IMG;
+    const char* Y = X + IMG;
+    const float* lse2s = rowc + buf * 2 * ROWC;
+    const float* dls = lse2s + ROWC;
+    const long gbase = (long)(item / a.H) * a.g_sb + (long)(item % a.H) * ATT_DH;
+    const uint32_t dkey = DROP ? drop_key(a.seed_lo, a.seed_hi, (uint32_t)item) : 0u;
+    __syncthreads();  // buffer `buf` has landed (every wave waited for its own pieces); every wave is done with the other buffer
+    const int next = item + gridDim.x;
+    if (next < nitems) {
+      issue_imgs(next, buf ^ 1);
+      load_regs(next, xn, yn);
+    }
+    f32x16 acc1[2], acc2[2];
+    if (active && PH == 1) {
+      // ---------------- dK, dV of key tile `wave` (the key on the lane)
+      const int j = wave * 32 + r;
+      const bool jvalid = j < a.L;
+      f32x16 (&dkt)[2] = acc1;
+      f32x16 (&dvt)[2] = acc2;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dkt[dt][e] = dvt[dt][e] = 0.f;
+#pragma unroll 1
+      for (int it = 0; it < NT; ++it) {
+        f32x16 sc, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[e] = dp[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(X + it * 4096 + il.row[kk]), xf[kk], sc, 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(Y + it * 4096 + il.row[kk]), yf[kk], dp, 0, 0, 0);
+        bf16x8 pf[2], df[2];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float4 l2 = *reinterpret_cast<const float4*>(lse2s + it * 32 + 8 * g4 + 4 * h);
+          const float4 dl = *reinterpret_cast<const float4*>(dls + it * 32 + 8 * g4 + 4 * h);
+          const float l2v[4] = {l2.x, l2.y, l2.z, l2.w};
+          const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const int e = 4 * g4 + e4;
+            const float p = jvalid ? att_exp2(fmaf(sc[e], sl2, -l2v[e4])) : 0.f;
+            float keep = 1.f;
+            if (DROP) {
+              const uint32_t w = drop_word(dkey, it * 32 + 8 * g4 + 4 * h + e4, j >> 1);
+              keep = ((w >> (16 * (j & 1))) & 0xFFFFu) < a.drop_thr ? 0.f : a.drop_scale;
+            }
+            pf[e >> 3][e & 7] = (bf16_t)(DROP ? p * keep : p);
+            df[e >> 3][e & 7] = (bf16_t)(p * ((DROP ? dp[e] * keep : dp[e]) - dlv[e4]));
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(Y, il, it * 4096 + s * 2048, dt), pf[s], dvt[dt], 0, 0, 0);
+            dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(X, il, it * 4096 + s * 2048, dt), df[s], dkt[dt], 0, 0, 0);
+          }
+      }
+    }
+    if (active && PH == 2) {
+      // ---------------- dQ of query tile `wave` (the query on the lane)
+      const int i = wave * 32 + r;
+      const float l2 = lse2s[i], dl = dls[i];
+      f32x16 (&dqt)[2] = acc1;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dqt[dt][e] = 0.f;
+#pragma unroll 1
+      for (int jt = 0; jt < NT; ++jt) {
+        f32x16 sc, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sc[e] = dp[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(X + jt * 4096 + il.row[kk]), xf[kk], sc, 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(Y + jt * 4096 + il.row[kk]), yf[kk], dp, 0, 0, 0);
+        if (DROP) {
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) {
+            const uint32_t w = drop_word(dkey, i, (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) >> 1);
+            dp[e] *= (w & 0xFFFFu) < a.drop_thr ? 0.f : a.drop_scale;
+            dp[e + 1] *= (w >> 16) < a.drop_thr ? 0.f : a.drop_scale;
+          }
+        }
+        bf16x8 df[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) df[e >> 3][e & 7] = (bf16_t)(att_exp2(fmaf(sc[e], sl2, -l2)) * (dp[e] - dl));
+        if (jt == NT - 1 && a.L < LP) {  // keys beyond L (finite filler rows): dS = 0
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            if (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= a.L) df[e >> 3][e & 7] = (bf16_t)0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            dqt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_tr_frag(X, il, jt * 4096 + s * 2048, dt), df[s], dqt[dt], 0, 0, 0);
+      }
+    }
+    wait_vmem_all();  // the next item's pieces and fragments (issued before this item's MFMAs)
+    if (active) {
+      if (PH == 1) {
+        store_rows_staged<SROWS>(stage, a.dk + gbase, a.g_sl, wave * 32, a.L, acc1, a.scale, opaque(lane));
+        store_rows_staged<SROWS>(stage, a.dv + gbase, a.g_sl, wave * 32, a.L, acc2, 1.f, opaque(lane));
+      } else {
+        store_rows_staged<SROWS>(stage, a.dq + gbase, a.g_sl, wave * 32, a.L, acc1, a.scale, opaque(lane));
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        xf[kk] = xn[kk];
+        yf[kk] = yn[kk];
+      }
+    }
+  }
+}
+
+#endif  // MMK_DEBUG_SWITCHES
+
 // ---- five-product backward for NT < NW (a spare wave exists; L = 197 -> 7 key waves + 1, L = 77 -> 3 + 1)
 // Waves 0..NT-1 each own 32 KEYS for the whole item and sweep the query tiles in lockstep: S = Q Kᵀ and dP = dO Vᵀ
 // with the key on the lane, P and dS = P∘(dP - δ) feed dVᵀ += dOᵀ P and dKᵀ += Qᵀ dS as B operands (as phase 1
@@ -1010,6 +1220,46 @@ static int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st) {
   return 0;
 }
 
+#ifdef MMK_DEBUG_SWITCHES
+template <int NT, int NW, bool DROP>
+static int launch_attn_bwd_split(const AttnBwdArgs& a, hipStream_t st) {
+  constexpr int LP = 32 * NT;
+  constexpr int bytes = 4 * LP * 128 + 4 * ROWC * 4 + NW * (NT <= 7 ? 32 : 16) * 128;
+  static_assert(bytes <= 160 * 1024, "LDS budget");
+  auto k1 = attn_bwd_split_kernel<NT, NW, DROP, 1>;
+  auto k2 = attn_bwd_split_kernel<NT, NW, DROP, 2>;
+  static int wgs_per_cu = 0, cus = 0;
+  if (!wgs_per_cu) {
+    if (bytes > 64 * 1024) {
+      MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+      MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    }
+    int dev = 0;
+    MMK_HIP(hipGetDevice(&dev));
+    MMK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int occ = 0;
+    MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k1, 64 * NW, bytes));
+    wgs_per_cu = std::max(1, occ);
+  }
+  const int grid = std::min(a.B * a.H, cus * wgs_per_cu * att_grid_factor());
+  {
+    const long chunks = (long)a.B * a.L * a.H * 8;
+    const int dgrid = (int)std::min<long>((chunks + 255) / 256, (long)cus * 16);
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, st, a.o, a.dout, a.lse, a.delta, a.B, a.H, a.L);
+  }
+  {
+    ProfEvents pe(MMK_K_ATTN_BWD);
+    hipExtLaunchKernelGGL(k1, dim3(grid), dim3(64 * NW), bytes, st, pe.start, pe.stop, 0, a);
+  }
+  {
+    ProfEvents pe(MMK_K_ATTN_BWD);
+    hipExtLaunchKernelGGL(k2, dim3(grid), dim3(64 * NW), bytes, st, pe.start, pe.stop, 0, a);
+  }
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+#endif  // MMK_DEBUG_SWITCHES
+
 }  // namespace mmk
 
 using namespace mmk;
@@ -1101,12 +1351,22 @@ extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const v
   const bool drop = drop_params(dropout_p, seed, &a.seed_lo, &a.seed_hi, &a.drop_thr, &a.drop_scale);
   hipStream_t st = static_cast<hipStream_t>(stream);
   static const bool seven = MMK_DBG_ENV("MMK_ATTN_BWD7") != nullptr;  // force the seven-product kernel (A/B runs)
+#ifdef MMK_DEBUG_SWITCHES
+  const bool split = MMK_DBG_ENV("MMK_ATTN_SPLIT") != nullptr && atoi(MMK_DBG_ENV("MMK_ATTN_SPLIT")) != 0;   // two-kernel form (A/B, read per call)
+#endif
   static const bool staged = MMK_DBG_ENV("MMK_ATTN_STAGED") ? atoi(MMK_DBG_ENV("MMK_ATTN_STAGED")) != 0 : kAttnStagedDefault;
   MMK_REQUIRE(!colsum_part || mmk_attn_bwd_has_colsum(L), "attn_bwd: column sums are not available for this sequence length");
 #define MMK_ATTN_BWD_CASE(NT, NW) \
   case NT: return drop ? launch_attn_bwd<NT, NW, true>(a, st) : launch_attn_bwd<NT, NW, false>(a, st);
+#ifdef MMK_DEBUG_SWITCHES
+#define MMK_ATTN_SPLIT_CASE(NT, NW) \
+  if (split && !colsum_part) return drop ? launch_attn_bwd_split<NT, NW, true>(a, st) : launch_attn_bwd_split<NT, NW, false>(a, st);
+#else
+#define MMK_ATTN_SPLIT_CASE(NT, NW)
+#endif
 #define MMK_ATTN_BWD5_CASE(NT, NW)                                                                                   \
   case NT:                                                                                                           \
+    MMK_ATTN_SPLIT_CASE(NT, NW)                                                                                      \
     if (seven) return drop ? launch_attn_bwd<NT, NW, true>(a, st) : launch_attn_bwd<NT, NW, false>(a, st);           \
     if (staged) return drop ? launch_attn_bwd5<NT, NW, true, true>(a, st) : launch_attn_bwd5<NT, NW, false, true>(a, st); \
     return drop ? launch_attn_bwd5<NT, NW, true, false>(a, st) : launch_attn_bwd5<NT, NW, false, false>(a, st);

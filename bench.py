@@ -527,6 +527,8 @@ def _loss_roofline(prof: dict, n_rows: int, n_cols: int, d: int, n_pairs: int, s
     launches_per_step = cnt / max(steps, 1)
     avg_s = ms / cnt * 1e-3
     achieved = algo[rep] / launches_per_step / avg_s / 1e12
+    if isinstance(traffic, dict):   # per-kernel HBM bytes per launch (PMC): quote the representative kernel's
+        traffic = (traffic.get(rep) or {}).get("hbm_bytes_per_launch")
     return {"bound": "mfma", "kernel": rep, "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt,
             "dominant_by_time": dom, "shape": {"rows": n_rows, "cols": n_cols, "d": d, "pairs": n_pairs},
@@ -640,7 +642,7 @@ def loss_shard_leg(dev, rows: int = 1024, cols: int = 8192, d: int = 512, rank: 
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / iters
     pmc = _shard_traffic(C)
-    roof = _loss_roofline(prof, R, C, D, 1, iters, pmc.get("dominant_hbm_bytes_per_launch") if pmc else None, loss_only=True)
+    roof = _loss_roofline(prof, R, C, D, 1, iters, pmc.get("per_kernel") if pmc else None, loss_only=True)
     if roof is not None:
         dev_us = sum(v[1] for v in prof.values()) / iters * 1e3
         roof["device_us_per_rank_share"] = round(dev_us, 1)
@@ -969,7 +971,7 @@ def main():
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
                 traffic = pmc.get("n1024", {}).get("hbm_bytes_per_launch")
             elif args.batch == 1024:   # N > 1: the rank's sharded shape (R = batch rows x C = batch * world columns)
-                traffic = (_shard_traffic(n_cols) or {}).get("dominant_hbm_bytes_per_launch")
+                traffic = (_shard_traffic(n_cols) or {}).get("per_kernel")
         except Exception:
             traffic = None
         roofline = _loss_roofline(prof, n_rows, n_cols, d, 1, prof_steps, traffic)

@@ -232,6 +232,12 @@ def test_per_tower_ddp_with_three_towers_and_a_shared_head():
     for (l0, n0, g0), (l1, n1, g1) in zip(plain, wrapped):
         assert n0 == n1 and "log_logit_scale" in n0
         assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0))
-        # not bitwise: f32 atomics (embedding backward) and the order in which the three towers' contributions reach the shared
-        # head differ from run to run at the 1e-6 level (see the measured spread in the RCCL test above)
-        assert (g0 - g1).abs().max().item() <= 1e-4 * g0.abs().max().item()
+        # Measured (round 4, MMK_TEST_SPREAD_OUT, six runs x two steps on one MI355X): the plain and the per-tower-DDP step of
+        # THIS configuration (MLP towers: no embedding-backward atomics, no library stream-K GEMMs) agree bit for bit, 0.0 in all
+        # twelve comparisons.  The bound stays at the two-tower test's 1e-4 allowance for towers that do have such kernels: what
+        # this test guards against -- a tower reading a bucket too early, a missing shared-head all-reduce -- is orders above it.
+        rel = (g0 - g1).abs().max().item() / g0.abs().max().item()
+        if os.environ.get("MMK_TEST_SPREAD_OUT"):   # measurement runs: append the observed difference (tools: see the comment above)
+            with open(os.environ["MMK_TEST_SPREAD_OUT"], "a") as f:
+                f.write(f"{rel:.3e}\n")
+        assert rel <= 1e-4

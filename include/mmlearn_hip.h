@@ -419,6 +419,15 @@ int mmk_cast_transpose(const void* w, void* w16, void* w16t, int n, int k, int d
  * the caller; runs of equal ids are summed in registers before one hardware float atomic per element (summation order is
  * not fixed: results can differ in the last bits between runs, as with ATen's atomic paths). */
 int mmk_embedding_bwd(const void* dout, const int64_t* ids, float* dw, int64_t rows, int d, int64_t vocab, int dtype, void* stream);
+/* The same gradient for many rows (mmlearn/modules/encoders/text.py:20-178: BERT's word and token-type tables at 78,848 token rows
+ * per step) on ids sorted by the caller: ids_sorted non-decreasing, perm[r] = the row of dout that sorted position r came from.
+ * A wave sums the runs of 32 consecutive sorted rows; runs strictly inside a chunk are plain stores, the chunk's first / last run go
+ * into an (id, partial row) list that is sorted again and 16 times shorter, on which the kernel recurses; only the last, short
+ * list (<= 1024 entries) ends in float atomics.  No same-address atomic storms for hot ids (token-type ids are all equal).
+ * scratch: mmk_embedding_bwd_scratch_bytes(rows, d) bytes; dw f32 [vocab, d] zeroed by the caller; ids outside [0, vocab) ignored. */
+int64_t mmk_embedding_bwd_scratch_bytes(int64_t rows, int d);
+int mmk_embedding_bwd_sorted(const void* dout, const int64_t* ids_sorted, const int64_t* perm, float* dw, void* scratch, int64_t rows,
+                             int d, int64_t vocab, int dtype, void* stream);
 
 /* HF QuickGELUActivation  x * sigmoid(1.702 x)  (CLIP MLP), forward and backward, n elements (multiple of 4) */
 int mmk_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);

@@ -126,6 +126,8 @@ _SIGNATURES = {
     "mmk_adamw_update": [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, C.c_int64, _vp],
     "mmk_adamw_update_dev": [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _vp, _vp],
     "mmk_embedding_bwd": [_vp, _vp, _vp, C.c_int64, _i, C.c_int64, _i, _vp],
+    "mmk_embedding_bwd_scratch_bytes": [C.c_int64, _i],
+    "mmk_embedding_bwd_sorted": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, C.c_int64, _i, _vp],
     "mmk_wgrad_plan": [C.c_int64, _i, _i, _vp, _vp],
     "mmk_wgrad_partial": [_vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp],
     "mmk_wgrad": [_vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _vp],
@@ -176,6 +178,7 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = C.c_int
+        l.mmk_embedding_bwd_scratch_bytes.restype = C.c_int64
         for name, args in _STR_FUNCS.items():
             fn = getattr(l, name)
             fn.argtypes = args

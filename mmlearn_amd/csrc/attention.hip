@@ -212,11 +212,12 @@ __device__ __forceinline__ void store_rows_staged(char* stage, bf16_t* dst, long
   }
 }
 
-// The same store for the five-product backward (32-row slabs), which can also hand out column sums: cs (optional) = 64
-// floats that receive the sums over the rows stored -- of the ROUNDED values, i.e. exactly what a later dY.sum(0) over the
-// stored tensor would add up (the bias gradient of a fused QKV projection, one partial per 32-row tile).
+// The same store for the five-product backward (32-row slabs), which also feeds column sums: cs8 accumulates, per lane, the sums of
+// its 8 columns (16-byte chunk lane & 7) over the rows it stored -- of the ROUNDED values, i.e. exactly what a later dY.sum(0) over
+// the stored tensor would add up (the bias gradient of a fused QKV projection).  cs_flush reduces them over the wave and writes
+// the 64 sums.
 __device__ __forceinline__ void store_rows_staged_cs(char* stage, bf16_t* dst, long row_stride, int row0, int nrows_valid,
-                                                     const f32x16 (&acc)[2], float mul, int lane, float* cs) {
+                                                     const f32x16 (&acc)[2], float mul, int lane, float (&cs8)[8]) {
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt)
@@ -227,7 +228,6 @@ __device__ __forceinline__ void store_rows_staged_cs(char* stage, bf16_t* dst, l
       for (int e = 0; e < 4; ++e) w[e] = (bf16_t)(acc[dt][4 * q4 + e] * mul);
       *reinterpret_cast<bf16x4*>(stage + r * 128 + (((dt * 4 + q4) ^ (r & 7)) << 4) + 8 * h) = w;
     }
-  float cs8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + (lane >> 3), ch = lane & 7;
@@ -239,20 +239,21 @@ __device__ __forceinline__ void store_rows_staged_cs(char* stage, bf16_t* dst, l
       for (int e = 0; e < 8; ++e) cs8[e] += (float)val[e];
     }
   }
-  if (cs) {  // wave-uniform; lanes with equal (lane & 7) hold the same 8 columns for different rows
+}
+
+// Lanes ch + 8 k (k = lane >> 3) hold partial sums of the same 8 columns 8 ch .. 8 ch + 7.  One trip through the wave's staging tile
+// (free again once its rows are read back; a wave's LDS operations execute in order) instead of three dependent levels of cross-lane
+// exchanges: lane (ch, k) leaves its 8 sums at [k][8 ch ..], lane c adds up column c over the 8 k and stores it -- one coalesced
+// 256-byte store.  cs (wave-uniform) may be null: nothing is wanted.
+__device__ __forceinline__ void cs_flush(char* stage, const float (&cs8)[8], int lane, float* cs) {
+  if (!cs) return;
+  float* st = reinterpret_cast<float*>(stage);
+  *reinterpret_cast<float4*>(st + (lane >> 3) * 64 + (lane & 7) * 8) = make_float4(cs8[0], cs8[1], cs8[2], cs8[3]);
+  *reinterpret_cast<float4*>(st + (lane >> 3) * 64 + (lane & 7) * 8 + 4) = make_float4(cs8[4], cs8[5], cs8[6], cs8[7]);
+  float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = cs8[e];
-      v += __shfl_xor(v, 8);
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      cs8[e] = v;
-    }
-    if (lane < 8) {
-      *reinterpret_cast<float4*>(cs + lane * 8) = make_float4(cs8[0], cs8[1], cs8[2], cs8[3]);
-      *reinterpret_cast<float4*>(cs + lane * 8 + 4) = make_float4(cs8[4], cs8[5], cs8[6], cs8[7]);
-    }
-  }
+  for (int k = 0; k < 8; ++k) v[k] = st[k * 64 + lane];
+  cs[lane] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 }
 
 // v_max3_f32 as one instruction: fmaxf on MFMA results makes the compiler canonicalise each operand first (v_max x, x)
@@ -1146,7 +1147,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
             acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ks < KH ? kt[ks < KH ? ks : 0][mt] : tr8(Ks + ks * 2048 + ktr[0][mt], Ks + ks * 2048 + ktr[1][mt]),
                                                                bfr, acc1[mt], 0, 0, 0);
         }
-        store_rows_staged_cs(stage, a.dq + gbase, a.g_sl, (it - 1) * 32, a.L, acc1, a.scale, opaque(lane), cs_slot(a, b, hh, it - 1, 0));
+        float csq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        store_rows_staged_cs(stage, a.dq + gbase, a.g_sl, (it - 1) * 32, a.L, acc1, a.scale, opaque(lane), csq);
+        cs_flush(stage, csq, lane, cs_slot(a, b, hh, it - 1, 0));
       }
       __syncthreads();
     }
@@ -1155,8 +1158,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
       for (int it = 0; it <= NT; ++it) __syncthreads();
     }
     if (keyw) {
-      store_rows_staged_cs(stage, a.dk + gbase, a.g_sl, wave * 32, a.L, acc1, a.scale, opaque(lane), cs_slot(a, b, hh, wave, 1));
-      store_rows_staged_cs(stage, a.dv + gbase, a.g_sl, wave * 32, a.L, acc2, 1.f, opaque(lane), cs_slot(a, b, hh, wave, 2));
+      {
+        float csk[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        store_rows_staged_cs(stage, a.dk + gbase, a.g_sl, wave * 32, a.L, acc1, a.scale, opaque(lane), csk);
+        cs_flush(stage, csk, lane, cs_slot(a, b, hh, wave, 1));
+      }
+      {
+        float csv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        store_rows_staged_cs(stage, a.dv + gbase, a.g_sl, wave * 32, a.L, acc2, 1.f, opaque(lane), csv);
+        cs_flush(stage, csv, lane, cs_slot(a, b, hh, wave, 2));
+      }
     }
     stamp(4 + NT);
   }

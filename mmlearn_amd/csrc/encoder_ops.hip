@@ -566,6 +566,89 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const G* __restrict_
   }
 }
 
+// The same scatter for many rows (>= 4096: the word and token-type tables of BERT at the bench batch, 78,848 rows each), on SORTED ids
+// and without one atomic per element and run: hot ids (token-type ids are all equal; real text is Zipfian) made the kernel above
+// serialise on same-address atomics (~800 us per table) and uniformly random ids cost it 60 M atomics.  Here a wave takes EMB_CHUNK
+// consecutive rows of the sorted order and sums runs of equal ids; a run that lies strictly between the chunk's first and last
+// run belongs to no other chunk and is written with plain stores, while the chunk's first and last run go -- as two (id, partial
+// row) entries per chunk -- into a list that is again sorted by id and EMB_CHUNK / 2 times shorter: the kernel runs on that list
+// in turn, until the list is short enough for its first / last runs to finish with atomics (78,848 rows: 4,928 entries, then 308).
+constexpr int EMB_CHUNK = 32;
+constexpr int EMB_FINAL = 1024;   // lists this short end the recursion
+
+template <typename G, bool PERM, bool LAST>
+__global__ __launch_bounds__(256) void embedding_bwd_runs_kernel(const G* __restrict__ src, const int64_t* __restrict__ ids,
+                                                                 const int64_t* __restrict__ perm, float* __restrict__ dw,
+                                                                 float* __restrict__ part_out, int64_t* __restrict__ ids_out,
+                                                                 long rows, int d, long vocab) {
+  const long w = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long r0 = w * EMB_CHUNK;
+  if (r0 >= rows) return;
+  const int n = (int)(rows - r0 < EMB_CHUNK ? rows - r0 : EMB_CHUNK);
+  const int lane = threadIdx.x & 63;
+  const long first_id = ids[r0], last_id = ids[r0 + n - 1];
+  if (!LAST && lane == 0) {
+    ids_out[2 * w] = first_id;
+    ids_out[2 * w + 1] = last_id;
+  }
+  for (int c0 = lane * 4; c0 < d; c0 += 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    long cur = first_id;
+    // a finished run: the chunk's first run -> list entry 2w (or atomics at the last level); any later run that is finished inside
+    // the loop lies strictly inside the chunk -> plain store
+    auto flush_inner = [&](long id, const float4& a) {
+      if (id == first_id) {
+        if (LAST) {
+          if (id >= 0 && id < vocab) {
+            float* o = dw + id * d + c0;
+            unsafeAtomicAdd(o, a.x); unsafeAtomicAdd(o + 1, a.y); unsafeAtomicAdd(o + 2, a.z); unsafeAtomicAdd(o + 3, a.w);
+          }
+        } else {
+          *reinterpret_cast<float4*>(part_out + (2 * w) * d + c0) = a;
+        }
+      } else if (id >= 0 && id < vocab) {
+        *reinterpret_cast<float4*>(dw + id * d + c0) = a;
+      }
+    };
+    for (int q0 = 0; q0 < n; q0 += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (q0 + j < n) {
+          const long row = PERM ? perm[r0 + q0 + j] : r0 + q0 + j;
+          v[j] = Vec4<G>::load(src + row * d + c0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (q0 + j < n) {
+          const long id = ids[r0 + q0 + j];
+          if (id != cur) {
+            flush_inner(cur, acc);
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            cur = id;
+          }
+          acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w;
+        }
+      }
+    }
+    // the chunk's last run (== its first run when the whole chunk is one run: the second entry is then a row of zeros)
+    if (cur == first_id) {
+      flush_inner(cur, acc);
+      if (!LAST) *reinterpret_cast<float4*>(part_out + (2 * w + 1) * d + c0) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (LAST) {
+      if (cur >= 0 && cur < vocab) {
+        float* o = dw + cur * d + c0;
+        unsafeAtomicAdd(o, acc.x); unsafeAtomicAdd(o + 1, acc.y); unsafeAtomicAdd(o + 2, acc.z); unsafeAtomicAdd(o + 3, acc.w);
+      }
+    } else {
+      *reinterpret_cast<float4*>(part_out + (2 * w + 1) * d + c0) = acc;
+    }
+  }
+}
+
+static inline long emb_list_len(long rows) { return 2 * ((rows + EMB_CHUNK - 1) / EMB_CHUNK); }
+
 }  // namespace mmk
 
 using namespace mmk;
@@ -883,6 +966,66 @@ int mmk_embedding_bwd(const void* dout, const int64_t* ids, float* dw, int64_t r
     return 0;
   });
   if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+// bytes of scratch mmk_embedding_bwd_sorted needs for `rows` rows of width d: the (id, partial row) lists of every level
+int64_t mmk_embedding_bwd_scratch_bytes(int64_t rows, int d) {
+  int64_t total = 0;
+  for (long n = rows; n > EMB_FINAL;) {
+    n = emb_list_len(n);
+    total += n * (int64_t)d * 4 + n * 8;
+    total = (total + 255) & ~(int64_t)255;
+  }
+  return total + 256;
+}
+
+int mmk_embedding_bwd_sorted(const void* dout, const int64_t* ids_sorted, const int64_t* perm, float* dw, void* scratch, int64_t rows, int d,
+                             int64_t vocab, int dtype, void* stream) {
+  // dw: f32 [vocab, d], zeroed by the caller; ids_sorted non-decreasing, perm[r] = the row of dout that sorted position r came from;
+  // ids outside [0, vocab) are ignored
+  MMK_REQUIRE(dout && ids_sorted && perm && dw && scratch && rows >= 0 && d > 0 && d % 4 == 0 && vocab > 0, "embedding_bwd_sorted: d must be a multiple of 4");
+  if (rows == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  auto grid_of = [](long n) { return dim3((unsigned)(((n + EMB_CHUNK - 1) / EMB_CHUNK + 3) / 4)); };
+  char* sc = static_cast<char*>(scratch);
+  const bool one_level = rows <= EMB_FINAL;
+  float* part = nullptr;
+  int64_t* pid = nullptr;
+  long n = rows;
+  if (!one_level) {
+    const long n1 = emb_list_len(rows);
+    part = reinterpret_cast<float*>(sc);
+    pid = reinterpret_cast<int64_t*>(sc + n1 * (int64_t)d * 4);
+    sc += ((n1 * (int64_t)d * 4 + n1 * 8) + 255) & ~(int64_t)255;
+  }
+  int rc = MMK_DISPATCH_DTYPE(dtype, G, [&]() -> int {
+    if (one_level)
+      hipLaunchKernelGGL((embedding_bwd_runs_kernel<G, true, true>), grid_of(rows), dim3(256), 0, st, static_cast<const G*>(dout), ids_sorted, perm, dw,
+                         (float*)nullptr, (int64_t*)nullptr, (long)rows, d, (long)vocab);
+    else
+      hipLaunchKernelGGL((embedding_bwd_runs_kernel<G, true, false>), grid_of(rows), dim3(256), 0, st, static_cast<const G*>(dout), ids_sorted, perm, dw,
+                         part, pid, (long)rows, d, (long)vocab);
+    return 0;
+  });
+  if (rc) return rc;
+  if (!one_level) {
+    n = emb_list_len(rows);
+    while (n > EMB_FINAL) {
+      const long n2 = emb_list_len(n);
+      float* part2 = reinterpret_cast<float*>(sc);
+      int64_t* pid2 = reinterpret_cast<int64_t*>(sc + n2 * (int64_t)d * 4);
+      sc += ((n2 * (int64_t)d * 4 + n2 * 8) + 255) & ~(int64_t)255;
+      hipLaunchKernelGGL((embedding_bwd_runs_kernel<float, false, false>), grid_of(n), dim3(256), 0, st, part, pid, (const int64_t*)nullptr, dw, part2, pid2, n, d,
+                         (long)vocab);
+      part = part2;
+      pid = pid2;
+      n = n2;
+    }
+    hipLaunchKernelGGL((embedding_bwd_runs_kernel<float, false, true>), grid_of(n), dim3(256), 0, st, part, pid, (const int64_t*)nullptr, dw, (float*)nullptr,
+                       (int64_t*)nullptr, n, d, (long)vocab);
+  }
   MMK_LAUNCH_CHECK();
   return 0;
 }

@@ -812,6 +812,9 @@ def unpatchify(dcols: torch.Tensor, shape: tuple, patch: int, dtype: torch.dtype
     return out
 
 
+EMBEDDING_SORT_MIN_ROWS = 4096   # from this many token rows the embedding backward sorts the ids first (module seam for the tests)
+
+
 def embedding_bwd(dout2: torch.Tensor, ids: torch.Tensor, vocab: int) -> torch.Tensor:
     """dW f32 [vocab, d] with dW[ids[r]] += dout2[r] (dout2 [rows, d] f32 / bf16, ids int64 [rows])."""
     require_gpu(dout2)
@@ -819,6 +822,14 @@ def embedding_bwd(dout2: torch.Tensor, ids: torch.Tensor, vocab: int) -> torch.T
     dout2, ids = dout2.contiguous(), ids.contiguous().view(-1)
     assert ids.dtype == torch.int64 and ids.numel() == rows
     dw = torch.zeros((vocab, d), dtype=torch.float32, device=dout2.device)
+    if rows >= EMBEDDING_SORT_MIN_ROWS:
+        # many rows: sort the ids, sum runs of the sorted order, recurse on the chunk-boundary partials (csrc/encoder_ops.hip): hot ids
+        # (token-type tables, frequent tokens) never meet in same-address atomics
+        sid, perm = torch.sort(ids)
+        scratch = torch.empty(int(_lib.lib().mmk_embedding_bwd_scratch_bytes(rows, d)), dtype=torch.uint8, device=dout2.device)
+        check(_lib.lib().mmk_embedding_bwd_sorted(ptr(dout2), ptr(sid), ptr(perm), ptr(dw), ptr(scratch), rows, d, int(vocab),
+                                                  dtype_tag(dout2.dtype), stream()))
+        return dw
     check(_lib.lib().mmk_embedding_bwd(ptr(dout2), ptr(ids), ptr(dw), rows, d, int(vocab), dtype_tag(dout2.dtype), stream()))
     return dw
 

@@ -399,6 +399,39 @@ def test_embedding_backward_matches_torch(ids_kind):
         assert grads[1][1][0].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,d,vocab,kind", [(40000, 768, 3000, "uniform"), (40000, 768, 3000, "zipf"), (33000, 256, 2, "all_equal"),
+                                                (4096, 64, 50, "uniform"), (70001, 132, 30522, "padding"), (1500, 768, 10, "uniform")])
+def test_sorted_run_embedding_backward_matches_index_add(rows, d, vocab, kind, dtype):
+    """``kernels.embedding_bwd`` from 4096 rows on: ids sorted, runs of the sorted order summed per 32-row chunk, chunk-boundary runs
+    carried through one or two shorter (id, partial row) lists before the last one ends in atomics.  Against a float64 ``index_add``;
+    hot ids (all rows on one id; Zipf), ids outside the table (the masked padding id), a ragged last chunk, one-level (1500 rows goes
+    through the atomic scatter) and three-level cases."""
+    from mmlearn_amd import kernels as Kn
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(rows + d)
+    if kind == "uniform":
+        ids = torch.randint(0, vocab, (rows,), generator=g)
+    elif kind == "zipf":
+        ids = torch.multinomial(1.0 / torch.arange(1, vocab + 1, dtype=torch.float64), rows, replacement=True, generator=g)
+    elif kind == "all_equal":
+        ids = torch.ones(rows, dtype=torch.long)
+    else:
+        ids = torch.randint(0, vocab, (rows,), generator=g)
+        ids[torch.rand(rows, generator=g) < 0.3] = -1          # what _EmbeddingFn passes for rows looked up at padding_idx
+    dout = torch.randn(rows, d, generator=g).to(dtype)
+    keep = ids >= 0
+    ref = torch.zeros(vocab, d, dtype=torch.float64).index_add_(0, ids[keep], dout[keep].double())
+    dw = Kn.embedding_bwd(dout.to(dev), ids.to(dev), vocab)
+    assert dw.dtype == torch.float32 and dw.shape == (vocab, d)
+    scale = max(1.0, ref.abs().max().item())
+    assert (dw.double().cpu() - ref).abs().max().item() <= 1e-5 * scale
+    # deterministic where no atomics meet: a second call gives the same bits for ids whose runs never straddle the last list
+    dw2 = Kn.embedding_bwd(dout.to(dev), ids.to(dev), vocab)
+    assert (dw2 - dw).abs().max().item() <= 1e-6 * scale
+
+
 def test_causal_text_towers_keep_their_causality_under_the_fused_qkv_patch():
     """HF's CLIP text tower (and a BERT configured as decoder) signal causality through ``is_causal`` / ``is_decoder`` with
     NO attention mask for sdpa-style implementations.  The fused-QKV patch is bidirectional, so it must step aside there:

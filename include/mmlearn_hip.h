@@ -429,6 +429,21 @@ int64_t mmk_embedding_bwd_scratch_bytes(int64_t rows, int d);
 int mmk_embedding_bwd_sorted(const void* dout, const int64_t* ids_sorted, const int64_t* perm, float* dw, void* scratch, int64_t rows,
                              int d, int64_t vocab, int dtype, void* stream);
 
+/* Windowed self-attention of HTSAT / Swin blocks (HF ClapAudioSelfAttention.forward, the audio tower of BASELINE configs[3]; in the
+ * reference it arrives through mmlearn/modules/encoders/ HF wrappers): per (window, head)  O = softmax(scale Q K^T + table) V  with
+ * 64-token windows and head dim 24 or 32.  q / k / v / o / dout / dq / dk / dv: bf16 [B * nW, 64, H * dh] contiguous (window bw = b * nW + w; the backward needs neither o nor P:
+ * delta = rowsum(P * dP));
+ * table: f32 [nWt, H, 64, 64] = relative-position bias per head (nWt = 1) or bias + shifted-window mask per (window position, head)
+ * (nWt = nW); lse2: f32 [B * nW, H, 64] (base-2 log of the softmax denominators, written by fwd, read by bwd); dtab_part: f32
+ * [mmk_win_attn_blocks(B, nW, H), 64, 64], one partial sum of dS per workgroup -- block id -> head: (id >> 3) % H when
+ * mmk_win_attn_blocks / H is a multiple of 8, id % H otherwise. */
+int mmk_win_attn_supported(int tokens, int dh, int c);
+int mmk_win_attn_blocks(int B, int nW, int H);
+int mmk_win_attn_fwd(const void* q, const void* k, const void* v, const float* table, void* o, float* lse2, int B, int nW, int nWt, int H, int dh,
+                     float scale, void* stream);
+int mmk_win_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse2, const float* table, void* dq, void* dk,
+                     void* dv, float* dtab_part, int B, int nW, int nWt, int H, int dh, float scale, void* stream);
+
 /* HF QuickGELUActivation  x * sigmoid(1.702 x)  (CLIP MLP), forward and backward, n elements (multiple of 4) */
 int mmk_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
 int mmk_quick_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);

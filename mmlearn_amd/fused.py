@@ -25,6 +25,7 @@ There is no CPU path: CPU tensors raise.
 
 from __future__ import annotations
 
+import math
 import types
 from typing import Iterable, Optional
 
@@ -867,8 +868,69 @@ def cls_only_last_layer(module: nn.Module) -> int:
     return n
 
 
+class _WindowAttentionFn(torch.autograd.Function):
+    """softmax(scale q k^T + bias[h] + mask[w]) v per 64-token window and head, one kernel each way (csrc/window_attention.hip)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, bias, mask, heads, scale):
+        n_win = 1 if mask is None else mask.shape[0]
+        table = bias.detach().float()[None] if mask is None else bias.detach().float()[None] + mask.float()[:, None]
+        table = table.contiguous()
+        o, lse2 = K.win_attn_fwd(q, k, v, table, heads, n_win, scale)
+        ctx.save_for_backward(q, k, v, lse2, table)
+        ctx.heads, ctx.n_win, ctx.scale, ctx.bias_dtype = heads, n_win, scale, bias.dtype
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, lse2, table = ctx.saved_tensors
+        dq, dk, dv, dtab = K.win_attn_bwd(q, k, v, do.contiguous(), lse2, table, ctx.heads, ctx.n_win, ctx.scale)
+        return dq, dk, dv, dtab.to(ctx.bias_dtype), None, None, None
+
+
+def window_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias: torch.Tensor, mask: Optional[torch.Tensor], heads: int,
+                     scale: float) -> torch.Tensor:
+    """``q, k, v``: bf16 ``[B * n_win, 64, heads * dh]`` (dh 24 or 32); ``bias``: ``[heads, 64, 64]`` relative-position bias (gets a
+    gradient); ``mask``: ``[n_win, 64, 64]`` additive shifted-window mask or None.  Returns the context ``[B * n_win, 64, heads * dh]``."""
+    return _WindowAttentionFn.apply(q.contiguous(), k.contiguous(), v.contiguous(), bias, mask, heads, scale)
+
+
+def _window_self_attention_forward(self, hidden_states, attention_mask=None, output_attentions=False):
+    """Replaces HF ``ClapAudioSelfAttention.forward`` / ``SwinSelfAttention.forward`` (same code: per-window attention with a
+    relative-position bias table and an optional shifted-window mask) when the fused kernel applies: bf16 projections, 64-token
+    windows, head dim 24 / 32, no attention-probability dropout in effect, no attention maps asked for."""
+    n_tok, ch = hidden_states.shape[1], hidden_states.shape[2]
+    p_drop = float(getattr(self.dropout, "p", 0.0)) if self.training else 0.0
+    ok = (hidden_states.is_cuda and not output_attentions and p_drop == 0.0 and ch == self.all_head_size
+          and K.win_attn_supported(n_tok, self.attention_head_size, ch) and _autocast_bf16()
+          and (attention_mask is None or (attention_mask.dim() == 3 and hidden_states.shape[0] % attention_mask.shape[0] == 0)))
+    if not ok:
+        return self._mmk_stock_forward(hidden_states, attention_mask, output_attentions)
+    q, k, v = self.query(hidden_states), self.key(hidden_states), self.value(hidden_states)
+    if q.dtype != torch.bfloat16:
+        return self._mmk_stock_forward(hidden_states, attention_mask, output_attentions)
+    bias = self.relative_position_bias_table[self.relative_position_index.view(-1)]
+    bias = bias.view(n_tok, n_tok, -1).permute(2, 0, 1).contiguous()
+    ctx_layer = window_attention(q, k, v, bias, attention_mask, self.num_attention_heads, 1.0 / math.sqrt(self.attention_head_size))
+    return (ctx_layer,)
+
+
+def fuse_window_attention(module: nn.Module) -> int:
+    """Patch every HF windowed self-attention module (``ClapAudioSelfAttention``, ``SwinSelfAttention``, ...: recognised by their
+    attributes) inside ``module`` with :func:`_window_self_attention_forward`.  Parameters and ``state_dict`` are untouched."""
+    n = 0
+    for m in module.modules():
+        if (all(hasattr(m, a) for a in ("relative_position_bias_table", "relative_position_index", "query", "key", "value", "dropout",
+                                        "num_attention_heads", "attention_head_size", "all_head_size"))
+                and not hasattr(m, "_mmk_stock_forward")):
+            m._mmk_stock_forward = m.forward
+            m.forward = types.MethodType(_window_self_attention_forward, m)
+            n += 1
+    return n
+
+
 def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), fuse_qkv: bool = False, fuse_add_ln: bool = False,
-                       cls_only: bool = False, wgrad_linear: bool = False) -> dict:
+                       cls_only: bool = False, wgrad_linear: bool = False, window_attention: bool = True) -> dict:
     """Swap ``nn.LayerNorm`` -> :class:`LayerNorm` and quick-GELU activations -> :class:`QuickGELU` inside ``module`` (in place);
     with ``fuse_qkv`` also patch the attention modules (:func:`fuse_qkv_attention`), with ``fuse_add_ln`` the residual
     add + LayerNorm pairs (:func:`fuse_add_layer_norm`).
@@ -879,6 +941,7 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
     ``layer_norm2`` of HF ``CLIPEncoderLayer`` get it automatically -- they feed nothing but that block's Linears.
     ``cls_only``: :func:`cls_only_last_layer` (opt-in; only for encoders pooled at token 0).
     ``wgrad_linear``: :func:`linear_wgrad` on every ``nn.Linear`` left unpatched (towers without a recognised block structure).
+    ``window_attention``: :func:`fuse_window_attention` (on by default; a no-op for towers without windowed attention modules).
     Returns the number of modules swapped per kind.
     """
     swapped = {"layernorm": 0, "quick_gelu": 0, "fused_qkv": fuse_qkv_attention(module) if fuse_qkv else 0, "fused_add_ln": 0}
@@ -900,6 +963,7 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
         swapped["fused_add_ln"] = fuse_add_layer_norm(module)
         swapped["patch_conv"] = patch_conv_as_gemm(module)
         swapped["embedding"] = patch_embedding_backward(module)
+    swapped["window_attention"] = fuse_window_attention(module) if window_attention else 0   # HTSAT / Swin towers; no such module elsewhere
     if wgrad_linear:
         swapped["linear_wgrad"] = linear_wgrad(module)
     if cls_only:     # last: it wraps whatever forward the last layer has by now (fused or stock)

@@ -984,6 +984,51 @@ def _strides3(t: torch.Tensor):
     return (C.c_int64 * 3)(sb, sh, sl)
 
 
+def win_attn_supported(tokens: int, head_dim: int, channels: int) -> bool:
+    return bool(_lib.lib().mmk_win_attn_supported(int(tokens), int(head_dim), int(channels)))
+
+
+def _win_attn_check(q, k, v, table, heads, n_win):
+    require_gpu(q)
+    Bw, T, Cc = q.shape
+    assert q.dtype == torch.bfloat16 and k.dtype == q.dtype and v.dtype == q.dtype, "windowed attention runs on bf16 projections"
+    assert k.shape == q.shape and v.shape == q.shape and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    assert Cc % heads == 0 and win_attn_supported(T, Cc // heads, Cc), "windowed attention: 64-token windows, head dim 24 or 32"
+    assert Bw % n_win == 0 and table.dtype == torch.float32 and table.is_contiguous()
+    assert table.shape in ((1, heads, T, T), (n_win, heads, T, T)), table.shape
+    return Bw // n_win, Cc // heads
+
+
+def win_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: torch.Tensor, heads: int, n_win: int, scale: float):
+    """Windowed attention (csrc/window_attention.hip): q/k/v bf16 [B * n_win, 64, heads * dh] (window ``b * n_win + w``), table f32
+    [1 | n_win, heads, 64, 64] = relative-position bias (+ mask of window position w) -> (o like q, lse2 f32 [B * n_win, heads, 64])."""
+    B, dh = _win_attn_check(q, k, v, table, heads, n_win)
+    o = torch.empty_like(q)
+    lse2 = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device)
+    check(_lib.lib().mmk_win_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(table), ptr(o), ptr(lse2), B, n_win, table.shape[0], heads, dh, float(scale),
+                                      stream()))
+    return o, lse2
+
+
+def win_attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dout: torch.Tensor, lse2: torch.Tensor, table: torch.Tensor, heads: int,
+                 n_win: int, scale: float):
+    """-> (dq, dk, dv like q, dtable f32 [heads, 64, 64] = the gradient of the relative-position bias: dS summed over windows and
+    batch).  The kernel leaves one partial per workgroup; they are added here per head in a fixed order."""
+    B, dh = _win_attn_check(q, k, v, table, heads, n_win)
+    assert dout.shape == q.shape and dout.dtype == q.dtype and dout.is_contiguous() and lse2.is_contiguous()
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    nblk = int(_lib.lib().mmk_win_attn_blocks(B, n_win, heads))
+    part = torch.empty((nblk, 64 * 64), dtype=torch.float32, device=q.device)
+    check(_lib.lib().mmk_win_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(dout), ptr(lse2), ptr(table), ptr(dq), ptr(dk), ptr(dv), ptr(part), B, n_win,
+                                      table.shape[0], heads, dh, float(scale), stream()))
+    npairs = nblk // heads
+    if npairs % 8 == 0:   # block id = ((group * heads + head) * 8 + x): see wa_decode_block
+        dtab = part.view(npairs // 8, heads, 8, 64 * 64).sum(dim=(0, 2))
+    else:                 # block id = pair * heads + head
+        dtab = part.view(npairs, heads, 64 * 64).sum(0)
+    return dq, dk, dv, dtab.view(heads, 64, 64)
+
+
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0):
     """q/k/v: [B, H, L, 64] bf16 views (last dim contiguous) -> (out [B, L, H, 64] contiguous, lse f32 [B, H, L]).
     ``dropout_p`` > 0 drops attention probabilities with the counter-based mask of ``seed`` (see csrc/attention.hip)."""

@@ -48,6 +48,7 @@ struct WinAttnArgs {
   bf16_t* dv;
   float* dtab_part;     // [gridDim.x][64][64] f32: per-workgroup sums of dS (block id = the forward's)
   int B, nW, nWt, H, C, nsplit;
+  int img_h, img_w, shift;   // img_w > 0: q .. dv are [B, img_h * img_w, C] token maps and the windows are gathered from / scattered to them (below)
   float scale;
 };
 
@@ -128,6 +129,27 @@ __device__ __forceinline__ void wa_store_tile(const char* stg, bf16_t* dst, cons
   }
 }
 
+// Byte offsets, from the sample's (token-map mode) or the window's (window mode) first row of this head, of the 16-byte chunks
+// c = lane + 64 n of the item's [64][DH] tile: chunk c = token c / CH, piece c % CH.  Window mode: the windows are contiguous
+// [64, C] blocks (HF's window_partition output).  Token-map mode: token (ty, tx) of window (wy, wx) of the image rolled by
+// -shift is row ((8 wy + ty + shift) mod img_h) * img_w + (8 wx + tx + shift) mod img_w of the sample -- torch.roll, window_partition
+// and, on the way out, window_reverse and the roll back (HF ClapAudioLayer.forward) as address arithmetic.  Same for every item
+// of the workgroup (they differ in the sample only).
+template <int CH>
+__device__ __forceinline__ void wa_chunk_offsets(const WinAttnArgs& a, int w, int lane, uint32_t (&voff)[CH]) {
+#pragma unroll
+  for (int n = 0; n < CH; ++n) {
+    const int c = lane + 64 * n, t = c / CH, piece = c % CH;
+    int row = t;
+    if (a.img_w > 0) {
+      const int wpr = a.img_w >> 3, wy = w / wpr, wx = w % wpr;
+      const int y = (8 * wy + (t >> 3) + a.shift) % a.img_h, x = (8 * wx + (t & 7) + a.shift) % a.img_w;
+      row = y * a.img_w + x;
+    }
+    voff[n] = (uint32_t)(row * a.C + piece * 8) * 2u;
+  }
+}
+
 template <int DH>
 __global__ __launch_bounds__(256, 3) void win_attn_fwd_kernel(const WinAttnArgs a) {
   constexpr int ROWB = DH * 2, CH = DH / 8, KS = DH / 8, TILE = WA_N * ROWB;
@@ -145,17 +167,13 @@ __global__ __launch_bounds__(256, 3) void win_attn_fwd_kernel(const WinAttnArgs 
   const int r = lane & 31, h = lane >> 5;
   const int tr_off = ((lane & 15) >> 2) * ROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
   uint32_t voff[CH];
-#pragma unroll
-  for (int n = 0; n < CH; ++n) {
-    const int c = lane + 64 * n;
-    voff[n] = (uint32_t)((c / CH) * a.C + (c % CH) * 8) * 2u;
-  }
+  wa_chunk_offsets<CH>(a, w, lane, voff);
   const float sc2 = a.scale * WA_LOG2E;
   const int bps = (a.B + a.nsplit - 1) / a.nsplit;
   const int b0 = slice * bps, b1 = min(a.B, b0 + bps);
   for (int b = b0 + wave; b < b1; b += 4) {
     const long bw = (long)b * a.nW + w;
-    const long ebase = bw * WA_N * a.C + hh * DH;
+    const long ebase = (a.img_w > 0 ? (long)b * a.nW : bw) * WA_N * a.C + hh * DH;
 #pragma unroll
     for (int n = 0; n < CH; ++n) {
       wa_dma16(a.q + ebase, voff[n], wa_lds_addr(Qs) + n * 1024);
@@ -247,11 +265,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_kernel(const WinAttnArgs 
   const int h = lane >> 5;
   const int tr_off = ((lane & 15) >> 2) * ROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
   uint32_t voff[CH];
-#pragma unroll
-  for (int n = 0; n < CH; ++n) {
-    const int c = lane + 64 * n;
-    voff[n] = (uint32_t)((c / CH) * a.C + (c % CH) * 8) * 2u;
-  }
+  wa_chunk_offsets<CH>(a, w, lane, voff);
   const float sc2 = a.scale * WA_LOG2E;
   const int bps = (a.B + a.nsplit - 1) / a.nsplit;
   const int b0 = slice * bps, b1 = min(a.B, b0 + bps);
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_kernel(const WinAttnArgs 
       for (int e = 0; e < 16; ++e) dT[it][jt][e] = 0.f;
   for (int b = b0 + wave; b < b1; b += 4) {
     const long bw = (long)b * a.nW + w;
-    const long ebase = bw * WA_N * a.C + hh * DH;
+    const long ebase = (a.img_w > 0 ? (long)b * a.nW : bw) * WA_N * a.C + hh * DH;
 #pragma unroll
     for (int n = 0; n < CH; ++n) {
       wa_dma16(a.q + ebase, voff[n], wa_lds_addr(Qs) + n * 1024);
@@ -431,19 +445,22 @@ int mmk_win_attn_supported(int tokens, int dh, int c) { return tokens == WA_N &&
 int mmk_win_attn_blocks(int B, int nW, int H) { return nW * wa_nsplit(B, nW, H) * H; }
 
 int mmk_win_attn_fwd(const void* q, const void* k, const void* v, const float* table, void* o, float* lse2, int B, int nW, int nWt, int H, int dh,
-                     float scale, void* stream) {
+                     float scale, int img_h, int img_w, int shift, void* stream) {
   MMK_REQUIRE(q && k && v && table && o && lse2 && B > 0 && nW > 0 && H > 0, "win_attn_fwd: bad arguments");
   MMK_REQUIRE(dh == 24 || dh == 32, "win_attn: head dim must be 24 or 32");
   MMK_REQUIRE(nWt == 1 || nWt == nW, "win_attn: the table has one entry per head or one per (window position, head)");
   WinAttnArgs a = {};
   a.q = static_cast<const bf16_t*>(q); a.k = static_cast<const bf16_t*>(k); a.v = static_cast<const bf16_t*>(v);
   a.o = static_cast<bf16_t*>(o); a.lse2 = lse2; a.table = table;
+  MMK_REQUIRE(img_w == 0 || (img_h > 0 && img_h % 8 == 0 && img_w % 8 == 0 && (img_h / 8) * (img_w / 8) == nW && shift >= 0 && shift < 8),
+              "win_attn: a token map must be a whole number of 8 x 8 windows");
   a.B = B; a.nW = nW; a.nWt = nWt; a.H = H; a.C = H * dh; a.nsplit = wa_nsplit(B, nW, H); a.scale = scale;
+  a.img_h = img_w > 0 ? img_h : 0; a.img_w = img_w; a.shift = img_w > 0 ? shift : 0;
   return dh == 24 ? wa_launch<24>(a, false, static_cast<hipStream_t>(stream)) : wa_launch<32>(a, false, static_cast<hipStream_t>(stream));
 }
 
 int mmk_win_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse2, const float* table, void* dq, void* dk,
-                     void* dv, float* dtab_part, int B, int nW, int nWt, int H, int dh, float scale, void* stream) {
+                     void* dv, float* dtab_part, int B, int nW, int nWt, int H, int dh, float scale, int img_h, int img_w, int shift, void* stream) {
   MMK_REQUIRE(q && k && v && dout && lse2 && table && dq && dk && dv && dtab_part && B > 0 && nW > 0 && H > 0, "win_attn_bwd: bad arguments");
   MMK_REQUIRE(dh == 24 || dh == 32, "win_attn: head dim must be 24 or 32");
   MMK_REQUIRE(nWt == 1 || nWt == nW, "win_attn: the table has one entry per head or one per (window position, head)");
@@ -451,7 +468,10 @@ int mmk_win_attn_bwd(const void* q, const void* k, const void* v, const void* do
   a.q = static_cast<const bf16_t*>(q); a.k = static_cast<const bf16_t*>(k); a.v = static_cast<const bf16_t*>(v);
   a.dout = static_cast<const bf16_t*>(dout); a.lse2 = const_cast<float*>(lse2);
   a.table = table; a.dq = static_cast<bf16_t*>(dq); a.dk = static_cast<bf16_t*>(dk); a.dv = static_cast<bf16_t*>(dv); a.dtab_part = dtab_part;
+  MMK_REQUIRE(img_w == 0 || (img_h > 0 && img_h % 8 == 0 && img_w % 8 == 0 && (img_h / 8) * (img_w / 8) == nW && shift >= 0 && shift < 8),
+              "win_attn: a token map must be a whole number of 8 x 8 windows");
   a.B = B; a.nW = nW; a.nWt = nWt; a.H = H; a.C = H * dh; a.nsplit = wa_nsplit(B, nW, H); a.scale = scale;
+  a.img_h = img_w > 0 ? img_h : 0; a.img_w = img_w; a.shift = img_w > 0 ? shift : 0;
   return dh == 24 ? wa_launch<24>(a, true, static_cast<hipStream_t>(stream)) : wa_launch<32>(a, true, static_cast<hipStream_t>(stream));
 }
 

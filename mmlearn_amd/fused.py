@@ -872,27 +872,30 @@ class _WindowAttentionFn(torch.autograd.Function):
     """softmax(scale q k^T + bias[h] + mask[w]) v per 64-token window and head, one kernel each way (csrc/window_attention.hip)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, bias, mask, heads, scale):
-        n_win = 1 if mask is None else mask.shape[0]
+    def forward(ctx, q, k, v, bias, mask, heads, scale, grid, shift):
+        n_win = (grid[0] // 8) * (grid[1] // 8) if grid is not None else (1 if mask is None else mask.shape[0])
         table = bias.detach().float()[None] if mask is None else bias.detach().float()[None] + mask.float()[:, None]
         table = table.contiguous()
-        o, lse2 = K.win_attn_fwd(q, k, v, table, heads, n_win, scale)
+        o, lse2 = K.win_attn_fwd(q, k, v, table, heads, n_win, scale, grid, shift)
         ctx.save_for_backward(q, k, v, lse2, table)
-        ctx.heads, ctx.n_win, ctx.scale, ctx.bias_dtype = heads, n_win, scale, bias.dtype
+        ctx.cfg, ctx.bias_dtype = (heads, n_win, scale, grid, shift), bias.dtype
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, lse2, table = ctx.saved_tensors
-        dq, dk, dv, dtab = K.win_attn_bwd(q, k, v, do.contiguous(), lse2, table, ctx.heads, ctx.n_win, ctx.scale)
-        return dq, dk, dv, dtab.to(ctx.bias_dtype), None, None, None
+        heads, n_win, scale, grid, shift = ctx.cfg
+        dq, dk, dv, dtab = K.win_attn_bwd(q, k, v, do.contiguous(), lse2, table, heads, n_win, scale, grid, shift)
+        return dq, dk, dv, dtab.to(ctx.bias_dtype), None, None, None, None, None
 
 
 def window_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias: torch.Tensor, mask: Optional[torch.Tensor], heads: int,
-                     scale: float) -> torch.Tensor:
+                     scale: float, grid: Optional[tuple] = None, shift: int = 0) -> torch.Tensor:
     """``q, k, v``: bf16 ``[B * n_win, 64, heads * dh]`` (dh 24 or 32); ``bias``: ``[heads, 64, 64]`` relative-position bias (gets a
-    gradient); ``mask``: ``[n_win, 64, 64]`` additive shifted-window mask or None.  Returns the context ``[B * n_win, 64, heads * dh]``."""
-    return _WindowAttentionFn.apply(q.contiguous(), k.contiguous(), v.contiguous(), bias, mask, heads, scale)
+    gradient); ``mask``: ``[n_win, 64, 64]`` additive shifted-window mask or None.  Returns the context ``[B * n_win, 64, heads * dh]``.
+    With ``grid = (h, w)``: ``q, k, v`` and the result are ``[B, h * w, C]`` token maps and the kernel gathers the 8 x 8 windows of the
+    map rolled by ``-shift`` itself (and puts the context rows back where they came from)."""
+    return _WindowAttentionFn.apply(q.contiguous(), k.contiguous(), v.contiguous(), bias, mask, heads, scale, grid, int(shift))
 
 
 def _window_self_attention_forward(self, hidden_states, attention_mask=None, output_attentions=False):
@@ -915,9 +918,45 @@ def _window_self_attention_forward(self, hidden_states, attention_mask=None, out
     return (ctx_layer,)
 
 
+def _swin_layer_forward(self, hidden_states, input_dimensions, output_attentions=False, always_partition=False):
+    """Replaces HF ``ClapAudioLayer.forward`` (Swin block: LN -> roll -> window_partition -> attention -> window_reverse -> roll back ->
+    residual -> LN -> MLP -> residual) when the fused windowed attention applies and the map needs no padding: the q / k / v
+    projections are per token, so they run on the un-rolled, un-partitioned map, and the kernel does the roll and the window
+    partition -- and their inverses on the way out -- as address arithmetic.  Four copies of the map per layer less, each way."""
+    att = self.attention.self
+    height, width = input_dimensions
+    if not always_partition:
+        self.set_shift_and_window_size(input_dimensions)
+    ws, shift = int(self.window_size), int(self.shift_size)
+    n_tok = ws * ws
+    p_drop = float(getattr(att.dropout, "p", 0.0)) if self.training else 0.0
+    ok = (hasattr(att, "_mmk_stock_forward") and not output_attentions and ws == 8 and height % 8 == 0 and width % 8 == 0 and 0 <= shift < 8
+          and hidden_states.is_cuda and p_drop == 0.0 and K.win_attn_supported(n_tok, att.attention_head_size, att.all_head_size)
+          and _autocast_bf16() and hidden_states.shape[1] == height * width)
+    if not ok:
+        return self._mmk_stock_forward(hidden_states, input_dimensions, output_attentions, True)   # shift / window size are set already
+    shortcut = hidden_states
+    x = self.layernorm_before(hidden_states)
+    q, k, v = att.query(x), att.key(x), att.value(x)
+    if q.dtype != torch.bfloat16:
+        return self._mmk_stock_forward(hidden_states, input_dimensions, output_attentions, True)
+    bias = att.relative_position_bias_table[att.relative_position_index.view(-1)]
+    bias = bias.view(n_tok, n_tok, -1).permute(2, 0, 1).contiguous()
+    mask = self.get_attn_mask(height, width, dtype=torch.float32, device=hidden_states.device)
+    ctx_map = window_attention(q, k, v, bias, mask, att.num_attention_heads, 1.0 / math.sqrt(att.attention_head_size), (height, width), shift)
+    attention_output = self.attention.output(ctx_map, x)
+    hidden_states = shortcut + self.drop_path(attention_output)
+    layer_output = self.layernorm_after(hidden_states)
+    layer_output = self.intermediate(layer_output)
+    layer_output = hidden_states + self.output(layer_output)
+    return (layer_output,)
+
+
 def fuse_window_attention(module: nn.Module) -> int:
     """Patch every HF windowed self-attention module (``ClapAudioSelfAttention``, ``SwinSelfAttention``, ...: recognised by their
-    attributes) inside ``module`` with :func:`_window_self_attention_forward`.  Parameters and ``state_dict`` are untouched."""
+    attributes) inside ``module`` with :func:`_window_self_attention_forward`, and every Swin-style layer around one
+    (``ClapAudioLayer``: ``layernorm_before`` / ``attention.self`` / ``get_attn_mask`` / ``shift_size``) with
+    :func:`_swin_layer_forward`.  Parameters and ``state_dict`` are untouched.  Returns the number of attention modules patched."""
     n = 0
     for m in module.modules():
         if (all(hasattr(m, a) for a in ("relative_position_bias_table", "relative_position_index", "query", "key", "value", "dropout",
@@ -926,6 +965,13 @@ def fuse_window_attention(module: nn.Module) -> int:
             m._mmk_stock_forward = m.forward
             m.forward = types.MethodType(_window_self_attention_forward, m)
             n += 1
+    for m in module.modules():
+        if (all(hasattr(m, a) for a in ("layernorm_before", "layernorm_after", "attention", "intermediate", "output", "drop_path", "shift_size",
+                                        "window_size", "get_attn_mask", "set_shift_and_window_size"))
+                and hasattr(m.attention, "self") and hasattr(m.attention.self, "_mmk_stock_forward") and hasattr(m.attention, "output")
+                and not hasattr(m, "_mmk_stock_forward")):
+            m._mmk_stock_forward = m.forward
+            m.forward = types.MethodType(_swin_layer_forward, m)
     return n
 
 

@@ -10,7 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from dataclasses import dataclass, field
-from typing import Optional, Sequence
+from typing import Optional, Sequence, Tuple
 
 import torch
 
@@ -999,34 +999,52 @@ def _win_attn_check(q, k, v, table, heads, n_win):
     return Bw // n_win, Cc // heads
 
 
-def win_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: torch.Tensor, heads: int, n_win: int, scale: float):
+def _win_map(q, n_win, grid, shift):
+    """Token-map mode: q .. are [B, h * w, C] maps of an (h, w) token grid, windows gathered in the kernel -> (q as [B * n_win, 64, C] view, h, w, shift)."""
+    if grid is None:
+        return q, 0, 0, 0
+    gh, gw = grid
+    assert gh % 8 == 0 and gw % 8 == 0 and (gh // 8) * (gw // 8) == n_win and 0 <= shift < 8 and q.shape[1] == gh * gw, (grid, n_win, q.shape)
+    return q.view(-1, 64, q.shape[-1]), gh, gw, int(shift)
+
+
+def win_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: torch.Tensor, heads: int, n_win: int, scale: float,
+                 grid: Optional[Tuple[int, int]] = None, shift: int = 0):
     """Windowed attention (csrc/window_attention.hip): q/k/v bf16 [B * n_win, 64, heads * dh] (window ``b * n_win + w``), table f32
-    [1 | n_win, heads, 64, 64] = relative-position bias (+ mask of window position w) -> (o like q, lse2 f32 [B * n_win, heads, 64])."""
+    [1 | n_win, heads, 64, 64] = relative-position bias (+ mask of window position w) -> (o like q, lse2 f32 [B * n_win, heads, 64]).
+    With ``grid = (h, w)`` the tensors are ``[B, h * w, C]`` token maps instead and window ``w`` of the map rolled by ``-shift`` is gathered
+    / scattered by the kernel (HF's ``roll -> window_partition -> ... -> window_reverse -> roll`` without the four copies)."""
+    shape = q.shape
+    q, gh, gw, shift = _win_map(q, n_win, grid, shift)
+    k, v = k.view(q.shape), v.view(q.shape)
     B, dh = _win_attn_check(q, k, v, table, heads, n_win)
     o = torch.empty_like(q)
     lse2 = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device)
     check(_lib.lib().mmk_win_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(table), ptr(o), ptr(lse2), B, n_win, table.shape[0], heads, dh, float(scale),
-                                      stream()))
-    return o, lse2
+                                      gh, gw, shift, stream()))
+    return o.view(shape), lse2
 
 
 def win_attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dout: torch.Tensor, lse2: torch.Tensor, table: torch.Tensor, heads: int,
-                 n_win: int, scale: float):
+                 n_win: int, scale: float, grid: Optional[Tuple[int, int]] = None, shift: int = 0):
     """-> (dq, dk, dv like q, dtable f32 [heads, 64, 64] = the gradient of the relative-position bias: dS summed over windows and
     batch).  The kernel leaves one partial per workgroup; they are added here per head in a fixed order."""
+    shape = q.shape
+    q, gh, gw, shift = _win_map(q, n_win, grid, shift)
+    k, v, dout = k.view(q.shape), v.view(q.shape), dout.view(q.shape)
     B, dh = _win_attn_check(q, k, v, table, heads, n_win)
-    assert dout.shape == q.shape and dout.dtype == q.dtype and dout.is_contiguous() and lse2.is_contiguous()
+    assert dout.dtype == q.dtype and dout.is_contiguous() and lse2.is_contiguous()
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     nblk = int(_lib.lib().mmk_win_attn_blocks(B, n_win, heads))
     part = torch.empty((nblk, 64 * 64), dtype=torch.float32, device=q.device)
     check(_lib.lib().mmk_win_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(dout), ptr(lse2), ptr(table), ptr(dq), ptr(dk), ptr(dv), ptr(part), B, n_win,
-                                      table.shape[0], heads, dh, float(scale), stream()))
+                                      table.shape[0], heads, dh, float(scale), gh, gw, shift, stream()))
     npairs = nblk // heads
     if npairs % 8 == 0:   # block id = ((group * heads + head) * 8 + x): see wa_decode_block
         dtab = part.view(npairs // 8, heads, 8, 64 * 64).sum(dim=(0, 2))
     else:                 # block id = pair * heads + head
         dtab = part.view(npairs, heads, 64 * 64).sum(0)
-    return dq, dk, dv, dtab.view(heads, 64, 64)
+    return dq.view(shape), dk.view(shape), dv.view(shape), dtab.view(heads, 64, 64)
 
 
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0):

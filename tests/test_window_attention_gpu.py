@@ -74,6 +74,46 @@ def test_window_attention_is_exact_on_a_one_hot_problem():
     assert diff.max().item() == 0.0, (int((diff > 0).sum()), diff.max().item(), torch.nonzero(diff > 0)[:8].tolist())
 
 
+@pytest.mark.parametrize("shift", [0, 4, 3])
+def test_token_map_mode_is_roll_partition_attention_reverse_roll(shift):
+    """``grid=(h, w)``: the kernel gathers the 8 x 8 windows of the map rolled by ``-shift`` and scatters the context back.  Against the
+    same kernel on windows that torch rolled and partitioned (HF ClapAudioLayer.forward's copies): the same arithmetic on the same
+    numbers, so outputs and all four gradients are bit-identical."""
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(11 + shift)
+    B, gh, gw, heads, dh = 3, 16, 24, 2, 24
+    C, nW = heads * dh, (gh // 8) * (gw // 8)
+    maps = [torch.randn(B, gh * gw, C, generator=g).bfloat16().to(dev).requires_grad_(True) for _ in range(3)]
+    bias = (torch.randn(heads, 64, 64, generator=g) * 0.5).to(dev).requires_grad_(True)
+    region = torch.randint(0, 3, (nW, 64), generator=g)
+    mask = ((region[:, :, None] != region[:, None, :]).float() * -100.0).to(dev) if shift else None
+    wgt = torch.randn(B, gh * gw, C, generator=g).to(dev)
+
+    def part(t):    # roll + window_partition of HF
+        t = torch.roll(t.view(B, gh, gw, C), shifts=(-shift, -shift), dims=(1, 2))
+        return t.view(B, gh // 8, 8, gw // 8, 8, C).permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, 64, C)
+
+    def unpart(t):  # window_reverse + roll back
+        t = t.view(B, gh // 8, gw // 8, 8, 8, C).permute(0, 1, 3, 2, 4, 5).contiguous().view(B, gh, gw, C)
+        return torch.roll(t, shifts=(shift, shift), dims=(1, 2)).view(B, gh * gw, C)
+
+    res = []
+    for mode in ("map", "copies"):
+        for t in maps + [bias]:
+            t.grad = None
+        if mode == "map":
+            out = fused.window_attention(*maps, bias, mask, heads, 1.0 / math.sqrt(dh), (gh, gw), shift)
+        else:
+            out = unpart(fused.window_attention(*(part(t) for t in maps), bias, mask, heads, 1.0 / math.sqrt(dh)))
+        (out.float() * wgt).sum().backward()
+        res.append([out.detach().clone()] + [t.grad.clone() for t in maps] + [bias.grad.clone()])
+    for name, a, b in zip(("o", "dq", "dk", "dv"), res[0], res[1]):
+        assert torch.equal(a, b), name
+    assert (res[0][4] - res[1][4]).abs().max().item() <= 1e-5 * max(1.0, res[1][4].abs().max().item())   # partial sums are grouped differently
+
+
 def test_patched_clap_audio_layers_match_the_stock_modules():
     """HF ClapAudioModel (HTSAT, head dim 24, shifted and unshifted layers, four resolutions) with and without the fused windowed
     attention: pooled output and every parameter gradient.  eval() so that the two passes see the same network (no dropout / drop

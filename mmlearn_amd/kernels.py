@@ -1084,7 +1084,13 @@ def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
                                   C.cast(qs, C.c_void_p), C.cast(ks, C.c_void_p), C.cast(vs, C.c_void_p), C.cast(gs, C.c_void_p),
                                   float(scale), float(dropout_p), int(seed), ptr(part), stream()))
     if packed and colsum:
-        return dqkv, (part.sum(0) if in_kernel else dqkv.view(B * L, -1).sum(0, dtype=torch.float32))
+        if not in_kernel:
+            return dqkv, dqkv.view(B * L, -1).sum(0, dtype=torch.float32)
+        n = part.shape[1]                       # the per-tile partials, summed in the two fixed-order stages of the row kernels
+        part2 = torch.empty((256, n), dtype=torch.float32, device=q.device)
+        dbias = torch.empty(n, dtype=torch.float32, device=q.device)
+        check(_lib.lib().mmk_colsum_f32(ptr(part), part.shape[0], n, ptr(part2), ptr(dbias), stream()))
+        return dqkv, dbias
     if packed:
         return dqkv
     return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)

@@ -28,6 +28,7 @@
 // Residency: a workgroup spins on counters that other workgroups of the same launch advance, so the whole grid must be
 // co-resident: mmk_clip_fused_plan reports the capacity (occupancy query x CUs, at most 2 workgroups per CU) and the host
 // only takes this path when the grid fits.  Every spin is bounded (s_memrealtime); a timeout poisons the loss with NaN.
+#include <mutex>
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -734,20 +735,30 @@ static FusedLayout pair_layout(size_t off, int n, int k_pad) {
   return L;
 }
 
+// Co-resident workgroups of clip_fused_kernel<S> on the CURRENT device.  Cached per device id (the > 64 KiB LDS opt-in is a per-device
+// attribute of the function, and the CU count is the device's), under a mutex: the first calls can come from the main thread and
+// an autograd worker at once.
 template <typename S>
 static int fused_capacity(int* out) {
-  static int cached = -1;
-  if (cached < 0) {
+  constexpr int MAX_DEV = 64;
+  static int cached[MAX_DEV];
+  static bool known[MAX_DEV] = {};
+  static std::mutex mu;
+  int dev = 0;
+  MMK_HIP(hipGetDevice(&dev));
+  MMK_REQUIRE(dev >= 0 && dev < MAX_DEV, "fused loss: device id out of range");
+  std::lock_guard<std::mutex> lock(mu);
+  if (!known[dev]) {
     auto kern = clip_fused_kernel<S>;
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS));
-    int per_cu = 0, dev = 0;
+    int per_cu = 0;
     MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, F_THREADS, F_LDS));
-    MMK_HIP(hipGetDevice(&dev));
     hipDeviceProp_t prop;
     MMK_HIP(hipGetDeviceProperties(&prop, dev));
-    cached = std::min(per_cu, 2) * prop.multiProcessorCount;   // LDS admits two workgroups per CU; never count on more
+    cached[dev] = std::min(per_cu, 2) * prop.multiProcessorCount;   // LDS admits two workgroups per CU; never count on more
+    known[dev] = true;
   }
-  *out = cached;
+  *out = cached[dev];
   return 0;
 }
 

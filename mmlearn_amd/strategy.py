@@ -84,7 +84,12 @@ class TowerDDPStrategy(DDPStrategy):
         task = _unwrap(model)
         if not hasattr(task, "wrap_towers_in_ddp"):
             return False
-        if self._want_towers:
+        if self._want_towers and not getattr(task, "concurrent_encoders", False):
+            # choosing this strategy is the request for the per-tower schedule; say so when it overrides the task's own setting
+            import warnings
+
+            warnings.warn("TowerDDPStrategy switches task.concurrent_encoders on (one stream and one DDP instance per tower); pass "
+                          "concurrent_encoders=False to the strategy to keep the task's setting", RuntimeWarning, stacklevel=2)
             task.concurrent_encoders = True
         if not getattr(task, "concurrent_encoders", False):
             return False

@@ -13,6 +13,7 @@ Differences from the reference, all inside the hot path:
 from __future__ import annotations
 
 import contextlib
+import copy
 import inspect
 
 import itertools
@@ -243,15 +244,46 @@ class ContrastivePretraining(TrainingTask):
 
     def encode(self, inputs: dict[str, Any], modality: Any, normalize: bool = False) -> torch.Tensor:
         """encoder -> postprocessor -> head -> (optional) L2 normalisation (reference :400-431)."""
-        ddp = self.__dict__.get("_tower_ddp") or {}   # per-tower DistributedDataParallel instances (wrap_towers_in_ddp)
-        output = (ddp.get(("encoders", modality.name)) or self.encoders[modality.name])(inputs)[0]
+        output = self._tower("encoders", modality.name)(inputs)[0]
         if self.postprocessors and modality.name in self.postprocessors:
-            output = (ddp.get(("postprocessors", modality.name)) or self.postprocessors[modality.name])(output)
+            output = self._tower("postprocessors", modality.name)(output)
         if self.heads and modality.name in self.heads:
-            output = (ddp.get(("heads", modality.name)) or self.heads[modality.name])(output)
+            output = self._tower("heads", modality.name)(output)
         if normalize:
             output = l2_normalize(output)
         return output
+
+    def _tower(self, group: str, name: str) -> nn.Module:
+        """The module ``encode`` calls for ``group[name]``: its per-tower DDP wrapper if ``wrap_towers_in_ddp`` made one -- and it still
+        wraps the module that is registered now (a tower replaced after wrapping must not silently keep training the old one)."""
+        module = getattr(self, group)[name]
+        ddp = (self.__dict__.get("_tower_ddp") or {}).get((group, name))
+        if ddp is None:
+            return module
+        if ddp.module is not module:
+            raise RuntimeError(f"{group}[{name!r}] was replaced after wrap_towers_in_ddp(): its DistributedDataParallel wrapper still holds "
+                               "the old module; call wrap_towers_in_ddp() again on a fresh task")
+        if ddp.training != module.training:   # the wrappers sit outside the module tree: train() / eval() do not reach them
+            ddp.train(module.training)
+        return ddp
+
+    def __deepcopy__(self, memo):
+        """The per-tower DDP wrappers and side streams are bound to a process group / device queue: a copy of the task starts without
+        them (call ``wrap_towers_in_ddp`` on the copy if it is to train under DDP)."""
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in ("_tower_ddp", "_side_streams"):
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_tower_ddp", None)
+        state.pop("_side_streams", None)
+        return state
 
     def _encoder_streams(self, n: int) -> list:
         """The side stream of tower k >= 1 is entry k - 1.  At most ``max_side_streams`` (default 1) distinct streams are

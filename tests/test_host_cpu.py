@@ -182,7 +182,8 @@ def test_tower_ddp_strategy_hands_the_wrapping_to_the_task():
     # choosing the strategy IS the request: a task built by hydra with the default concurrent_encoders=False is switched on
     t3 = Task()
     t3.concurrent_encoders = False
-    assert S.TowerDDPStrategy()._setup_model(t3) is t3 and t3.concurrent_encoders is True and len(calls) == 3
+    with pytest.warns(RuntimeWarning, match="switches task.concurrent_encoders on"):       # ... and says so
+        assert S.TowerDDPStrategy()._setup_model(t3) is t3 and t3.concurrent_encoders is True and len(calls) == 3
 
 
 def test_per_tower_ddp_keeps_the_reference_checkpoint_keys():
@@ -230,6 +231,21 @@ def test_per_tower_ddp_keeps_the_reference_checkpoint_keys():
         assert torch.allclose(out_w, out_p)
         out_w.sum().backward()                                                   # DDP's reducer sees the backward
         assert all(p_.grad is not None for p_ in task2.encoders["rgb"].parameters())
+        # the wrappers sit outside the module tree, so the task looks after them itself --
+        import copy
+        import pickle
+        clone = copy.deepcopy(task2)                                             # a copy starts without process-group-bound wrappers
+        assert "_tower_ddp" not in clone.__dict__ and torch.allclose(clone.encode(x, Modalities.get_modality("rgb")), out_p)
+        assert "_tower_ddp" not in pickle.loads(pickle.dumps(task2.__getstate__())) and "_tower_ddp" in task2.__dict__
+        task2.eval()                                                             # train() / eval() reach them through encode()
+        task2.encode(x, Modalities.get_modality("rgb"))
+        assert not task2._tower_ddp[("encoders", "rgb")].training
+        task2.train()
+        task2.encode(x, Modalities.get_modality("rgb"))
+        assert task2._tower_ddp[("encoders", "rgb")].training
+        task2.encoders["rgb"] = tiny_models.FlatMLPEncoder("rgb", 3 * 4 * 4, 8, 6)   # a tower replaced after wrapping is refused, not ignored
+        with pytest.raises(RuntimeError, match="replaced after wrap_towers_in_ddp"):
+            task2.encode(x, Modalities.get_modality("rgb"))
     finally:
         dist.destroy_process_group()
 

@@ -968,7 +968,7 @@ def main():
         n_rows, n_cols, d = args.batch, args.batch * world, 512
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes of the same kernel and shape (profiles/)
         try:
-            if world == 1 and not force_dist and args.batch == 1024:
+            if world == 1 and args.batch == 1024:   # (also the 1-rank dry run of the N > 1 path: one rank still runs the one-launch kernel)
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
                 traffic = pmc.get("n1024", {}).get("hbm_bytes_per_launch")
             elif args.batch == 1024:   # N > 1: the rank's sharded shape (R = batch rows x C = batch * world columns)

@@ -348,6 +348,14 @@ def linear_nobias(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
     return linear(x, lin.weight, None)
 
 
+MLP_PAD_MIN_ROWS = 2048   # below this an MLP is too small for the persistent GEMM to pay; rows are never padded then
+
+
+def _pad_rows(m: int) -> int:
+    """Row count the MLP GEMMs run on: ``m`` rounded up to a multiple of 256 (unchanged when it is one, or when the MLP is small)."""
+    return m if (m % 256 == 0 or m < MLP_PAD_MIN_ROWS) else (m + 255) // 256 * 256
+
+
 class _MLPFn(torch.autograd.Function):
     """``act(x W1^T + b1) W2^T`` -- a two-layer MLP without fc2's bias (the consumer kernel adds it) as ONE autograd node around
     the two GEMMs of ``csrc/mlp_gemm.hip`` that carry the activation pass in their epilogue:
@@ -371,14 +379,20 @@ class _MLPFn(torch.autograd.Function):
         w2_16, w2_bwd, ctx.w2_twin = _weight_operands(w2)
         b32 = b1.detach().float().contiguous()
         M, H, E = x2.shape[0], w1.shape[0], w2.shape[0]
+        # The kernels walk whole 256-row tiles.  A row count that is not a multiple of 256 (I-JEPA: batch x kept patches) is padded
+        # with zero rows -- one small copy of x here and of dY in the backward against a pass over [rows, hidden] each way; the
+        # padded rows of act' meet zero rows of dY in the backward, so nothing of them reaches a gradient.
+        Mp = _pad_rows(M)
         # both kernels or neither: the forward leaves act'(pre + b1) behind INSTEAD of the pre-activation, which only the fused
         # backward can use
         ctx.fused = bool(not os.environ.get("MMK_NO_MLP_FUSION")   # (A/B switch)
-                         and ctx.w2_twin and K.mlp_gemm_supported(M, H, k, x2.stride(0), w1_16.stride(0), H)
-                         and K.mlp_gemm_supported(M, H, E, E, w2_bwd.stride(0), H))
+                         and ctx.w2_twin and K.mlp_gemm_supported(Mp, H, k, k if Mp != M else x2.stride(0), w1_16.stride(0), H)
+                         and K.mlp_gemm_supported(Mp, H, E, E, w2_bwd.stride(0), H))
         with torch.autocast("cuda", enabled=False):
             if ctx.fused:
-                a2, h2 = K.mlp_gemm_fwd_act_grad(x2, w1_16, b32, act)     # h2 = act'(x W1^T + b1)
+                xp = x2 if Mp == M else F.pad(x2, (0, 0, 0, Mp - M))
+                a2, h2 = K.mlp_gemm_fwd_act_grad(xp, w1_16, b32, act)     # h2 = act'(x W1^T + b1), [Mp, H]
+                a2 = a2[:M]
             else:
                 h2 = x2 @ w1_16.t()                                       # h2 = x W1^T
                 a2 = K.bias_act_fwd(h2, b32, act)
@@ -399,7 +413,10 @@ class _MLPFn(torch.autograd.Function):
                 dw2 = K.wgrad(dy2, a2, wdt(w2_dtype)).to(w2_dtype)
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
                 if ctx.fused:
-                    dpre, db1 = K.mlp_gemm_bwd_mul(dy2, w2_bwd, h2, want_dbias=ctx.needs_input_grad[2])
+                    M = dy2.shape[0]
+                    dyp = dy2 if h2.shape[0] == M else F.pad(dy2, (0, 0, 0, h2.shape[0] - M))
+                    dpre, db1 = K.mlp_gemm_bwd_mul(dyp, w2_bwd, h2, want_dbias=ctx.needs_input_grad[2])
+                    dpre = dpre[:M]
                 else:
                     dpre, db1 = K.bias_act_bwd(h2, b32, _dx_gemm(dy2, w2_bwd, ctx.w2_twin), act)
                 if ctx.needs_input_grad[0]:
@@ -420,6 +437,20 @@ def mlp_fc1_act_fc2(x: torch.Tensor, fc1: nn.Linear, act: str, fc2: nn.Linear) -
     if (_wgrad_linear_ok(fc1.weight, x) and fc2.weight.requires_grad and fc1.bias is not None and fc2.weight.dim() == 2
             and fc2.weight.shape[1] == fc1.weight.shape[0] and fc2.weight.shape[0] % 8 == 0 and fc2.weight.shape[1] % 8 == 0):
         return _MLPFn.apply(x, fc1.weight, fc1.bias, fc2.weight, {"quick_gelu": K.ACT_QUICK_GELU, "gelu": K.ACT_GELU}[act])
+    if (not torch.is_grad_enabled() and x.is_cuda and _autocast_bf16() and fc1.bias is not None and fc1.weight.dim() == 2
+            and not os.environ.get("MMK_NO_MLP_FUSION")):
+        # forward only (an EMA teacher, evaluation): fc1 + bias + activation in one kernel, no second output
+        k = x.shape[-1]
+        x2 = x.reshape(-1, k).to(torch.bfloat16)
+        M, H = x2.shape[0], fc1.weight.shape[0]
+        Mp = _pad_rows(M)
+        w16 = fc1.weight.detach().to(torch.bfloat16)
+        if x2.stride(1) == 1 and K.mlp_gemm_supported(Mp, H, k, k if Mp != M else x2.stride(0), w16.stride(0), H):
+            with torch.autocast("cuda", enabled=False):
+                xp = x2 if Mp == M else F.pad(x2, (0, 0, 0, Mp - M))
+                a2, _ = K.mlp_gemm_fwd_act(xp, w16, fc1.bias.detach().float().contiguous(), {"quick_gelu": K.ACT_QUICK_GELU, "gelu": K.ACT_GELU}[act],
+                                           want_pre=False)
+            return linear_nobias(fc2, a2[:M].view(*x.shape[:-1], H))
     return linear_nobias(fc2, bias_act(linear_nobias(fc1, x), fc1.bias, act))
 
 

@@ -199,3 +199,43 @@ def test_mlp_node_matches_the_unfused_ops_and_f32_autograd(E, H, act, monkeypatc
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         y_eval = fused.mlp_fc1_act_fc2(x0, fc1, act, fc2)
     assert (y_eval.float() - ref[0]).abs().max().item() <= 3e-2 * max(1.0, ref[0].abs().max().item())
+
+
+@pytest.mark.parametrize("rows", [8192 + 100, 6144 + 1, 1000])
+def test_mlp_node_pads_ragged_row_counts_and_the_no_grad_forward_is_fused_too(rows, monkeypatch):
+    """Row counts that are not a multiple of 256 (I-JEPA: batch x kept patches): the node pads x / dY with zero rows for the fused
+    GEMMs (the node itself starts at 6,144 rows, like the weight-gradient path; 1000 rows stay on the separate ops) -- output and every gradient against the unfused
+    node; under ``no_grad`` (EMA teacher, evaluation) fc1 + bias + activation run as one kernel and give the same activations."""
+    from mmlearn_amd import fused, kernels as Kn
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(rows)
+    E, H = 256, 512
+    fc1, fc2 = torch.nn.Linear(E, H).to(dev), torch.nn.Linear(H, E).to(dev)
+    x0 = torch.randn(rows, E, device=dev)
+    wgt = torch.randn(rows, E, device=dev)
+    calls = []
+    real = Kn.mlp_gemm_fwd_act_grad
+    monkeypatch.setattr(Kn, "mlp_gemm_fwd_act_grad", lambda *a, **k: (calls.append(a[0].shape[0]), real(*a, **k))[1])
+
+    def run():
+        for p in list(fc1.parameters()) + list(fc2.parameters()):
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = fused.mlp_fc1_act_fc2(x, fc1, "gelu", fc2)
+        (y.float() * wgt).sum().backward()
+        return [y.detach().float(), x.grad.float(), fc1.weight.grad.float(), fc1.bias.grad.float(), fc2.weight.grad.float()]
+
+    got = run()
+    assert calls == ([(rows + 255) // 256 * 256] if rows >= 6144 else [])
+    monkeypatch.setenv("MMK_NO_MLP_FUSION", "1")
+    want = run()
+    monkeypatch.delenv("MMK_NO_MLP_FUSION")
+    for name, a, b in zip(("y", "dx", "dW1", "db1", "dW2"), got, want):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 2e-2 * max(1.0, b.abs().max().item()), name
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y_ng = fused.mlp_fc1_act_fc2(x0, fc1, "gelu", fc2)
+    assert y_ng.shape == got[0].shape and (y_ng.float() - got[0]).abs().max().item() <= 2e-2 * max(1.0, got[0].abs().max().item())
+

@@ -31,7 +31,8 @@ class LearnableLogitScaling(torch.nn.Module):
         return torch.clip(self.log_logit_scale.exp(), max=self.max_logit_scale) * x
 
     def extra_repr(self) -> str:
-        return f"logit_scale_init={self.init_logit_scale},learnable={self.learnable}, max_logit_scale={self.max_logit_scale}"
+        kind = "parameter" if self.learnable else "buffer"
+        return f"init={self.init_logit_scale:g}, cap={self.max_logit_scale:g}, log-scale held as a {kind}"
 
 
 @store(group="modules/layers", name="L2NormHIP")

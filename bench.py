@@ -389,7 +389,8 @@ def accelerate_tower(tower, modality: str):
         return accelerate_encoder(tower, fuse_qkv=True, fuse_add_ln=True)
     # HTSAT: the LayerNorm swap (f32 in / f32 out), every Linear's weight gradient on csrc/wgrad.hip, its windowed attention as
     # one kernel each way (csrc/window_attention.hip; MMK_BENCH_NO_WINDOW_ATTN=1 leaves it on ATen) ...
-    swapped = accelerate_encoder(tower, wgrad_linear=os.environ.get("MMK_BENCH_NO_AUDIO_WGRAD") is None,
+    swapped = accelerate_encoder(tower, low_precision_ln=("layernorm_before", "layernorm_after"),   # both feed nothing but Linears
+                                 wgrad_linear=os.environ.get("MMK_BENCH_NO_AUDIO_WGRAD") is None,
                                  window_attention=os.environ.get("MMK_BENCH_NO_WINDOW_ATTN") is None)
     # ... and its 4 x 4 / stride 4 patch embedding as im2col + GEMM (the image comes out of a BatchNorm: patchify has a backward).
     # Besides the time, this takes MIOpen's implicit-GEMM convolution kernels out of the leg: with AMD_SERIALIZE_KERNEL=3 +

@@ -1014,8 +1014,9 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
 
     ``low_precision_ln``: substrings of qualified module names whose LayerNorm may emit the autocast dtype directly
     (only LayerNorms that feed autocast ``Linear`` layers, e.g. ``("layer_norm1", "layer_norm2", "post_layernorm")``
-    for HF CLIP); ``norm1`` / ``norm2`` of timm-style pre-LN blocks (mmlearn's own ViT / predictor) and ``layer_norm1`` /
-    ``layer_norm2`` of HF ``CLIPEncoderLayer`` get it automatically -- they feed nothing but that block's Linears.
+    for HF CLIP); ``norm1`` / ``norm2`` of timm-style pre-LN blocks (mmlearn's own ViT / predictor), ``layer_norm1`` /
+    ``layer_norm2`` of HF ``CLIPEncoderLayer`` and ``layernorm_before`` / ``layernorm_after`` of Swin-style layers (HTSAT) get it
+    automatically -- they feed nothing but that block's Linears.
     ``cls_only``: :func:`cls_only_last_layer` (opt-in; only for encoders pooled at token 0).
     ``wgrad_linear``: :func:`linear_wgrad` on every ``nn.Linear`` left unpatched (towers without a recognised block structure).
     ``window_attention``: :func:`fuse_window_attention` (on by default; a no-op for towers without windowed attention modules).
@@ -1030,7 +1031,9 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
                     and child.normalized_shape[0] <= 2048:
                 # norm1 / norm2 of a timm-style pre-LN block feed nothing but its qkv / fc1 Linear: bf16 out is always safe there
                 lowp = any(s in full for s in low) or (child_name in ("norm1", "norm2") and _is_preln_block(parent)) \
-                    or (type(parent).__name__ == "CLIPEncoderLayer" and child_name in ("layer_norm1", "layer_norm2"))
+                    or (type(parent).__name__ == "CLIPEncoderLayer" and child_name in ("layer_norm1", "layer_norm2")) \
+                    or (child_name in ("layernorm_before", "layernorm_after") and hasattr(parent, "shift_size")
+                        and hasattr(parent, "attention") and hasattr(parent, "intermediate"))   # Swin-style layer (HTSAT): Linears only
                 setattr(parent, child_name, LayerNorm.from_torch(child, lowp))
                 swapped["layernorm"] += 1
             elif type(child).__name__ in ("QuickGELUActivation", "QuickGELU") and not isinstance(child, QuickGELU):

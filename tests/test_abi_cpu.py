@@ -97,3 +97,14 @@ def test_product_does_not_import_oracle():
                         names = [node.module]
                     bad += [(f, n) for n in names if n.split(".")[0] == "oracle"]
     assert not bad, bad
+
+
+def test_the_driver_build_entry_point_passes(built):
+    """``__graft_entry__.build()`` is what the driver runs every round: it must build (a no-op here, the fixture did), load the library
+    and agree with the ABI version of the header and the ctypes stub -- a hard-coded version number there broke it once."""
+    import __graft_entry__ as g
+
+    g.build()
+    src = open(g.__file__).read()
+    assert "_lib.ABI_VERSION" in src and built.lib().mmk_abi_version() == built.ABI_VERSION
+

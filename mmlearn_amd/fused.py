@@ -25,6 +25,7 @@ There is no CPU path: CPU tensors raise.
 
 from __future__ import annotations
 
+import inspect
 import math
 import types
 from typing import Iterable, Optional
@@ -988,10 +989,17 @@ def fuse_window_attention(module: nn.Module) -> int:
     attributes) inside ``module`` with :func:`_window_self_attention_forward`, and every Swin-style layer around one
     (``ClapAudioLayer``: ``layernorm_before`` / ``attention.self`` / ``get_attn_mask`` / ``shift_size``) with
     :func:`_swin_layer_forward`.  Parameters and ``state_dict`` are untouched.  Returns the number of attention modules patched."""
+    def takes(m, names):   # the replacement forwards mirror these call signatures exactly; anything else (a head_mask, ...) stays stock
+        try:
+            return [p for p in inspect.signature(m.forward).parameters] == names
+        except (TypeError, ValueError):
+            return False
+
     n = 0
     for m in module.modules():
         if (all(hasattr(m, a) for a in ("relative_position_bias_table", "relative_position_index", "query", "key", "value", "dropout",
                                         "num_attention_heads", "attention_head_size", "all_head_size"))
+                and takes(m, ["hidden_states", "attention_mask", "output_attentions"])
                 and not hasattr(m, "_mmk_stock_forward")):
             m._mmk_stock_forward = m.forward
             m.forward = types.MethodType(_window_self_attention_forward, m)
@@ -1000,6 +1008,7 @@ def fuse_window_attention(module: nn.Module) -> int:
         if (all(hasattr(m, a) for a in ("layernorm_before", "layernorm_after", "attention", "intermediate", "output", "drop_path", "shift_size",
                                         "window_size", "get_attn_mask", "set_shift_and_window_size"))
                 and hasattr(m.attention, "self") and hasattr(m.attention.self, "_mmk_stock_forward") and hasattr(m.attention, "output")
+                and takes(m, ["hidden_states", "input_dimensions", "output_attentions", "always_partition"])
                 and not hasattr(m, "_mmk_stock_forward")):
             m._mmk_stock_forward = m.forward
             m.forward = types.MethodType(_swin_layer_forward, m)

@@ -1,4 +1,4 @@
-"""Randomised shape sweep of the attention and weight-gradient kernels against torch references (run by hand on the GPU)."""
+"""Randomised shape sweep of the attention, weight-gradient, row, recall, windowed-attention and embedding-backward kernels against torch references (run by hand on the GPU)."""
 import os, sys, random
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -98,3 +98,54 @@ for it in range(int(os.environ.get("N", 60)) // 2):
         bad3 += 1; print("RECALL MISMATCH", n, m, d, int((~ok).sum()))
 torch.cuda.synchronize()
 print("fuzz recall kernel done, mismatches:", bad3)
+
+# ---- windowed attention (window mode and token-map mode) and the sorted-run embedding backward
+import math
+bad4 = 0
+for it in range(int(os.environ.get("N", 60)) // 2):
+    heads, dh = rng.randint(1, 12), rng.choice([24, 24, 32])
+    gh, gw = 8 * rng.randint(1, 4), 8 * rng.randint(1, 4)
+    nW, B, C = (gh // 8) * (gw // 8), rng.randint(1, 9), heads * dh
+    shift = rng.choice([0, 0, rng.randint(1, 7)])
+    use_map = rng.random() < 0.5
+    q, k, v = ((torch.randn(B, gh * gw, C, device=dev) * 1.3).bfloat16().requires_grad_(True) for _ in range(3))
+    bias = (torch.randn(heads, 64, 64, device=dev) * 0.5).requires_grad_(True)
+    region = torch.randint(0, 3, (nW, 64), device=dev)
+    mask = (region[:, :, None] != region[:, None, :]).float() * -100.0 if (shift or rng.random() < 0.3) else None
+    w = torch.randn(B, gh * gw, C, device=dev)
+    part = lambda t: torch.roll(t.view(B, gh, gw, C), (-shift, -shift), (1, 2)).view(B, gh // 8, 8, gw // 8, 8, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, 64, C)
+    unpart = lambda t: torch.roll(t.view(B, gh // 8, gw // 8, 8, 8, C).permute(0, 1, 3, 2, 4, 5).reshape(B, gh, gw, C), (shift, shift), (1, 2)).view(B, gh * gw, C)
+    if use_map:
+        out = fused.window_attention(q, k, v, bias, mask, heads, 1 / math.sqrt(dh), (gh, gw), shift)
+    else:
+        out = unpart(fused.window_attention(part(q), part(k), part(v), bias, mask, heads, 1 / math.sqrt(dh)))
+    (out.float() * w).sum().backward()
+    q2, k2, v2, b2 = (t.detach().float().requires_grad_(True) for t in (q, k, v, bias))
+    qh, kh, vh = (part(t).view(-1, 64, heads, dh).transpose(1, 2) for t in (q2, k2, v2))
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(dh) + b2[None]
+    if mask is not None:
+        s = (s.view(B, nW, heads, 64, 64) + mask[None, :, None]).view(-1, heads, 64, 64)
+    ref = unpart((torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(-1, 64, C))
+    (ref * w).sum().backward()
+    errs = [(a.float() - b).abs().max().item() / max(1.0, b.abs().max().item())
+            for a, b in ((out, ref), (q.grad, q2.grad), (k.grad, k2.grad), (v.grad, v2.grad), (bias.grad, b2.grad))]
+    if max(errs) > 2e-2 or not all(math.isfinite(e) for e in errs):
+        bad4 += 1; print("WINDOW-ATTN MISMATCH", B, gh, gw, heads, dh, shift, use_map, mask is not None, errs)
+for it in range(int(os.environ.get("N", 60)) // 3):
+    rows, d, vocab = rng.randint(4096, 120000), 4 * rng.randint(1, 300), rng.choice([2, 7, 1000, 30522])
+    kind = rng.choice(["uniform", "hot", "runs"])
+    ids = torch.randint(0, vocab, (rows,), device=dev)
+    if kind == "hot":
+        ids[torch.rand(rows, device=dev) < 0.7] = rng.randrange(vocab)
+    elif kind == "runs":
+        ids = ids[:: rng.randint(2, 50)].repeat_interleave(rng.randint(2, 50))[:rows]; rows = ids.numel()
+    ids[torch.rand(rows, device=dev) < 0.05] = -1
+    dout = torch.randn(rows, d, device=dev)
+    keep = ids >= 0
+    ref = torch.zeros(vocab, d, device=dev, dtype=torch.float64).index_add_(0, ids[keep], dout[keep].double())
+    got = K.embedding_bwd(dout, ids, vocab)
+    e = (got.double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    if e > 1e-5:
+        bad4 += 1; print("EMBEDDING-BWD MISMATCH", rows, d, vocab, kind, e)
+torch.cuda.synchronize()
+print("fuzz window attention / embedding backward done, mismatches:", bad4)

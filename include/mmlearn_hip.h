@@ -365,6 +365,11 @@ int mmk_bias_act_bwd(const void* x, const float* bias, const void* dy, void* dx,
                      int d, int act, int dtype, void* stream);
 /* column sums of a f32 [n_rows, d] buffer of partial rows (fixed summation order): out f32[d]; part2: f32[256, d] scratch */
 int mmk_colsum_f32(const float* part, int n_rows, int d, float* part2, float* out, void* stream);
+/* out[n] (f32) = column sums of x [rows, n] (bf16, n % 8 == 0, or f32, n % 4 == 0; contiguous): `grad_output.sum(0)`, the bias gradient
+ * of every nn.Linear whose bias no neighbouring kernel takes care of (HTSAT's, under mmlearn/modules/encoders/).  part: f32 workspace
+ * [mmk_colsum_rows_slices(rows), n]; fixed summation order. */
+int mmk_colsum_rows_slices(int64_t rows);
+int mmk_colsum_rows(const void* x, int64_t rows, int n, int dtype, float* part, float* out, void* stream);
 
 /* The two GEMMs of an encoder MLP that sit next to its activation, with the activation pass in the epilogue (csrc/mlp_gemm.hip).
  * Replaces, in the reference's op sequence (mmlearn/modules/layers/mlp.py; HF CLIPMLP / BertIntermediate+BertOutput under

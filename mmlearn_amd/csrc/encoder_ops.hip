@@ -566,6 +566,74 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const G* __restrict_
   }
 }
 
+// ------------------------------------------------------------------ column sums of a [rows, n] bf16 / f32 matrix (bias gradient of a Linear)
+// dY.sum(0) for the Linears whose bias no other kernel takes care of (HTSAT's: 73 per step, [1 M x 96] ... [16 k x 3072] bf16).  The block is
+// laid out as (256 / cw) rows x cw 16-byte chunks, cw = chunks of the column group (<= 256 columns of bf16 x 8): every load instruction of
+// a wave covers whole rows back to back, whatever n is (96 columns = 12 chunks -> 21 rows per pass), rows are unrolled four deep, and the
+// threads of one chunk column are added up through LDS.  One f32 partial row per (slice, column group); colsum_final_kernel finishes.
+constexpr int CSR_MAX_SLICES = 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const T* __restrict__ x, long rows, int n, float* __restrict__ part, long rows_per_slice) {
+  constexpr int EPC = 16 / sizeof(T);              // elements per 16-byte chunk
+  __shared__ float red[256][EPC + 1];
+  const int cpr = n / EPC;                         // chunks per row
+  const int c0 = blockIdx.x * 256, cw = min(256, cpr - c0);
+  const int rpp = 256 / cw;                        // rows per pass of the block
+  const int t = threadIdx.x, tr = t / cw, tc = t - tr * cw;
+  const long r0 = (long)blockIdx.y * rows_per_slice, r1 = min(rows, r0 + rows_per_slice);
+  float acc[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+  if (tr < rpp) {
+    const T* base = x + (long)(c0 + tc) * EPC;
+    long r = r0 + tr;
+    for (; r + 3L * rpp < r1; r += 4L * rpp) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(base + (r + (long)u * rpp) * n);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (sizeof(T) == 4) {
+          acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w;
+        } else {
+          const uint32_t w[4] = {__float_as_uint(v[u].x), __float_as_uint(v[u].y), __float_as_uint(v[u].z), __float_as_uint(v[u].w)};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[(2 * q) % EPC] += __uint_as_float(w[q] << 16);
+            acc[(2 * q + 1) % EPC] += __uint_as_float(w[q] & 0xffff0000u);
+          }
+        }
+      }
+    }
+    for (; r < r1; r += rpp) {
+      const float4 v = *reinterpret_cast<const float4*>(base + r * n);
+      if (sizeof(T) == 4) {
+        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+      } else {
+        const uint32_t w[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[(2 * q) % EPC] += __uint_as_float(w[q] << 16);
+          acc[(2 * q + 1) % EPC] += __uint_as_float(w[q] & 0xffff0000u);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) red[t][e] = acc[e];
+  __syncthreads();
+  if (t < cw) {
+    float s[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+    for (int q = 0; q < rpp; ++q)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s[e] += red[q * cw + t][e];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) part[(long)blockIdx.y * n + (long)(c0 + t) * EPC + e] = s[e];
+  }
+}
+
 // The same scatter for many rows (>= 4096: the word and token-type tables of BERT at the bench batch, 78,848 rows each), on SORTED ids
 // and without one atomic per element and run: hot ids (token-type ids are all equal; real text is Zipfian) made the kernel above
 // serialise on same-address atomics (~800 us per table) and uniformly random ids cost it 60 M atomics.  Here a wave takes EMB_CHUNK
@@ -966,6 +1034,29 @@ int mmk_embedding_bwd(const void* dout, const int64_t* ids, float* dw, int64_t r
     return 0;
   });
   if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+// slices (= rows of the f32 workspace `part`, each n wide) mmk_colsum_rows uses for `rows` rows
+int mmk_colsum_rows_slices(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(CSR_MAX_SLICES, rows / 128)); }
+
+// out[n] (f32) = column sums of x [rows, n] (bf16 / f32, contiguous, n a multiple of 8 / 4): the bias gradient dY.sum(0) of an
+// nn.Linear (mmlearn/modules/encoders/*: every Linear whose bias is not folded into a neighbouring kernel).  part: f32 [slices, n].
+int mmk_colsum_rows(const void* x, int64_t rows, int n, int dtype, float* part, float* out, void* stream) {
+  MMK_REQUIRE(x && part && out && rows > 0 && n > 0, "colsum_rows: bad arguments");
+  MMK_REQUIRE(dtype == MMK_F32 ? n % 4 == 0 : (dtype == MMK_BF16 && n % 8 == 0), "colsum_rows: bf16 with n % 8 == 0 or f32 with n % 4 == 0");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int slices = mmk_colsum_rows_slices(rows);
+  const long rps = (rows + slices - 1) / slices;
+  const int cpr = dtype == MMK_F32 ? n / 4 : n / 8;
+  const dim3 grid((cpr + 255) / 256, slices);
+  if (dtype == MMK_F32)
+    hipLaunchKernelGGL((colsum_rows_kernel<float>), grid, dim3(256), 0, st, static_cast<const float*>(x), (long)rows, n, part, rps);
+  else
+    hipLaunchKernelGGL((colsum_rows_kernel<bf16_t>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(x), (long)rows, n, part, rps);
+  ColsumOuts outs = {{out, nullptr, nullptr}};
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((n + 63) / 64), dim3(256), 0, st, part, slices, n, 1, outs);
   MMK_LAUNCH_CHECK();
   return 0;
 }

@@ -249,7 +249,7 @@ class _LinearWgradFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = K.wgrad(dy2, x2, ctx.w_dtype if ctx.w_dtype in (torch.float32, torch.bfloat16) else torch.float32).to(ctx.w_dtype)
             if ctx.b_dtype is not None and ctx.needs_input_grad[2]:
-                db = dy2.sum(0, dtype=torch.float32).to(ctx.b_dtype)
+                db = (K.colsum_rows(dy2) if dy2.shape[1] % 8 == 0 else dy2.sum(0, dtype=torch.float32)).to(ctx.b_dtype)
         return dx, dw, db
 
 

@@ -812,6 +812,17 @@ def unpatchify(dcols: torch.Tensor, shape: tuple, patch: int, dtype: torch.dtype
     return out
 
 
+def colsum_rows(x2: torch.Tensor) -> torch.Tensor:
+    """f32 [n] column sums of a contiguous [rows, n] bf16 / f32 matrix in a fixed order (a Linear's bias gradient ``dY.sum(0)``)."""
+    require_gpu(x2)
+    rows, n = x2.shape
+    assert x2.is_contiguous() and rows > 0 and ((x2.dtype == torch.bfloat16 and n % 8 == 0) or (x2.dtype == torch.float32 and n % 4 == 0))
+    part = torch.empty((int(_lib.lib().mmk_colsum_rows_slices(rows)), n), dtype=torch.float32, device=x2.device)
+    out = torch.empty(n, dtype=torch.float32, device=x2.device)
+    check(_lib.lib().mmk_colsum_rows(ptr(x2), rows, n, dtype_tag(x2.dtype), ptr(part), ptr(out), stream()))
+    return out
+
+
 EMBEDDING_SORT_MIN_ROWS = 4096   # from this many token rows the embedding backward sorts the ids first (module seam for the tests)
 
 

@@ -432,6 +432,23 @@ def test_sorted_run_embedding_backward_matches_index_add(rows, d, vocab, kind, d
     assert (dw2 - dw).abs().max().item() <= 1e-6 * scale
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,n", [(1, 8), (127, 96), (50000, 96), (4099, 3072), (300, 2056), (70000, 768)])
+def test_column_sums_of_a_gradient_matrix(rows, n, dtype):
+    """``kernels.colsum_rows`` = ``dY.sum(0)`` in f32 (the bias gradient of a Linear in ``fused.linear``'s backward): narrow and wide
+    matrices, more than one column group (2056 columns of bf16 = 257 chunks), ragged slices, a single row; fixed order, so two calls agree bit for bit."""
+    from mmlearn_amd import kernels as Kn
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(rows + n)
+    x = torch.randn(rows, n, generator=g).to(dtype).to(dev)
+    got = Kn.colsum_rows(x)
+    want = x.double().sum(0)
+    assert got.dtype == torch.float32 and got.shape == (n,)
+    assert (got.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()) * max(1.0, rows ** 0.5 / 30)
+    assert torch.equal(got, Kn.colsum_rows(x))
+
+
 def test_causal_text_towers_keep_their_causality_under_the_fused_qkv_patch():
     """HF's CLIP text tower (and a BERT configured as decoder) signal causality through ``is_causal`` / ``is_decoder`` with
     NO attention mask for sdpa-style implementations.  The fused-QKV patch is bidirectional, so it must step aside there:

@@ -443,13 +443,16 @@ int mmk_embedding_bwd_sorted(const void* dout, const int64_t* ids_sorted, const 
  * [mmk_win_attn_blocks(B, nW, H), 64, 64], one partial sum of dS per workgroup -- block id -> head: (id >> 3) % H when
  * mmk_win_attn_blocks / H is a multiple of 8, id % H otherwise.  img_w > 0 (token-map mode): the eight tensors are [B, img_h * img_w, C] token
  * maps instead, window w = (wy, wx) of the map rolled by -shift is gathered on the way in and scattered back on the way out: the
- * torch.roll / window_partition / window_reverse / roll of ClapAudioLayer.forward as address arithmetic (img_h, img_w multiples of 8). */
+ * torch.roll / window_partition / window_reverse / roll of ClapAudioLayer.forward as address arithmetic (img_h, img_w multiples of 8).
+ * ld: row stride in elements of q / k / v and dq / dk / dv -- C, or 3 C when they are the three thirds of one packed [.., 3 C] projection
+ * output / gradient buffer (the three Linears run as one GEMM each way); o and dout always have row stride C. */
 int mmk_win_attn_supported(int tokens, int dh, int c);
 int mmk_win_attn_blocks(int B, int nW, int H);
 int mmk_win_attn_fwd(const void* q, const void* k, const void* v, const float* table, void* o, float* lse2, int B, int nW, int nWt, int H, int dh,
-                     float scale, int img_h, int img_w, int shift, void* stream);
+                     float scale, int img_h, int img_w, int shift, int ld, void* stream);
 int mmk_win_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse2, const float* table, void* dq, void* dk,
-                     void* dv, float* dtab_part, int B, int nW, int nWt, int H, int dh, float scale, int img_h, int img_w, int shift, void* stream);
+                     void* dv, float* dtab_part, int B, int nW, int nWt, int H, int dh, float scale, int img_h, int img_w, int shift, int ld,
+                     void* stream);
 
 /* HF QuickGELUActivation  x * sigmoid(1.702 x)  (CLIP MLP), forward and backward, n elements (multiple of 4) */
 int mmk_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);

@@ -131,8 +131,8 @@ _SIGNATURES = {
     "mmk_embedding_bwd_scratch_bytes": [C.c_int64, _i],
     "mmk_win_attn_supported": [_i, _i, _i],
     "mmk_win_attn_blocks": [_i, _i, _i],
-    "mmk_win_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _i, _i, _vp],
-    "mmk_win_attn_bwd": [_vp] * 10 + [_i, _i, _i, _i, _i, C.c_float, _i, _i, _i, _vp],
+    "mmk_win_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, _i, _i, _i, _i, _vp],
+    "mmk_win_attn_bwd": [_vp] * 10 + [_i, _i, _i, _i, _i, C.c_float, _i, _i, _i, _i, _vp],
     "mmk_embedding_bwd_sorted": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, C.c_int64, _i, _vp],
     "mmk_wgrad_plan": [C.c_int64, _i, _i, _vp, _vp],
     "mmk_wgrad_partial": [_vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp],

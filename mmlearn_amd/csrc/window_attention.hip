@@ -49,6 +49,7 @@ struct WinAttnArgs {
   float* dtab_part;     // [gridDim.x][64][64] f32: per-workgroup sums of dS (block id = the forward's)
   int B, nW, nWt, H, C, nsplit;
   int img_h, img_w, shift;   // img_w > 0: q .. dv are [B, img_h * img_w, C] token maps and the windows are gathered from / scattered to them (below)
+  int ld;                    // row stride (elements) of q, k, v, dq, dk, dv: C, or 3 C when they are the thirds of one packed [.., 3 C] projection
   float scale;
 };
 
@@ -136,7 +137,7 @@ __device__ __forceinline__ void wa_store_tile(const char* stg, bf16_t* dst, cons
 // and, on the way out, window_reverse and the roll back (HF ClapAudioLayer.forward) as address arithmetic.  Same for every item
 // of the workgroup (they differ in the sample only).
 template <int CH>
-__device__ __forceinline__ void wa_chunk_offsets(const WinAttnArgs& a, int w, int lane, uint32_t (&voff)[CH]) {
+__device__ __forceinline__ void wa_chunk_offsets(const WinAttnArgs& a, int w, int lane, int ld, uint32_t (&voff)[CH]) {
 #pragma unroll
   for (int n = 0; n < CH; ++n) {
     const int c = lane + 64 * n, t = c / CH, piece = c % CH;
@@ -146,7 +147,7 @@ __device__ __forceinline__ void wa_chunk_offsets(const WinAttnArgs& a, int w, in
       const int y = (8 * wy + (t >> 3) + a.shift) % a.img_h, x = (8 * wx + (t & 7) + a.shift) % a.img_w;
       row = y * a.img_w + x;
     }
-    voff[n] = (uint32_t)(row * a.C + piece * 8) * 2u;
+    voff[n] = (uint32_t)(row * ld + piece * 8) * 2u;
   }
 }
 
@@ -166,14 +167,16 @@ __global__ __launch_bounds__(256, 3) void win_attn_fwd_kernel(const WinAttnArgs 
   __syncthreads();
   const int r = lane & 31, h = lane >> 5;
   const int tr_off = ((lane & 15) >> 2) * ROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-  uint32_t voff[CH];
-  wa_chunk_offsets<CH>(a, w, lane, voff);
+  uint32_t voff[CH], voff_o[CH];   // chunk offsets in the q / k / v tensors (row stride ld) and in o (row stride C)
+  wa_chunk_offsets<CH>(a, w, lane, a.ld, voff);
+  wa_chunk_offsets<CH>(a, w, lane, a.C, voff_o);
   const float sc2 = a.scale * WA_LOG2E;
   const int bps = (a.B + a.nsplit - 1) / a.nsplit;
   const int b0 = slice * bps, b1 = min(a.B, b0 + bps);
   for (int b = b0 + wave; b < b1; b += 4) {
     const long bw = (long)b * a.nW + w;
-    const long ebase = (a.img_w > 0 ? (long)b * a.nW : bw) * WA_N * a.C + hh * DH;
+    const long rbase = (a.img_w > 0 ? (long)b * a.nW : bw) * WA_N;   // first row of the item's window (window mode) or sample (token-map mode)
+    const long ebase = rbase * a.ld + hh * DH, obase = rbase * a.C + hh * DH;
 #pragma unroll
     for (int n = 0; n < CH; ++n) {
       wa_dma16(a.q + ebase, voff[n], wa_lds_addr(Qs) + n * 1024);
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_fwd_kernel(const WinAttnArgs 
     // ---- rows of O through the (now free) Q tile
 #pragma unroll
     for (int it = 0; it < 2; ++it) wa_stage_out<DH>(Qs, 32 * it + r, h, oacc[it], 1.f);
-    wa_store_tile<DH>(Qs, a.o + ebase, voff, lane);
+    wa_store_tile<DH>(Qs, a.o + obase, voff_o, lane);
   }
 }
 
@@ -264,8 +267,9 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_kernel(const WinAttnArgs 
   __syncthreads();
   const int h = lane >> 5;
   const int tr_off = ((lane & 15) >> 2) * ROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-  uint32_t voff[CH];
-  wa_chunk_offsets<CH>(a, w, lane, voff);
+  uint32_t voff[CH], voff_o[CH];   // chunk offsets in q / k / v / dq / dk / dv (row stride ld) and in dO (row stride C)
+  wa_chunk_offsets<CH>(a, w, lane, a.ld, voff);
+  wa_chunk_offsets<CH>(a, w, lane, a.C, voff_o);
   const float sc2 = a.scale * WA_LOG2E;
   const int bps = (a.B + a.nsplit - 1) / a.nsplit;
   const int b0 = slice * bps, b1 = min(a.B, b0 + bps);
@@ -279,13 +283,14 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_kernel(const WinAttnArgs 
       for (int e = 0; e < 16; ++e) dT[it][jt][e] = 0.f;
   for (int b = b0 + wave; b < b1; b += 4) {
     const long bw = (long)b * a.nW + w;
-    const long ebase = (a.img_w > 0 ? (long)b * a.nW : bw) * WA_N * a.C + hh * DH;
+    const long rbase = (a.img_w > 0 ? (long)b * a.nW : bw) * WA_N;
+    const long ebase = rbase * a.ld + hh * DH, obase = rbase * a.C + hh * DH;
 #pragma unroll
     for (int n = 0; n < CH; ++n) {
       wa_dma16(a.q + ebase, voff[n], wa_lds_addr(Qs) + n * 1024);
       wa_dma16(a.k + ebase, voff[n], wa_lds_addr(Ks) + n * 1024);
       wa_dma16(a.v + ebase, voff[n], wa_lds_addr(Vs) + n * 1024);
-      wa_dma16(a.dout + ebase, voff[n], wa_lds_addr(Gs) + n * 1024);
+      wa_dma16(a.dout + obase, voff_o[n], wa_lds_addr(Gs) + n * 1024);
     }
     const float my_lse = a.lse2[(bw * a.H + hh) * WA_N + lane];
     wa_wait_dma();
@@ -445,7 +450,7 @@ int mmk_win_attn_supported(int tokens, int dh, int c) { return tokens == WA_N &&
 int mmk_win_attn_blocks(int B, int nW, int H) { return nW * wa_nsplit(B, nW, H) * H; }
 
 int mmk_win_attn_fwd(const void* q, const void* k, const void* v, const float* table, void* o, float* lse2, int B, int nW, int nWt, int H, int dh,
-                     float scale, int img_h, int img_w, int shift, void* stream) {
+                     float scale, int img_h, int img_w, int shift, int ld, void* stream) {
   MMK_REQUIRE(q && k && v && table && o && lse2 && B > 0 && nW > 0 && H > 0, "win_attn_fwd: bad arguments");
   MMK_REQUIRE(dh == 24 || dh == 32, "win_attn: head dim must be 24 or 32");
   MMK_REQUIRE(nWt == 1 || nWt == nW, "win_attn: the table has one entry per head or one per (window position, head)");
@@ -456,11 +461,14 @@ int mmk_win_attn_fwd(const void* q, const void* k, const void* v, const float* t
               "win_attn: a token map must be a whole number of 8 x 8 windows");
   a.B = B; a.nW = nW; a.nWt = nWt; a.H = H; a.C = H * dh; a.nsplit = wa_nsplit(B, nW, H); a.scale = scale;
   a.img_h = img_w > 0 ? img_h : 0; a.img_w = img_w; a.shift = img_w > 0 ? shift : 0;
+  MMK_REQUIRE(ld == a.C || ld == 3 * a.C, "win_attn: q / k / v rows are C or 3 C elements apart");
+  a.ld = ld;
   return dh == 24 ? wa_launch<24>(a, false, static_cast<hipStream_t>(stream)) : wa_launch<32>(a, false, static_cast<hipStream_t>(stream));
 }
 
 int mmk_win_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse2, const float* table, void* dq, void* dk,
-                     void* dv, float* dtab_part, int B, int nW, int nWt, int H, int dh, float scale, int img_h, int img_w, int shift, void* stream) {
+                     void* dv, float* dtab_part, int B, int nW, int nWt, int H, int dh, float scale, int img_h, int img_w, int shift, int ld,
+                     void* stream) {
   MMK_REQUIRE(q && k && v && dout && lse2 && table && dq && dk && dv && dtab_part && B > 0 && nW > 0 && H > 0, "win_attn_bwd: bad arguments");
   MMK_REQUIRE(dh == 24 || dh == 32, "win_attn: head dim must be 24 or 32");
   MMK_REQUIRE(nWt == 1 || nWt == nW, "win_attn: the table has one entry per head or one per (window position, head)");
@@ -472,6 +480,8 @@ int mmk_win_attn_bwd(const void* q, const void* k, const void* v, const void* do
               "win_attn: a token map must be a whole number of 8 x 8 windows");
   a.B = B; a.nW = nW; a.nWt = nWt; a.H = H; a.C = H * dh; a.nsplit = wa_nsplit(B, nW, H); a.scale = scale;
   a.img_h = img_w > 0 ? img_h : 0; a.img_w = img_w; a.shift = img_w > 0 ? shift : 0;
+  MMK_REQUIRE(ld == a.C || ld == 3 * a.C, "win_attn: q / k / v rows are C or 3 C elements apart");
+  a.ld = ld;
   return dh == 24 ? wa_launch<24>(a, true, static_cast<hipStream_t>(stream)) : wa_launch<32>(a, true, static_cast<hipStream_t>(stream));
 }
 

@@ -921,6 +921,36 @@ class _WindowAttentionFn(torch.autograd.Function):
         return dq, dk, dv, dtab.to(ctx.bias_dtype), None, None, None, None, None
 
 
+class _WindowAttentionPackedFn(torch.autograd.Function):
+    """The same node on ONE packed ``[..., 3 C]`` projection output (q | k | v): the kernels read the thirds in place and write the
+    three gradients into the thirds of one ``[..., 3 C]`` buffer, so the projection is one GEMM each way (and one weight-gradient
+    launch, one bias column sum) instead of three, and the three input gradients need no adding up."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias, mask, heads, scale, grid, shift):
+        c = qkv.shape[-1] // 3
+        n_win = (grid[0] // 8) * (grid[1] // 8) if grid is not None else (1 if mask is None else mask.shape[0])
+        table = (bias.detach().float()[None] if mask is None else bias.detach().float()[None] + mask.float()[:, None]).contiguous()
+        o, lse2 = K.win_attn_fwd(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], table, heads, n_win, scale, grid, shift)
+        ctx.save_for_backward(qkv, lse2, table)
+        ctx.cfg, ctx.bias_dtype = (heads, n_win, scale, grid, shift), bias.dtype
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, lse2, table = ctx.saved_tensors
+        heads, n_win, scale, grid, shift = ctx.cfg
+        c = qkv.shape[-1] // 3
+        dq, _, _, dtab = K.win_attn_bwd(qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], do.contiguous(), lse2, table, heads, n_win, scale, grid, shift)
+        return dq._base, dtab.to(ctx.bias_dtype), None, None, None, None, None
+
+
+def window_attention_packed(qkv: torch.Tensor, bias: torch.Tensor, mask: Optional[torch.Tensor], heads: int, scale: float,
+                            grid: Optional[tuple] = None, shift: int = 0) -> torch.Tensor:
+    """:func:`window_attention` on a packed bf16 ``[..., 3 C]`` tensor holding q | k | v along the last dimension; returns ``[..., C]``."""
+    return _WindowAttentionPackedFn.apply(qkv.contiguous(), bias, mask, heads, scale, grid, int(shift))
+
+
 def window_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias: torch.Tensor, mask: Optional[torch.Tensor], heads: int,
                      scale: float, grid: Optional[tuple] = None, shift: int = 0) -> torch.Tensor:
     """``q, k, v``: bf16 ``[B * n_win, 64, heads * dh]`` (dh 24 or 32); ``bias``: ``[heads, 64, 64]`` relative-position bias (gets a
@@ -969,13 +999,19 @@ def _swin_layer_forward(self, hidden_states, input_dimensions, output_attentions
         return self._mmk_stock_forward(hidden_states, input_dimensions, output_attentions, True)   # shift / window size are set already
     shortcut = hidden_states
     x = self.layernorm_before(hidden_states)
-    q, k, v = att.query(x), att.key(x), att.value(x)
-    if q.dtype != torch.bfloat16:
+    # the three projections as ONE GEMM on the concatenated weights (a copy of three small matrices per step; autograd hands the
+    # thirds of the packed weight gradient back to the three parameters)
+    biases = (att.query.bias, att.key.bias, att.value.bias)
+    if any(b is None for b in biases) != all(b is None for b in biases):
+        return self._mmk_stock_forward(hidden_states, input_dimensions, output_attentions, True)
+    w = torch.cat([att.query.weight, att.key.weight, att.value.weight], 0)
+    qkv = linear(x, w, None if biases[0] is None else torch.cat(biases, 0))
+    if qkv.dtype != torch.bfloat16:
         return self._mmk_stock_forward(hidden_states, input_dimensions, output_attentions, True)
     bias = att.relative_position_bias_table[att.relative_position_index.view(-1)]
     bias = bias.view(n_tok, n_tok, -1).permute(2, 0, 1).contiguous()
     mask = self.get_attn_mask(height, width, dtype=torch.float32, device=hidden_states.device)
-    ctx_map = window_attention(q, k, v, bias, mask, att.num_attention_heads, 1.0 / math.sqrt(att.attention_head_size), (height, width), shift)
+    ctx_map = window_attention_packed(qkv, bias, mask, att.num_attention_heads, 1.0 / math.sqrt(att.attention_head_size), (height, width), shift)
     attention_output = self.attention.output(ctx_map, x)
     hidden_states = shortcut + self.drop_path(attention_output)
     layer_output = self.layernorm_after(hidden_states)

@@ -999,63 +999,75 @@ def win_attn_supported(tokens: int, head_dim: int, channels: int) -> bool:
     return bool(_lib.lib().mmk_win_attn_supported(int(tokens), int(head_dim), int(channels)))
 
 
-def _win_attn_check(q, k, v, table, heads, n_win):
-    require_gpu(q)
-    Bw, T, Cc = q.shape
-    assert q.dtype == torch.bfloat16 and k.dtype == q.dtype and v.dtype == q.dtype, "windowed attention runs on bf16 projections"
-    assert k.shape == q.shape and v.shape == q.shape and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
-    assert Cc % heads == 0 and win_attn_supported(T, Cc // heads, Cc), "windowed attention: 64-token windows, head dim 24 or 32"
-    assert Bw % n_win == 0 and table.dtype == torch.float32 and table.is_contiguous()
-    assert table.shape in ((1, heads, T, T), (n_win, heads, T, T)), table.shape
-    return Bw // n_win, Cc // heads
-
-
-def _win_map(q, n_win, grid, shift):
-    """Token-map mode: q .. are [B, h * w, C] maps of an (h, w) token grid, windows gathered in the kernel -> (q as [B * n_win, 64, C] view, h, w, shift)."""
+def _win_geometry(rows_total: int, n_win: int, grid, shift):
+    """-> (B, img_h, img_w, shift) for ``rows_total`` token rows: window mode (grid None: rows = B * n_win * 64) or token-map mode."""
+    assert rows_total % (n_win * 64) == 0, (rows_total, n_win)
     if grid is None:
-        return q, 0, 0, 0
+        return rows_total // (n_win * 64), 0, 0, 0
     gh, gw = grid
-    assert gh % 8 == 0 and gw % 8 == 0 and (gh // 8) * (gw // 8) == n_win and 0 <= shift < 8 and q.shape[1] == gh * gw, (grid, n_win, q.shape)
-    return q.view(-1, 64, q.shape[-1]), gh, gw, int(shift)
+    assert gh % 8 == 0 and gw % 8 == 0 and (gh // 8) * (gw // 8) == n_win and 0 <= shift < 8, (grid, n_win, shift)
+    return rows_total // (gh * gw), gh, gw, int(shift)
+
+
+def _win_operands(q, k, v, heads):
+    """q / k / v: bf16 [..., C] with equal shapes and strides, last dim contiguous, rows ``ld`` elements apart with ld = C (separate
+    contiguous tensors) or 3 C (the thirds of one packed [..., 3 C] projection output) -> (rows, C, dh, ld)."""
+    require_gpu(q)
+    Cc = q.shape[-1]
+    assert q.dtype == torch.bfloat16 and k.dtype == q.dtype and v.dtype == q.dtype, "windowed attention runs on bf16 projections"
+    assert k.shape == q.shape and v.shape == q.shape and q.stride() == k.stride() == v.stride() and q.stride(-1) == 1
+    ld = q.stride(-2)
+    rows = q.numel() // Cc
+    assert ld in (Cc, 3 * Cc) and all(q.stride(i) == q.stride(i + 1) * q.shape[i + 1] for i in range(q.dim() - 2)), "rows must be evenly spaced"
+    assert Cc % heads == 0 and win_attn_supported(64, Cc // heads, Cc), "windowed attention: 64-token windows, head dim 24 or 32"
+    return rows, Cc, Cc // heads, ld
+
+
+def _win_table(table, heads, n_win):
+    assert table.dtype == torch.float32 and table.is_contiguous() and table.shape in ((1, heads, 64, 64), (n_win, heads, 64, 64)), table.shape
 
 
 def win_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: torch.Tensor, heads: int, n_win: int, scale: float,
                  grid: Optional[Tuple[int, int]] = None, shift: int = 0):
     """Windowed attention (csrc/window_attention.hip): q/k/v bf16 [B * n_win, 64, heads * dh] (window ``b * n_win + w``), table f32
-    [1 | n_win, heads, 64, 64] = relative-position bias (+ mask of window position w) -> (o like q, lse2 f32 [B * n_win, heads, 64]).
+    [1 | n_win, heads, 64, 64] = relative-position bias (+ mask of window position w) -> (o like q, contiguous, lse2 f32 [B * n_win, heads, 64]).
     With ``grid = (h, w)`` the tensors are ``[B, h * w, C]`` token maps instead and window ``w`` of the map rolled by ``-shift`` is gathered
-    / scattered by the kernel (HF's ``roll -> window_partition -> ... -> window_reverse -> roll`` without the four copies)."""
-    shape = q.shape
-    q, gh, gw, shift = _win_map(q, n_win, grid, shift)
-    k, v = k.view(q.shape), v.view(q.shape)
-    B, dh = _win_attn_check(q, k, v, table, heads, n_win)
-    o = torch.empty_like(q)
-    lse2 = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device)
+    / scattered by the kernel (HF's ``roll -> window_partition -> ... -> window_reverse -> roll`` without the four copies).
+    q / k / v may be the three thirds of one packed ``[..., 3 C]`` tensor (row stride 3 C)."""
+    rows, Cc, dh, ld = _win_operands(q, k, v, heads)
+    _win_table(table, heads, n_win)
+    B, gh, gw, shift = _win_geometry(rows, n_win, grid, shift)
+    o = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    lse2 = torch.empty((rows // 64, heads, 64), dtype=torch.float32, device=q.device)
     check(_lib.lib().mmk_win_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(table), ptr(o), ptr(lse2), B, n_win, table.shape[0], heads, dh, float(scale),
-                                      gh, gw, shift, stream()))
-    return o.view(shape), lse2
+                                      gh, gw, shift, ld, stream()))
+    return o, lse2
 
 
 def win_attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dout: torch.Tensor, lse2: torch.Tensor, table: torch.Tensor, heads: int,
                  n_win: int, scale: float, grid: Optional[Tuple[int, int]] = None, shift: int = 0):
-    """-> (dq, dk, dv like q, dtable f32 [heads, 64, 64] = the gradient of the relative-position bias: dS summed over windows and
-    batch).  The kernel leaves one partial per workgroup; they are added here per head in a fixed order."""
-    shape = q.shape
-    q, gh, gw, shift = _win_map(q, n_win, grid, shift)
-    k, v, dout = k.view(q.shape), v.view(q.shape), dout.view(q.shape)
-    B, dh = _win_attn_check(q, k, v, table, heads, n_win)
-    assert dout.dtype == q.dtype and dout.is_contiguous() and lse2.is_contiguous()
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    """-> (dq, dk, dv, dtable f32 [heads, 64, 64] = the gradient of the relative-position bias: dS summed over windows and batch).
+    dq / dk / dv have q's layout: three contiguous tensors, or -- for packed q / k / v -- the thirds of ONE new ``[..., 3 C]`` tensor
+    (``dq._base`` is it).  The kernel leaves one bias-gradient partial per workgroup; they are added here per head in a fixed order."""
+    rows, Cc, dh, ld = _win_operands(q, k, v, heads)
+    _win_table(table, heads, n_win)
+    B, gh, gw, shift = _win_geometry(rows, n_win, grid, shift)
+    assert dout.shape == q.shape and dout.dtype == q.dtype and dout.is_contiguous() and lse2.is_contiguous()
+    if ld == Cc:
+        dq, dk, dv = torch.empty_like(dout), torch.empty_like(dout), torch.empty_like(dout)
+    else:
+        dqkv = torch.empty(q.shape[:-1] + (3 * Cc,), dtype=q.dtype, device=q.device)
+        dq, dk, dv = dqkv[..., :Cc], dqkv[..., Cc:2 * Cc], dqkv[..., 2 * Cc:]
     nblk = int(_lib.lib().mmk_win_attn_blocks(B, n_win, heads))
     part = torch.empty((nblk, 64 * 64), dtype=torch.float32, device=q.device)
     check(_lib.lib().mmk_win_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(dout), ptr(lse2), ptr(table), ptr(dq), ptr(dk), ptr(dv), ptr(part), B, n_win,
-                                      table.shape[0], heads, dh, float(scale), gh, gw, shift, stream()))
+                                      table.shape[0], heads, dh, float(scale), gh, gw, shift, ld, stream()))
     npairs = nblk // heads
     if npairs % 8 == 0:   # block id = ((group * heads + head) * 8 + x): see wa_decode_block
         dtab = part.view(npairs // 8, heads, 8, 64 * 64).sum(dim=(0, 2))
     else:                 # block id = pair * heads + head
         dtab = part.view(npairs, heads, 64 * 64).sum(0)
-    return dq.view(shape), dk.view(shape), dv.view(shape), dtab.view(heads, 64, 64)
+    return dq, dk, dv, dtab.view(heads, 64, 64)
 
 
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0):

@@ -114,6 +114,34 @@ def test_token_map_mode_is_roll_partition_attention_reverse_roll(shift):
     assert (res[0][4] - res[1][4]).abs().max().item() <= 1e-5 * max(1.0, res[1][4].abs().max().item())   # partial sums are grouped differently
 
 
+@pytest.mark.parametrize("grid,shift", [(None, 0), ((16, 16), 5)])
+def test_packed_projection_mode_equals_three_separate_tensors(grid, shift):
+    """q | k | v as the thirds of one ``[..., 3 C]`` tensor (row stride 3 C in the kernels, the three gradients written into one packed
+    buffer): bit-identical to the same call on three contiguous tensors, in window mode and in token-map mode."""
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    heads, dh, B = 3, 24, 2
+    C, nW = heads * dh, 4
+    shape = (B * nW, 64, 3 * C) if grid is None else (B, grid[0] * grid[1], 3 * C)
+    if grid is not None:
+        nW = (grid[0] // 8) * (grid[1] // 8)
+    qkv = torch.randn(*shape, generator=g).bfloat16().to(dev).requires_grad_(True)
+    bias = (torch.randn(heads, 64, 64, generator=g) * 0.5).to(dev).requires_grad_(True)
+    region = torch.randint(0, 3, (nW, 64), generator=g)
+    mask = ((region[:, :, None] != region[:, None, :]).float() * -100.0).to(dev)
+    wgt = torch.randn(*shape[:-1], C, generator=g).to(dev)
+    out_p = fused.window_attention_packed(qkv, bias, mask, heads, 0.2, grid, shift)
+    (out_p.float() * wgt).sum().backward()
+    g_p, gb_p = qkv.grad.clone(), bias.grad.clone()
+    qkv.grad = bias.grad = None
+    q, k, v = (qkv[..., i * C:(i + 1) * C].contiguous() for i in range(3))
+    out_s = fused.window_attention(q, k, v, bias, mask, heads, 0.2, grid, shift)
+    (out_s.float() * wgt).sum().backward()
+    assert torch.equal(out_p, out_s) and torch.equal(g_p, qkv.grad) and torch.equal(gb_p, bias.grad)
+
+
 def test_patched_clap_audio_layers_match_the_stock_modules():
     """HF ClapAudioModel (HTSAT, head dim 24, shifted and unshifted layers, four resolutions) with and without the fused windowed
     attention: pooled output and every parameter gradient.  eval() so that the two passes see the same network (no dropout / drop

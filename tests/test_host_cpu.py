@@ -276,3 +276,53 @@ def test_tuned_gemm_selection_file_is_well_formed():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):
             tuned.enable()
+
+
+def test_round4_host_side_planning_functions_without_a_gpu():
+    """Pure host arithmetic of the round-4 entry points (no compute call): scratch sizes of the sorted-run embedding backward follow
+    its level structure, the windowed-attention launch has a pair count that is a multiple of 8 whenever the batch allows (the XCD map
+    of the block ids relies on it) and never more slices than samples, the MLP node pads row counts to whole 256-row tiles."""
+    from mmlearn_amd import _lib, fused
+
+    lib = _lib.lib()
+    d = 768
+    assert lib.mmk_embedding_bwd_scratch_bytes(1024, d) == 256                      # one level: nothing but the alignment slack
+    n1 = 2 * ((78848 + 31) // 32)
+    n2 = 2 * ((n1 + 31) // 32)
+    want = 0
+    for n in (n1, n2):                                                                  # 78,848 rows -> 4,928 -> 308 entries
+        want = (want + n * d * 4 + n * 8 + 255) // 256 * 256
+    assert n2 <= 1024 < n1 and lib.mmk_embedding_bwd_scratch_bytes(78848, d) == want + 256
+    for B, nW, H in ((256, 64, 4), (256, 16, 8), (256, 4, 16), (256, 1, 32), (3, 64, 2), (2, 1, 16), (1, 1, 1)):
+        blocks = lib.mmk_win_attn_blocks(B, nW, H)
+        assert blocks % (nW * H) == 0
+        nsplit = blocks // (nW * H)
+        assert 1 <= nsplit <= B and (B < 8 or (nW * nsplit) % 8 == 0), (B, nW, H, nsplit)
+    assert lib.mmk_win_attn_supported(64, 24, 96) == 1 and lib.mmk_win_attn_supported(64, 32, 96) == 1
+    assert lib.mmk_win_attn_supported(49, 32, 96) == 0 and lib.mmk_win_attn_supported(64, 64, 768) == 0
+    assert lib.mmk_colsum_rows_slices(1) == 1 and lib.mmk_colsum_rows_slices(1 << 20) == 1024
+    assert [fused._pad_rows(m) for m in (256, 1000, 2048, 2049, 5760, 25088)] == [256, 1000, 2048, 2304, 5888, 25088]
+
+
+def test_window_attention_patch_takes_only_the_forward_signatures_it_mirrors():
+    """``fuse_window_attention`` on CPU-built HF models: all of HTSAT's attention modules and layers (``ClapAudioSelfAttention.forward(hidden_states,
+    attention_mask, output_attentions)``), none of a Swin whose forwards carry further arguments; parameters and state_dict keys untouched."""
+    from transformers import ClapAudioConfig, ClapAudioModel
+
+    from mmlearn_amd import fused
+
+    m = ClapAudioModel(ClapAudioConfig(depths=(2, 1), num_attention_heads=(2, 4), patch_embeds_hidden_size=48, hidden_size=96))
+    keys = list(m.state_dict().keys())
+    assert fused.fuse_window_attention(m) == 3 and fused.fuse_window_attention(m) == 0          # idempotent
+    assert sum(getattr(getattr(x, "forward", None), "__func__", None) is fused._swin_layer_forward for x in m.modules()) == 3
+    assert list(m.state_dict().keys()) == keys
+    try:
+        from transformers import SwinConfig, SwinModel
+    except ImportError:
+        return
+    sw = SwinModel(SwinConfig(image_size=64, embed_dim=48, depths=(1, 1), num_heads=(2, 4), window_size=8))
+    import inspect
+    takes = [p for p in inspect.signature(next(x for x in sw.modules() if hasattr(x, "relative_position_bias_table")).forward).parameters]
+    assert fused.fuse_window_attention(sw) == (len([x for x in sw.modules() if hasattr(x, "relative_position_bias_table")])
+                                               if takes == ["hidden_states", "attention_mask", "output_attentions"] else 0)
+

@@ -38,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0          # HBM3E, same guide
 
 
 class VisionEncoder(nn.Module):
@@ -374,8 +375,45 @@ def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2, s
            "tower_fwd_bwd_ms": tower_ms,
            "ms_per_step": round(sec * 1e3, 2), "samples_s": round(b / sec, 1), "steps": steps, "warmup": warmup, "loss": round(float(loss.detach().float()), 4),
            "roofline": _loss_roofline(prof, n_rows=b, n_cols=b, d=512, n_pairs=3, steps=1)}
+    wa = _window_attn_roofline(prof, audio, b)
+    if wa is not None:
+        out["roofline_widened"] = wa
     del task, opt, batch
     torch.cuda.empty_cache()
+    return out
+
+
+def _window_attn_roofline(prof: dict, audio, b: int):
+    """HBM roofline of the windowed-attention kernels of the audio tower (csrc/window_attention.hip) over one step: algorithmic bytes --
+    per window and head q, k, v in and o out forward, q, k, v, dO in and dq, dk, dv out backward, [64 x head_dim] bf16 each, + lse --
+    summed over the tower's layers, over the kernels' dispatch-stamped durations.  `traffic` = HBM-side bytes of ONE first-resolution
+    launch pair from the committed PMC passes (profiles/r04_window_attn_pmc_traffic.json), with its algorithmic bytes beside it."""
+    f, g = prof.get("win_attn_fwd"), prof.get("win_attn_bwd")
+    if not f or not g or not f[0] or not g[0]:
+        return None
+    units = 0       # sum over layers of (window-heads x 64 x head_dim x 2 bytes) = bytes of one [tokens, C] operand
+    lse = 0
+    for m in audio.modules():
+        if hasattr(m, "relative_position_bias_table") and hasattr(m, "all_head_size"):
+            rows = getattr(m, "_mmk_rows", None)    # token rows its last fused call attended over (set by the patched forwards)
+            if not rows:
+                continue
+            units += rows * m.all_head_size * 2
+            lse += rows * m.num_attention_heads * 4
+    if not units:
+        return None
+    alg = (4 + 7) * units + 2 * lse
+    sec = (f[1] + g[1]) * 1e-3
+    out = {"bound": "hbm", "kernel": "win_attn_fwd + win_attn_bwd", "achieved": round(alg / sec * 1e-9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": round(alg / sec * 1e-9 / HBM_PEAK_GBPS, 4), "traffic": None, "launches": int(f[0] + g[0]),
+           "device_us_per_step": round(sec * 1e6, 1), "algorithmic_bytes_per_step": int(alg)}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_window_attn_pmc_traffic.json")))
+        out["traffic"] = int(pmc["fwd"]["hbm_bytes_per_launch"] + pmc["bwd"]["hbm_bytes_per_launch"])
+        out["traffic_note"] = (f"one forward + backward launch at the first resolution ({pmc['windows_per_sample']} windows x {pmc['heads']} heads, batch "
+                               f"{pmc['batch']}): {pmc['fwd']['algorithmic_bytes'] + pmc['bwd']['algorithmic_bytes']} algorithmic bytes")
+    except Exception:
+        pass
     return out
 
 

@@ -47,7 +47,7 @@ enum {
   MMK_K_SIM_GRAD, MMK_K_GRAD_GEMM, MMK_K_GRAD_FINALIZE, MMK_K_L2NORM, MMK_K_IJEPA_LOSS_FWD,
   MMK_K_IJEPA_LOSS_BWD, MMK_K_GATHER_ROWS, MMK_K_SCATTER_ROWS, MMK_K_PRED_ASSEMBLE, MMK_K_PRED_ASSEMBLE_BWD,
   MMK_K_EMA, MMK_K_MASK_INDEX, MMK_K_LAYERNORM_FWD, MMK_K_LAYERNORM_BWD, MMK_K_ACT, MMK_K_ATTN_FWD,
-  MMK_K_ATTN_BWD, MMK_K_WGRAD, MMK_K_RECALL, MMK_K_CLIP_FUSED, MMK_K_MLP_GEMM, MMK_K_COUNT
+  MMK_K_ATTN_BWD, MMK_K_WGRAD, MMK_K_RECALL, MMK_K_CLIP_FUSED, MMK_K_MLP_GEMM, MMK_K_WIN_ATTN_FWD, MMK_K_WIN_ATTN_BWD, MMK_K_COUNT
 };
 int mmk_profile_enable(int on);          /* on=1 start recording (clears), on=0 stop */
 /* resolve recorded events (synchronises on them); fills count[k] and total_ms[k] for k < MMK_K_COUNT */

@@ -20,7 +20,7 @@
 // orientation's registers; the bias gradient, sum over items of dS, stays in 64 registers per wave across the items of the
 // workgroup and leaves as one [64][64] partial per workgroup.  The pass is HBM-bound by design: 4 reads + 3 writes of [64][24]
 // per item, ~100 small MFMAs.
-#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "common.h"
@@ -429,10 +429,12 @@ static int wa_launch(const WinAttnArgs& a0, bool bwd, hipStream_t st) {
   const unsigned grid = (unsigned)(a.nW * a.nsplit * a.H);
   if (bwd) {
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn_bwd_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((win_attn_bwd_kernel<DH>), dim3(grid), dim3(256), lds, st, a);
+    ProfEvents pe(MMK_K_WIN_ATTN_BWD);   // dispatch-stamped start / stop (bench.py's per-kernel times), null when profiling is off
+    hipExtLaunchKernelGGL((win_attn_bwd_kernel<DH>), dim3(grid), dim3(256), lds, st, pe.start, pe.stop, 0, a);
   } else {
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn_fwd_kernel<DH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((win_attn_fwd_kernel<DH>), dim3(grid), dim3(256), lds, st, a);
+    ProfEvents pe(MMK_K_WIN_ATTN_FWD);
+    hipExtLaunchKernelGGL((win_attn_fwd_kernel<DH>), dim3(grid), dim3(256), lds, st, pe.start, pe.stop, 0, a);
   }
   MMK_LAUNCH_CHECK();
   return 0;

@@ -977,6 +977,7 @@ def _window_self_attention_forward(self, hidden_states, attention_mask=None, out
     bias = self.relative_position_bias_table[self.relative_position_index.view(-1)]
     bias = bias.view(n_tok, n_tok, -1).permute(2, 0, 1).contiguous()
     ctx_layer = window_attention(q, k, v, bias, attention_mask, self.num_attention_heads, 1.0 / math.sqrt(self.attention_head_size))
+    self._mmk_rows = q.shape[0] * q.shape[1]
     return (ctx_layer,)
 
 
@@ -1012,6 +1013,7 @@ def _swin_layer_forward(self, hidden_states, input_dimensions, output_attentions
     bias = bias.view(n_tok, n_tok, -1).permute(2, 0, 1).contiguous()
     mask = self.get_attn_mask(height, width, dtype=torch.float32, device=hidden_states.device)
     ctx_map = window_attention_packed(qkv, bias, mask, att.num_attention_heads, 1.0 / math.sqrt(att.attention_head_size), (height, width), shift)
+    att._mmk_rows = qkv.shape[0] * qkv.shape[1]   # (host-side bookkeeping for bench.py's byte count)
     attention_output = self.attention.output(ctx_map, x)
     hidden_states = shortcut + self.drop_path(attention_output)
     layer_output = self.layernorm_after(hidden_states)

@@ -207,7 +207,10 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel16(const WgradArgs a) {
 }
 #endif  // MMK_DEBUG_SWITCHES
 
-template <bool PAIR>
+// NARROW: instantiated for weights whose N or K is not a multiple of 256 -- only there can a wave's 64 x 64 block fall outside [N, K].
+// The full-size shapes keep the loop without the test (with it they ran 1-4 % slower in a same-box A/B: the early `continue`
+// changes the stage loop's code).
+template <bool PAIR, bool NARROW = false>
 __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -249,7 +252,12 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
   const long row_end = min((long)a.M, row0 + a.rows_per_split);
   const int nstages = (int)((row_end - row0 + WG_BM - 1) / WG_BM);
 
-  const int wm = wave >> 2, wn = wave & 3;  // wave grid 4 x 4: output rows 64 wm.., output columns 64 wn..
+  // wave grid 4 x 4: output rows 64 wm.., output columns 64 wn...  A wave whose 64 x 64 block lies wholly beyond [N, K] (narrow
+  // layers: a 96 x 96 weight fills 4 of the 16 blocks) takes part in the fills and barriers only -- it issues no fragment reads and
+  // no MFMAs, and stores its zero accumulators into the workspace padding.  (Spreading a narrow tile's active waves over all four
+  // SIMDs by another wave -> block map was tried: +1 % on the full-size shapes, nothing on the narrow ones, which are load-bound.)
+  const int wm = wave >> 2, wn = wave & 3;
+  const bool active = !NARROW || (tn * WG_TILE + 64 * wm < a.N && tk * WG_TILE + 64 * wn < a.K);
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -291,6 +299,7 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of stage st
     __syncthreads();                     // stage st complete; every wave is done with the other buffer
     if (st + 1 < nstages) issue(st + 1);
+    if (NARROW && !active) continue;
     // per-stage base through an opaque value: the 12 per-lane fragment addresses are rebuilt here once per stage instead of
     // being hoisted for both buffers out of the loop (LDS offsets >= 64 KiB do not fit an instruction immediate, the
     // hoisted copies spilled)
@@ -437,6 +446,7 @@ static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int
   if (!attr) {
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     attr = true;
   }
   {
@@ -445,7 +455,9 @@ static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int
     if (mfma16) hipExtLaunchKernelGGL(wgrad_kernel16, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
     else
 #endif
-    if (pair) hipExtLaunchKernelGGL(wgrad_kernel<true>, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
+    if (pair && (N % WG_TILE != 0 || K % WG_TILE != 0))
+      hipExtLaunchKernelGGL((wgrad_kernel<true, true>), dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
+    else if (pair) hipExtLaunchKernelGGL(wgrad_kernel<true>, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
     else hipExtLaunchKernelGGL(wgrad_kernel<false>, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
   }
   MMK_LAUNCH_CHECK();

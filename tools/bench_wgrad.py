@@ -14,6 +14,8 @@ SHAPES = [(M, N, K_) for M in (1024 * 197, 1024 * 77) for N, K_ in ((768, 768), 
 if os.environ.get("SHAPES") == "ijepa":   # ViT-L/16 context / target rows and the 384-wide predictor (tools/bench_ijepa_step.py)
     SHAPES = [(M, N, K_) for M in (4096, 8192, 12288, 25088) for N, K_ in ((1024, 1024), (3072, 1024), (4096, 1024), (1024, 4096))]
     SHAPES += [(M, N, K_) for M in (16384, 53760) for N, K_ in ((384, 384), (1152, 384), (1536, 384), (384, 1536))]
+if os.environ.get("SHAPES") == "htsat":   # HTSAT at batch 256: four resolutions, packed q|k|v, out, fc1, fc2
+    SHAPES = [(256 * t, n * c, k * c) for t, c in ((4096, 96), (1024, 192), (256, 384), (64, 768)) for n, k in ((3, 1), (1, 1), (4, 1), (1, 4))]
 for M, N, K_ in SHAPES:
     if True:
         dy = torch.randn(M, N, device=dev).bfloat16()

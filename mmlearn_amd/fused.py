@@ -367,8 +367,9 @@ class _MLPFn(torch.autograd.Function):
     * backward: ``dPre = (dY W2) * G`` and ``db1 = dPre.sum(0)`` inside fc2's dX GEMM (the unfused step writes ``dY W2``, reads it
       back with the pre-activation and writes ``dPre``: two passes over [rows, hidden] more).
 
-    fc2's forward and fc1's dX stay library GEMMs, both weight gradients run on ``csrc/wgrad.hip``.  Shapes the kernels do not serve
-    (rows not a multiple of 256, ...) take the library GEMM + ``bias_act`` kernels inside the same node."""
+    fc2's forward and fc1's dX stay library GEMMs, both weight gradients run on ``csrc/wgrad.hip``.  Row counts that are not a
+    multiple of 256 are padded with zero rows for the two fused kernels (``_pad_rows``); shapes the kernels do not serve at all
+    (widths that are not multiples of 256 / 64, small MLPs) take the library GEMM + ``bias_act`` kernels inside the same node."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, act):

@@ -368,6 +368,10 @@ int mmk_colsum_f32(const float* part, int n_rows, int d, float* part2, float* ou
 /* out[n] (f32) = column sums of x [rows, n] (bf16, n % 8 == 0, or f32, n % 4 == 0; contiguous): `grad_output.sum(0)`, the bias gradient
  * of every nn.Linear whose bias no neighbouring kernel takes care of (HTSAT's, under mmlearn/modules/encoders/).  part: f32 workspace
  * [mmk_colsum_rows_slices(rows), n]; fixed summation order. */
+/* F.interpolate(x, (h_out, w), mode="bicubic", align_corners=True) for an input whose last axis keeps its length -- the spectrogram
+ * stretch of HF ClapAudioEncoder.reshape_mel2img (HTSAT, BASELINE configs[3]): x f32 [n_img, h_in, w] -> y [n_img, h_out, w], ATen's
+ * taps and arithmetic along the one axis that changes; backward != 0 computes the input gradient from the output gradient. */
+int mmk_cubic_resize_rows(const float* x, float* y, int64_t n_img, int h_in, int h_out, int w, int backward, void* stream);
 int mmk_colsum_rows_slices(int64_t rows);
 int mmk_colsum_rows(const void* x, int64_t rows, int n, int dtype, float* part, float* out, void* stream);
 

@@ -127,6 +127,7 @@ _SIGNATURES = {
     "mmk_adamw_update": [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, C.c_int64, _vp],
     "mmk_adamw_update_dev": [_vp, _vp, _vp, _vp, _i, _vp, _f, _f, _f, _f, _vp, _vp],
     "mmk_embedding_bwd": [_vp, _vp, _vp, C.c_int64, _i, C.c_int64, _i, _vp],
+    "mmk_cubic_resize_rows": [_vp, _vp, C.c_int64, _i, _i, _i, _i, _vp],
     "mmk_colsum_rows_slices": [C.c_int64],
     "mmk_colsum_rows": [_vp, C.c_int64, _i, _i, _vp, _vp, _vp],
     "mmk_embedding_bwd_scratch_bytes": [C.c_int64, _i],

@@ -566,6 +566,74 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const G* __restrict_
   }
 }
 
+// ------------------------------------------------------------------ bicubic resize along one axis (HTSAT's spectrogram stretch)
+// HF ClapAudioEncoder.reshape_mel2img stretches the [B, 1, T = 1001, F = 64] log-mel input to T' = 1024 frames with
+// F.interpolate(mode="bicubic", align_corners=True): ATen's 2-D kernel evaluates 4 x 4 taps per output although the F axis keeps
+// its length (its four weights are exactly 0, 1, 0, 0) -- 1.3 ms forward and 1.3 ms backward for 67 MB, the gradient being needed
+// because a BatchNorm sits in front.  These are the same taps along T only (A = -0.75, source coordinate scale * o with
+// scale = (T - 1) / (T' - 1) in float, indices clamped: ATen's arithmetic, same order of the four products), float4 along F.
+__device__ __forceinline__ void cubic_taps(float scale, int o, int h_in, int (&idx)[4], float (&c)[4]) {
+  // the product is rounded to float BEFORE the fraction is taken, as in ATen's kernel: at o ~ 1000 its spacing is 6e-5, and the fused
+  // multiply-subtract the compiler forms here otherwise (v_fma_f32 scale, o, -floor) moves the outputs by 2e-4.  The empty asm makes
+  // the rounded product a value the subtraction cannot look through.
+  float real = scale * (float)o;
+  asm volatile("" : "+v"(real));
+  const int i0 = (int)floorf(real);
+  const float t = real - (float)i0, A = -0.75f;
+  const float x0 = t + 1.f, x2 = 1.f - t, x3 = x2 + 1.f;
+  c[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+  c[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+  c[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+  c[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) idx[k] = min(max(i0 - 1 + k, 0), h_in - 1);
+}
+
+__global__ __launch_bounds__(256) void cubic_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n_img, int h_in, int h_out,
+                                                             int w4, float scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_img * h_out * w4) return;
+  const int c = (int)(i % w4), o = (int)((i / w4) % h_out);
+  const long n = i / ((long)w4 * h_out);
+  int idx[4];
+  float cf[4];
+  cubic_taps(scale, o, h_in, idx, cf);
+  const float4* xs = reinterpret_cast<const float4*>(x) + n * h_in * w4 + c;
+  const float4 a = xs[(long)idx[0] * w4], b = xs[(long)idx[1] * w4], d = xs[(long)idx[2] * w4], e = xs[(long)idx[3] * w4];
+  float4 r;
+  r.x = a.x * cf[0] + b.x * cf[1] + d.x * cf[2] + e.x * cf[3];
+  r.y = a.y * cf[0] + b.y * cf[1] + d.y * cf[2] + e.y * cf[3];
+  r.z = a.z * cf[0] + b.z * cf[1] + d.z * cf[2] + e.z * cf[3];
+  r.w = a.w * cf[0] + b.w * cf[1] + d.w * cf[2] + e.w * cf[3];
+  reinterpret_cast<float4*>(y)[i] = r;
+}
+
+// gradient in gather form: input row h collects from the (few) output rows one of whose clamped taps is h -- no atomics, fixed order
+__global__ __launch_bounds__(256) void cubic_rows_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long n_img, int h_in, int h_out,
+                                                             int w4, float scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_img * h_in * w4) return;
+  const int c = (int)(i % w4), h = (int)((i / w4) % h_in);
+  const long n = i / ((long)w4 * h_in);
+  // outputs whose source coordinate lies within [h - 2, h + 2] (+ one of slack each side for the float rounding of scale * o)
+  const int o_lo = max(0, (int)floorf((float)(h - 2) / scale) - 1), o_hi = min(h_out - 1, (int)ceilf((float)(h + 2) / scale) + 1);
+  const float4* gs = reinterpret_cast<const float4*>(dy) + n * h_out * w4 + c;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int o = o_lo; o <= o_hi; ++o) {
+    int idx[4];
+    float cf[4];
+    cubic_taps(scale, o, h_in, idx, cf);
+    float wsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wsum += idx[k] == h ? cf[k] : 0.f;
+    if (wsum != 0.f) {
+      const float4 g = gs[(long)o * w4];
+      acc.x += g.x * wsum; acc.y += g.y * wsum; acc.z += g.z * wsum; acc.w += g.w * wsum;
+    }
+  }
+  reinterpret_cast<float4*>(dx)[i] = acc;
+}
+
 // ------------------------------------------------------------------ column sums of a [rows, n] bf16 / f32 matrix (bias gradient of a Linear)
 // dY.sum(0) for the Linears whose bias no other kernel takes care of (HTSAT's: 73 per step, [1 M x 96] ... [16 k x 3072] bf16).  The block is
 // laid out as (256 / cw) rows x cw 16-byte chunks, cw = chunks of the column group (<= 256 columns of bf16 x 8): every load instruction of
@@ -1034,6 +1102,22 @@ int mmk_embedding_bwd(const void* dout, const int64_t* ids, float* dw, int64_t r
     return 0;
   });
   if (rc) return rc;
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+// y [n_img, h_out, w] = bicubic (A = -0.75, align_corners) stretch of x [n_img, h_in, w] along the middle axis; f32, w % 4 == 0.
+// `backward` != 0: x is the gradient w.r.t. y ([n_img, h_out, w]) and y receives the gradient w.r.t. x ([n_img, h_in, w]).
+int mmk_cubic_resize_rows(const float* x, float* y, int64_t n_img, int h_in, int h_out, int w, int backward, void* stream) {
+  MMK_REQUIRE(x && y && n_img > 0 && h_in > 1 && h_out > 1 && w > 0 && w % 4 == 0, "cubic_resize_rows: f32 [n, h, w] with w % 4 == 0 and h > 1");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const float scale = (float)(h_in - 1) / (float)(h_out - 1);
+  const long total = n_img * (long)(backward ? h_in : h_out) * (w / 4);
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (backward)
+    hipLaunchKernelGGL(cubic_rows_bwd_kernel, dim3(grid), dim3(256), 0, st, x, y, (long)n_img, h_in, h_out, w / 4, scale);
+  else
+    hipLaunchKernelGGL(cubic_rows_fwd_kernel, dim3(grid), dim3(256), 0, st, x, y, (long)n_img, h_in, h_out, w / 4, scale);
   MMK_LAUNCH_CHECK();
   return 0;
 }

@@ -812,6 +812,25 @@ def unpatchify(dcols: torch.Tensor, shape: tuple, patch: int, dtype: torch.dtype
     return out
 
 
+def cubic_resize_rows(x: torch.Tensor, h_out: int, backward_from: Optional[int] = None) -> torch.Tensor:
+    """Bicubic (align_corners) stretch of f32 ``[..., h_in, w]`` to ``[..., h_out, w]`` along the second-to-last axis; with
+    ``backward_from=h_in`` the argument is the gradient w.r.t. the ``[..., h_out, w]`` output and the result the gradient w.r.t. the input."""
+    require_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() >= 2 and x.shape[-1] % 4 == 0
+    w = x.shape[-1]
+    if backward_from is None:
+        h_in = x.shape[-2]
+        y = torch.empty(x.shape[:-2] + (h_out, w), dtype=x.dtype, device=x.device)
+        n_img = x.numel() // (h_in * w)
+        check(_lib.lib().mmk_cubic_resize_rows(ptr(x), ptr(y), n_img, h_in, int(h_out), w, 0, stream()))
+        return y
+    assert x.shape[-2] == h_out
+    y = torch.empty(x.shape[:-2] + (backward_from, w), dtype=x.dtype, device=x.device)
+    n_img = x.numel() // (h_out * w)
+    check(_lib.lib().mmk_cubic_resize_rows(ptr(x), ptr(y), n_img, int(backward_from), int(h_out), w, 1, stream()))
+    return y
+
+
 def colsum_rows(x2: torch.Tensor) -> torch.Tensor:
     """f32 [n] column sums of a contiguous [rows, n] bf16 / f32 matrix in a fixed order (a Linear's bias gradient ``dY.sum(0)``)."""
     require_gpu(x2)

@@ -169,7 +169,7 @@ def test_patched_clap_audio_layers_match_the_stock_modules():
         return out.detach().float(), {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
 
     o0, g0 = run()
-    assert fused.fuse_window_attention(model) == 7
+    assert fused.fuse_window_attention(model) == 7 and fused.patch_mel_stretch(model) == 1
     o1, g1 = run()
     assert (o0 - o1).abs().max().item() <= 3e-2 * max(1.0, o0.abs().max().item())
     assert g0.keys() == g1.keys() and any("relative_position_bias_table" in name for name in g1)
@@ -178,3 +178,24 @@ def test_patched_clap_audio_layers_match_the_stock_modules():
             continue   # softmax is invariant to a constant added to every key's logit: the true gradient is 0, both passes hold rounding noise
         scale = max(1e-3, g0[name].abs().max().item())
         assert (g0[name] - g1[name]).abs().max().item() <= 5e-2 * scale, (name, (g0[name] - g1[name]).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("n,h_in,h_out,w", [(3, 1001, 1024, 64), (2, 10, 37, 8), (1, 2, 5, 4), (4, 300, 301, 12)])
+def test_one_axis_bicubic_stretch_matches_aten(n, h_in, h_out, w):
+    """``kernels.cubic_resize_rows`` against ``F.interpolate(mode="bicubic", align_corners=True)`` on an input whose last axis keeps its
+    length (HTSAT's spectrogram stretch 1001 -> 1024 frames), forward and backward: the same taps in the same order, so equal to f32 rounding."""
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(n + h_in)
+    x = torch.randn(n, 1, h_in, w, generator=g).to(dev).requires_grad_(True)
+    wgt = torch.randn(n, 1, h_out, w, generator=g).to(dev)
+    y = fused._CubicRowsFn.apply(x, h_out)
+    (y * wgt).sum().backward()
+    gx = x.grad.clone()
+    x.grad = None
+    ref = torch.nn.functional.interpolate(x, (h_out, w), mode="bicubic", align_corners=True)
+    (ref * wgt).sum().backward()
+    assert y.shape == ref.shape and (y - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    assert (gx - x.grad).abs().max().item() <= 1e-5 * max(1.0, x.grad.abs().max().item())
+

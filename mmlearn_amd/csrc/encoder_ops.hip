@@ -140,6 +140,87 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const X* __restrict_
     part[(size_t)blockIdx.x * 2 * d + c] = lds[c] + lds[2 * d + c] + lds[4 * d + c] + lds[6 * d + c];
 }
 
+// ------------------------------------------------------------------ LayerNorm of narrow rows (d <= 128): two rows per wave
+// With one row per wave a 96-wide row (HTSAT's first resolution: 1 M rows per LayerNorm) keeps 24 of 64 lanes busy and the kernels run
+// at 2 TB/s.  Here a row takes 32 lanes x float4: lanes 0-31 / 32-63 hold two consecutive rows, the reductions stay inside a half
+// (xor 16 .. 1).  Same arithmetic as the wide kernels (two-pass variance in registers); the backward keeps the wide kernel's
+// block -> rows map (64 rows per block partial), so the callers' workspace sizes do not change.
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <typename X, typename Y>
+__global__ __launch_bounds__(256) void layernorm_fwd_narrow_kernel(const X* __restrict__ x, const float* __restrict__ w,
+                                                                   const float* __restrict__ b, Y* __restrict__ y,
+                                                                   float* __restrict__ mean_out, float* __restrict__ rstd_out, long rows,
+                                                                   int d, float eps) {
+  const int lane = threadIdx.x & 63, sub = lane & 31, c = sub * 4;
+  const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + (lane >> 5);
+  const bool on = row < rows && c < d;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (on) v = Vec4<X>::load(x + row * d + c);
+  const float mean = half_sum(v.x + v.y + v.z + v.w) / d;
+  const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+  const float rstd = rsqrtf(half_sum(on ? a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3 : 0.f) / d + eps);
+  if (sub == 0 && row < rows) {
+    mean_out[row] = mean;
+    rstd_out[row] = rstd;
+  }
+  if (on) {
+    float4 g = make_float4(1.f, 1.f, 1.f, 1.f), o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (w) g = *reinterpret_cast<const float4*>(w + c);
+    if (b) o = *reinterpret_cast<const float4*>(b + c);
+    Vec4<Y>::store(y + row * d + c, make_float4(a0 * rstd * g.x + o.x, a1 * rstd * g.y + o.y, a2 * rstd * g.z + o.z, a3 * rstd * g.w + o.w));
+  }
+}
+
+template <typename X, typename G>
+__global__ __launch_bounds__(256) void layernorm_bwd_narrow_kernel(const X* __restrict__ x, const G* __restrict__ dy, const float* __restrict__ w,
+                                                                   const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                                   X* __restrict__ dx, float* __restrict__ part, long rows, int d) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [4 waves x 2 halves][2][d]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane & 31, seg = lane >> 5, c = sub * 4;
+  float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+  const float4 wv = (w && c < d) ? *reinterpret_cast<const float4*>(w + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const long row0 = ((long)blockIdx.x * 4 + wave) * LN_ROWS_PER_WAVE;
+  for (int q = 0; q < LN_ROWS_PER_WAVE / 2; ++q) {
+    const long row = row0 + 2 * q + seg;
+    const bool on = row < rows && c < d;
+    float4 xh = make_float4(0.f, 0.f, 0.f, 0.f), gy = xh;
+    float rstd = 0.f;
+    if (on) {
+      const float mean = mean_in[row];
+      rstd = rstd_in[row];
+      const float4 xv = Vec4<X>::load(x + row * d + c);
+      const float4 g = Vec4<G>::load(dy + row * d + c);
+      xh = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+      gy = make_float4(g.x * wv.x, g.y * wv.y, g.z * wv.z, g.w * wv.w);
+      dg.x += g.x * xh.x; dg.y += g.y * xh.y; dg.z += g.z * xh.z; dg.w += g.w * xh.w;
+      db.x += g.x; db.y += g.y; db.z += g.z; db.w += g.w;
+    }
+    const float m1 = half_sum(gy.x + gy.y + gy.z + gy.w) / d;
+    const float m2 = half_sum(gy.x * xh.x + gy.y * xh.y + gy.z * xh.z + gy.w * xh.w) / d;
+    if (on)
+      Vec4<X>::store(dx + row * d + c, make_float4(rstd * (gy.x - m1 - xh.x * m2), rstd * (gy.y - m1 - xh.y * m2),
+                                                  rstd * (gy.z - m1 - xh.z * m2), rstd * (gy.w - m1 - xh.w * m2)));
+  }
+  if (part == nullptr) return;
+  float* mine = lds + (size_t)(wave * 2 + seg) * 2 * d;
+  if (c < d) {
+    *reinterpret_cast<float4*>(mine + c) = dg;
+    *reinterpret_cast<float4*>(mine + d + c) = db;
+  }
+  __syncthreads();
+  for (int cc = threadIdx.x; cc < 2 * d; cc += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += lds[(size_t)j * 2 * d + cc];
+    part[(size_t)blockIdx.x * 2 * d + cc] = t;
+  }
+}
+
 // ------------------------------------------------------------------ residual add (+ dropout) + LayerNorm, fused
 // s = r + dropout(x);  y = LN(s).   The transformer blocks' "hidden = residual + sublayer(...)" followed by the next
 // LayerNorm (HF CLIPEncoderLayer: residual + attn -> layer_norm2; BertSelfOutput / BertOutput: LayerNorm(dropout(dense)
@@ -803,7 +884,10 @@ int mmk_layernorm_fwd(const void* x, const float* w, const float* b, void* y, fl
   ProfScope ps(MMK_K_LAYERNORM_FWD, st);
   int rc = MMK_DISPATCH_DTYPE(dtype & 15, X, [&]() -> int {
     return MMK_DISPATCH_DTYPE((dtype >> 4) & 15, Y, [&]() -> int {
-      if (d <= 1024)
+      if (d <= 128)
+        hipLaunchKernelGGL((layernorm_fwd_narrow_kernel<X, Y>), dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st,
+                           static_cast<const X*>(x), w, b, static_cast<Y*>(y), mean, rstd, (long)rows, d, eps);
+      else if (d <= 1024)
         hipLaunchKernelGGL((layernorm_fwd_kernel<X, Y, 4>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st,
                            static_cast<const X*>(x), w, b, static_cast<Y*>(y), mean, rstd, (long)rows, d, eps);
       else
@@ -829,7 +913,11 @@ int mmk_layernorm_bwd(const void* x, const void* dy, const float* w, const float
   const int n_blocks = mmk_layernorm_part_blocks(rows);
   int rc = MMK_DISPATCH_DTYPE(dtype & 15, X, [&]() -> int {
     return MMK_DISPATCH_DTYPE((dtype >> 4) & 15, G, [&]() -> int {
-      if (d <= 1024)
+      if (d <= 128)
+        hipLaunchKernelGGL((layernorm_bwd_narrow_kernel<X, G>), dim3(n_blocks), dim3(256), dw ? 16 * d * sizeof(float) : 0, st,
+                           static_cast<const X*>(x), static_cast<const G*>(dy), w, mean, rstd, static_cast<X*>(dx),
+                           dw ? part : nullptr, (long)rows, d);
+      else if (d <= 1024)
         hipLaunchKernelGGL((layernorm_bwd_kernel<X, G, 4>), dim3(n_blocks), dim3(256), dw ? 8 * d * sizeof(float) : 0, st,
                            static_cast<const X*>(x), static_cast<const G*>(dy), w, mean, rstd, static_cast<X*>(dx),
                            dw ? part : nullptr, (long)rows, d);

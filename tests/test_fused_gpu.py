@@ -15,7 +15,8 @@ def _dev():
 
 
 @pytest.mark.parametrize("rows,d,dtype", [(1000, 768, torch.float32), (17, 64, torch.float32), (33, 2048, torch.float32),
-                                          (513, 1024, torch.bfloat16), (64, 384, torch.float16), (4099, 768, torch.bfloat16)])
+                                          (513, 1024, torch.bfloat16), (64, 384, torch.float16), (4099, 768, torch.bfloat16),
+                                          (1001, 96, torch.float32), (4097, 128, torch.bfloat16), (7, 4, torch.float32), (129, 132, torch.float32)])
 def test_layernorm_fwd_bwd_vs_torch(rows, d, dtype):
     from mmlearn_amd import fused
 

@@ -416,17 +416,9 @@ static int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   constexpr int NW = NT <= 4 ? 4 : 8;
   constexpr int bytes = 4 * LP * 128 + NW * STAGE_BYTES;
   auto kern = attn_fwd_kernel<NT, NW, DROP>;
-  static int wgs_per_cu = 0, cus = 0;
-  if (!wgs_per_cu) {
-    if (bytes > 64 * 1024)
-      MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    int dev = 0;
-    MMK_HIP(hipGetDevice(&dev));
-    MMK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    int occ = 0;
-    MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * NW, bytes));
-    wgs_per_cu = std::max(1, occ);
-  }
+  KernelSetup ks;   // LDS opt-in, occupancy and CU count of this kernel on the current device
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(kern), 64 * NW, bytes, &ks)) return rc;
+  const int cus = ks.cus, wgs_per_cu = ks.wgs_per_cu;
   const int grid = std::min(a.B * a.H, cus * wgs_per_cu * att_grid_factor());
   ProfEvents pe(MMK_K_ATTN_FWD);
   hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), bytes, st, pe.start, pe.stop, 0, a);
@@ -1179,17 +1171,9 @@ static int launch_attn_bwd5(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int bytes = 3 * LP * 128 + 2 * LP * 64 + 2 * ROWC * 4 + NW * STAGE_BYTES;
   static_assert(bytes <= 160 * 1024, "LDS budget");
   auto kern = attn_bwd5_kernel<NT, NW, DROP, STAGED>;
-  static int wgs_per_cu = 0, cus = 0;
-  if (!wgs_per_cu) {
-    if (bytes > 64 * 1024)
-      MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    int dev = 0;
-    MMK_HIP(hipGetDevice(&dev));
-    MMK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    int occ = 0;
-    MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * NW, bytes));
-    wgs_per_cu = std::max(1, occ);
-  }
+  KernelSetup ks;   // LDS opt-in, occupancy and CU count of this kernel on the current device
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(kern), 64 * NW, bytes, &ks)) return rc;
+  const int cus = ks.cus, wgs_per_cu = ks.wgs_per_cu;
   const int grid = std::min(a.B * a.H, cus * wgs_per_cu * att_grid_factor());
   {
     const long chunks = (long)a.B * a.L * a.H * 8;
@@ -1208,17 +1192,9 @@ static int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int bytes = 4 * LP * 128 + 4 * ROWC * 4 + NW * (NT <= 7 ? 32 : 16) * 128;
   static_assert(bytes <= 160 * 1024, "LDS budget");
   auto kern = attn_bwd_kernel<NT, NW, DROP>;
-  static int wgs_per_cu = 0, cus = 0;
-  if (!wgs_per_cu) {
-    if (bytes > 64 * 1024)
-      MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    int dev = 0;
-    MMK_HIP(hipGetDevice(&dev));
-    MMK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    int occ = 0;
-    MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 64 * NW, bytes));
-    wgs_per_cu = std::max(1, occ);
-  }
+  KernelSetup ks;   // LDS opt-in, occupancy and CU count of this kernel on the current device
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(kern), 64 * NW, bytes, &ks)) return rc;
+  const int cus = ks.cus, wgs_per_cu = ks.wgs_per_cu;
   const int grid = std::min(a.B * a.H, cus * wgs_per_cu * att_grid_factor());
   {
     const long chunks = (long)a.B * a.L * a.H * 8;
@@ -1239,19 +1215,10 @@ static int launch_attn_bwd_split(const AttnBwdArgs& a, hipStream_t st) {
   static_assert(bytes <= 160 * 1024, "LDS budget");
   auto k1 = attn_bwd_split_kernel<NT, NW, DROP, 1>;
   auto k2 = attn_bwd_split_kernel<NT, NW, DROP, 2>;
-  static int wgs_per_cu = 0, cus = 0;
-  if (!wgs_per_cu) {
-    if (bytes > 64 * 1024) {
-      MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-      MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    }
-    int dev = 0;
-    MMK_HIP(hipGetDevice(&dev));
-    MMK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    int occ = 0;
-    MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k1, 64 * NW, bytes));
-    wgs_per_cu = std::max(1, occ);
-  }
+  KernelSetup ks, ks2;   // both kernels of the split form: LDS opt-in per device; the grid follows the first one's occupancy
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(k1), 64 * NW, bytes, &ks)) return rc;
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(k2), 64 * NW, bytes, &ks2)) return rc;
+  const int cus = ks.cus, wgs_per_cu = ks.wgs_per_cu;
   const int grid = std::min(a.B * a.H, cus * wgs_per_cu * att_grid_factor());
   {
     const long chunks = (long)a.B * a.L * a.H * 8;

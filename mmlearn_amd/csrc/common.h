@@ -53,6 +53,15 @@ struct ProfEvents {
   ~ProfEvents();
 };
 
+// Launch facts of one kernel on the CURRENT device: the > 64 KiB dynamic-LDS opt-in (a per-device attribute of the function) made,
+// co-resident workgroups per CU at (threads, lds_bytes), and the device's CU count.  Cached per (kernel, device id) under a mutex:
+// first calls can come from the main thread and an autograd worker at once, and a process may drive more than one device.
+struct KernelSetup {
+  int cus;
+  int wgs_per_cu;
+};
+int kernel_setup(const void* kern, int threads, int lds_bytes, KernelSetup* out);
+
 #define MMK_LAUNCH_CHECK()                                                                 \
   do {                                                                                     \
     hipError_t _e = hipGetLastError();                                                     \

@@ -526,15 +526,7 @@ static int mlp_gemm_launch(int mode, int act, MlpGemmArgs& a, hipStream_t st) {
   a.tiles_n = cdiv(a.N, MG_TILE);
   a.dbg = MMK_DBG_ENV("MMK_MLP_GEMM_DBG") ? atoi(MMK_DBG_ENV("MMK_MLP_GEMM_DBG")) : 0;
   a.stamps = MMK_DBG_ENV("MMK_MLP_GEMM_STAMPS") ? reinterpret_cast<unsigned long long*>(strtoull(MMK_DBG_ENV("MMK_MLP_GEMM_STAMPS"), nullptr, 0)) : nullptr;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    MMK_HIP(hipGetDevice(&dev));
-    MMK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    n_cu = std::max(8, n_cu / 8 * 8);
-  }
   const int total = a.tiles_m * a.tiles_n;
-  const int grid = std::min(n_cu, round_up(total, 8));
   // PIPE for the backward only: on the plain product it measured 894 vs 899 us (M = 201,728), i.e. nothing -- the C stores cost
   // the launch ~130 us whenever they are issued (MMK_MLP_GEMM_DBG=4 removes them: 799 us) -- while with G to fetch it is
   // 1130 vs 1189 us
@@ -549,17 +541,9 @@ static int mlp_gemm_launch(int mode, int act, MlpGemmArgs& a, hipStream_t st) {
   MG_PICK(MG_BWD_MUL, 0, false) MG_PICK(MG_BWD_MUL, 0, true)
 #undef MG_PICK
   MMK_REQUIRE(kern != nullptr, "mlp_gemm: unknown (mode, activation)");
-  // opt-in to > 64 KiB of dynamic LDS, once per device and kernel
-  {
-    static bool done[16][16] = {};
-    int dev = 0;
-    MMK_HIP(hipGetDevice(&dev));
-    const int ki = (mode == MG_PLAIN ? 0 : mode == MG_BWD_MUL ? 7 : mode == MG_FWD_ACT_G ? 5 + act : 1 + 2 * (mode - 1) + act) + (pipe ? 8 : 0);
-    if (dev < 0 || dev >= 16 || !done[dev][ki]) {
-      MMK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, MG_LDS));
-      if (dev >= 0 && dev < 16) done[dev][ki] = true;
-    }
-  }
+  KernelSetup ks;   // > 64 KiB LDS opt-in and the CU count, per device and kernel
+  if (int rc = kernel_setup(kern, 512, MG_LDS, &ks)) return rc;
+  const int grid = std::min(std::max(8, ks.cus / 8 * 8), round_up(total, 8));
   {
     ProfEvents pe(MMK_K_MLP_GEMM);
     void* params[] = {&a};

@@ -1,5 +1,7 @@
 // Error reporting, device check and the HIP-event profiling recorder.
+#include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -8,6 +10,26 @@ namespace mmk {
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
+
+int kernel_setup(const void* kern, int threads, int lds_bytes, KernelSetup* out) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, KernelSetup> cache;
+  int dev = 0;
+  MMK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find({kern, dev});
+  if (it == cache.end()) {
+    KernelSetup ks{0, 1};
+    if (lds_bytes > 64 * 1024) MMK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    MMK_HIP(hipDeviceGetAttribute(&ks.cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int occ = 0;
+    MMK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, lds_bytes));
+    ks.wgs_per_cu = occ > 1 ? occ : 1;
+    it = cache.emplace(std::make_pair(kern, dev), ks).first;
+  }
+  *out = it->second;
+  return 0;
+}
 
 struct EventPair {
   int id;

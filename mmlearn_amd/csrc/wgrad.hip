@@ -431,34 +431,25 @@ static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int
   a.splits = cdiv((int)M, a.rows_per_split);
   const int T = a.tiles_n * a.tiles_k;
   const int grid = T <= 32 ? 8 * cdiv(a.splits, 8) * T : 8 * cdiv(a.splits * T, 8);
-  static bool attr = false;
   const int bytes = 4 * WG_STAGE;
   static const bool pair = !(MMK_DBG_ENV("MMK_WGRAD_PAIR") && atoi(MMK_DBG_ENV("MMK_WGRAD_PAIR")) == 0);
 #ifdef MMK_DEBUG_SWITCHES
   // MFMA shape experiment: MMK_WGRAD_MFMA=16 selects the 16x16x32 kernel (read per call: interleaved A/B runs)
   const bool mfma16 = MMK_DBG_ENV("MMK_WGRAD_MFMA") && atoi(MMK_DBG_ENV("MMK_WGRAD_MFMA")) == 16;
-  static bool attr16 = false;
-  if (!attr16) {
-    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel16), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    attr16 = true;
-  }
 #endif
-  if (!attr) {
-    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    MMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    attr = true;
-  }
+  // the variant this shape runs; its > 64 KiB LDS opt-in is made per device (kernel_setup)
+  const void* kern = pair && (N % WG_TILE != 0 || K % WG_TILE != 0) ? reinterpret_cast<const void*>(wgrad_kernel<true, true>)
+                     : pair                                         ? reinterpret_cast<const void*>(wgrad_kernel<true>)
+                                                                    : reinterpret_cast<const void*>(wgrad_kernel<false>);
+#ifdef MMK_DEBUG_SWITCHES
+  if (mfma16) kern = reinterpret_cast<const void*>(wgrad_kernel16);
+#endif
+  KernelSetup ks;
+  if (int rc = kernel_setup(kern, 1024, bytes, &ks)) return rc;
   {
     ProfEvents pe(MMK_K_WGRAD);
-#ifdef MMK_DEBUG_SWITCHES
-    if (mfma16) hipExtLaunchKernelGGL(wgrad_kernel16, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
-    else
-#endif
-    if (pair && (N % WG_TILE != 0 || K % WG_TILE != 0))
-      hipExtLaunchKernelGGL((wgrad_kernel<true, true>), dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
-    else if (pair) hipExtLaunchKernelGGL(wgrad_kernel<true>, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
-    else hipExtLaunchKernelGGL(wgrad_kernel<false>, dim3(grid), dim3(1024), bytes, st, pe.start, pe.stop, 0, a);
+    void* params[] = {&a};
+    MMK_HIP(hipExtLaunchKernel(kern, dim3(grid), dim3(1024), params, bytes, st, pe.start, pe.stop, 0));
   }
   MMK_LAUNCH_CHECK();
   *out = a;

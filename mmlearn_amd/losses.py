@@ -273,7 +273,7 @@ class _Run:
             if ma not in views or mb not in views:
                 continue  # contrastive.py:266-274 / :303-307
             va, vb = views[ma], views[mb]
-            mg = self._paired_match(va.counts, vb.counts, ma, mb) if self.paired else o._matched(va.ids, vb.ids)
+            mg = self._paired_match(va.counts, vb.counts, ma, mb) if self.paired else o._matched(va.ids, vb.ids, (ma, mb, "global"))
             if mg.n == 0:
                 continue  # :283-287 / :314-316
             p = _Pair(spec=spec, r_global=mg.n)
@@ -302,7 +302,7 @@ class _Run:
                 elif self.paired:
                     p.ml = self._paired_match([va.local.shape[0]], [vb.local.shape[0]], ma, mb)
                 else:
-                    p.ml = o._matched(self.example_ids[ma].to(torch.int64), self.example_ids[mb].to(torch.int64))
+                    p.ml = o._matched(self.example_ids[ma].to(torch.int64), self.example_ids[mb].to(torch.int64), (ma, mb, "local"))
                 local_counts_needed.append(p)
 
         if local_mode and self.pairs:
@@ -361,7 +361,7 @@ class _Run:
         # would round every row to the same bits while staging it
         def _twin(t):   # (copy, version of t when the copy was written): stale after an in-place edit of t
             pair = getattr(t, "_mmk_bf16_nograd", None)
-            return pair[0] if pair is not None and pair[1] == t._version else None
+            return pair[0] if pair is not None and not t.is_inference() and pair[1] == t._version else None
 
         twins = {m: _twin(views[m].local) for m in src}
         if all(t is not None and t.dtype == torch.bfloat16 and t.shape == src[m].shape and t.device == src[m].device and t.is_contiguous()
@@ -900,13 +900,14 @@ class ContrastiveLoss(nn.Module):
                 pm.side_stream = stream
                 self._pending_match.append(pm)
 
-    def _matched_in_capture(self, ids_a: torch.Tensor, ids_b: torch.Tensor) -> "K.Match":
+    def _matched_in_capture(self, ids_a: torch.Tensor, ids_b: torch.Tensor, who: tuple = ()) -> "K.Match":
         """The matcher inside a HIP-graph capture: its kernels are captured (every replay pairs that batch's ids on the device), its
         16-byte status is NOT read back -- the counts that size the launches come from the last eager step with these shapes, and
         a device-side comparison poisons the loss (NaN) and raises ``capture_mismatch`` when a replayed batch pairs differently
         (another pair count, identity vs. permuted order, repeated ids).  A permutation-paired batch of the captured size always
-        replays correctly: warm up with a representative (shuffled) batch."""
-        key = (tuple(ids_a.shape), tuple(ids_b.shape))
+        replays correctly: warm up with a representative (shuffled) batch.  The expectation is kept per modality pair (``who``), so
+        pairs whose id columns have equal shapes but pair differently (three modalities, one of them shuffled) capture too."""
+        key = (who, tuple(ids_a.shape), tuple(ids_b.shape))
         seen = self._match_seen.get(key)
         if seen is None:
             raise RuntimeError("mmlearn_amd.ContrastiveLoss: the id matcher cannot learn its pair count during graph capture -- run one "
@@ -921,13 +922,14 @@ class ContrastiveLoss(nn.Module):
             return K.Match(total, True, None, None)
         return K.Match(total, False, pm.idx_a[:total], pm.idx_b[:total], bool(rep_a), bool(rep_b))
 
-    def _matched(self, ids_a: torch.Tensor, ids_b: torch.Tensor) -> "K.Match":
-        """The pairing of two id columns: the prefetched answer if it was computed for exactly these tensors."""
+    def _matched(self, ids_a: torch.Tensor, ids_b: torch.Tensor, who: tuple = ()) -> "K.Match":
+        """The pairing of two id columns: the prefetched answer if it was computed for exactly these tensors.  ``who`` names the
+        call (modality pair, global / local pairing): the key of what a captured step may expect of it."""
         if ids_a.is_cuda and torch.cuda.is_current_stream_capturing():
-            return self._matched_in_capture(ids_a, ids_b)
+            return self._matched_in_capture(ids_a, ids_b, who)
         m = self._matched_eager(ids_a, ids_b)
         if ids_a.is_cuda:
-            key = (tuple(ids_a.shape), tuple(ids_b.shape))
+            key = (who, tuple(ids_a.shape), tuple(ids_b.shape))
             seen = self._match_seen.get(key)
             if seen is None or seen[:4] != (m.n, m.identity, m.repeats_a, m.repeats_b):   # (device copy made once per change)
                 expect = torch.tensor([m.n, int(m.identity), int(m.repeats_a), int(m.repeats_b)], dtype=torch.int32, device=ids_a.device)

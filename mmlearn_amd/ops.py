@@ -58,7 +58,8 @@ def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     if (autocast and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.dtype == torch.float32 and x.dim() == 2
             and x.shape[1] % 8 == 0):
         y, y16 = _L2Normalize.apply(x, True)
-        y._mmk_bf16_nograd = (y16, y._version)
+        if not y.is_inference():   # inference tensors (Lightning's validate / test / predict loops) track no version: no stamp, no twin
+            y._mmk_bf16_nograd = (y16, y._version)
         return y
     return _L2Normalize.apply(x, False)
 

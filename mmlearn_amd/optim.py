@@ -12,6 +12,13 @@ forms the bias corrections itself, and ``step()`` neither reads anything back no
 training step can then be captured into a HIP graph (``torch.cuda.graph``) and replayed (tests/test_graph_capture_gpu.py).
 Per-parameter ``step`` entries of the state are then device tensors, as in torch; a scheduler that changes ``group["lr"]`` is
 honoured by eager steps and, between replays of a graph, through ``opt.lr_device(g).fill_(...)`` (a replay reads the word).
+
+Capture needs STATIC gradients: a captured launch bakes in the addresses of the optimizer's device tables (tensor / chunk tables,
+the gradient-pointer table, the step and learning-rate words).  Run one eager step first with the gradient buffers the capture
+will use (``zero_grad(set_to_none=False)``); ``step()`` under capture refuses to (re)build a table (a rebuild would allocate pinned
+memory inside the capture and point the graph at buffers a later eager step could replace), and every table a capture has used is
+kept alive for the optimizer's lifetime, so an eager step with other gradient addresses (a ragged last batch,
+``zero_grad(set_to_none=True)``) between replays cannot free what the graph still reads.
 """
 
 from __future__ import annotations
@@ -46,6 +53,12 @@ class AdamW(torch.optim.Optimizer):
         self._tables: Dict[int, Any] = {}
         self._grad_tables: Dict[int, Any] = {}
         self._dev_words: Dict[int, Any] = {}
+        self._captured: List[Any] = []   # tables / words whose addresses live inside a captured graph: never freed
+
+    def _keep_for_graph(self, *objs) -> None:
+        for o in objs:
+            if not any(o is k for k in self._captured):
+                self._captured.append(o)
 
     def load_state_dict(self, state_dict) -> None:
         super().load_state_dict(state_dict)
@@ -60,6 +73,9 @@ class AdamW(torch.optim.Optimizer):
         tab = self._tables.get(gi)
         if tab is not None and tab["key"] == key:
             return tab
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mmlearn_amd.optim.AdamW: the parameter / moment tables must exist before capture -- run one eager step "
+                               "with the same set of parameters receiving gradients, then capture")
         chunk = _lib.lib().mmk_adamw_chunk_elems()
         tens = (_Tensor * len(plist))()
         chunks = []
@@ -145,15 +161,23 @@ class AdamW(torch.optim.Optimizer):
         if not capturing and float(group["lr"]) != words["lr_seen"]:   # a scheduler moved the float: follow it (eager steps only)
             words["lr"].fill_(float(group["lr"]))
             words["lr_seen"] = float(group["lr"])
+        if capturing and not all(p.grad.is_contiguous() for p in plist):
+            raise RuntimeError("mmlearn_amd.optim.AdamW(capturable=True): non-contiguous gradients cannot be captured")
         grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in plist]
         key = tuple((g.data_ptr(), g.dtype) for g in grads)
         gt = self._grad_tables.get(gi)
         if gt is None or gt["key"] != key:
+            if capturing:
+                raise RuntimeError("mmlearn_amd.optim.AdamW(capturable=True): the gradients' addresses differ from the last eager step's. "
+                                   "A captured step needs static gradient buffers: call zero_grad(set_to_none=False) and run one eager "
+                                   "step with those buffers before capturing")
             # pinned staging that lives as long as the table: a captured copy node re-reads it at every replay
             pin_p = torch.tensor([g.data_ptr() for g in grads], dtype=torch.int64).pin_memory()
             pin_t = torch.tensor([dtype_tag(g.dtype) for g in grads], dtype=torch.int32).pin_memory()
             gt = {"key": key, "pin": (pin_p, pin_t), "gptr": pin_p.to(dev, non_blocking=True), "gdt": pin_t.to(dev, non_blocking=True)}
             self._grad_tables[gi] = gt
+        if capturing:
+            self._keep_for_graph(tab, gt, words)
         words["step"].add_(1.0)
         b1, b2 = group["betas"]
         check(_lib.lib().mmk_adamw_update_dev(tab["tensors"].data_ptr(), gt["gptr"].data_ptr(), gt["gdt"].data_ptr(), tab["chunks"].data_ptr(),

@@ -14,15 +14,15 @@ import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
+import mp_util
 from conftest import Golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DIST = Golden("g3_clip_dist")
 
 
-def _worker(rank, world, port, case_names, q):
+def _worker(rank, world, port, case_names, q, done):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -85,27 +85,26 @@ def _worker(rank, world, port, case_names, q):
                                     else np.zeros_like(c[f"r{rank}_in_{m}"])) for m in mods}
                 rec["dscale"] = float(s.grad) if s.grad is not None else 0.0
                 results[(name, static)] = rec
-        q.put((rank, results, None))
-        dist.barrier()
-        dist.destroy_process_group()
+        item = (rank, results, None)
     except Exception:  # surface the traceback in the parent
-        q.put((rank, None, traceback.format_exc()))
+        item = (rank, None, traceback.format_exc())
+    try:
+        mp_util.send(q, done, item)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
-def _run(world, case_names, port):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case_names, q)) for r in range(world)]
-    for p in procs:
-        p.start()
+def _collect(items):
     out = {}
-    for _ in procs:
-        rank, res, err = q.get(timeout=240)
+    for rank, res, err in items:
         assert err is None, f"rank {rank} failed:\n{err}"
         out[rank] = res
-    for p in procs:
-        p.join(timeout=60)
     return out
+
+
+def _run(world, case_names):
+    return _collect(mp_util.run(_worker, world, lambda r, port: (r, world, port, case_names), timeout=240))
 
 
 def _check(world, case_names, out):
@@ -133,13 +132,13 @@ def _check(world, case_names, out):
 def test_world2_all_flag_cells_uneven_and_missing_modality():
     names = [n for n in DIST.names() if n.startswith("w2_")]
     assert len(names) == 9
-    out = _run(2, names, 29711)
+    out = _run(2, names)
     _check(2, names, out)
     paired = out[0]["_paired_ranks"]
     assert any(paired.values()) and not all(paired.values()), paired   # both the fast path and its refusal were exercised
 
 
-def _align_worker(rank, world, port, q):
+def _align_worker(rank, world, port, q, done):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -165,28 +164,20 @@ def _align_worker(rank, world, port, q):
             loss.backward()
             results[name] = {"loss": float(loss.detach()), "dscale": float(s.grad),
                              "grads": {m: embs[f"{m}_embedding"].grad.numpy().copy() for m in ("rgb", "text")}}
-        q.put((rank, results, None))
-        dist.barrier()
-        dist.destroy_process_group()
+        item = (rank, results, None)
     except Exception:
-        q.put((rank, None, traceback.format_exc()))
+        item = (rank, None, traceback.format_exc())
+    try:
+        mp_util.send(q, done, item)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
 def test_world2_modality_alignment_all_flag_cells():
     gold = Golden("g9_align")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_align_worker, args=(r, 2, 29713, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    out = {}
-    for _ in procs:
-        rank, res, err = q.get(timeout=240)
-        assert err is None, f"rank {rank} failed:\n{err}"
-        out[rank] = res
-    for p in procs:
-        p.join(timeout=60)
+    out = _collect(mp_util.run(_align_worker, 2, lambda r, port: (r, 2, port), timeout=240))
     for name in [n for n in gold.names() if n.startswith("w2_")]:
         c = gold[name]
         for rank in range(2):
@@ -202,11 +193,11 @@ def test_world2_modality_alignment_all_flag_cells():
 def test_world4_all_flag_cells():
     names = [n for n in DIST.names() if n.startswith("w4_")]
     assert len(names) == 4
-    out = _run(4, names, 29712)
+    out = _run(4, names)
     _check(4, names, out)
 
 
-def _static_worker(rank, world, port, q):
+def _static_worker(rank, world, port, q, done):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -257,11 +248,14 @@ def _static_worker(rank, world, port, q):
             except ValueError as e:
                 res[tag] = str(e)
         L._all_gather = orig
-        q.put((rank, res, None))
-        dist.barrier()
-        dist.destroy_process_group()
+        item = (rank, res, None)
     except Exception:
-        q.put((rank, None, traceback.format_exc()))
+        item = (rank, None, traceback.format_exc())
+    try:
+        mp_util.send(q, done, item)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
@@ -271,7 +265,7 @@ def test_world2_three_modalities_three_weighted_pairs():
     audio rows matched across ranks (scattered ownership) and a rank without audio."""
     names = [n for n in DIST.names() if n.startswith("n3w2_")]
     assert len(names) == 8
-    out = _run(2, names, 29715)
+    out = _run(2, names)
     _check(2, names, out)
 
 
@@ -279,7 +273,7 @@ def test_world2_three_modalities_three_weighted_pairs():
 def test_world4_three_modalities_three_weighted_pairs():
     names = [n for n in DIST.names() if n.startswith("n3w4_")]
     assert len(names) == 4
-    out = _run(4, names, 29716)
+    out = _run(4, names)
     _check(4, names, out)
 
 
@@ -288,7 +282,7 @@ def test_world8_all_flag_cells():
     """SURVEY 8(c) G3 asks for W in {2, 4, 8}: eight gloo processes against the reference's eight per-rank outputs."""
     names = [n for n in DIST.names() if n.startswith("w8_")]
     assert len(names) == 4
-    out = _run(8, names, 29717)
+    out = _run(8, names)
     _check(8, names, out)
 
 
@@ -298,18 +292,7 @@ def test_static_shapes_is_a_checked_promise():
     ranks issue mismatched collectives.  Now the first step (and any step on which the local shapes change) exchanges a
     header and raises on disagreement; steady-state steps add no collective, and with an identity global pairing the
     local-loss cell no longer exchanges its per-pair row counts."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_static_worker, args=(r, 2, 29714, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    out = {}
-    for _ in procs:
-        rank, res, err = q.get(timeout=240)
-        assert err is None, f"rank {rank} failed:\n{err}"
-        out[rank] = res
-    for p in procs:
-        p.join(timeout=60)
+    out = _collect(mp_util.run(_static_worker, 2, lambda r, port: (r, 2, port), timeout=240))
     for rank in range(2):
         r = out[rank]
         # embeddings + ids gathers every step; the validation header only on the first

@@ -16,8 +16,8 @@ import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
-import torch.multiprocessing as mp
 
+import mp_util
 from conftest import Golden
 
 pytestmark = pytest.mark.gpu
@@ -71,7 +71,7 @@ def _golden_rank(rank, world, prefixes=None):
     return results
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, done):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -79,14 +79,17 @@ def _worker(rank, world, port, q):
             if p not in sys.path:
                 sys.path.insert(0, p)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        q.put((rank, _golden_rank(rank, world), None))
-        dist.barrier()
-        dist.destroy_process_group()
+        item = (rank, _golden_rank(rank, world), None)
     except Exception:
-        q.put((rank, None, traceback.format_exc()))
+        item = (rank, None, traceback.format_exc())
+    try:
+        mp_util.send(q, done, item)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
-def _golden_threads_worker(world, q):
+def _golden_threads_worker(world, q, done):
     """The golden cases of `world` ranks with the ranks as threads of one process (see _ThreadRanks)."""
     try:
         import threading
@@ -120,31 +123,25 @@ def _golden_threads_worker(world, q):
                     total = sum(out[r][key]["dscale"] for r in range(world))
                     for r in range(world):
                         out[r][key]["dscale"] = total
-        for r in range(world):
-            q.put((r, out.get(r), errs.get(r)))
+        items = [(r, out.get(r), errs.get(r)) for r in range(world)]
     except Exception:
-        for r in range(world):
-            q.put((r, None, traceback.format_exc()))
+        items = [(r, None, traceback.format_exc()) for r in range(world)]
+    for it in items[:-1]:
+        mp_util.send(q, done, it, wait_s=0.0)
+    mp_util.send(q, done, items[-1])
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.timeout(600)
 def test_multi_rank_hip_path_vs_reference(world):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
     if world > 4:   # process guard of the GPU box: ranks become threads of one child
-        procs = [ctx.Process(target=_golden_threads_worker, args=(world, q))]
+        items = mp_util.run(_golden_threads_worker, 1, lambda r, port: (world,), n_results=world, timeout=500)
     else:
-        procs = [ctx.Process(target=_worker, args=(r, world, 29720 + world, q)) for r in range(world)]
-    for p in procs:
-        p.start()
+        items = mp_util.run(_worker, world, lambda r, port: (r, world, port), timeout=500)
     out = {}
-    for _ in range(world):
-        rank, res, err = q.get(timeout=500)
+    for rank, res, err in items:
         assert err is None, f"rank {rank} failed:\n{err}"
         out[rank] = res
-    for p in procs:
-        p.join(timeout=60)
     n_checked, n_multi_pair = 0, 0
     for rank in range(world):
         for (gname, name, static), got in out[rank].items():
@@ -204,7 +201,7 @@ def _seeded_rank(rank, b, d, dtype, n_mods=2):
     return res
 
 
-def _seeded_worker(rank, world, port, b, d, dtype, n_mods, q):
+def _seeded_worker(rank, world, port, b, d, dtype, n_mods, q, done):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -212,11 +209,14 @@ def _seeded_worker(rank, world, port, b, d, dtype, n_mods, q):
             if p not in sys.path:
                 sys.path.insert(0, p)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        q.put((rank, _seeded_rank(rank, b, d, dtype, n_mods), None))
-        dist.barrier()
-        dist.destroy_process_group()
+        item = (rank, _seeded_rank(rank, b, d, dtype, n_mods), None)
     except Exception:
-        q.put((rank, None, traceback.format_exc()))
+        item = (rank, None, traceback.format_exc())
+    try:
+        mp_util.send(q, done, item)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 class _ThreadRanks:
@@ -268,7 +268,7 @@ class _ThreadRanks:
         dist.get_backend = lambda group=None: "gloo"
 
 
-def _seeded_threads_worker(world, b, d, dtype, n_mods, q):
+def _seeded_threads_worker(world, b, d, dtype, n_mods, q, done):
     try:
         import threading
 
@@ -301,11 +301,12 @@ def _seeded_threads_worker(world, b, d, dtype, n_mods, q):
             total = sum(out[r][(False, False)]["ds"] for r in range(world))
             for r in range(world):
                 out[r][(False, False)]["ds"] = total
-        for r in range(world):
-            q.put((r, out.get(r), errs.get(r)))
+        items = [(r, out.get(r), errs.get(r)) for r in range(world)]
     except Exception:
-        for r in range(world):
-            q.put((r, None, traceback.format_exc()))
+        items = [(r, None, traceback.format_exc()) for r in range(world)]
+    for it in items[:-1]:
+        mp_util.send(q, done, it, wait_s=0.0)
+    mp_util.send(q, done, items[-1])
 
 
 @pytest.mark.parametrize("world,b,d,dtype,n_mods", [(2, 1024, 512, "bfloat16", 2), (4, 333, 200, "float32", 2), (8, 1024, 512, "bfloat16", 2),
@@ -318,21 +319,14 @@ def test_multi_rank_hip_path_seeded_vs_oracle(world, b, d, dtype, n_mods):
     (F,F) and (T,T); with n_mods = 3 three modalities and three weighted pairs (the multi-pair exchange buffer)."""
     from oracle import clip_oracle as co
 
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
     if world > 4:   # process guard of the GPU box: ranks become threads of one child
-        procs = [ctx.Process(target=_seeded_threads_worker, args=(world, b, d, dtype, n_mods, q))]
+        items = mp_util.run(_seeded_threads_worker, 1, lambda r, port: (world, b, d, dtype, n_mods), n_results=world, timeout=800)
     else:
-        procs = [ctx.Process(target=_seeded_worker, args=(r, world, 29730 + world + 10 * n_mods, b, d, dtype, n_mods, q)) for r in range(world)]
-    for p in procs:
-        p.start()
+        items = mp_util.run(_seeded_worker, world, lambda r, port: (r, world, port, b, d, dtype, n_mods), timeout=800)
     out = {}
-    for _ in range(world):
-        rank, res, err = q.get(timeout=800)
+    for rank, res, err in items:
         assert err is None, f"rank {rank} failed:\n{err}"
         out[rank] = res
-    for p in procs:
-        p.join(timeout=60)
     names = ["rgb", "text", "audio"][:n_mods]
     ins = [_seeded_inputs(r, b, d, dtype, n_mods) for r in range(world)]
     embs = [{n: m.numpy() for n, m in zip(names, i[0])} for i in ins]

@@ -139,3 +139,63 @@ def test_the_task_runs_under_torch_compile_and_trains_to_the_same_parameters(bac
         assert torch.equal(pc.detach(), pe.detach())
     torch._dynamo.reset()
 
+
+
+def test_eager_steps_between_replays_cannot_free_what_the_graph_reads_and_capture_refuses_moving_gradients():
+    """a captured AdamW launch bakes in the addresses of the optimizer's device tables.  An eager step with
+    other gradient addresses (``zero_grad(set_to_none=True)``: a ragged last batch run eagerly) replaces the optimizer's current
+    tables; the ones the graph points at must stay alive, and a replay afterwards must still be the step it captured.  Capturing
+    with gradients that are not the last eager step's is refused with a clear error instead of allocating pinned memory inside
+    the capture."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import graph_step as G
+
+    dev = torch.device("cuda", 0)
+    batch = G.make_batch(64, dev)
+    task_e, opt_e = G.make(dev, 512, own_adamw=True)
+    task_g, opt_g = G.make(dev, 512, own_adamw=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            G.step(task_g, opt_g, batch)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        G.step(task_g, opt_g, batch)
+    assert opt_g._captured, "tables used under capture are pinned to the optimizer"
+    held = {id(o) for o in opt_g._captured}
+    graph.replay()                                   # step 4
+    # step 5 eagerly on fresh gradient tensors: the optimizer's current gradient table is replaced ...
+    static_grads = [p.grad for p in task_g.parameters()]   # the buffers the graph's backward writes: the caller keeps those alive
+    opt_g.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = task_g.training_step(batch, 0)
+    loss.backward()
+    moved = [p.grad for p in task_g.parameters()]
+    opt_g.step()
+    assert all(id(t) not in held for t in opt_g._grad_tables.values()), "an eager step on new gradients builds its own table"
+    assert {id(o) for o in opt_g._captured} == held
+    del moved
+    opt_g.zero_grad(set_to_none=True)                 # the eager step's gradients are gone; the graph owns its own
+    torch.cuda.synchronize()
+    graph.replay()                                   # step 6, through the tables captured before the eager step
+    torch.cuda.synchronize()
+    for _ in range(6):
+        G.step(task_e, opt_e, batch)
+    torch.cuda.synchronize()
+    for pe, pg in zip(task_e.parameters(), task_g.parameters()):
+        assert torch.equal(pe.detach(), pg.detach())
+    assert len(static_grads) == len(list(task_g.parameters()))
+    # refusal: pretend to capture with gradients at new addresses (no real capture is opened, so nothing is left half-captured)
+    opt_g.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        task_g.training_step(batch, 0).backward()
+    real = torch.cuda.is_current_stream_capturing
+    torch.cuda.is_current_stream_capturing = lambda: True
+    try:
+        with pytest.raises(RuntimeError, match="static gradient buffers"):
+            opt_g.step()
+    finally:
+        torch.cuda.is_current_stream_capturing = real

@@ -135,9 +135,10 @@ def test_rank_kernel_properties_at_evaluation_scale():
         assert abs(float(got[k]) - float(want)) <= 2.0 / B, (k, float(got[k]), float(want))   # hipBLAS vs MFMA-f32 near-ties
 
 
-def _recall_rank_worker(rank, world, port, q):
+def _recall_rank_worker(rank, world, port, q, done):
     import os, sys, traceback
     import torch.distributed as dist
+    import mp_util
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -159,28 +160,24 @@ def _recall_rank_worker(rank, world, port, q):
             yy = torch.empty_like(y[u, rank])
             yy[perm] = y[u, rank]                                          # row perm[i] of yy matches query i
             m.update(x[u, rank].cuda(), yy.cuda(), perm.cuda())
-        q.put((rank, float(m.compute()), m.ranks().cpu(), None))
-        dist.barrier()
-        dist.destroy_process_group()
+        item = (rank, float(m.compute()), m.ranks().cpu().numpy(), None)
     except Exception:
-        q.put((rank, None, None, traceback.format_exc()))
+        item = (rank, None, None, traceback.format_exc())
+    try:
+        mp_util.send(q, done, item)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 def test_recall_metric_across_ranks_matches_the_oracle_on_the_gathered_set():
     """Two ranks, two updates each: every rank ends up with the global set in (update, rank) order with the positives
     shifted by what came before -- retrieval_recall.py:137-160 -- and computes the same value; checked against the numpy
     oracle fed the same concatenation."""
-    import torch.multiprocessing as mp
+    import mp_util
     from oracle import metrics_oracle as mo
-    world, port = 2, 29500 + (os.getpid() % 2000) + 31
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_recall_rank_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
-    for p in procs:
-        p.join(timeout=60)
+    world = 2
+    res = sorted(mp_util.run(_recall_rank_worker, world, lambda r, port: (r, world, port), timeout=300), key=lambda r: r[0])
     for r in res:
         assert r[3] is None, r[3]
     g = torch.Generator().manual_seed(5)
@@ -198,6 +195,6 @@ def test_recall_metric_across_ranks_matches_the_oracle_on_the_gathered_set():
     want_ranks = mo.ranks(X, Y, I)
     want = mo.recall_at_k(X, Y, I, 3)
     for rk, val, ranks, _ in res:
-        assert np.array_equal(ranks.numpy(), want_ranks), rk
+        assert np.array_equal(ranks, want_ranks), rk
         assert abs(val - want) < 1e-6, (rk, val, want)
     assert 0.0 < want < 1.0

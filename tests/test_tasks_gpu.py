@@ -107,6 +107,39 @@ def test_contrastive_task_surface():
     assert Modalities.get_modality("rgb").embedding == "rgb_embedding"
 
 
+def test_validation_step_under_inference_mode_and_bf16_autocast():
+    """Lightning's validate / test / predict loops run under `torch.inference_mode()` (inference tensors track no version
+    counter): `encode(normalize=True)` and the loss must run there under bf16 autocast with a twin-eligible width (a multiple of
+    8), and give the value of the same step under `no_grad`."""
+    import tiny_models
+    from mmlearn_amd import ContrastiveLoss
+    from mmlearn_amd.tasks import ContrastivePretraining
+
+    dev = _dev()
+    B, D = 64, 32
+    torch.manual_seed(11)
+    enc = {"rgb": tiny_models.FlatMLPEncoder("rgb", 3 * 8 * 8, 48, D), "text": tiny_models.TokenMLPEncoder("text", 50, 24, D)}
+    task = ContrastivePretraining(encoders=enc, loss=ContrastiveLoss(), compute_validation_loss=True, compute_test_loss=True).to(dev).eval()
+    batch = {"rgb": torch.randn(B, 3, 8, 8, device=dev), "text": torch.randint(0, 50, (B, 6), device=dev),
+             "example_ids": {"rgb": _ids(B, dev), "text": _ids(B, dev)}}
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        want = float(task.validation_step(batch, 0))
+    with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):
+        e = task.encode(batch, task_modality("rgb"), normalize=True)
+        assert e.is_inference() and e.dtype == torch.float32 and not hasattr(e, "_mmk_bf16_nograd")
+        got = float(task.validation_step(batch, 0))
+        assert np.isfinite(float(task.test_step(batch, 0)))
+    assert abs(got - want) <= 1e-2 * max(1.0, abs(want)), (got, want)   # twin vs in-kernel rounding of the same rows: same bits expected
+    with torch.inference_mode():   # f32, no autocast
+        assert np.isfinite(float(task.validation_step(batch, 0)))
+
+
+def task_modality(name):
+    from mmlearn_amd import Modalities
+
+    return Modalities.get_modality(name)
+
+
 def test_ijepa_training_step_vs_reference():
     import tiny_models
     from mmlearn_amd import ops

@@ -876,6 +876,37 @@ _CLS_LAST_LAYER = {"CLIPEncoder": ("layers", "CLIPEncoderLayer", _clip_last_laye
                    "BertEncoder": ("layer", "BertLayer", _bert_last_layer_cls_forward)}
 
 
+def reads_only_token0(module: nn.Module) -> tuple:
+    """Is it PROVABLE that the consumer of ``module``'s HF ``CLIPEncoder`` / ``BertEncoder`` reads nothing but token 0 of the final
+    hidden state?  -> ``(yes, why)``.  The test is on the code that consumes the encoder output, which is the tower wrapper's
+    ``forward``; so it is answered only for wrappers whose ``forward`` is known:
+
+    * a wrapper that declares it: class or instance attribute ``mmk_reads_only_token0`` (True / False) -- the tower's author states
+      that ``forward`` reads token 0 only (``.image_embeds`` / ``.pooler_output`` / ``last_hidden_state[:, 0]``);
+    * mmlearn's ``HFCLIPVisionEncoderWithProjection`` (mmlearn/modules/encoders/clip.py:444-470): its ``forward`` calls
+      ``vision_model.encoder(...)`` and reads ``last_hidden_state[:, 0, :]`` unless ``use_all_token_embeddings`` is set;
+    * a bare HF ``CLIPVisionModelWithProjection`` is NOT enough: its output object also carries ``last_hidden_state`` for the
+      caller to read.
+
+    In every case the HF configs inside must not ask for ``output_hidden_states`` / ``output_attentions`` (the per-layer tuple would
+    show the shortened last entry).  Anything else -- mmlearn's ``HFTextEncoder`` (hands the whole last hidden state to a pooling
+    layer, text.py:170-175), token-level heads, mean pooling -- is not provable and is refused."""
+    for m in module.modules():
+        cfg = getattr(m, "config", None)
+        if cfg is not None and (getattr(cfg, "output_hidden_states", False) or getattr(cfg, "output_attentions", False)):
+            return False, f"{type(m).__name__}.config asks for output_hidden_states / output_attentions"
+    declared = getattr(module, "mmk_reads_only_token0", None)
+    if declared is not None:
+        return bool(declared), f"{type(module).__name__}.mmk_reads_only_token0 = {bool(declared)}"
+    if type(module).__name__ == "HFCLIPVisionEncoderWithProjection" and hasattr(module, "use_all_token_embeddings"):
+        if module.use_all_token_embeddings:
+            return False, "use_all_token_embeddings=True reads every token"
+        if getattr(module, "patch_dropout", None) is not None and getattr(module.patch_dropout, "exclude_first_token", True) is False:
+            return False, "patch dropout may drop the class token"
+        return True, "HFCLIPVisionEncoderWithProjection pools last_hidden_state[:, 0] (clip.py:463-470)"
+    return False, f"{type(module).__name__}: forward is not a known token-0 consumer (declare mmk_reads_only_token0 = True on the tower to opt in)"
+
+
 def cls_only_last_layer(module: nn.Module) -> int:
     """Opt-in, for encoders whose consumer reads ONLY token 0 of the final hidden state (CLS pooling: mmlearn's
     ``HFCLIPVisionEncoderWithProjection`` with ``use_all_token_embeddings=False``, a BERT text encoder pooled at [CLS]): the last
@@ -1099,7 +1130,7 @@ def patch_mel_stretch(module: nn.Module) -> int:
 
 
 def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), fuse_qkv: bool = False, fuse_add_ln: bool = False,
-                       cls_only: bool = False, wgrad_linear: bool = False, window_attention: bool = True) -> dict:
+                       cls_only="auto", wgrad_linear: bool = False, window_attention: bool = True) -> dict:
     """Swap ``nn.LayerNorm`` -> :class:`LayerNorm` and quick-GELU activations -> :class:`QuickGELU` inside ``module`` (in place);
     with ``fuse_qkv`` also patch the attention modules (:func:`fuse_qkv_attention`), with ``fuse_add_ln`` the residual
     add + LayerNorm pairs (:func:`fuse_add_layer_norm`).
@@ -1109,7 +1140,11 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
     for HF CLIP); ``norm1`` / ``norm2`` of timm-style pre-LN blocks (mmlearn's own ViT / predictor), ``layer_norm1`` /
     ``layer_norm2`` of HF ``CLIPEncoderLayer`` and ``layernorm_before`` / ``layernorm_after`` of Swin-style layers (HTSAT) get it
     automatically -- they feed nothing but that block's Linears.
-    ``cls_only``: :func:`cls_only_last_layer` (opt-in; only for encoders pooled at token 0).
+    ``cls_only``: :func:`cls_only_last_layer`.  ``"auto"`` (default): switched on exactly when :func:`reads_only_token0` can prove
+    that the tower reads token 0 only (an exact saving: same loss, same gradient for every parameter), left off otherwise;
+    ``True``: the caller's own promise -- still refused (``ValueError``) when :func:`reads_only_token0` finds a contradiction
+    (``use_all_token_embeddings``, ``output_hidden_states``, a declared ``mmk_reads_only_token0 = False``); ``False``: off.
+    The decision and its reason are returned under ``"cls_only"``.
     ``wgrad_linear``: :func:`linear_wgrad` on every ``nn.Linear`` left unpatched (towers without a recognised block structure).
     ``window_attention``: :func:`fuse_window_attention` (on by default; a no-op for towers without windowed attention modules).
     Returns the number of modules swapped per kind.
@@ -1140,6 +1175,14 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
         swapped["mel_stretch"] = patch_mel_stretch(module)
     if wgrad_linear:
         swapped["linear_wgrad"] = linear_wgrad(module)
-    if cls_only:     # last: it wraps whatever forward the last layer has by now (fused or stock)
-        swapped["cls_only_last_layer"] = cls_only_last_layer(module)
+    if cls_only not in (True, False, "auto"):
+        raise ValueError(f"cls_only must be True, False or 'auto', got {cls_only!r}")
+    if cls_only is not False:
+        proven, why = reads_only_token0(module)
+        contradicted = not proven and "not a known token-0 consumer" not in why
+        if cls_only is True and contradicted:
+            raise ValueError(f"accelerate_encoder(cls_only=True) refused: {why}")
+        swapped["cls_only"] = why if (proven or cls_only is True) else f"off: {why}"
+        if proven or cls_only is True:     # last: it wraps whatever forward the last layer has by now (fused or stock)
+            swapped["cls_only_last_layer"] = cls_only_last_layer(module)
     return swapped

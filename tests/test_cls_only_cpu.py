@@ -66,3 +66,76 @@ def test_bert_last_layer_for_cls_only():
     a = full(input_ids=ids, attention_mask=mask).last_hidden_state
     b = cls(input_ids=ids, attention_mask=mask).last_hidden_state
     assert b.shape == a.shape and torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def _tiny_clip():
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    return CLIPVisionModelWithProjection(CLIPVisionConfig(patch_size=8, image_size=32, projection_dim=16, hidden_size=64, intermediate_size=128,
+                                                          num_hidden_layers=2, num_attention_heads=2))
+
+
+def test_auto_switches_the_saving_on_only_where_token_0_pooling_is_provable():
+    """``accelerate_encoder(cls_only="auto")`` (the default).  On: mmlearn's HFCLIPVisionEncoderWithProjection with
+    ``use_all_token_embeddings=False`` (mmlearn/modules/encoders/clip.py:463-470) and towers that declare ``mmk_reads_only_token0``.
+    Off: bare HF models (the output object carries ``last_hidden_state``), ``use_all_token_embeddings=True``, configs that ask for
+    ``output_hidden_states``.  ``cls_only=True`` against a contradiction raises."""
+    from mmlearn_amd import fused
+
+    class HFCLIPVisionEncoderWithProjection(torch.nn.Module):   # the reference wrapper's shape: same class name, same attributes
+        def __init__(self, all_tokens):
+            super().__init__()
+            self.use_all_token_embeddings, self.model, self.patch_dropout = all_tokens, _tiny_clip(), None
+
+        def forward(self, inputs):
+            vm = self.model.vision_model
+            h = vm.encoder(inputs_embeds=vm.pre_layrnorm(vm.embeddings(inputs["rgb"])), return_dict=True).last_hidden_state
+            h = h if self.use_all_token_embeddings else h[:, 0, :]
+            return (self.model.visual_projection(vm.post_layernorm(h)),)
+
+    class Declared(torch.nn.Module):
+        mmk_reads_only_token0 = True
+
+        def __init__(self):
+            super().__init__()
+            self.model = _tiny_clip()
+
+        def forward(self, inputs):
+            return (self.model(pixel_values=inputs["rgb"]).image_embeds,)
+
+    torch.manual_seed(0)
+    x = {"rgb": torch.randn(3, 3, 32, 32)}
+    for make in (lambda: HFCLIPVisionEncoderWithProjection(False), Declared):
+        full = make().train()
+        out = fused.accelerate_encoder(copy.deepcopy(full))   # (the patched model itself needs the GPU: its LayerNorms are HIP now)
+        assert out.get("cls_only_last_layer") == 1 and not out["cls_only"].startswith("off"), out
+        auto = copy.deepcopy(full)
+        assert fused.reads_only_token0(auto)[0] and fused.cls_only_last_layer(auto) == 1   # what "auto" did, on the stock layers
+        assert fused.accelerate_encoder(copy.deepcopy(full), cls_only=False).get("cls_only_last_layer") is None
+        ref = full(x)[0]
+        got = auto(x)[0]
+        assert torch.allclose(ref, got, rtol=1e-5, atol=1e-6)
+        ref.square().sum().backward()
+        got.square().sum().backward()
+        for (k, a), (_, b) in zip(full.named_parameters(), auto.named_parameters()):
+            assert (a.grad is None) == (b.grad is None), k
+            if a.grad is not None:
+                assert (a.grad - b.grad).abs().max() <= 1e-4 * max(a.grad.abs().max().item(), 1e-3), k   # f32 summation order
+    # not provable: left off, with the reason
+    for tower in (_tiny_clip(), HFCLIPVisionEncoderWithProjection(True)):
+        out = fused.accelerate_encoder(tower)
+        assert out["cls_only"].startswith("off:") and "cls_only_last_layer" not in out, out
+    hs = Declared()
+    hs.model.config.output_hidden_states = True
+    assert fused.accelerate_encoder(hs)["cls_only"].startswith("off:")
+    no = Declared()
+    no.mmk_reads_only_token0 = False
+    assert fused.accelerate_encoder(no)["cls_only"].startswith("off:")
+    # the caller's promise is honoured for an unknown consumer, refused against a contradiction
+    assert fused.accelerate_encoder(_tiny_clip(), cls_only=True)["cls_only_last_layer"] == 1
+    with pytest.raises(ValueError, match="use_all_token_embeddings"):
+        fused.accelerate_encoder(HFCLIPVisionEncoderWithProjection(True), cls_only=True)
+    with pytest.raises(ValueError, match="output_hidden_states"):
+        fused.accelerate_encoder(hs, cls_only=True)
+    with pytest.raises(ValueError, match="must be True, False"):
+        fused.accelerate_encoder(_tiny_clip(), cls_only="yes")

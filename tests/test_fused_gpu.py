@@ -104,6 +104,7 @@ def test_accelerate_encoder_matches_stock_hf_models():
     clip_f, bert_f = copy.deepcopy(clip), copy.deepcopy(bert)
     n1 = fused.accelerate_encoder(clip_f, ("layer_norm1", "layer_norm2", "post_layernorm"))
     n2 = fused.accelerate_encoder(bert_f)
+    assert n1.pop("cls_only").startswith("off:") and "cls_only_last_layer" not in n1   # a bare HF model: its consumer is unknown, auto stays off
     assert n1 == {"layernorm": 6, "quick_gelu": 2, "fused_qkv": 0, "fused_add_ln": 0, "window_attention": 0} and n2["layernorm"] == 5
     px = torch.rand(6, 3, 64, 64, device=dev)
     tok = torch.randint(0, 30522, (6, 16), device=dev)

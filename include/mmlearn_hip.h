@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMK_ABI_VERSION 4
+#define MMK_ABI_VERSION 5
 
 /* element types of user tensors */
 enum { MMK_F32 = 0, MMK_BF16 = 1, MMK_F16 = 2 };
@@ -294,6 +294,11 @@ typedef struct {
 } mmk_ema_entry;
 int mmk_ema_update(const mmk_ema_entry* table, int n_tensors, int64_t max_numel, float decay, int mode,
                    void* stream);
+/* The same launch with the decay read from a device word (decay_dev[0], f32): a step captured into a HIP graph replays with
+ * the value the word holds at replay time (the annealed schedule of modules/ema.py:79-89,166-177 advances on the host and is
+ * written into the word between replays).  ABI 5. */
+int mmk_ema_update_dev(const mmk_ema_entry* table, int n_tensors, int64_t max_numel, const float* decay_dev, int mode,
+                       void* stream);
 
 /* Multi-tensor AdamW step for one parameter group (torch.optim.AdamW semantics: decoupled weight decay, bias
  * correction, eps added to sqrt(v)/sqrt(bc2); amsgrad / maximize off).  f32 parameters and moments; gradients f32 or

@@ -22,7 +22,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 F32, BF16, F16 = 0, 1, 2
 COMPUTE_BF16, COMPUTE_F32 = 1, 0
-ABI_VERSION = 4   # include/mmlearn_hip.h MMK_ABI_VERSION this ctypes mirror was written against
+ABI_VERSION = 5   # include/mmlearn_hip.h MMK_ABI_VERSION this ctypes mirror was written against
 
 _DTYPE_TAG = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -113,6 +113,7 @@ _SIGNATURES = {
     "mmk_pred_assemble": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "mmk_pred_assemble_bwd": [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
     "mmk_ema_update": [_vp, _i, C.c_int64, _f, _i, _vp],
+    "mmk_ema_update_dev": [_vp, _i, C.c_int64, _vp, _i, _vp],
     "mmk_layernorm_part_blocks": [C.c_long],
     "mmk_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _f, _i, _vp],
     "mmk_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _vp],

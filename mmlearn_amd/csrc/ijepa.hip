@@ -377,8 +377,11 @@ __device__ __forceinline__ void store_tag(void* p, long i, int dt, float v) {
   else static_cast<f16_t*>(p)[i] = (f16_t)v;
 }
 constexpr int EMA_CHUNK = 256 * 16;
-__global__ __launch_bounds__(256) void ema_kernel(const mmk_ema_entry* __restrict__ table, float decay, int mode) {
+// decay_dev != nullptr: the decay is read from a device word (a captured launch then replays with whatever the word holds)
+__global__ __launch_bounds__(256) void ema_kernel(const mmk_ema_entry* __restrict__ table, float decay, const float* __restrict__ decay_dev,
+                                                  int mode) {
   const mmk_ema_entry e = table[blockIdx.y];
+  if (decay_dev != nullptr) decay = decay_dev[0];
   const long base = (long)blockIdx.x * EMA_CHUNK;
   if (base >= e.numel) return;
   const float one_minus = 1.f - decay;
@@ -682,7 +685,19 @@ int mmk_ema_update(const mmk_ema_entry* table, int n_tensors, int64_t max_numel,
   hipStream_t st = static_cast<hipStream_t>(stream);
   ProfScope ps(MMK_K_EMA, st);
   const long chunks = (max_numel + EMA_CHUNK - 1) / EMA_CHUNK;
-  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)chunks, n_tensors), dim3(256), 0, st, table, decay, mode);
+  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)chunks, n_tensors), dim3(256), 0, st, table, decay, static_cast<const float*>(nullptr), mode);
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+int mmk_ema_update_dev(const mmk_ema_entry* table, int n_tensors, int64_t max_numel, const float* decay_dev, int mode, void* stream) {
+  MMK_REQUIRE(table && decay_dev && n_tensors > 0 && max_numel > 0, "bad arguments");
+  MMK_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (copy) or 1 (ema)");
+  MMK_REQUIRE(n_tensors <= 65535, "too many tensors for one launch");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  ProfScope ps(MMK_K_EMA, st);
+  const long chunks = (max_numel + EMA_CHUNK - 1) / EMA_CHUNK;
+  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)chunks, n_tensors), dim3(256), 0, st, table, 0.f, decay_dev, mode);
   MMK_LAUNCH_CHECK();
   return 0;
 }

@@ -11,6 +11,12 @@ that -- as ONE kernel launch over a device-resident pointer table instead of one
 ``.float()/clone/load_state_dict`` round per tensor.  ``true_ema=True`` applies the evidently intended
 ``teacher = decay * teacher + (1 - decay) * student`` (f32 math) to floating-point parameters and
 copies buffers / ``skip_keys``.
+
+``capturable = True`` (attribute; what ``torch.optim.AdamW(capturable=True)`` is for the optimizer): the update launch reads the
+decay from a device word, and ``step()`` inside a HIP-graph capture launches only -- the host schedule (``num_updates``,
+``decay``) does not move at capture time, because a capture executes nothing.  After every replay of a captured step call
+:meth:`advance` (one increment of ``num_updates``, the next annealed ``decay``, one ``fill_`` of the word).  Eager steps
+keep the word in step with ``decay`` by themselves.
 """
 
 from __future__ import annotations
@@ -43,6 +49,9 @@ class ExponentialMovingAverage:
         self.true_ema = true_ema
         self._model_configured = False
         self._tables: dict[int, Any] = {}
+        self.capturable = False
+        self._decay_word: Optional[torch.Tensor] = None   # device f32[1] = self.decay (capturable mode)
+        self._decay_word_value: Optional[float] = None
 
     @staticmethod
     def deepcopy_model(model: torch.nn.Module) -> torch.nn.Module:
@@ -66,8 +75,30 @@ class ExponentialMovingAverage:
     def step(self, new_model: torch.nn.Module) -> None:
         if not self._model_configured:
             raise RuntimeError("Model is not configured for EMA. Call `configure_model` first.")
+        if self.capturable and torch.cuda.is_current_stream_capturing():
+            self._update_weights(new_model, capturing=True)   # the launch only: see advance()
+            return
         self._update_weights(new_model)
         self._update_ema_decay()
+        if self.capturable:
+            self._sync_decay_word()
+
+    def advance(self) -> None:
+        """Host side of one update that a replayed graph has just made on the device: ``num_updates`` + 1, the next annealed
+        ``decay``, and the device word the next replay reads it from."""
+        if self.decay < 1:
+            self.num_updates += 1
+        self._update_ema_decay()
+        self._sync_decay_word()
+
+    def _sync_decay_word(self) -> None:
+        dev = next(self.model.parameters()).device
+        if self._decay_word is None or self._decay_word.device != dev:
+            self._decay_word = torch.empty(1, dtype=torch.float32, device=dev)
+            self._decay_word_value = None
+        if self._decay_word_value != float(self.decay):
+            self._decay_word.fill_(float(self.decay))
+            self._decay_word_value = float(self.decay)
 
     def restore(self, model: torch.nn.Module) -> torch.nn.Module:
         """Load the teacher's weights into ``model`` (strict=False), as the reference does."""
@@ -104,7 +135,7 @@ class ExponentialMovingAverage:
         return tables, slow, keep
 
     @torch.no_grad()
-    def _update_weights(self, new_model: torch.nn.Module) -> None:
+    def _update_weights(self, new_model: torch.nn.Module, capturing: bool = False) -> None:
         if self.decay < 1:
             # keyed on the storages themselves: ``.to()`` / ``.half()`` / re-wrapping re-allocates parameters, and a table
             # built for the old storages would keep updating tensors nobody reads
@@ -112,14 +143,25 @@ class ExponentialMovingAverage:
             # on the critical path of every step -- ADVICE r2)
             key = (id(new_model), tuple(t.data_ptr() for m in (self.model, new_model) for it in (m.parameters(), m.buffers()) for t in it))
             if key not in self._tables:
+                if capturing:
+                    raise RuntimeError("ExponentialMovingAverage: the pointer tables must exist before capture -- run one eager "
+                                       "step() with the same student first")
                 self._tables = {key: self._build_tables(new_model)}
             tables, slow, _ = self._tables[key]
+            decay = self.decay
+            if self.capturable:
+                if capturing and (self._decay_word is None or self._decay_word_value != float(self.decay)):
+                    raise RuntimeError("ExponentialMovingAverage(capturable): run one eager step() before capturing")
+                if not capturing:
+                    self._sync_decay_word()
+                decay = self._decay_word
             for mode, tab in tables.items():
                 if tab is not None:
-                    K.ema_update(*tab, self.decay, mode == "ema")
+                    K.ema_update(*tab, decay, mode == "ema")
             for t, s in slow:
                 t.copy_(s)
-            self.num_updates += 1
+            if not capturing:
+                self.num_updates += 1
         else:
             rank_zero_warn("Exponential Moving Average decay is 1.0, no update is applied to the model.", category=UserWarning)
 

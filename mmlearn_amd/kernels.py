@@ -8,6 +8,7 @@ ATen math runs here.  There is deliberately no CPU path: CPU tensors raise.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 from dataclasses import dataclass, field
 from typing import Optional, Sequence, Tuple
@@ -215,10 +216,19 @@ class Direction:
     _keep: list = field(default_factory=list)
 
 
+@functools.lru_cache(maxsize=256)
 def _plan(r: int, c: int, k_pad: int, compute: int):
+    """(column tiles, gradient blocks, K splits) of one direction: a pure function of the shape, asked once per shape."""
     a, b, s = C.c_int32(), C.c_int32(), C.c_int32()
     check(_lib.lib().mmk_clip_plan(r, c, k_pad, compute, C.addressof(a), C.addressof(b), C.addressof(s)))
     return a.value, b.value, s.value
+
+
+@functools.lru_cache(maxsize=256)
+def _wgrad_ws_floats(m: int, n: int, k: int) -> int:
+    splits, wsf = C.c_int(0), C.c_int64(0)
+    check(_lib.lib().mmk_wgrad_plan(m, n, k, C.cast(C.pointer(splits), C.c_void_p), C.cast(C.pointer(wsf), C.c_void_p)))
+    return int(wsf.value)
 
 
 def _mirror_of(a: Direction, b: Direction, backward: bool = False) -> bool:
@@ -401,11 +411,10 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.
             e.src_dtype = dtype_tag(dr.src.dtype) if dr.src is not None else 0
             e.g_ready = int(ready)
             if tn:
-                splits, wsf = C.c_int(0), C.c_int64(0)
-                check(_lib.lib().mmk_wgrad_plan(dr.c, r_pad, k_pad, C.cast(C.pointer(splits), C.c_void_p), C.cast(C.pointer(wsf), C.c_void_p)))
-                tn_ws = torch.empty(wsf.value, dtype=torch.float32, device=dev)
+                wsf = _wgrad_ws_floats(dr.c, r_pad, k_pad)
+                tn_ws = torch.empty(wsf, dtype=torch.float32, device=dev)
                 keep.append(tn_ws)
-                e.g_transposed, e.tn_ws, e.tn_ws_floats = 1, ptr(tn_ws), wsf.value
+                e.g_transposed, e.tn_ws, e.tn_ws_floats = 1, ptr(tn_ws), wsf
                 e.ldg = g.shape[1]
             mir = next((b for b in chunk[k + 1:k + 2] if mirror_src.get(id(b)) is dr), None)
             if mir is not None and id(mir) in in_chunk:
@@ -691,7 +700,12 @@ def ema_table(teacher: Sequence[torch.Tensor], student: Sequence[torch.Tensor]):
     return host.to(teacher[0].device), n, max_numel
 
 
-def ema_update(table: torch.Tensor, n: int, max_numel: int, decay: float, true_ema: bool) -> None:
+def ema_update(table: torch.Tensor, n: int, max_numel: int, decay, true_ema: bool) -> None:
+    """``decay``: a python float, or a 1-element f32 device tensor the launch reads it from (capturable)."""
+    if isinstance(decay, torch.Tensor):
+        assert decay.is_cuda and decay.dtype == torch.float32 and decay.numel() == 1
+        check(_lib.lib().mmk_ema_update_dev(ptr(table), n, max_numel, ptr(decay), int(true_ema), stream()))
+        return
     check(_lib.lib().mmk_ema_update(ptr(table), n, max_numel, float(decay), int(true_ema), stream()))
 
 

@@ -199,3 +199,64 @@ def test_eager_steps_between_replays_cannot_free_what_the_graph_reads_and_captur
             opt_g.step()
     finally:
         torch.cuda.is_current_stream_capturing = real
+
+
+@pytest.mark.parametrize("true_ema", [False, True])
+def test_ijepa_vit_s_step_with_ema_is_captured_and_replays_bit_identically(true_ema):
+    """the I-JEPA step as HIP graphs (``mmlearn_amd.graph.CapturedIJEPAStep``).  The masks are drawn one step
+    ahead on the host -- the generator's own call sequence on the global RNG (mmlearn/datasets/processors/masking.py:384-387) --
+    staged in pinned memory and uploaded on a side stream; the captured region (teacher, context encoder, predictor, fused target +
+    loss, backward, AdamW, EMA update) holds no host RNG and no pageable copy.  ViT-S/16 + 6 x 384 predictor, seven steps on seven
+    batches: three eager warm-up calls, then four replays (one graph per mask geometry); student AND teacher end bit-identical to
+    seven plain eager steps that sample their masks inside the step, and the EMA schedule (``decay``, ``num_updates``) agrees.
+    ``true_ema``: the decay word of the annealed schedule is what the replayed update reads."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_ijepa_step as T
+    from mmlearn_amd.graph import CapturedIJEPAStep
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(17)
+    images = [torch.rand(32, 3, 224, 224, generator=g).to(dev) for _ in range(7)]
+
+    def make():
+        task = T.build("vits", True, dev, capturable=True, true_ema=true_ema)
+        opt = task.configure_optimizers()
+        return task, (opt["optimizer"] if isinstance(opt, dict) else opt)
+
+    # eager: masks sampled inside every step
+    task_e, opt_e = make()
+    torch.manual_seed(5)
+    for k in range(7):
+        opt_e.zero_grad(set_to_none=False)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss_e = task_e.training_step({"rgb": images[k]}, 0)
+        loss_e.backward()
+        opt_e.step()
+        task_e.on_before_zero_grad(opt_e)
+    # captured: same host RNG seed, masks staged ahead
+    task_g, opt_g = make()
+    runner = CapturedIJEPAStep(task_g, opt_g, warmup=3)
+    torch.manual_seed(5)
+    for k in range(7):
+        loss_g = runner({"rgb": images[k]})
+    torch.cuda.synchronize()
+    assert runner.replays == 4 and 1 <= len(runner.graphs) <= 4
+    assert torch.isfinite(loss_g.detach()).all() and float(loss_g.detach()) == float(loss_e.detach())
+    for (n, pe), (_, pg) in zip(task_e.named_parameters(), task_g.named_parameters()):
+        assert torch.equal(pe.detach(), pg.detach()), n
+    for (n, te), (_, tg) in zip(task_e.target_encoder.model.state_dict().items(), task_g.target_encoder.model.state_dict().items()):
+        assert torch.equal(te, tg), n
+    assert task_e.target_encoder.num_updates == task_g.target_encoder.num_updates == 7
+    assert task_e.target_encoder.decay == task_g.target_encoder.decay
+    if true_ema:   # the teacher is an average, not a copy, and the word holds the annealed value the next replay will read
+        assert not torch.equal(next(task_g.target_encoder.model.parameters()), next(task_g.encoder.parameters()))
+        assert abs(float(task_g.target_encoder._decay_word) - task_g.target_encoder.decay) < 1e-7
+    # a step that has not staged its masks cannot be captured: clear error, nothing half-captured
+    real = torch.cuda.is_current_stream_capturing
+    task_g._mask_stage.pending = task_g._mask_stage.ready = None
+    torch.cuda.is_current_stream_capturing = lambda: True
+    try:
+        with pytest.raises(RuntimeError, match="stage_masks"):
+            task_g._masks_for_step(32, dev)
+    finally:
+        torch.cuda.is_current_stream_capturing = real

@@ -90,20 +90,27 @@ class Predictor(nn.Module):
         self.predictor_proj = nn.Linear(pred_dim, embed_dim)
 
 
-def build(small: bool, fused: bool, dev):
+def build(small, fused: bool, dev, capturable: bool = False, true_ema: bool = False):
+    """``small``: False = ViT-L/16 + 12 x 384 predictor (configs[4]), True = a two-block toy, "vits" = ViT-S/16 + 6 x 384 predictor
+    (projects/ijepa/configs/experiment/in1k_vit_small.yaml:52-57, with 64-wide predictor heads)."""
     torch.manual_seed(0)
-    dim, depth, heads = (256, 2, 4) if small else (1024, 24, 16)
+    if small == "vits":
+        dim, depth, heads, pdim, pdepth, pheads = 384, 12, 6, 384, 6, 6
+    elif small:
+        dim, depth, heads, pdim, pdepth, pheads = 256, 2, 4, 128, 2, 2
+    else:
+        dim, depth, heads, pdim, pdepth, pheads = 1024, 24, 16, 384, 12, 6
     enc = ViT(dim, depth, heads)
-    pred = Predictor(196, dim, 128 if small else 384, 2 if small else 12, 2 if small else 6)   # 64-wide predictor heads
+    pred = Predictor(196, dim, pdim, pdepth, pheads)   # 64-wide predictor heads
     if fused:
         from mmlearn_amd.fused import accelerate_encoder
         accelerate_encoder(enc, fuse_qkv=True, fuse_add_ln=True)    # norm1 / norm2 of the pre-LN blocks emit bf16 (automatic)
         accelerate_encoder(pred, fuse_qkv=True, fuse_add_ln=True)
         from mmlearn_amd.optim import AdamW
-        optimizer = partial(AdamW, lr=1e-4, weight_decay=0.05)
+        optimizer = partial(AdamW, lr=1e-4, weight_decay=0.05, capturable=capturable)
     else:
-        optimizer = partial(torch.optim.AdamW, lr=1e-4, weight_decay=0.05)
-    task = IJEPA(encoder=enc, predictor=pred, optimizer=optimizer).to(dev)
+        optimizer = partial(torch.optim.AdamW, lr=1e-4, weight_decay=0.05, capturable=capturable)
+    task = IJEPA(encoder=enc, predictor=pred, optimizer=optimizer, true_ema=true_ema).to(dev)
     task.configure_model()
     return task
 

@@ -74,12 +74,66 @@ def step(task, opt, batch):
     return loss
 
 
+def ijepa_main(a):
+    """--ijepa: the I-JEPA ViT-S/16 step (EMA teacher, 6 x 384 predictor), eager vs ``mmlearn_amd.graph.CapturedIJEPAStep``."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bench_ijepa_step as T
+    from mmlearn_amd.graph import CapturedIJEPAStep
+
+    dev = torch.device("cuda", 0)
+    imgs = torch.rand(a.batch, 3, 224, 224, generator=torch.Generator().manual_seed(1)).to(dev)
+    out = {"workload": f"I-JEPA ViT-S/16 + 6x384 predictor, batch {a.batch}, bf16 autocast, own AdamW(capturable), EMA teacher"}
+
+    def make():
+        task = T.build("vits", True, dev, capturable=True)
+        opt = task.configure_optimizers()
+        return task, (opt["optimizer"] if isinstance(opt, dict) else opt)
+
+    task_e, opt_e = make()
+
+    def eager():
+        opt_e.zero_grad(set_to_none=False)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = task_e.training_step({"rgb": imgs}, 0)
+        loss.backward()
+        opt_e.step()
+        task_e.on_before_zero_grad(opt_e)
+
+    torch.manual_seed(3)
+    for _ in range(5):
+        eager()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        eager()
+    torch.cuda.synchronize()
+    out["eager_ms"] = round((time.perf_counter() - t0) / a.iters * 1e3, 3)
+    task_g, opt_g = make()
+    runner = CapturedIJEPAStep(task_g, opt_g, warmup=3)
+    torch.manual_seed(3)
+    for _ in range(3 + 40):    # warm-up + enough steps to have captured the common mask geometries
+        runner({"rgb": imgs})
+    torch.cuda.synchronize()
+    n_before = len(runner.graphs)
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        runner({"rgb": imgs})
+    torch.cuda.synchronize()
+    out["graph_ms"] = round((time.perf_counter() - t0) / a.iters * 1e3, 3)
+    out["graphs"] = {"before_timing": n_before, "after": len(runner.graphs), "keys": sorted(map(list, runner.graphs))}
+    out["speedup"] = round(out["eager_ms"] / out["graph_ms"], 3)
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--dim", type=int, default=512)
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--ijepa", action="store_true", help="the I-JEPA ViT-S step instead of the configs[0] contrastive step")
     a = ap.parse_args()
+    if a.ijepa:
+        return ijepa_main(a)
     dev = torch.device("cuda", 0)
     b = a.batch
     batch = make_batch(b, dev)

@@ -24,14 +24,25 @@ namespace mmk {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int WG_TILE = 256;   // output tile edge
+constexpr int WG_TILE = 256;   // output tile edge of the full-size kernel
 constexpr int WG_BM = 64;      // contraction rows per LDS stage
-constexpr int WG_STAGE = WG_BM * WG_TILE * 2;  // bytes of one operand stage (32 KiB)
+[[maybe_unused]] constexpr int WG_STAGE = WG_BM * WG_TILE * 2;  // bytes of one operand stage (32 KiB) at the 256 tile (debug-switch kernel)
+// Narrow layers (HTSAT's 96 / 288 / 384-wide Linears, the I-JEPA predictor's 384: mmlearn/modules/encoders/vision.py:397-569) fill
+// a 256 x 256 tile to 14-56 %: the same kernel is instantiated on 128 x 128 tiles -- four waves (2 x 2, still 64 x 64 per wave),
+// 16 KiB stages, 64 KiB of LDS so that TWO workgroups share a CU -- and wg_tile_edge() picks it where it saves padded work.
+constexpr int WG_TILE_NARROW = 128;
+
+// Output tile edge for an [N, K] weight: 128 when the 128-tiles cover it with at most 0.8 x the padded area of the 256-tiles.
+static inline int wg_tile_edge(int N, int K) {
+  const long a256 = (long)cdiv(N, 256) * cdiv(K, 256) * 256 * 256;
+  const long a128 = (long)cdiv(N, 128) * cdiv(K, 128) * 128 * 128;
+  return 5 * a128 <= 4 * a256 ? WG_TILE_NARROW : WG_TILE;
+}
 
 struct WgradArgs {
   const bf16_t* dy;  // [M, N], row stride ldy
   const bf16_t* x;   // [M, K], row stride ldx
-  float* ws;         // [splits][N_pad][K_pad] partial tiles (N_pad, K_pad = multiples of 256)
+  float* ws;         // [splits][N_pad][K_pad] partial tiles (N_pad, K_pad = multiples of the tile edge)
   long ldy, ldx;
   int M, N, K;
   int splits, tiles_n, tiles_k, rows_per_split;
@@ -52,6 +63,29 @@ __device__ __forceinline__ int wg_opaque(int x) {
 // LDS stage image: 64 rows x 512 B, 16-byte chunk index (0..31) ^= (row & 3) << 2: the four rows of a transposed-read
 // block land in four different 64-byte groups of a 256-byte bank window (conflict-free ds_read_b64_tr_b16).
 // Fill: piece p (0..31) = rows 2p, 2p+1; lane l writes chunk position l & 31 of row 2p + (l >> 5).
+// TE = 128 (256-byte rows, 16 chunks, same swizzle): one DMA instruction covers FOUR rows, piece p = rows 4p .. 4p + 3, four pieces per
+// wave of the four-wave workgroup.
+template <int TE>
+__device__ __forceinline__ void wg_fill_te(char* stage, const bf16_t* base, long ld, int col0, int ncols, long row0, long row_end, int wave,
+                                           int lane) {
+  constexpr int CH = TE / 8;                 // 16-byte chunks per row
+  constexpr int RP = 64 / CH;                // rows per DMA instruction (1 KiB)
+  constexpr int NW = (TE / 64) * (TE / 64);  // waves of the workgroup
+  constexpr int PPW = (WG_BM / RP) / NW;     // pieces per wave
+  const uint32_t saddr = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)stage);
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int p = wave_s * PPW + i;
+    const int rr = RP * p + lane / CH;
+    const int ch = (lane & (CH - 1)) ^ ((rr & 3) << 2);
+    const long srow = min(row0 + RP * p, row_end - 1);                 // wave-uniform part of the address
+    const int drow = (int)(min(row0 + rr, row_end - 1) - srow);        // 0 .. RP - 1
+    const int col = min(col0 + ch * 8, ncols - 8);
+    wg_dma16(base + srow * ld, (uint32_t)(drow * (int)ld + col) * 2u, saddr + p * 1024);
+  }
+}
+
 template <bool SW16 = false>
 __device__ __forceinline__ void wg_fill(char* stage, const bf16_t* base, long ld, int col0, int ncols, long row0, long row_end, int wave,
                                         int lane) {
@@ -210,15 +244,20 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel16(const WgradArgs a) {
 // NARROW: instantiated for weights whose N or K is not a multiple of 256 -- only there can a wave's 64 x 64 block fall outside [N, K].
 // The full-size shapes keep the loop without the test (with it they ran 1-4 % slower in a same-box A/B: the early `continue`
 // changes the stage loop's code).
-template <bool PAIR, bool NARROW = false>
-__global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
+// TE: output tile edge, 256 (16 waves, one workgroup per CU) or 128 (4 waves, two per CU); per_xcd = workgroup slots of one XCD.
+template <bool PAIR, bool NARROW = false, int TE = WG_TILE>
+__global__ __launch_bounds__(64 * (TE / 64) * (TE / 64), TE == WG_TILE ? 1 : 2) void wgrad_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
+  constexpr int WPR = TE / 64;              // waves per row of the wave grid
+  constexpr int PITCH = TE * 2;             // bytes of a stage row
+  constexpr int STAGE = WG_BM * PITCH;      // bytes of one operand stage
+  constexpr int PER_XCD = TE == WG_TILE ? 32 : 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware unit map: block b runs on XCD b % 8; XCD x owns splits x, x + 8, ...; consecutive slots of an XCD are the
   // tiles of one split
   const int T = a.tiles_n * a.tiles_k;
   int split, tn, tk;
-  if (T <= 32) {
+  if (T <= PER_XCD) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     split = (slot / T) * 8 + xcd;
     const int tile = slot % T;
@@ -256,8 +295,8 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
   // layers: a 96 x 96 weight fills 4 of the 16 blocks) takes part in the fills and barriers only -- it issues no fragment reads and
   // no MFMAs, and stores its zero accumulators into the workspace padding.  (Spreading a narrow tile's active waves over all four
   // SIMDs by another wave -> block map was tried: +1 % on the full-size shapes, nothing on the narrow ones, which are load-bound.)
-  const int wm = wave >> 2, wn = wave & 3;
-  const bool active = !NARROW || (tn * WG_TILE + 64 * wm < a.N && tk * WG_TILE + 64 * wn < a.K);
+  const int wm = wave / WPR, wn = wave % WPR;
+  const bool active = !NARROW || (tn * TE + 64 * wm < a.N && tk * TE + 64 * wn < a.K);
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -272,7 +311,7 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
   // block's chunks are 4t + 2 g1 + (p >> 1), and row & 3 == q, so the swizzle turns into the tile index t ^ q
   int troff[2], xa[2], xb[2];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) troff[u] = (8 * h + 4 * u + q) * 512 + ((2 * g1 + (p >> 1)) << 4) + 8 * (p & 1);
+  for (int u = 0; u < 2; ++u) troff[u] = (8 * h + 4 * u + q) * PITCH + ((2 * g1 + (p >> 1)) << 4) + 8 * (p & 1);
 #pragma unroll
   for (int i = 0; i < 2; ++i) xa[i] = (((wm * 2 + i) ^ q) << 6);
 #pragma unroll
@@ -289,10 +328,15 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
   };
 
   auto issue = [&](int st) {
-    char* sa = smem + (st & 1) * 2 * WG_STAGE;
+    char* sa = smem + (st & 1) * 2 * STAGE;
     const int lo = wg_opaque(lane);
-    wg_fill(sa, a.dy, a.ldy, tn * WG_TILE, a.N, row0 + (long)st * WG_BM, row_end, wave, lo);
-    wg_fill(sa + WG_STAGE, a.x, a.ldx, tk * WG_TILE, a.K, row0 + (long)st * WG_BM, row_end, wave, lo);
+    if constexpr (TE == WG_TILE) {
+      wg_fill(sa, a.dy, a.ldy, tn * TE, a.N, row0 + (long)st * WG_BM, row_end, wave, lo);
+      wg_fill(sa + STAGE, a.x, a.ldx, tk * TE, a.K, row0 + (long)st * WG_BM, row_end, wave, lo);
+    } else {
+      wg_fill_te<TE>(sa, a.dy, a.ldy, tn * TE, a.N, row0 + (long)st * WG_BM, row_end, wave, lo);
+      wg_fill_te<TE>(sa + STAGE, a.x, a.ldx, tk * TE, a.K, row0 + (long)st * WG_BM, row_end, wave, lo);
+    }
   };
   issue(0);
   for (int st = 0; st < nstages; ++st) {
@@ -303,8 +347,8 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
     // per-stage base through an opaque value: the 12 per-lane fragment addresses are rebuilt here once per stage instead of
     // being hoisted for both buffers out of the loop (LDS offsets >= 64 KiB do not fit an instruction immediate, the
     // hoisted copies spilled)
-    char* sa = smem + wg_opaque((st & 1) * 2 * WG_STAGE) + troff[0];
-    char* sb = sa + WG_STAGE;
+    char* sa = smem + wg_opaque((st & 1) * 2 * STAGE) + troff[0];
+    char* sb = sa + STAGE;
     const int valid = (int)min((long)WG_BM, row_end - (row0 + (long)st * WG_BM));
     // two 16-row steps per iteration, all sixteen fragment reads of the pair requested before its eight MFMAs: half as many
     // LDS waits per stage, and the second step's reads land behind the first step's MFMAs.  Every row of a stage is written by
@@ -315,9 +359,9 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
       for (int ks = 0; ks < ksteps; ++ks) {
         bf16x8 af[2], bfr[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = tr8(sa + ks * 8192 + xa[i]);
+        for (int i = 0; i < 2; ++i) af[i] = tr8(sa + ks * (16 * PITCH) + xa[i]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bfr[j] = tr8(sb + ks * 8192 + xb[j]);
+        for (int j = 0; j < 2; ++j) bfr[j] = tr8(sb + ks * (16 * PITCH) + xb[j]);
         if ((ks + 1) * 16 > valid) {
 #pragma unroll
           for (int jj = 0; jj < 8; ++jj)
@@ -337,14 +381,14 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll 1
     for (int kp = 0; kp < kpairs; ++kp) {
       bf16x8 af[2][2], bfr[2][2];
-      const char* pa = sa + kp * 16384;
-      const char* pb = sb + kp * 16384;
+      const char* pa = sa + kp * (32 * PITCH);
+      const char* pb = sb + kp * (32 * PITCH);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[u][i] = tr8(pa + u * 8192 + xa[i]);
+        for (int i = 0; i < 2; ++i) af[u][i] = tr8(pa + u * (16 * PITCH) + xa[i]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bfr[u][j] = tr8(pb + u * 8192 + xb[j]);
+        for (int j = 0; j < 2; ++j) bfr[u][j] = tr8(pb + u * (16 * PITCH) + xb[j]);
       }
       if ((kp + 1) * 32 > valid) {  // last stage of the last split
 #pragma unroll
@@ -365,8 +409,8 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel(const WgradArgs a) {
     }
   }
   // ---- partial tile -> workspace: acc[i][j][e] = C[n = 64 wm + 32 i + (e&3) + 8(e>>2) + 4h][k = 64 wn + 32 j + (lane&31)]
-  const int n_pad = a.tiles_n * WG_TILE, k_pad = a.tiles_k * WG_TILE;
-  float* wsb = a.ws + ((size_t)split * n_pad + (size_t)tn * WG_TILE) * k_pad + (size_t)tk * WG_TILE;
+  const int n_pad = a.tiles_n * TE, k_pad = a.tiles_k * TE;
+  float* wsb = a.ws + ((size_t)split * n_pad + (size_t)tn * TE) * k_pad + (size_t)tk * TE;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -387,16 +431,17 @@ extern "C" {
 // plan: number of M splits and workspace floats for a [N, K] weight gradient over M rows
 int mmk_wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* ws_floats_out) {
   MMK_REQUIRE(M > 0 && N > 0 && K > 0 && splits_out && ws_floats_out, "bad arguments");
-  const int tn = cdiv(N, WG_TILE), tk = cdiv(K, WG_TILE), T = tn * tk;
+  const int te = wg_tile_edge(N, K);
+  const int tn = cdiv(N, te), tk = cdiv(K, te), T = tn * tk;
   // one workgroup per CU and a single round: with T <= 32 tiles every XCD (32 CUs) hosts floor(32 / T) whole splits.
   // MMK_WGRAD_RESERVE_CUS (per XCD, default 0) leaves CUs to a concurrent kernel such as RCCL's all-reduce -- a launch
   // that no longer fits one round takes two -- at +8 % for the 36-tile shapes when the GPU is not shared.
   static const int reserve = getenv("MMK_WGRAD_RESERVE_CUS") ? std::min(16, std::max(0, atoi(getenv("MMK_WGRAD_RESERVE_CUS")))) : 0;
-  const int per_xcd = 32 - reserve;
+  const int per_xcd = (te == WG_TILE ? 32 : 64) - (te == WG_TILE ? reserve : 2 * reserve);   // 128-tiles: two workgroups per CU
   int splits = T <= per_xcd ? 8 * (per_xcd / T) : std::max(1, 8 * per_xcd / T);
   splits = (int)std::min<int64_t>(splits, std::max<int64_t>(1, M / 512));
   *splits_out = splits;
-  *ws_floats_out = (int64_t)splits * tn * WG_TILE * tk * WG_TILE;
+  *ws_floats_out = (int64_t)splits * tn * te * tk * te;
   return 0;
 }
 
@@ -414,8 +459,9 @@ int mmk_wgrad_partial(const void* dy, const void* x, float* ws, int64_t M, int N
   int rc = wgrad_launch(dy, x, ws, M, N, K, ldy, ldx, &a, static_cast<hipStream_t>(stream));
   if (rc) return rc;
   if (splits_out) *splits_out = a.splits;
-  if (n_pad_out) *n_pad_out = a.tiles_n * WG_TILE;
-  if (k_pad_out) *k_pad_out = a.tiles_k * WG_TILE;
+  const int te = wg_tile_edge(N, K);
+  if (n_pad_out) *n_pad_out = a.tiles_n * te;
+  if (k_pad_out) *k_pad_out = a.tiles_k * te;
   return 0;
 }
 
@@ -424,32 +470,39 @@ static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int
   WgradArgs a;
   a.dy = static_cast<const bf16_t*>(dy); a.x = static_cast<const bf16_t*>(x); a.ws = ws;
   a.ldy = ldy; a.ldx = ldx; a.M = (int)M; a.N = N; a.K = K;
-  a.tiles_n = cdiv(N, WG_TILE); a.tiles_k = cdiv(K, WG_TILE);
+  const int te = wg_tile_edge(N, K);
+  a.tiles_n = cdiv(N, te); a.tiles_k = cdiv(K, te);
   int64_t wsf;
   mmk_wgrad_plan(M, N, K, &a.splits, &wsf);
   a.rows_per_split = round_up((int)cdiv((int)M, a.splits), WG_BM);
   a.splits = cdiv((int)M, a.rows_per_split);
   const int T = a.tiles_n * a.tiles_k;
-  const int grid = T <= 32 ? 8 * cdiv(a.splits, 8) * T : 8 * cdiv(a.splits * T, 8);
-  const int bytes = 4 * WG_STAGE;
+  const int per_xcd = te == WG_TILE ? 32 : 64;
+  const int grid = T <= per_xcd ? 8 * cdiv(a.splits, 8) * T : 8 * cdiv(a.splits * T, 8);
+  const int bytes = 4 * WG_BM * te * 2;
+  const int threads = 64 * (te / 64) * (te / 64);
   static const bool pair = !(MMK_DBG_ENV("MMK_WGRAD_PAIR") && atoi(MMK_DBG_ENV("MMK_WGRAD_PAIR")) == 0);
 #ifdef MMK_DEBUG_SWITCHES
   // MFMA shape experiment: MMK_WGRAD_MFMA=16 selects the 16x16x32 kernel (read per call: interleaved A/B runs)
   const bool mfma16 = MMK_DBG_ENV("MMK_WGRAD_MFMA") && atoi(MMK_DBG_ENV("MMK_WGRAD_MFMA")) == 16;
 #endif
   // the variant this shape runs; its > 64 KiB LDS opt-in is made per device (kernel_setup)
-  const void* kern = pair && (N % WG_TILE != 0 || K % WG_TILE != 0) ? reinterpret_cast<const void*>(wgrad_kernel<true, true>)
-                     : pair                                         ? reinterpret_cast<const void*>(wgrad_kernel<true>)
-                                                                    : reinterpret_cast<const void*>(wgrad_kernel<false>);
+  const bool ragged = N % te != 0 || K % te != 0;
+  const void* kern = pair && ragged ? reinterpret_cast<const void*>(wgrad_kernel<true, true>)
+                     : pair         ? reinterpret_cast<const void*>(wgrad_kernel<true>)
+                                    : reinterpret_cast<const void*>(wgrad_kernel<false>);
+  if (te == WG_TILE_NARROW)
+    kern = ragged ? reinterpret_cast<const void*>(wgrad_kernel<true, true, WG_TILE_NARROW>)
+                  : reinterpret_cast<const void*>(wgrad_kernel<true, false, WG_TILE_NARROW>);
 #ifdef MMK_DEBUG_SWITCHES
-  if (mfma16) kern = reinterpret_cast<const void*>(wgrad_kernel16);
+  if (mfma16 && te == WG_TILE) kern = reinterpret_cast<const void*>(wgrad_kernel16);
 #endif
   KernelSetup ks;
-  if (int rc = kernel_setup(kern, 1024, bytes, &ks)) return rc;
+  if (int rc = kernel_setup(kern, threads, bytes, &ks)) return rc;
   {
     ProfEvents pe(MMK_K_WGRAD);
     void* params[] = {&a};
-    MMK_HIP(hipExtLaunchKernel(kern, dim3(grid), dim3(1024), params, bytes, st, pe.start, pe.stop, 0));
+    MMK_HIP(hipExtLaunchKernel(kern, dim3(grid), dim3(threads), params, bytes, st, pe.start, pe.stop, 0));
   }
   MMK_LAUNCH_CHECK();
   *out = a;
@@ -467,7 +520,8 @@ int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int
     if (rc) return rc;
   }
   const long n4 = (long)N * (K / 4);
-  const int n_pad = a.tiles_n * WG_TILE, k_pad = a.tiles_k * WG_TILE;
+  const int te_ = wg_tile_edge(N, K);
+  const int n_pad = a.tiles_n * te_, k_pad = a.tiles_k * te_;
   int rc = MMK_DISPATCH_DTYPE(out_dtype, OUT, [&]() -> int {
     hipLaunchKernelGGL((wgrad_reduce_kernel<OUT>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, ws, static_cast<OUT*>(dw), (long)ldw,
                        N, K, n_pad, k_pad, a.splits);

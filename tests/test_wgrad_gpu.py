@@ -7,7 +7,12 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 768, 768), (1000, 256, 512), (77 * 13, 768, 3072), (64, 8, 8), (5000, 2304, 768),
-                                   (130, 520, 264)])
+                                   (130, 520, 264),
+                                   # the 128 x 128-tile instantiation (narrow layers: HTSAT's 96 / 288 / 384-wide Linears, the I-JEPA
+                                   # predictor's 384 / 1152 / 1536): full tiles, ragged tiles, M not a multiple of the 64-row stage,
+                                   # more tiles than one XCD has workgroup slots (9 x 12 = 108 > 64)
+                                   (8192, 96, 96), (8192, 288, 96), (8192, 384, 96), (8192, 96, 384), (4099, 384, 384), (6000, 1152, 384),
+                                   (6000, 384, 1536), (1000, 104, 72), (129, 128, 128), (3000, 1152, 1536)])
 def test_wgrad_vs_torch(M, N, K):
     from mmlearn_amd import kernels as Kn
 

@@ -34,6 +34,10 @@ constexpr int WG_TILE_NARROW = 128;
 
 // Output tile edge for an [N, K] weight: 128 when the 128-tiles cover it with at most 0.8 x the padded area of the 256-tiles.
 static inline int wg_tile_edge(int N, int K) {
+  if (const char* e = MMK_DBG_ENV("MMK_WGRAD_TILE")) {   // A/B in debug-switch builds: force one tile edge
+    if (atoi(e) == 256) return WG_TILE;
+    if (atoi(e) == 128) return WG_TILE_NARROW;
+  }
   const long a256 = (long)cdiv(N, 256) * cdiv(K, 256) * 256 * 256;
   const long a128 = (long)cdiv(N, 128) * cdiv(K, 128) * 128 * 128;
   return 5 * a128 <= 4 * a256 ? WG_TILE_NARROW : WG_TILE;
@@ -46,7 +50,22 @@ struct WgradArgs {
   long ldy, ldx;
   int M, N, K;
   int splits, tiles_n, tiles_k, rows_per_split;
+  int aligned;       // unit map: 1 = every XCD hosts whole splits (T tiles each), 0 = positions of an XCD run through splits and tiles
 };
+
+// Splits of M and the unit map for T tiles on `per_xcd` workgroup slots per XCD (8 XCDs, one round).  XCD-aligned splits keep all
+// tiles of a split on one L2; when whole splits leave more than 1/8 of the slots idle (T = 9: 27 of 32, T = 27: 27 of 32, T = 36 on
+// the 64-slot narrow kernel: 36 of 64) the positions of an XCD run through (split, tile) pairs instead and the splits fill the chip.
+static inline void wg_plan_units(int T, int per_xcd, int* splits, int* aligned) {
+  const int s_al = T <= per_xcd ? 8 * (per_xcd / T) : 0;
+  const int s_gen = std::max(1, 8 * per_xcd / T);
+  bool al = s_al > 0 && (long)s_al * T * 8 >= (long)7 * 8 * per_xcd;
+  if (const char* e = MMK_DBG_ENV("MMK_WGRAD_MAP")) {   // A/B in debug-switch builds: 1 = aligned whenever possible (rounds 1-4)
+    if (atoi(e) == 1 && s_al > 0) al = true;
+  }
+  *splits = al ? s_al : s_gen;
+  *aligned = al ? 1 : 0;
+}
 
 __device__ __forceinline__ void wg_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
   const uint64_t pb = reinterpret_cast<uint64_t>(sbase);
@@ -122,6 +141,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   Vec4<OUT>::store(dw + (long)n * ldw + k, acc);
 }
 
+// Many splits of a small weight (narrow layers over ~1 M rows: 256-512 splits of a 96 x 96 tile): the loop over splits of the kernel
+// above is a few thousand threads each walking hundreds of dependent-latency loads (150 us for 19 MB).  Here 16 lanes share one
+// output float4 and stride through the splits, then fold through LDS in a fixed order (deterministic, like the serial sum).
+template <typename OUT>
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ ws, OUT* __restrict__ dw, long ldw, int N, int K,
+                                                                int n_pad, int k_pad, int splits) {
+  __shared__ float4 sm[16][16];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long idx = (long)blockIdx.x * 16 + o;
+  const int k4 = K / 4;
+  const bool valid = idx < (long)N * k4;
+  const int n = valid ? (int)(idx / k4) : 0, k = valid ? (int)(idx % k4) * 4 : 0;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid)
+    for (int s = g; s < splits; s += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + ((size_t)s * n_pad + n) * k_pad + k);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  sm[g][o] = acc;
+  __syncthreads();
+#pragma unroll
+  for (int half = 8; half >= 1; half >>= 1) {
+    if (g < half) {
+      const float4 a = sm[g][o], b = sm[g + half][o];
+      sm[g][o] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    __syncthreads();
+  }
+  if (g == 0 && valid) Vec4<OUT>::store(dw + (long)n * ldw + k, sm[0][o]);
+}
+
 #ifdef MMK_DEBUG_SWITCHES
 // EXPERIMENT (debug-switch builds only, MMK_WGRAD_MFMA=16; measured, not kept: 1-11 % SLOWER than 32x32x16 on all eight encoder
 // shapes in an interleaved same-process A/B, profiles/r03_wgrad_mfma_shape_ab.json -- this kernel is fed by L2 -> LDS, not bound
@@ -136,7 +186,7 @@ __global__ __launch_bounds__(1024, 1) void wgrad_kernel16(const WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = a.tiles_n * a.tiles_k;
   int split, tn, tk;
-  if (T <= 32) {
+  if (a.aligned) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     split = (slot / T) * 8 + xcd;
     const int tile = slot % T;
@@ -251,13 +301,12 @@ __global__ __launch_bounds__(64 * (TE / 64) * (TE / 64), TE == WG_TILE ? 1 : 2) 
   constexpr int WPR = TE / 64;              // waves per row of the wave grid
   constexpr int PITCH = TE * 2;             // bytes of a stage row
   constexpr int STAGE = WG_BM * PITCH;      // bytes of one operand stage
-  constexpr int PER_XCD = TE == WG_TILE ? 32 : 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware unit map: block b runs on XCD b % 8; XCD x owns splits x, x + 8, ...; consecutive slots of an XCD are the
   // tiles of one split
   const int T = a.tiles_n * a.tiles_k;
   int split, tn, tk;
-  if (T <= PER_XCD) {
+  if (a.aligned) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     split = (slot / T) * 8 + xcd;
     const int tile = slot % T;
@@ -438,7 +487,8 @@ int mmk_wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* ws_floats_
   // that no longer fits one round takes two -- at +8 % for the 36-tile shapes when the GPU is not shared.
   static const int reserve = getenv("MMK_WGRAD_RESERVE_CUS") ? std::min(16, std::max(0, atoi(getenv("MMK_WGRAD_RESERVE_CUS")))) : 0;
   const int per_xcd = (te == WG_TILE ? 32 : 64) - (te == WG_TILE ? reserve : 2 * reserve);   // 128-tiles: two workgroups per CU
-  int splits = T <= per_xcd ? 8 * (per_xcd / T) : std::max(1, 8 * per_xcd / T);
+  int splits, aligned;
+  wg_plan_units(T, per_xcd, &splits, &aligned);
   splits = (int)std::min<int64_t>(splits, std::max<int64_t>(1, M / 512));
   *splits_out = splits;
   *ws_floats_out = (int64_t)splits * tn * te * tk * te;
@@ -477,8 +527,11 @@ static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int
   a.rows_per_split = round_up((int)cdiv((int)M, a.splits), WG_BM);
   a.splits = cdiv((int)M, a.rows_per_split);
   const int T = a.tiles_n * a.tiles_k;
-  const int per_xcd = te == WG_TILE ? 32 : 64;
-  const int grid = T <= per_xcd ? 8 * cdiv(a.splits, 8) * T : 8 * cdiv(a.splits * T, 8);
+  {
+    int s_unused;
+    wg_plan_units(T, te == WG_TILE ? 32 : 64, &s_unused, &a.aligned);
+  }
+  const int grid = a.aligned ? 8 * cdiv(a.splits, 8) * T : 8 * cdiv(a.splits * T, 8);
   const int bytes = 4 * WG_BM * te * 2;
   const int threads = 64 * (te / 64) * (te / 64);
   static const bool pair = !(MMK_DBG_ENV("MMK_WGRAD_PAIR") && atoi(MMK_DBG_ENV("MMK_WGRAD_PAIR")) == 0);
@@ -523,8 +576,12 @@ int mmk_wgrad(const void* dy, const void* x, void* dw, float* ws, int64_t M, int
   const int te_ = wg_tile_edge(N, K);
   const int n_pad = a.tiles_n * te_, k_pad = a.tiles_k * te_;
   int rc = MMK_DISPATCH_DTYPE(out_dtype, OUT, [&]() -> int {
-    hipLaunchKernelGGL((wgrad_reduce_kernel<OUT>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, ws, static_cast<OUT*>(dw), (long)ldw,
-                       N, K, n_pad, k_pad, a.splits);
+    if (a.splits >= 32)
+      hipLaunchKernelGGL((wgrad_reduce_wide_kernel<OUT>), dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, ws, static_cast<OUT*>(dw),
+                         (long)ldw, N, K, n_pad, k_pad, a.splits);
+    else
+      hipLaunchKernelGGL((wgrad_reduce_kernel<OUT>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, ws, static_cast<OUT*>(dw),
+                         (long)ldw, N, K, n_pad, k_pad, a.splits);
     return 0;
   });
   if (rc) return rc;

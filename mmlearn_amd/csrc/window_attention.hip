@@ -414,10 +414,19 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_kernel(const WinAttnArgs 
     *reinterpret_cast<float4*>(out + (threadIdx.x + 256 * n) * 4) = *reinterpret_cast<const float4*>(tab + (threadIdx.x + 256 * n) * 4);
 }
 
-static int wa_nsplit(int B, int nW, int H) {
-  // enough workgroups to fill the chip a few times over, a pair count that is a multiple of 8 (XCD map), at most one slice per sample
+// Slices of the batch per (window position, head): enough workgroups to fill the chip a few times over, a pair count that is a multiple
+// of 8 (XCD map), at most one slice per sample -- and SHORT runs of items per workgroup.  The H workgroups that share a pair's 128-byte
+// lines (48-byte head segments) start together and drift apart over a long run; round 5 measured the HBM-side bytes per launch against
+// the run length (profiles/r05_window_attn_locality.json, 64 windows x 4 heads x 256 samples, samples per workgroup 32 .. 1):
+//   forward  1.55 x algorithmic / 229 us at 32,  1.35 / 211 at 8,  1.12 / 225 at 4,  1.005 / 396 at 1 (three of four waves idle);
+//   backward 1.69 / 499 at 32,  1.42 / 470 at 16,  1.25 / 558 at 8 (the per-workgroup bias-gradient partial and table load take over).
+// Neither kernel is bound by those bytes: the fastest points are 8 samples per workgroup forward and 16 backward, chosen here.
+static int wa_nsplit(int B, int nW, int H, bool bwd) {
   int ns = 1;
-  while (ns < B && ((long)nW * ns * H < 2048 || ((nW * ns) & 7) != 0)) ns *= 2;
+  long min_wgs = 2048;
+  int run = bwd ? 16 : 8;     // samples per workgroup (4 waves: 4 resp. 2 items per wave)
+  if (const char* e = MMK_DBG_ENV("MMK_WIN_MIN_WGS")) min_wgs = atol(e), run = B;   // experiment (debug-switch builds): the r5 sweep
+  while (ns < B && ((long)nW * ns * H < min_wgs || ((nW * ns) & 7) != 0 || (B + ns - 1) / ns > run)) ns *= 2;
   return ns > B ? B : ns;
 }
 
@@ -449,7 +458,7 @@ extern "C" {
 int mmk_win_attn_supported(int tokens, int dh, int c) { return tokens == WA_N && (dh == 24 || dh == 32) && c % dh == 0 && c % 8 == 0; }
 
 // workgroups of the launch for (B samples, nW windows per sample, H heads) = rows of dtab_part the backward fills
-int mmk_win_attn_blocks(int B, int nW, int H) { return nW * wa_nsplit(B, nW, H) * H; }
+int mmk_win_attn_blocks(int B, int nW, int H) { return nW * wa_nsplit(B, nW, H, true) * H; }
 
 int mmk_win_attn_fwd(const void* q, const void* k, const void* v, const float* table, void* o, float* lse2, int B, int nW, int nWt, int H, int dh,
                      float scale, int img_h, int img_w, int shift, int ld, void* stream) {
@@ -461,7 +470,7 @@ int mmk_win_attn_fwd(const void* q, const void* k, const void* v, const float* t
   a.o = static_cast<bf16_t*>(o); a.lse2 = lse2; a.table = table;
   MMK_REQUIRE(img_w == 0 || (img_h > 0 && img_h % 8 == 0 && img_w % 8 == 0 && (img_h / 8) * (img_w / 8) == nW && shift >= 0 && shift < 8),
               "win_attn: a token map must be a whole number of 8 x 8 windows");
-  a.B = B; a.nW = nW; a.nWt = nWt; a.H = H; a.C = H * dh; a.nsplit = wa_nsplit(B, nW, H); a.scale = scale;
+  a.B = B; a.nW = nW; a.nWt = nWt; a.H = H; a.C = H * dh; a.nsplit = wa_nsplit(B, nW, H, false); a.scale = scale;
   a.img_h = img_w > 0 ? img_h : 0; a.img_w = img_w; a.shift = img_w > 0 ? shift : 0;
   MMK_REQUIRE(ld == a.C || ld == 3 * a.C, "win_attn: q / k / v rows are C or 3 C elements apart");
   a.ld = ld;
@@ -480,7 +489,7 @@ int mmk_win_attn_bwd(const void* q, const void* k, const void* v, const void* do
   a.table = table; a.dq = static_cast<bf16_t*>(dq); a.dk = static_cast<bf16_t*>(dk); a.dv = static_cast<bf16_t*>(dv); a.dtab_part = dtab_part;
   MMK_REQUIRE(img_w == 0 || (img_h > 0 && img_h % 8 == 0 && img_w % 8 == 0 && (img_h / 8) * (img_w / 8) == nW && shift >= 0 && shift < 8),
               "win_attn: a token map must be a whole number of 8 x 8 windows");
-  a.B = B; a.nW = nW; a.nWt = nWt; a.H = H; a.C = H * dh; a.nsplit = wa_nsplit(B, nW, H); a.scale = scale;
+  a.B = B; a.nW = nW; a.nWt = nWt; a.H = H; a.C = H * dh; a.nsplit = wa_nsplit(B, nW, H, true); a.scale = scale;
   a.img_h = img_w > 0 ? img_h : 0; a.img_w = img_w; a.shift = img_w > 0 ? shift : 0;
   MMK_REQUIRE(ld == a.C || ld == 3 * a.C, "win_attn: q / k / v rows are C or 3 C elements apart");
   a.ld = ld;

@@ -7,8 +7,10 @@ ATen math runs here.  There is deliberately no CPU path: CPU tensors raise.
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import functools
+import threading
 import os
 from dataclasses import dataclass, field
 from typing import Optional, Sequence, Tuple
@@ -25,6 +27,27 @@ MAX_DIRS_PER_CALL = 8
 BOUNDED_SOFTMAX = True    # False: never hand the row norms to the tile kernels -> per-row / per-column maxima everywhere
 PAIR_MIRRORS = True       # False: the two directions of a pair on one rank as two tile passes (round-1 behaviour)
 TN_MIN_ROWS = 2048        # from this many rows a mirrored pair stores G once; the mirror's dX uses the transposed-read kernel
+
+_SEAMS = ("BOUNDED_SOFTMAX", "PAIR_MIRRORS", "TN_MIN_ROWS", "FUSED_LOSS")
+_seam_lock = threading.RLock()
+
+
+@contextlib.contextmanager
+def seams(**values):
+    """``with kernels.seams(FUSED_LOSS=False, TN_MIN_ROWS=256): ...`` -- set measurement seams for the duration of a block and put
+    the previous values back, under a process-wide lock (tests and tools flip them in processes that may run other threads'
+    losses; a bare ``kernels.FUSED_LOSS = False`` in a long-lived process stays set for everybody, for ever)."""
+    unknown = set(values) - set(_SEAMS)
+    if unknown:
+        raise KeyError(f"unknown seam(s) {sorted(unknown)}; known: {_SEAMS}")
+    g = globals()
+    with _seam_lock:
+        saved = {k: g[k] for k in values}
+        g.update(values)
+        try:
+            yield
+        finally:
+            g.update(saved)
 
 
 def round_up(a: int, b: int) -> int:

@@ -25,6 +25,8 @@ There is no eager/CPU fallback: CPU tensors raise ``RuntimeError``.
 
 from __future__ import annotations
 
+import contextlib
+
 import math
 from dataclasses import dataclass, field
 from typing import Any, Optional, Sequence
@@ -790,6 +792,16 @@ class ContrastiveLoss(nn.Module):
         self._match_seen: dict[tuple, tuple] = {}
         self._capture_poison: Optional[torch.Tensor] = None
         self.capture_mismatch: Optional[torch.Tensor] = None   # device bool: some replayed batch matched differently than captured
+
+    @contextlib.contextmanager
+    def forcing_gather(self, on: bool = True):
+        """Test seam as a context manager: run the gather path (packed all-gathers, prefetch) on a 1-rank process group inside the
+        block, and put the previous setting back afterwards."""
+        saved, self._force_gather = self._force_gather, bool(on)
+        try:
+            yield self
+        finally:
+            self._force_gather = saved
 
     # ------------------------------------------------------------------ static_shapes: a checked promise
     def _check_static_shapes(self, rows: dict[str, int]) -> None:

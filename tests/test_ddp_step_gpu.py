@@ -97,25 +97,24 @@ def _nccl_world1_worker(port, q, done):
         # them; the fifth repeats the second on the one-launch loss (other summation orders: compared at 2e-3).
         for streams, gather, static, fused in ((False, False, True, False), (True, False, True, False), (True, True, True, False),
                                                (True, True, False, False), (True, False, True, True)):
-            K.FUSED_LOSS = fused
             loss_fn = ContrastiveLoss(static_shapes=static)
-            loss_fn._force_gather = gather
-            task = bench.build_task(loss_fn, small=True, fused=True).to(dev)
-            task.eval()   # dropout off
-            task.concurrent_encoders = streams
-            if streams:   # per-tower DDP instances with many small buckets, bucket-view gradients as in bench.py
-                task.wrap_towers_in_ddp(bucket_cap_mb=1)
-                stepper = bench._Step(task)
-            else:
-                stepper = torch.nn.parallel.DistributedDataParallel(bench._Step(task), device_ids=[0], bucket_cap_mb=1,
-                                                                    gradient_as_bucket_view=True)
-            batch = bench.synthetic_batch(1024, 0, dev)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                loss = stepper(batch)
-            loss.backward()
-            torch.cuda.synchronize()
-            g = torch.cat([p.grad.detach().float().flatten() for p in task.parameters() if p.grad is not None])
-            out.append((float(loss.detach().float().item()), g.cpu().numpy(), loss_fn.prefetched_gathers_used, loss_fn.prefetched_matches_used))
+            with K.seams(FUSED_LOSS=fused), loss_fn.forcing_gather(gather):
+                task = bench.build_task(loss_fn, small=True, fused=True).to(dev)
+                task.eval()   # dropout off
+                task.concurrent_encoders = streams
+                if streams:   # per-tower DDP instances with many small buckets, bucket-view gradients as in bench.py
+                    task.wrap_towers_in_ddp(bucket_cap_mb=1)
+                    stepper = bench._Step(task)
+                else:
+                    stepper = torch.nn.parallel.DistributedDataParallel(bench._Step(task), device_ids=[0], bucket_cap_mb=1,
+                                                                        gradient_as_bucket_view=True)
+                batch = bench.synthetic_batch(1024, 0, dev)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    loss = stepper(batch)
+                loss.backward()
+                torch.cuda.synchronize()
+                g = torch.cat([p.grad.detach().float().flatten() for p in task.parameters() if p.grad is not None])
+                out.append((float(loss.detach().float().item()), g.cpu().numpy(), loss_fn.prefetched_gathers_used, loss_fn.prefetched_matches_used))
         item = (out, None)
     except Exception:  # pragma: no cover
         item = (None, traceback.format_exc())

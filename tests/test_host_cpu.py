@@ -326,3 +326,27 @@ def test_window_attention_patch_takes_only_the_forward_signatures_it_mirrors():
     assert fused.fuse_window_attention(sw) == (len([x for x in sw.modules() if hasattr(x, "relative_position_bias_table")])
                                                if takes == ["hidden_states", "attention_mask", "output_attentions"] else 0)
 
+
+
+def test_measurement_seams_are_scoped():
+    """VERDICT r4 housekeeping: the module-level seams that tests and tools flip (`kernels.FUSED_LOSS`, `TN_MIN_ROWS`, ...,
+    `ContrastiveLoss._force_gather`) sit behind context managers that restore the previous value -- also when the block raises."""
+    import mmlearn_amd.kernels as K
+    from mmlearn_amd import ContrastiveLoss
+
+    before = (K.FUSED_LOSS, K.TN_MIN_ROWS, K.PAIR_MIRRORS, K.BOUNDED_SOFTMAX)
+    with pytest.raises(ZeroDivisionError):
+        with K.seams(FUSED_LOSS=False, TN_MIN_ROWS=256):
+            assert (K.FUSED_LOSS, K.TN_MIN_ROWS) == (False, 256)
+            with K.seams(PAIR_MIRRORS=False):   # nests (re-entrant lock)
+                assert K.PAIR_MIRRORS is False
+            assert K.PAIR_MIRRORS is True
+            1 / 0
+    assert (K.FUSED_LOSS, K.TN_MIN_ROWS, K.PAIR_MIRRORS, K.BOUNDED_SOFTMAX) == before
+    with pytest.raises(KeyError):
+        with K.seams(FUSED=False):
+            pass
+    fn = ContrastiveLoss()
+    with fn.forcing_gather():
+        assert fn._force_gather
+    assert not fn._force_gather

@@ -97,6 +97,7 @@ struct ProbBatch {
   Prob p[MAX_PROBS];
   int n_split;
   int n_probs;
+  int unit_map;           // EPI_PLAIN: 1 = every (problem, K split) unit lives on ONE XCD (see the tile decode of gemm_nt_kernel)
   int dbg;                // -DMMK_DEBUG_SWITCHES builds only (MMK_SIM_DBG; wrong results): 1 = no row statistics, 2 = no column
                           // statistics, 4 = no MFMAs, 16 = no main loop, 32 = return at once; 8 = never take the bounded fast path.
                           // The shipped build ignores the field; the exact path is selected by passing no row norms.
@@ -133,17 +134,31 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void gemm_nt_kernel(cons
   constexpr int STAGE_BYTES = ROWS * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // NSTAGE * STAGE_BYTES (dynamic: may exceed 64 KiB)
 
-  const int zsplit = (EPI == EPI_PLAIN) ? (blockIdx.z % batch.n_split) : 0;
-  const int zprob = (EPI == EPI_PLAIN) ? (blockIdx.z / batch.n_split) : blockIdx.z;
+  int zsplit = (EPI == EPI_PLAIN) ? (blockIdx.z % batch.n_split) : 0;
+  int zprob = (EPI == EPI_PLAIN) ? (blockIdx.z / batch.n_split) : blockIdx.z;
+  int raw_tile = blockIdx.x;
+  // Row-sharded gradient GEMM (few G row tiles, many K splits: R = 1024 x C = 8192 is 32 tiles x 8 splits x 2 directions): a unit =
+  // (problem, split) reads ITS K range of G and of Y^T and nothing else, so all tiles of a unit go to one XCD -- G and Y^T are then
+  // fetched once.  (The tile-range map below keeps a G row tile in one L2 but has all eight XCDs read every Y^T range: 128 of the
+  // 180 MB this launch fetched for 48 MB of operands, profiles/r04_pmc_traffic_shard.json.)  Workgroups are dealt to the XCDs
+  // round-robin in dispatch order (x fastest, then z); the host sets unit_map when the unit count is a multiple of 8.
+  const bool unit_map = EPI == EPI_PLAIN && batch.unit_map;
+  if (unit_map) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.z, xcd = lin & 7, j = lin >> 3;
+    const int unit = xcd + 8 * (j / (int)gridDim.x);
+    raw_tile = j % (int)gridDim.x;
+    zsplit = unit % batch.n_split;
+    zprob = unit / batch.n_split;
+  }
   const Prob& p = batch.p[zprob];
   const int n_tiles = p.tiles_m * p.tiles_n;
-  if ((int)blockIdx.x >= n_tiles) return;
+  if (raw_tile >= n_tiles) return;
   const int dbg = kDebugSwitches ? batch.dbg : 0;   // folded to 0 in the shipped build: no ablation branch survives
   // XCD-aware tile order (speed only, any placement is correct): workgroups are dealt round-robin over the 8 XCDs,
   // so XCD x can be given the contiguous tile range [base_x, base_x + cnt_x): neighbours in (tn, tm) order then share
   // the Q row tile in one L2 instead of it being fetched by all eight (rocprofv3 FETCH_SIZE, N = 8192: 1082 -> 392 MB).
-  int tile = blockIdx.x;
-  if (EPI == EPI_PLAIN) {
+  int tile = raw_tile;
+  if (EPI == EPI_PLAIN && !unit_map) {
     // gradient GEMM: the k_pad/BM blocks that share a G row tile must meet in one L2 (G does not fit any cache).
     // The similarity kernels keep the plain order: there each XCD sees every 8th P tile, a 1/8 slice of P that
     // stays L2-resident while Q streams through once (measured: 142 MB fetched vs 1040 MB with the remap).
@@ -1215,6 +1230,21 @@ static Plan make_plan(int r_max, int c_max, int k_pad, int n_dirs, int compute) 
   if (split > 16) split = 16;
   if (split < 1) split = 1;
   pl.n_split = split;
+  // Row-sharded shapes (few G row tiles, a long contraction: R = 1024 x C = 8192 on each of 8 ranks).  With 128 x 128 tiles and a
+  // split count that makes (directions x splits) a multiple of 8, every (direction, split) unit sits on ONE XCD (unit_map in
+  // gemm_nt_kernel) and its K range of G and of Y^T is fetched from HBM once; the tile-range map has all eight XCDs read every
+  // Y^T range.  Taken when it fills one round of the chip (448 .. 640 workgroups); the slabs it adds (splits x R x D f32) are
+  // less than the Y^T re-reads it removes from 4096 columns on (measured, profiles/r05_pmc_traffic_shard.json: the rank share's HBM-side
+  // bytes 346 -> 272 MB at C = 8192, 202 -> 185 MB at 4096, but 130 -> 142 MB at 2048).
+  if (c_pad >= 4096 && !MMK_DBG_ENV("MMK_TILE") && !(MMK_DBG_ENV("MMK_GRAD_UNIT_MAP") && atoi(MMK_DBG_ENV("MMK_GRAD_UNIT_MAP")) == 0)) {
+    const long gt128 = (long)cdiv(k_pad, 128) * cdiv(r_max, 128) * n_dirs;
+    for (int s8 = 4; s8 <= 16 && s8 <= max_split; s8 += 4)
+      if ((n_dirs * s8) % 8 == 0 && gt128 * s8 >= 448 && gt128 * s8 <= 640) {
+        pl.bm_g = pl.bn_g = 128;
+        pl.n_split = s8;
+        break;
+      }
+  }
   return pl;
 }
 
@@ -1296,6 +1326,7 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
     pl.bn = 128;
   }
   ProbBatch b;
+  b.unit_map = 0;
   MergeBatch mb;
   AlignReduceBatch ab;
   int max_tiles = 0, n_red = 0, r_red_max = 0;
@@ -1454,11 +1485,13 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
     max_r = std::max(max_r, d.r);
   }
   gb.n_split = 1;
+  gb.unit_map = 0;
   gb.n_probs = n_tile_probs;
   xb.n_probs = n_x;
   gb.dbg = MMK_DBG_ENV("MMK_SIM_DBG") ? (atoi(MMK_DBG_ENV("MMK_SIM_DBG")) & 8) : 0;   // 8 = never take the bounded fast path
   xb.dbg = 0;
   xb.n_split = pl.n_split;
+  xb.unit_map = (n_x * pl.n_split) % 8 == 0 && !(MMK_DBG_ENV("MMK_GRAD_UNIT_MAP") && atoi(MMK_DBG_ENV("MMK_GRAD_UNIT_MAP")) == 0);
   fb.d = d_user;
   if (n_tile_probs > 0) {
     int rc = dirs[0].mode == 1 ? launch_gemm<T, EPI_ALIGN_GRAD>(gb, n_tile_probs, pl.bm, pl.bn, max_tiles_g, scale, st)

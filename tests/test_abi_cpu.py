@@ -42,7 +42,8 @@ def test_shipped_library_reads_no_experiment_switches(built):
     -DMMK_DEBUG_SWITCHES builds; the shipped library does not even contain their names."""
     blob = open(built.LIB_PATH, "rb").read()
     for name in (b"MMK_SIM_DBG", b"MMK_TILE", b"MMK_LOADER", b"MMK_STAGES", b"MMK_STATS_TILE", b"MMK_ATTN_BWD7", b"MMK_ATTN_STAGED", b"MMK_FUSED_DBG", b"MMK_WGRAD_MFMA", b"MMK_WGRAD_PAIR",
-                 b"MMK_ATTN_STAMPS", b"MMK_ATTN_SPLIT", b"MMK_MLP_GEMM_DBG", b"MMK_MLP_GEMM_STAMPS"):
+                 b"MMK_ATTN_STAMPS", b"MMK_ATTN_SPLIT", b"MMK_MLP_GEMM_DBG", b"MMK_MLP_GEMM_STAMPS", b"MMK_WGRAD_TILE", b"MMK_WGRAD_MAP",
+                 b"MMK_WIN_MIN_WGS", b"MMK_GRAD_UNIT_MAP"):
         assert name not in blob, name
 
 

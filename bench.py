@@ -651,10 +651,10 @@ def loss_n8192_leg(dev, n: int = 8192, d: int = 512, iters: int = 10):
 
 
 def _shard_traffic(cols: int):
-    """HBM-side bytes of one rank's share at this column count from the committed PMC passes (profiles/r04_pmc_traffic_shard.json:
+    """HBM-side bytes of one rank's share at this column count from the committed PMC passes (profiles/r05_pmc_traffic_shard.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/bench_loss_shard.py), or None."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_shard.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic_shard.json")))
         return pmc.get(f"cols{cols}")
     except Exception:
         return None

@@ -260,3 +260,45 @@ def test_ijepa_vit_s_step_with_ema_is_captured_and_replays_bit_identically(true_
             task_g._masks_for_step(32, dev)
     finally:
         torch.cuda.is_current_stream_capturing = real
+
+
+def test_captured_ijepa_step_with_stock_blocks_and_torch_adamw():
+    """The runner does not depend on this package's encoder kernels or optimizer: stock timm-style blocks (SDPA attention, ATen LayerNorm),
+    `torch.optim.AdamW(capturable=True)`, the I-JEPA path ops (index gathers, predictor assembly, fused target + loss, EMA) on HIP.
+    Library attention / GEMM kernels may reorder sums between an eager launch and a replay, so the comparison is to 1e-4 of the
+    largest parameter, not bitwise."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_ijepa_step as T
+    from mmlearn_amd.graph import CapturedIJEPAStep
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(23)
+    images = [torch.rand(8, 3, 224, 224, generator=g).to(dev) for _ in range(6)]
+
+    def make():
+        task = T.build(True, False, dev, capturable=True)   # the two-block toy ViT, stock modules, torch.optim.AdamW
+        opt = task.configure_optimizers()
+        return task, (opt["optimizer"] if isinstance(opt, dict) else opt)
+
+    task_e, opt_e = make()
+    assert type(opt_e).__module__.startswith("torch.optim")
+    torch.manual_seed(9)
+    for k in range(6):
+        opt_e.zero_grad(set_to_none=False)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss_e = task_e.training_step({"rgb": images[k]}, 0)
+        loss_e.backward()
+        opt_e.step()
+        task_e.on_before_zero_grad(opt_e)
+    task_g, opt_g = make()
+    runner = CapturedIJEPAStep(task_g, opt_g, warmup=3)
+    torch.manual_seed(9)
+    for k in range(6):
+        loss_g = runner({"rgb": images[k]})
+    torch.cuda.synchronize()
+    assert runner.replays == 3
+    assert abs(float(loss_g.detach()) - float(loss_e.detach())) <= 1e-3 * max(1.0, abs(float(loss_e.detach())))
+    scale = max(p.detach().abs().max().item() for p in task_e.parameters())
+    for (n, pe), (_, pg) in zip(task_e.named_parameters(), task_g.named_parameters()):
+        assert (pe.detach() - pg.detach()).abs().max().item() <= 1e-4 * scale, n
+    assert task_e.target_encoder.num_updates == task_g.target_encoder.num_updates == 6

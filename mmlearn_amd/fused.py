@@ -1049,8 +1049,19 @@ def _swin_layer_forward(self, hidden_states, input_dimensions, output_attentions
     attention_output = self.attention.output(ctx_map, x)
     hidden_states = shortcut + self.drop_path(attention_output)
     layer_output = self.layernorm_after(hidden_states)
-    layer_output = self.intermediate(layer_output)
-    layer_output = hidden_states + self.output(layer_output)
+    inter, outp = self.intermediate, self.output
+    act = _act_name(getattr(inter, "intermediate_act_fn", None))
+    fc1, fc2 = getattr(inter, "dense", None), getattr(outp, "dense", None)
+    if (act is not None and type(fc1) is nn.Linear and type(fc2) is nn.Linear and fc1.bias is not None
+            and fc2.in_features == fc1.out_features):
+        # the block's MLP as the encoders' MLP node (``mlp_fc1_act_fc2``: bias + GELU in the GEMM epilogue where the shape allows, one
+        # bias + activation kernel each way otherwise) instead of dense -> ATen GELU -> dense: no new kernel, the same ones CLIP / BERT run
+        y = mlp_fc1_act_fc2(layer_output, fc1, act, fc2)
+        if fc2.bias is not None:
+            y = y + fc2.bias.to(y.dtype)
+        layer_output = hidden_states + outp.dropout(y)
+    else:
+        layer_output = hidden_states + outp(inter(layer_output))
     return (layer_output,)
 
 

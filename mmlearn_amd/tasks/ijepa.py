@@ -219,7 +219,7 @@ class _MaskStage:
     def __init__(self, device: torch.device):
         self.device = device
         self.stream = torch.cuda.Stream(device=device)
-        self.slots: list = [None, None]      # (pinned int32, device staging int32, upload event)
+        self.slots: list = [None, None]      # [pinned int32, device staging int32, upload event, event after the last commit that read the staging buffer]
         self.turn = 0
         self.pending = None                  # (slot, key, layout, batch_size) staged, not committed
         self.ready = None                    # (key, layout, batch_size) committed, not taken
@@ -244,12 +244,14 @@ class _MaskStage:
         slot = self.slots[k]
         if slot is None or slot[0].numel() < n:
             cap = max(2 * n, 4096)
-            slot = (torch.empty(cap, dtype=torch.int32).pin_memory(), torch.empty(cap, dtype=torch.int32, device=self.device), torch.cuda.Event())
+            slot = [torch.empty(cap, dtype=torch.int32).pin_memory(), torch.empty(cap, dtype=torch.int32, device=self.device), torch.cuda.Event(), None]
             self.slots[k] = slot
         else:
             slot[2].synchronize()   # the upload that last read this pinned slot (two stagings ago) has long finished
         slot[0][:n].copy_(flat)
         with torch.cuda.stream(self.stream):
+            if slot[3] is not None:   # the commit (on the step's stream) that last read this device staging buffer comes first
+                self.stream.wait_event(slot[3])
             slot[1][:n].copy_(slot[0][:n], non_blocking=True)
             slot[2].record(self.stream)
         self.pending = (k, key, layout, batch_size, n)
@@ -270,6 +272,9 @@ class _MaskStage:
             buf = torch.empty(n, dtype=torch.int32, device=self.device)
             self.static[(key, layout)] = buf
         buf.copy_(slot[1][:n])
+        if slot[3] is None:
+            slot[3] = torch.cuda.Event()
+        slot[3].record(torch.cuda.current_stream(self.device))
         self.pending, self.ready = None, (key, layout, batch_size)
         return key
 

@@ -764,7 +764,10 @@ def _leg_full_last_layer(args, dev):
 
 
 def _leg_ijepa(args, dev):
-    return ijepa_leg(16 if args.small else 128, dev, args.small)
+    tuned_gemms = _enable_tuned_gemms(args)   # the product's library-GEMM selections (look-up only); the stock leg never loads them
+    out = ijepa_leg(16 if args.small else 128, dev, args.small)
+    out["library_gemm_selection"] = "mmlearn_amd/tuned/gemm_gfx950.csv" if tuned_gemms else "library default"
+    return out
 
 
 def _leg_three_tower_eager(args, dev):

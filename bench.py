@@ -412,7 +412,7 @@ def _window_attn_roofline(prof: dict, audio, b: int):
     """HBM roofline of the windowed-attention kernels of the audio tower (csrc/window_attention.hip) over one step: algorithmic bytes --
     per window and head q, k, v in and o out forward, q, k, v, dO in and dq, dk, dv out backward, [64 x head_dim] bf16 each, + lse --
     summed over the tower's layers, over the kernels' dispatch-stamped durations.  `traffic` = HBM-side bytes of ONE first-resolution
-    launch pair from the committed PMC passes (profiles/r04_window_attn_pmc_traffic.json), with its algorithmic bytes beside it."""
+    launch pair from the committed PMC passes (profiles/r05_window_attn_pmc_traffic.json), with its algorithmic bytes beside it."""
     f, g = prof.get("win_attn_fwd"), prof.get("win_attn_bwd")
     if not f or not g or not f[0] or not g[0]:
         return None
@@ -433,7 +433,7 @@ def _window_attn_roofline(prof: dict, audio, b: int):
            "frac": round(alg / sec * 1e-9 / HBM_PEAK_GBPS, 4), "traffic": None, "launches": int(f[0] + g[0]),
            "device_us_per_step": round(sec * 1e6, 1), "algorithmic_bytes_per_step": int(alg)}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_window_attn_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_window_attn_pmc_traffic.json")))
         out["traffic"] = int(pmc["fwd"]["hbm_bytes_per_launch"] + pmc["bwd"]["hbm_bytes_per_launch"])
         out["traffic_note"] = (f"one forward + backward launch at the first resolution ({pmc['windows_per_sample']} windows x {pmc['heads']} heads, batch "
                                f"{pmc['batch']}): {pmc['fwd']['algorithmic_bytes'] + pmc['bwd']['algorithmic_bytes']} algorithmic bytes")

@@ -4,7 +4,9 @@ The encoders' forward and dX products stay on hipBLASLt / rocBLAS.
 default heuristic does not pick its own fastest kernel; ``gemm_gfx950.csv`` holds the winners TunableOp measured on an MI355X
 for the [batch x tokens, 768 / 2304 / 3072] products of ViT-B/16 and BERT-base at per-GPU batch 1024 and 256 and (round 5,
 ``tools/tune_gemms.py --workload ijepa_vitl``) for the ViT-L/16 and 384-wide predictor products of the I-JEPA step at batch 128, every
-mask geometry that occurs (4 x 128 x (169 + 30 .. 40) predictor rows).  ``enable()`` loads
+mask geometry that occurs (4 x 128 x (169 + 30 .. 40) predictor rows), and for HTSAT's plain products at batch 256
+(``tools/probes/record_untuned_three_tower.py`` lists them without tuning -- no strided-batched op is left in that tower since its
+windowed attention is one kernel -- and ``tools/tune_gemms.py --untuned`` tunes exactly that list offline).  ``enable()`` loads
 them (no tuning at run time, nothing written); a shape that is not in the file runs the library's default, and a file recorded
 with another PyTorch / hipBLASLt / rocBLAS build is refused by TunableOp's validators, which leaves every shape on the default.
 

@@ -14,7 +14,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=("ijepa_vitl",), default="ijepa_vitl")
+    ap.add_argument("--workload", choices=("ijepa_vitl", "none"), default="ijepa_vitl")
+    ap.add_argument("--untuned", default=None, help="a TunableOp record-untuned file (tools/probes/record_untuned_three_tower.py): tune exactly "
+                                                     "its plain GEMM shapes offline instead of running a workload")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tuned_new.csv"))
     ap.add_argument("--merge", action="store_true", help="append the new plain-GEMM shapes to the shipped selections file")
@@ -30,7 +32,16 @@ def main():
     tunable.tuning_enable(True)
     tunable.set_filename(a.out)
     tunable.read_file(tuned.DEFAULT_FILE)   # shapes already selected are not tuned again
-    if a.workload == "ijepa_vitl":
+    task = opt = None
+    if a.untuned:
+        lines = [ln for ln in open(a.untuned).read().splitlines() if ln.startswith(("GemmTunableOp", "GemmAndBiasTunableOp"))]
+        if any("Batched" in ln for ln in open(a.untuned).read().splitlines()):
+            print("[tune] the untuned file lists strided-batched ops: they are skipped", flush=True)
+        tmp = a.out + ".untuned_plain.csv"
+        open(tmp, "w").write("\n".join(lines) + "\n")
+        print(f"[tune] tuning {len(lines)} shapes of {a.untuned}", flush=True)
+        tunable.tune_gemm_in_file(tmp)
+    elif a.workload == "ijepa_vitl":
         import bench_ijepa_step as T
 
         task = T.build(False, True, dev)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMK_ABI_VERSION 5
+#define MMK_ABI_VERSION 6
 
 /* element types of user tensors */
 enum { MMK_F32 = 0, MMK_BF16 = 1, MMK_F16 = 2 };
@@ -496,6 +496,20 @@ int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
                  float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
                  const int64_t* k_strides, const int64_t* v_strides, const int64_t* grad_strides, float scale,
                  float dropout_p, uint64_t seed, float* colsum_part, void* stream);
+
+/* Attention of ONE query per (sample, head) against L <= 256 keys (head dim 64, bf16): the token-0 row of the last layer of a tower
+ * pooled at token 0 (mmlearn/modules/encoders/clip.py:463-470 reads last_hidden_state[:, 0, :]; HF CLIPEncoderLayer / BertLayer are the
+ * callers' stock forms).  q, o, dout, dq: [B, H, 64] contiguous.  k, v: element (b, l, h, d) at base + b * kv_sb + l * kv_sl + h * 64 + d
+ * (the halves of one packed [B, L, 2, H, 64] projection output: kv_sl = 2 H 64); dk, dv likewise with g_sb, g_sl.  lse2: f32 [B, H], the
+ * base-2 log-sum-exp of the scaled logits (forward output, backward input).  dropout_p drops attention probabilities with the counter
+ * -based mask of mmk_attn_fwd (query index 0), regenerated by the backward from the same seed.  Replaces
+ * F.scaled_dot_product_attention(q[:, :, :1], k, v, dropout_p, scale) and its autograd.  ABI 6. */
+int mmk_cls_attn_supported(int L, int dh);
+int mmk_cls_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, int B, int H, int L, int dh, int64_t kv_sb,
+                     int64_t kv_sl, float scale, float dropout_p, uint64_t seed, void* stream);
+int mmk_cls_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse2, void* dq, void* dk, void* dv, int B,
+                     int H, int L, int dh, int64_t kv_sb, int64_t kv_sl, int64_t g_sb, int64_t g_sl, float scale, float dropout_p,
+                     uint64_t seed, void* stream);
 
 #ifdef __cplusplus
 }

@@ -819,17 +819,44 @@ def patch_embedding_backward(module: nn.Module) -> int:
     return n
 
 
+class _ClsAttnFn(torch.autograd.Function):
+    """softmax(scale q k^T) v for ONE query per (sample, head), keys / values as one packed ``[B, L, 2, H, 64]`` tensor
+    (csrc/cls_attention.hip: one wave per (sample, head), every key / value row read once each way, every gradient row written once)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, scale, dropout_p, seed):
+        o, lse2 = K.cls_attn_fwd(q, kv, scale, dropout_p, seed)
+        ctx.save_for_backward(q, kv, lse2)
+        ctx.cfg = (scale, dropout_p, seed)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, lse2 = ctx.saved_tensors
+        dq, dkv = K.cls_attn_bwd(q, kv, do.contiguous(), lse2, *ctx.cfg)
+        return dq, dkv, None, None, None
+
+
 def _cls_query_attention(x: torch.Tensor, q_lin: nn.Linear, k_lin: nn.Linear, v_lin: nn.Linear, heads: int, scale: float,
                          dropout_p: float) -> torch.Tensor:
     """Attention output of query token 0 alone, ``[B, 1, E]``: keys and values of ALL tokens through one packed ``[2E, E]``
-    projection (the HIP weight-gradient path of :func:`linear`), the query of token 0 only."""
+    projection (the HIP weight-gradient path of :func:`linear`), the query of token 0 only.  On the GPU in bf16 with 64-wide heads and
+    L <= 256 the attention itself is the single-query kernel pair (``_ClsAttnFn``; the library's SDPA takes 1.6 ms for what moves in
+    0.4); anything else (the CPU tests, other head sizes) runs ``F.scaled_dot_product_attention``."""
     B, L, E = x.shape
     dh = E // heads
     wkv = torch.cat([k_lin.weight, v_lin.weight], 0)
     bkv = torch.cat([k_lin.bias, v_lin.bias], 0) if (k_lin.bias is not None and v_lin.bias is not None) else None
-    k, v = linear(x, wkv, bkv).view(B, L, 2, heads, dh).unbind(2)       # one stack in the backward, no zero-filled halves
-    q = F.linear(x[:, :1], q_lin.weight, q_lin.bias).view(B, 1, heads, dh).transpose(1, 2).to(k.dtype)
-    a = F.scaled_dot_product_attention(q, k.transpose(1, 2), v.transpose(1, 2), dropout_p=dropout_p, scale=scale)
+    kv = linear(x, wkv, bkv).view(B, L, 2, heads, dh)                   # one stack in the backward, no zero-filled halves
+    q = F.linear(x[:, :1], q_lin.weight, q_lin.bias).view(B, heads, dh).to(kv.dtype)
+    if (kv.is_cuda and kv.dtype == torch.bfloat16 and dh == 64 and L <= 256 and kv.is_contiguous() and not os.environ.get("MMK_NO_CLS_ATTN")
+            and getattr(K, "cls_attn_supported", None) is not None):
+        from .attention import draw_seed
+
+        seed = draw_seed() if dropout_p > 0.0 else 0
+        return _ClsAttnFn.apply(q.contiguous(), kv, float(scale), float(dropout_p), seed).view(B, 1, E)
+    k, v = kv.unbind(2)
+    a = F.scaled_dot_product_attention(q.unsqueeze(2), k.transpose(1, 2), v.transpose(1, 2), dropout_p=dropout_p, scale=scale)
     return a.transpose(1, 2).reshape(B, 1, E)
 
 

@@ -1126,6 +1126,41 @@ def win_attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dout: torch.
     return dq, dk, dv, dtab.view(heads, 64, 64)
 
 
+def cls_attn_supported(L: int, dh: int) -> bool:
+    return bool(_lib.lib().mmk_cls_attn_supported(int(L), int(dh)))
+
+
+def _cls_kv(kv: torch.Tensor):
+    """``kv``: bf16 ``[B, L, 2, H, 64]`` contiguous (the packed key | value projection) -> (k view, v view, B, L, H, batch stride, row stride)."""
+    require_gpu(kv)
+    assert kv.dim() == 5 and kv.shape[2] == 2 and kv.shape[4] == 64 and kv.dtype == torch.bfloat16 and kv.is_contiguous()
+    B, L, _, H, dh = kv.shape
+    return kv[:, :, 0], kv[:, :, 1], B, L, H, L * 2 * H * dh, 2 * H * dh
+
+
+def cls_attn_fwd(q: torch.Tensor, kv: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0):
+    """One query per (sample, head): ``q`` bf16 ``[B, H, 64]`` contiguous, ``kv`` bf16 ``[B, L <= 256, 2, H, 64]`` ->
+    (o bf16 ``[B, H, 64]``, lse2 f32 ``[B, H]``).  csrc/cls_attention.hip."""
+    k, v, B, L, H, sb, sl = _cls_kv(kv)
+    assert q.shape == (B, H, 64) and q.dtype == torch.bfloat16 and q.is_contiguous()
+    o = torch.empty_like(q)
+    lse2 = torch.empty((B, H), dtype=torch.float32, device=q.device)
+    check(_lib.lib().mmk_cls_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse2), B, H, L, 64, sb, sl, float(scale), float(dropout_p), int(seed),
+                                      stream()))
+    return o, lse2
+
+
+def cls_attn_bwd(q: torch.Tensor, kv: torch.Tensor, dout: torch.Tensor, lse2: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0):
+    """-> (dq bf16 ``[B, H, 64]``, dkv bf16 ``[B, L, 2, H, 64]``: every key / value row written)."""
+    k, v, B, L, H, sb, sl = _cls_kv(kv)
+    assert dout.shape == q.shape and dout.dtype == torch.bfloat16 and dout.is_contiguous() and lse2.is_contiguous()
+    dq = torch.empty_like(q)
+    dkv = torch.empty_like(kv)
+    check(_lib.lib().mmk_cls_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(dout), ptr(lse2), ptr(dq), ptr(dkv[:, :, 0]), ptr(dkv[:, :, 1]), B, H, L, 64,
+                                      sb, sl, sb, sl, float(scale), float(dropout_p), int(seed), stream()))
+    return dq, dkv
+
+
 def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0):
     """q/k/v: [B, H, L, 64] bf16 views (last dim contiguous) -> (out [B, L, H, 64] contiguous, lse f32 [B, H, L]).
     ``dropout_p`` > 0 drops attention probabilities with the counter-based mask of ``seed`` (see csrc/attention.hip)."""

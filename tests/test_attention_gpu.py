@@ -184,3 +184,80 @@ def test_packed_backward_column_sums_equal_the_sum_over_the_stored_gradient(B, H
     assert cs.shape == (3 * H * 64,) and cs.dtype == torch.float32
     scale = max(1.0, want.abs().max().item())
     assert (cs.double() - want).abs().max().item() <= 1e-5 * scale * max(1.0, (B * L) ** 0.5 / 8), (cs.double() - want).abs().max().item()
+
+
+@pytest.mark.parametrize("B,H,L,p", [(6, 12, 197, 0.0), (5, 3, 77, 0.1), (2, 2, 256, 0.0), (3, 4, 1, 0.0), (4, 2, 65, 0.25), (1025, 12, 50, 0.0)])
+def test_single_query_attention_matches_row_0_of_the_oracle(B, H, L, p):
+    """csrc/cls_attention.hip (the token-0 query of a tower's last layer, fused.cls_only_last_layer): output, d q, and EVERY row of
+    d k / d v against row 0 of the full attention oracle (float32 torch + the numpy restatement of the dropout mask at query index 0)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import attention_oracle as AO
+    from mmlearn_amd.fused import _ClsAttnFn
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(31 * L + B)
+    dh, scale, seed = 64, 0.125, 0x0BAD_5EED_0000_0000 + L
+    q0 = (torch.randn(B, H, dh, generator=g) * 1.5).bfloat16()
+    kv0 = (torch.randn(B, L, 2, H, dh, generator=g) * 1.5).bfloat16()
+    w = torch.randn(B, H, dh, generator=g)
+    Bo = min(B, 8)   # the oracle walks (sample, head) pairs in python: the first samples are enough, the kernel's grid covers all of them
+    qr = torch.zeros(Bo, H, L, dh)
+    qr[:, :, 0] = q0[:Bo].float()
+    qr.requires_grad_(True)
+    kr = kv0[:Bo, :, 0].float().transpose(1, 2).clone().requires_grad_(True)    # [B, H, L, dh]
+    vr = kv0[:Bo, :, 1].float().transpose(1, 2).clone().requires_grad_(True)
+    out_r = AO.attention(qr, kr, vr, scale, p, seed)[:, 0]                      # [B, H, dh]: query 0
+    (out_r * w[:Bo]).sum().backward()
+    qd, kvd = q0.to(dev).requires_grad_(True), kv0.to(dev).requires_grad_(True)
+    out = _ClsAttnFn.apply(qd, kvd, scale, p, seed)
+    assert out.shape == (B, H, dh) and out.dtype == torch.bfloat16
+    err = (out[:Bo].float().cpu() - out_r.detach()).abs().max().item()
+    assert err <= 2e-2 * max(1.0, out_r.abs().max().item()), err
+    (out.float() * w.to(dev)).sum().backward()
+    dq_ref = qr.grad[:, :, 0]
+    assert (qd.grad[:Bo].float().cpu() - dq_ref).abs().max().item() <= 3e-2 * max(dq_ref.abs().max().item(), 1e-3)
+    for part, ref, name in ((0, kr.grad, "dk"), (1, vr.grad, "dv")):
+        ref_l = ref.transpose(1, 2)                                            # [B, L, H, dh]
+        e = (kvd.grad[:Bo, :, part].float().cpu() - ref_l).abs().max().item()
+        assert e <= 3e-2 * max(ref_l.abs().max().item(), 1e-3), (name, e, ref_l.abs().max().item())
+    assert torch.isfinite(kvd.grad.float()).all() and torch.isfinite(out.float()).all()   # every (sample, head) was served
+    if B > Bo:   # the samples the oracle did not walk: against the library's SDPA on the device
+        with torch.no_grad():
+            k, v = kvd.detach().unbind(2)
+            ref = torch.nn.functional.scaled_dot_product_attention(qd.detach().unsqueeze(2).float(), k.transpose(1, 2).float(), v.transpose(1, 2).float(),
+                                                                   scale=scale)[:, :, 0]
+        assert (out.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+
+
+def test_cls_only_path_uses_the_single_query_kernel_and_agrees_with_sdpa(monkeypatch):
+    """fused._cls_query_attention: the HIP single-query node against the same function on F.scaled_dot_product_attention
+    (MMK_NO_CLS_ATTN=1), forward and all gradients, on a ViT-shaped problem."""
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(4)
+    E, heads, B, L = 768, 12, 40, 197
+    ql, kl, vl = (torch.nn.Linear(E, E).to(dev) for _ in range(3))
+    x0 = torch.randn(B, L, E, device=dev)
+    w = torch.randn(B, 1, E, device=dev)
+    outs = []
+    for hip in (False, True):
+        if hip:
+            monkeypatch.delenv("MMK_NO_CLS_ATTN", raising=False)
+        else:
+            monkeypatch.setenv("MMK_NO_CLS_ATTN", "1")
+        for m in (ql, kl, vl):
+            m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            a = fused._cls_query_attention(x, ql, kl, vl, heads, 0.125, 0.0)
+        assert a.shape == (B, 1, E)
+        (a.float() * w).sum().backward()
+        outs.append([a.float().detach(), x.grad.clone()] + [p.grad.clone() for m in (ql, kl, vl) for p in m.parameters()])
+    top = max(t.abs().max().item() for t in outs[0][1:])
+    for k, (r, h) in enumerate(zip(*outs)):
+        # the key bias' gradient is zero analytically (a constant added to every key's logit cancels in the softmax): both runs hold
+        # bf16 noise there, so every tensor is compared on the scale of the real gradients
+        scale = r.abs().max().item() if k == 0 else max(r.abs().max().item(), 2e-2 * top)
+        assert (r - h).abs().max().item() <= 3e-2 * max(scale, 1e-3), k

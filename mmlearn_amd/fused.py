@@ -905,7 +905,8 @@ _CLS_LAST_LAYER = {"CLIPEncoder": ("layers", "CLIPEncoderLayer", _clip_last_laye
 
 def reads_only_token0(module: nn.Module) -> tuple:
     """Is it PROVABLE that the consumer of ``module``'s HF ``CLIPEncoder`` / ``BertEncoder`` reads nothing but token 0 of the final
-    hidden state?  -> ``(yes, why)``.  The test is on the code that consumes the encoder output, which is the tower wrapper's
+    hidden state?  -> ``(verdict, why)`` with ``verdict`` True (proven), False (contradicted: something reads other positions) or
+    None (unknown consumer: not provable either way).  The test is on the code that consumes the encoder output, which is the tower wrapper's
     ``forward``; so it is answered only for wrappers whose ``forward`` is known:
 
     * a wrapper that declares it: class or instance attribute ``mmk_reads_only_token0`` (True / False) -- the tower's author states
@@ -931,7 +932,7 @@ def reads_only_token0(module: nn.Module) -> tuple:
         if getattr(module, "patch_dropout", None) is not None and getattr(module.patch_dropout, "exclude_first_token", True) is False:
             return False, "patch dropout may drop the class token"
         return True, "HFCLIPVisionEncoderWithProjection pools last_hidden_state[:, 0] (clip.py:463-470)"
-    return False, f"{type(module).__name__}: forward is not a known token-0 consumer (declare mmk_reads_only_token0 = True on the tower to opt in)"
+    return None, f"{type(module).__name__}: forward is not a known token-0 consumer (declare mmk_reads_only_token0 = True on the tower to opt in)"
 
 
 def cls_only_last_layer(module: nn.Module) -> int:
@@ -1216,10 +1217,10 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
     if cls_only not in (True, False, "auto"):
         raise ValueError(f"cls_only must be True, False or 'auto', got {cls_only!r}")
     if cls_only is not False:
-        proven, why = reads_only_token0(module)
-        contradicted = not proven and "not a known token-0 consumer" not in why
-        if cls_only is True and contradicted:
+        verdict, why = reads_only_token0(module)
+        if cls_only is True and verdict is False:
             raise ValueError(f"accelerate_encoder(cls_only=True) refused: {why}")
+        proven = verdict is True
         swapped["cls_only"] = why if (proven or cls_only is True) else f"off: {why}"
         if proven or cls_only is True:     # last: it wraps whatever forward the last layer has by now (fused or stock)
             swapped["cls_only_last_layer"] = cls_only_last_layer(module)

@@ -110,7 +110,7 @@ def test_auto_switches_the_saving_on_only_where_token_0_pooling_is_provable():
         out = fused.accelerate_encoder(copy.deepcopy(full))   # (the patched model itself needs the GPU: its LayerNorms are HIP now)
         assert out.get("cls_only_last_layer") == 1 and not out["cls_only"].startswith("off"), out
         auto = copy.deepcopy(full)
-        assert fused.reads_only_token0(auto)[0] and fused.cls_only_last_layer(auto) == 1   # what "auto" did, on the stock layers
+        assert fused.reads_only_token0(auto)[0] is True and fused.cls_only_last_layer(auto) == 1   # what "auto" did, on the stock layers
         assert fused.accelerate_encoder(copy.deepcopy(full), cls_only=False).get("cls_only_last_layer") is None
         ref = full(x)[0]
         got = auto(x)[0]
@@ -121,7 +121,8 @@ def test_auto_switches_the_saving_on_only_where_token_0_pooling_is_provable():
             assert (a.grad is None) == (b.grad is None), k
             if a.grad is not None:
                 assert (a.grad - b.grad).abs().max() <= 1e-4 * max(a.grad.abs().max().item(), 1e-3), k   # f32 summation order
-    # not provable: left off, with the reason
+    # not provable: left off, with the reason (unknown consumer -> None, a contradiction -> False)
+    assert fused.reads_only_token0(_tiny_clip())[0] is None and fused.reads_only_token0(HFCLIPVisionEncoderWithProjection(True))[0] is False
     for tower in (_tiny_clip(), HFCLIPVisionEncoderWithProjection(True)):
         out = fused.accelerate_encoder(tower)
         assert out["cls_only"].startswith("off:") and "cls_only_last_layer" not in out, out

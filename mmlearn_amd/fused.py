@@ -331,6 +331,19 @@ def _linear_module_forward(self, x):
     return linear(x, self.weight, self.bias)
 
 
+def _plain_linear(m) -> bool:
+    """Does ``m(x)`` compute exactly ``F.linear(x, m.weight, m.bias)``?  Every fusion below reads ``.weight`` / ``.bias`` directly and
+    never calls the module, which is only sound for a stock ``nn.Linear``: an adapter-wrapped projection (peft's LoRA ``Linear`` keeps
+    the base layer's ``.weight`` visible while its ``forward`` adds the adapter delta), a subclass, an instance-level ``forward`` that is
+    not this package's own, or a module with forward / backward hooks would silently lose its extra terms and their gradients."""
+    if type(m) is not nn.Linear:
+        return False
+    own = m.__dict__.get("forward")
+    if own is not None and getattr(own, "__func__", None) is not _linear_module_forward:
+        return False
+    return not (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks)
+
+
 def linear_wgrad(module: nn.Module) -> int:
     """Patch every plain ``nn.Linear`` inside ``module`` to run through :func:`linear`: where the layer sees >= 6k rows in bf16
     its weight gradient comes from ``csrc/wgrad.hip`` (split over the rows), its dX from the transposed twin.  For towers none of
@@ -466,7 +479,7 @@ def _act_name(fn) -> Optional[str]:
 
 
 def _bias_deferrable(lin: nn.Linear, x: torch.Tensor) -> bool:
-    return (lin.bias is not None and x.is_cuda and lin.out_features % 8 == 0
+    return (_plain_linear(lin) and lin.bias is not None and x.is_cuda and lin.out_features % 8 == 0
             and (torch.is_autocast_enabled() or lin.weight.dtype == x.dtype))
 
 
@@ -597,7 +610,8 @@ def _preln_block_forward(self, x, return_attention: bool = False):
     p_attn, p_proj = _drop_p(attn.attn_drop, self.training), _drop_p(attn.proj_drop, self.training)
     ok = (not return_attention and isinstance(self.drop_path, nn.Identity) and p_attn is not None and p_proj is not None
           and x.dim() == 3 and x.is_cuda and _autocast_bf16() and x.shape[1] <= 256 and x.shape[2] == 64 * attn.num_heads
-          and attn.qkv.out_features == 3 * x.shape[2] and _ln_fusable(self.norm2, x) and _bias_deferrable(attn.proj, x))
+          and _plain_linear(attn.qkv) and attn.qkv.out_features == 3 * x.shape[2] and _ln_fusable(self.norm2, x)
+          and _bias_deferrable(attn.proj, x))
     if not ok:
         if hasattr(x, "_mmk_prenormed"):
             del x._mmk_prenormed
@@ -682,7 +696,7 @@ def _fused_qkv(self, hidden_states: torch.Tensor, names, scale: float, dropout_p
     from .attention import attention_qkvpacked
 
     q, k, v = (getattr(self, n) for n in names)
-    if hidden_states.dim() != 3 or not hidden_states.is_cuda:
+    if hidden_states.dim() != 3 or not hidden_states.is_cuda or not (_plain_linear(q) and _plain_linear(k) and _plain_linear(v)):
         return None
     B, L, E = hidden_states.shape
     if E % 64 or L > 256 or q.weight.shape != (E, E) or not (0.0 <= dropout_p < 1.0):
@@ -860,7 +874,9 @@ def _cls_query_attention(x: torch.Tensor, q_lin: nn.Linear, k_lin: nn.Linear, v_
     return a.transpose(1, 2).reshape(B, 1, E)
 
 
-def _cls_forward_applies(attn, hidden_states, attention_mask, kwargs) -> bool:
+def _cls_forward_applies(attn, hidden_states, attention_mask, kwargs, projections=()) -> bool:
+    if not all(_plain_linear(p) for p in projections):   # e.g. a LoRA-wrapped q_proj / v_proj: the full layer calls the modules
+        return False
     causal = bool(kwargs.get("is_causal", False)) or bool(getattr(attn, "is_causal", False)) or bool(getattr(attn, "is_decoder", False))
     return (attention_mask is None and not causal and hidden_states.dim() == 3 and hidden_states.shape[1] > 1
             and kwargs.get("past_key_values") is None and not kwargs.get("output_attentions", False))
@@ -873,7 +889,7 @@ def _clip_last_layer_cls_forward(self, hidden_states, attention_mask=None, **kwa
     both residual adds -- for token 0 only.  Returns ``[B, 1, E]``: token 0 of what the full layer returns, and the same gradients
     for every parameter (the other tokens' outputs of the last layer reach nothing).  Masked / causal calls run the full layer."""
     attn = self.self_attn
-    if not _cls_forward_applies(attn, hidden_states, attention_mask, kwargs):
+    if not _cls_forward_applies(attn, hidden_states, attention_mask, kwargs, (attn.q_proj, attn.k_proj, attn.v_proj)):
         return self._mmk_full_forward(hidden_states, attention_mask, **kwargs)
     x = getattr(hidden_states, "_mmk_prenormed", None)
     if x is None:
@@ -890,7 +906,7 @@ def _bert_last_layer_cls_forward(self, hidden_states, attention_mask=None, encod
     calls run the full layer."""
     sa = self.attention.self
     if (encoder_hidden_states is not None or past_key_values is not None or getattr(self, "is_decoder", False)
-            or not _cls_forward_applies(sa, hidden_states, attention_mask, kwargs)):
+            or not _cls_forward_applies(sa, hidden_states, attention_mask, kwargs, (sa.query, sa.key, sa.value))):
         return self._mmk_full_forward(hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask,
                                       past_key_values=past_key_values, **kwargs)
     a = _cls_query_attention(hidden_states, sa.query, sa.key, sa.value, sa.num_attention_heads, sa.scaling,

@@ -140,3 +140,59 @@ def test_auto_switches_the_saving_on_only_where_token_0_pooling_is_provable():
         fused.accelerate_encoder(hs, cls_only=True)
     with pytest.raises(ValueError, match="must be True, False"):
         fused.accelerate_encoder(_tiny_clip(), cls_only="yes")
+
+
+class _LoRALinear(torch.nn.Module):
+    """The shape of peft's LoRA ``Linear``: the base layer's ``.weight`` / ``.bias`` stay visible, ``forward`` adds an adapter delta."""
+
+    def __init__(self, base, r=2):
+        super().__init__()
+        self.base_layer = base
+        self.lora_A = torch.nn.Linear(base.in_features, r, bias=False)
+        self.lora_B = torch.nn.Linear(r, base.out_features, bias=False)
+        torch.nn.init.normal_(self.lora_B.weight, std=0.5)
+
+    weight = property(lambda self: self.base_layer.weight)
+    bias = property(lambda self: self.base_layer.bias)
+
+    def forward(self, x):
+        return self.base_layer(x) + self.lora_B(self.lora_A(x))
+
+
+def test_adapter_wrapped_projections_keep_their_delta_and_their_gradients():
+    """the token-0 last layer builds its K|V and Q projections from ``.weight`` / ``.bias`` and never calls the
+    modules.  With a LoRA-wrapped ``q_proj`` / ``v_proj`` (the reference's ``HFCLIPVisionEncoder*`` classes take ``peft_config``,
+    mmlearn/modules/encoders/clip.py) that would drop the adapter's delta from the forward and leave its parameters without gradient.
+    ``_plain_linear`` refuses anything but a stock, hook-free ``nn.Linear``: such a layer runs the full forward, which calls the modules."""
+    from mmlearn_amd import fused
+
+    lin = torch.nn.Linear(4, 4)
+    assert fused._plain_linear(lin)
+    assert not fused._plain_linear(_LoRALinear(lin))
+    hooked = torch.nn.Linear(4, 4)
+    hooked.register_forward_hook(lambda m, i, o: o * 2)
+    assert not fused._plain_linear(hooked)
+    over = torch.nn.Linear(4, 4)
+    over.forward = lambda x: x
+    assert not fused._plain_linear(over)
+    ours = torch.nn.Sequential(torch.nn.Linear(8, 8))
+    assert fused.linear_wgrad(ours) == 1 and fused._plain_linear(ours[0])      # this package's own instance-level forward is fine
+
+    torch.manual_seed(0)
+    full = _tiny_clip().train()
+    last = full.vision_model.encoder.layers[-1].self_attn
+    last.q_proj, last.v_proj = _LoRALinear(last.q_proj), _LoRALinear(last.v_proj)
+    cls = copy.deepcopy(full)
+    assert fused.cls_only_last_layer(cls) == 1
+    x = torch.randn(3, 3, 32, 32)
+    outs = []
+    for m in (full, cls):
+        e = m(pixel_values=x).image_embeds
+        e.square().sum().backward()
+        outs.append((e.detach(), _grads(m)))
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6)        # the delta is in the forward
+    lora = [k for k in outs[0][1] if "lora_" in k]
+    assert len(lora) == 4 and outs[0][1].keys() == outs[1][1].keys()           # and the adapters get their gradients
+    for k in outs[0][1]:
+        assert torch.allclose(outs[0][1][k], outs[1][1][k], rtol=1e-4, atol=1e-6), k
+    assert all(outs[1][1][k].abs().max() > 0 for k in lora if "lora_B" in k)

@@ -85,7 +85,8 @@ class TextEncoder(nn.Module):
         self.proj = nn.Linear(cfg.hidden_size, 512, bias=False)
 
     def forward(self, inputs):
-        h = self.model(input_ids=inputs["text"]).last_hidden_state[:, 0]
+        # the tokenizer's mask rides along as the reference's text towers forward it (mmlearn/modules/encoders/text.py:160-165)
+        h = self.model(input_ids=inputs["text"], attention_mask=inputs.get("attention_mask")).last_hidden_state[:, 0]
         return (self.proj(h),)
 
 
@@ -100,7 +101,9 @@ class _Step(nn.Module):
         return self.task.training_step(batch, 0)
 
 
-def synthetic_batch(b: int, rank: int, device):
+def synthetic_batch(b: int, rank: int, device, padded: bool = False):
+    """random pixels, random tokens "with an all-ones attention mask", fully paired ids.  ``padded``: caption lengths
+    ~ U[8, 77] instead (right padding, the tokenizer's form) -- the `padded_text` leg."""
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     ids = torch.stack([torch.zeros(b, dtype=torch.long), torch.arange(rank * b, (rank + 1) * b)], 1)
     batch = {
@@ -108,6 +111,10 @@ def synthetic_batch(b: int, rank: int, device):
         "text": torch.randint(0, 30522, (b, 77), generator=g).to(device),
         "example_ids": {"rgb": ids.to(device), "text": ids.to(device)},
     }
+    mask = torch.ones(b, 77, dtype=torch.long)
+    if padded:
+        mask = (torch.arange(77)[None, :] < torch.randint(8, 78, (b, 1), generator=g)).long()
+    batch["attention_mask"] = mask.to(device)
     if os.environ.get("MMK_BENCH_PAIRED_HINT"):  # A/B: what mmlearn_amd.wire.DefaultDataCollator adds (default: the matcher runs)
         batch["fully_paired"] = True
     return batch
@@ -284,7 +291,7 @@ class _PooledText(nn.Module):
         self.model = BertModel(cfg, add_pooling_layer=False)
 
     def forward(self, inputs):
-        return (self.model(input_ids=inputs["text"]).last_hidden_state[:, 0],)
+        return (self.model(input_ids=inputs["text"], attention_mask=inputs.get("attention_mask")).last_hidden_state[:, 0],)
 
 
 class _PooledAudio(nn.Module):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMK_ABI_VERSION 6
+#define MMK_ABI_VERSION 7
 
 /* element types of user tensors */
 enum { MMK_F32 = 0, MMK_BF16 = 1, MMK_F16 = 2 };
@@ -467,16 +467,37 @@ int mmk_win_attn_bwd(const void* q, const void* k, const void* v, const void* do
 int mmk_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
 int mmk_quick_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
 
+/* Key-padding mask of a batch -> the per-sample key bias records the attention kernels read: rec is f32 [B][256], entry (b, j) is added
+ * to the base-2 logit of key j of sample b for every head and every query: 0 = attended, -1e30 = masked (finite: a sample whose keys are
+ * all masked averages V uniformly, HF's additive finfo.min convention, instead of NaN), -inf for j >= L.  The text towers of the
+ * reference always forward the tokenizer's mask (mmlearn/modules/encoders/text.py:160-165, clip.py:104-107, 329-346); HF turns it into
+ * a [B, 1, L, L] / [B, 1, 1, L] tensor per call.  `mask` by `kind`:
+ *   MMK_KEYMASK_LENGTHS   int32 [B]: keys 0 .. len-1 attended (right padding)
+ *   MMK_KEYMASK_U8 / I32 / I64 / F32_KEEP   [B, L] rows mask_sb elements apart: nonzero = attended (torch.bool is U8)
+ *   MMK_KEYMASK_F32_ADD / BF16_ADD          [B, L] additive mask in natural-log units (0 / finfo.min or any bias; clamped to >= -1e30)
+ * One record serves every layer and both passes of a tower's step.  ABI 7. */
+#define MMK_KEYMASK_LENGTHS 0
+#define MMK_KEYMASK_U8 1
+#define MMK_KEYMASK_I32 2
+#define MMK_KEYMASK_I64 3
+#define MMK_KEYMASK_F32_KEEP 4
+#define MMK_KEYMASK_F32_ADD 5
+#define MMK_KEYMASK_BF16_ADD 6
+int mmk_attn_key_bias(const void* mask, int kind, int B, int L, int64_t mask_sb, float* rec, void* stream);
+
 /* Short-sequence self-attention of the encoders' blocks (mmlearn/modules/layers/attention.py:60-75 materialises
- * softmax(QK^T); HF encoders call SDPA): out = softmax(scale * Q K^T) V per (batch, head), bf16, head_dim 64, L <= 256,
- * no mask, no dropout.  q/k/v are [B, H, L, 64] views given by element strides {batch, head, row} (last dim contiguous);
+ * softmax(QK^T); HF encoders call SDPA): out = softmax(scale * Q K^T + mask) V per (batch, head), bf16, head_dim 64, L <= 256.
+ * q/k/v are [B, H, L, 64] views given by element strides {batch, head, row} (last dim contiguous);
  * out is [B, L, H, 64] contiguous; lse (f32 [B, H, L], natural log of the scaled scores' sum) feeds the backward.
  * dropout_p > 0 applies attention-probability dropout (BERT's attention_probs_dropout_prob) with a counter-based
  * keep mask that is a pure function of (seed, batch, head, query, key): the backward regenerates it from the same
- * seed, nothing is stored. */
+ * seed, nothing is stored.
+ * key_bias (may be NULL: no mask): the records of mmk_attn_key_bias for this batch -- a key-padding mask, F.scaled_dot_product_attention's
+ * attn_mask [B, 1, 1, L].  causal != 0 (needs key_bias; an all-attended record for no padding) also masks key j > query i (HF CLIP's
+ * text tower, clip.py:329-346). */
 int mmk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int L, int dh,
                  const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, float scale,
-                 float dropout_p, uint64_t seed, void* stream);
+                 float dropout_p, uint64_t seed, const float* key_bias, int causal, void* stream);
 
 /* Backward of mmk_attn_fwd: out / dout are [B, L, H, 64] contiguous, lse is the forward's [B, H, L]; dq / dk / dv are
  * [B, L, H, 64] views with element strides grad_strides = {batch, row} (heads 64 apart), so the three gradients can be
@@ -486,6 +507,7 @@ int mmk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* 
  * sums of the dq / dk / dv values as stored (rounded to bf16); summed over its first dimension it is the bias gradient
  * `dY.sum(0)` of the fused QKV projection (reference: autograd of the q/k/v nn.Linear biases), without re-reading dY.
  * Only where mmk_attn_bwd_has_colsum(L) == 1 (all L <= 224 except 97..128); passing it elsewhere is an error.
+ * key_bias / causal: the forward's.
  * Replaces autograd through the same reference expressions (softmax(QK^T)V backward). */
 /* debugging: shader-clock stamps of workgroup 0 of the five-product backward (needs a library built with
  * -DMMK_ATTN_STAMPS_BUILD and MMK_ATTN_STAMPS=1 in the environment before the first backward call): 16 per item -- item start, loads issued, loads landed, after each of the NT + 1 step
@@ -495,7 +517,7 @@ int mmk_attn_bwd_has_colsum(int L);
 int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
                  float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
                  const int64_t* k_strides, const int64_t* v_strides, const int64_t* grad_strides, float scale,
-                 float dropout_p, uint64_t seed, float* colsum_part, void* stream);
+                 float dropout_p, uint64_t seed, float* colsum_part, const float* key_bias, int causal, void* stream);
 
 /* Attention of ONE query per (sample, head) against L <= 256 keys (head dim 64, bf16): the token-0 row of the last layer of a tower
  * pooled at token 0 (mmlearn/modules/encoders/clip.py:463-470 reads last_hidden_state[:, 0, :]; HF CLIPEncoderLayer / BertLayer are the
@@ -503,13 +525,14 @@ int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, c
  * (the halves of one packed [B, L, 2, H, 64] projection output: kv_sl = 2 H 64); dk, dv likewise with g_sb, g_sl.  lse2: f32 [B, H], the
  * base-2 log-sum-exp of the scaled logits (forward output, backward input).  dropout_p drops attention probabilities with the counter
  * -based mask of mmk_attn_fwd (query index 0), regenerated by the backward from the same seed.  Replaces
- * F.scaled_dot_product_attention(q[:, :, :1], k, v, dropout_p, scale) and its autograd.  ABI 6. */
+ * F.scaled_dot_product_attention(q[:, :, :1], k, v, attn_mask, dropout_p, scale) and its autograd.  key_bias (may be NULL): the
+ * key-padding records of mmk_attn_key_bias.  ABI 7. */
 int mmk_cls_attn_supported(int L, int dh);
 int mmk_cls_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, int B, int H, int L, int dh, int64_t kv_sb,
-                     int64_t kv_sl, float scale, float dropout_p, uint64_t seed, void* stream);
+                     int64_t kv_sl, float scale, float dropout_p, uint64_t seed, const float* key_bias, void* stream);
 int mmk_cls_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse2, void* dq, void* dk, void* dv, int B,
                      int H, int L, int dh, int64_t kv_sb, int64_t kv_sl, int64_t g_sb, int64_t g_sl, float scale, float dropout_p,
-                     uint64_t seed, void* stream);
+                     uint64_t seed, const float* key_bias, void* stream);
 
 #ifdef __cplusplus
 }

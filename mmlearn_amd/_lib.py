@@ -22,7 +22,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 F32, BF16, F16 = 0, 1, 2
 COMPUTE_BF16, COMPUTE_F32 = 1, 0
-ABI_VERSION = 6   # include/mmlearn_hip.h MMK_ABI_VERSION this ctypes mirror was written against
+ABI_VERSION = 7   # include/mmlearn_hip.h MMK_ABI_VERSION this ctypes mirror was written against
 
 _DTYPE_TAG = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -152,13 +152,14 @@ _SIGNATURES = {
     "mmk_mlp_gemm_bwd_mul": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp],
     "mmk_quick_gelu_fwd": [_vp, _vp, C.c_int64, _i, _vp],
     "mmk_quick_gelu_bwd": [_vp, _vp, _vp, C.c_int64, _i, _vp],
-    "mmk_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, C.c_uint64, _vp],
+    "mmk_attn_key_bias": [_vp, _i, _i, _i, C.c_int64, _vp, _vp],
+    "mmk_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _f, C.c_uint64, _vp, _i, _vp],
     "mmk_attn_bwd_has_colsum": [_i],
     "mmk_attn_debug_stamps": [_vp, _i],
     "mmk_cls_attn_supported": [_i, _i],
-    "mmk_cls_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, C.c_int64, _f, _f, C.c_uint64, _vp],
-    "mmk_cls_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _f, _f, C.c_uint64, _vp],
-    "mmk_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, C.c_uint64, _vp, _vp],
+    "mmk_cls_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, C.c_int64, _f, _f, C.c_uint64, _vp, _vp],
+    "mmk_cls_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _f, _f, C.c_uint64, _vp, _vp],
+    "mmk_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, C.c_uint64, _vp, _vp, _i, _vp],
 }
 _STR_FUNCS = {"mmk_last_error": [], "mmk_kernel_name": [_i]}
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + list(_STR_FUNCS))

@@ -57,7 +57,16 @@ struct AttnArgs {
   float scale;
   uint32_t seed_lo, seed_hi, drop_thr;  // attention dropout: drop (i, j) when its 16-bit draw < drop_thr (0 = off)
   float drop_scale;                     // 65536 / (65536 - drop_thr)
+  const float* kbias;                   // MASK kernels: per-sample key bias records [B][ROWC] (mmk_attn_key_bias), base-2 logit units
+  int causal;                           // MASK kernels: key j > query i is masked as well
 };
+
+// Key bias record of one sample (MASK kernels): ROWC floats, added to the base-2 logits of key j for EVERY head and query -- 0 for a
+// key that is attended, KB_MASKED for a key behind a padding mask, -inf for j >= L.  KB_MASKED is finite on purpose (the HF convention of
+// an additive finfo.min): a row whose keys are all masked averages V uniformly instead of producing NaN that a weight gradient summed
+// over the batch would spread to every sample.
+constexpr int ROWC = 256;
+constexpr float KB_MASKED = -1e30f;
 
 __device__ __forceinline__ float att_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -263,32 +272,52 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
   return r;
 }
 
+// rows of a wave's output staging slab in the forward: 32, or 16 where the key bias records would not fit beside 32 (L > 224 fills
+// the 160 KiB with its four images and eight 4-KiB slabs)
+constexpr int fwd_stage_rows(int NT, bool MASK) { return (MASK && NT == 8) ? 16 : 32; }
+
 // One 32-query tile of one (batch, head): queries i = 32t + (lane&31) against all keys of the K / V images.
 // S^T tile jt: acc[reg] = sum_d K[j][d] Q[i][d],  j = 32jt + (reg&3) + 8(reg>>2) + 4h, the query on the LANE, so the
 // row maximum and sum are lane-local.  ONEPASS keeps all NT score tiles in registers (16 NT VGPRs, NT <= 7 at two waves
 // per SIMD); otherwise QK^T is formed twice (pass 1: maximum, pass 2: exponentials + PV).
-template <int NT, bool DROP, bool ONEPASS>
-__device__ __forceinline__ void attn_fwd_tile(const AttnArgs& a, const char* Ks, const char* Vs, char* stage,
+template <int NT, bool DROP, bool ONEPASS, bool MASK>
+__device__ __forceinline__ void attn_fwd_tile(const AttnArgs& a, const char* Ks, const char* Vs, char* stage, const float* kb,
                                               const ImgLane& il, const bf16x8 (&qf)[4], int bh, int t, int lane) {
   const int r = lane & 31, h = lane >> 5;
   const int b = bh / a.H, hh = bh % a.H;
   const int i = t * 32 + r;  // this lane's query row
   const float sl2 = a.scale * 1.4426950408889634f;  // scale > 0: the row maximum commutes with the scaling
   const uint32_t dkey = DROP ? drop_key(a.seed_lo, a.seed_hi, (uint32_t)bh) : 0u;
-  auto score_tile = [&](int jt) {  // raw q.k; keys beyond L (last tile only) = -inf
+  // raw q.k with keys beyond L (last tile only) = -inf; MASK: base-2 logits  sl2 q.k + kb[j]  (the record holds -inf beyond L)
+  auto score_tile = [&](int jt) {
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_row_frag(Ks + jt * 4096 + il.row[kk]), qf[kk], acc, 0, 0, 0);
-    if (jt == NT - 1 && a.L < 32 * NT) {
+    if (MASK) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 b4 = *reinterpret_cast<const float4*>(kb + jt * 32 + 8 * g4 + 4 * h);
+        acc[4 * g4 + 0] = fmaf(acc[4 * g4 + 0], sl2, b4.x);
+        acc[4 * g4 + 1] = fmaf(acc[4 * g4 + 1], sl2, b4.y);
+        acc[4 * g4 + 2] = fmaf(acc[4 * g4 + 2], sl2, b4.z);
+        acc[4 * g4 + 3] = fmaf(acc[4 * g4 + 3], sl2, b4.w);
+      }
+      if (a.causal) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h > i) acc[e] = -INFINITY;
+      }
+    } else if (jt == NT - 1 && a.L < 32 * NT) {
 #pragma unroll
       for (int e = 0; e < 16; ++e)
         if (jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= a.L) acc[e] = -INFINITY;
     }
     return acc;
   };
+  const float mul = MASK ? 1.f : sl2;   // what is left to apply to a score tile
   float sum = 0.f;
   f32x16 o[2];
 #pragma unroll
@@ -301,7 +330,7 @@ __device__ __forceinline__ void attn_fwd_tile(const AttnArgs& a, const char* Ks,
   auto pv_tile = [&](int jt, f32x16 x, float nm2) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      x[e] = att_exp2(fmaf(x[e], sl2, nm2));
+      x[e] = att_exp2(fmaf(x[e], mul, nm2));
       sum += x[e];
     }
     if (DROP) {  // the row sum above is the softmax denominator; dropped weights only leave the PV product
@@ -332,7 +361,7 @@ __device__ __forceinline__ void attn_fwd_tile(const AttnArgs& a, const char* Ks,
 #pragma unroll
       for (int e = 0; e < 16; e += 2) m = max3(m, sc[jt][e], sc[jt][e + 1]);
     m = fmaxf(m, __shfl_xor(m, 32));
-    const float nm2 = -m * sl2;
+    const float nm2 = -m * mul;
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) pv_tile(jt, sc[jt], nm2);
   } else {
@@ -343,15 +372,15 @@ __device__ __forceinline__ void attn_fwd_tile(const AttnArgs& a, const char* Ks,
       for (int e = 0; e < 16; e += 2) m = max3(m, x[e], x[e + 1]);
     }
     m = fmaxf(m, __shfl_xor(m, 32));
-    const float nm2 = -m * sl2;
+    const float nm2 = -m * mul;
 #pragma unroll 1
     for (int jt = 0; jt < NT; ++jt) pv_tile(jt, score_tile(jt), nm2);
   }
   sum += __shfl_xor(sum, 32);
   // ---- epilogue: o[dt][reg] = O^T[d][i], d = 32dt + (reg&3) + 8(reg>>2) + 4h ; normalise per lane, store whole rows
   const float inv = (DROP ? a.drop_scale : 1.f) / sum;
-  store_rows_staged(stage, a.out + ((long)b * a.L * a.H + hh) * ATT_DH, (long)a.H * ATT_DH, t * 32, a.L, o, inv, lane);
-  if (i < a.L && h == 0) a.lse[((long)b * a.H + hh) * a.L + i] = (m * sl2 + log2f(sum)) * 0.6931471805599453f;
+  store_rows_staged<fwd_stage_rows(NT, MASK)>(stage, a.out + ((long)b * a.L * a.H + hh) * ATT_DH, (long)a.H * ATT_DH, t * 32, a.L, o, inv, lane);
+  if (i < a.L && h == 0) a.lse[((long)b * a.H + hh) * a.L + i] = (m * mul + log2f(sum)) * 0.6931471805599453f;
 }
 
 // Q fragments straight from global: lane (r, h) of the wave owning tile t needs Q[i][16kk + 8h .. +8]
@@ -371,19 +400,23 @@ __device__ __forceinline__ void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0
 // Persistent workgroups: NT <= NW, wave w owns query tile w of every (batch, head) item the workgroup walks.  The K / V
 // images are double-buffered: the LDS-DMA of item n+1 and its Q fragments are in flight while item n is computed, so
 // the HBM stream never stops behind a compute phase (one barrier per item).
-template <int NT, int NW, bool DROP>
+template <int NT, int NW, bool DROP, bool MASK>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int LP = 32 * NT;
   constexpr int IMG = LP * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nitems = a.B * a.H;
+  constexpr int STG = fwd_stage_rows(NT, MASK) * 128;                         // one wave's staging slab
+  float* kbs = reinterpret_cast<float*>(smem + 4 * IMG + NW * STG);           // MASK: [2 buffers][ROWC] key bias records
   auto issue_kv = [&](int bh, int buf) {
     const int b = bh / a.H, hh = bh % a.H;
     img_load(smem + (2 * buf) * IMG, a.k + b * a.k_sb + hh * a.k_sh, a.k_sl, a.L, LP, wave, NW, lane);
     img_load(smem + (2 * buf + 1) * IMG, a.v + b * a.v_sb + hh * a.v_sh, a.v_sl, a.L, LP, wave, NW, lane);
+    if (MASK && __builtin_amdgcn_readfirstlane(wave) == NW - 1)   // the sample's record rides with the images (one 1-KiB piece)
+      lds_dma16(a.kbias + (long)b * ROWC, (uint32_t)lane * 16u, lds_addr_of(reinterpret_cast<const char*>(kbs + buf * ROWC)));
   };
-  char* stage = smem + 4 * IMG + wave * STAGE_BYTES;
+  char* stage = smem + 4 * IMG + wave * STG;
   const ImgLane il = img_lane(lane);
   int item = blockIdx.x;
   bf16x8 qn[4];  // Q fragments of the item whose images are in flight
@@ -406,16 +439,18 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
       issue_kv(next, (n + 1) & 1);
     }
     if (wave < NT)
-      attn_fwd_tile<NT, DROP, (DROP ? NT <= 6 : NT <= 7)>(a, smem + (2 * (n & 1)) * IMG, smem + (2 * (n & 1) + 1) * IMG, stage, il, qf, item, wave, lane);
+      attn_fwd_tile<NT, DROP, (DROP ? NT <= 6 : NT <= 7), MASK>(a, smem + (2 * (n & 1)) * IMG, smem + (2 * (n & 1) + 1) * IMG, stage,
+                                                                kbs + (n & 1) * ROWC, il, qf, item, wave, lane);
   }
 }
 
-template <int NT, bool DROP>
+template <int NT, bool DROP, bool MASK>
 static int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   constexpr int LP = 32 * NT;
   constexpr int NW = NT <= 4 ? 4 : 8;
-  constexpr int bytes = 4 * LP * 128 + NW * STAGE_BYTES;
-  auto kern = attn_fwd_kernel<NT, NW, DROP>;
+  constexpr int bytes = 4 * LP * 128 + NW * fwd_stage_rows(NT, MASK) * 128 + (MASK ? 2 * ROWC * 4 : 0);
+  static_assert(bytes <= 160 * 1024, "LDS budget");
+  auto kern = attn_fwd_kernel<NT, NW, DROP, MASK>;
   KernelSetup ks;   // LDS opt-in, occupancy and CU count of this kernel on the current device
   if (int rc = kernel_setup(reinterpret_cast<const void*>(kern), 64 * NW, bytes, &ks)) return rc;
   const int cus = ks.cus, wgs_per_cu = ks.wgs_per_cu;
@@ -457,6 +492,8 @@ struct AttnBwdArgs {
   uint32_t seed_lo, seed_hi, drop_thr;
   float drop_scale;
   float* cs;  // optional [B * ceil(L / 32)][3][H][64] f32: per 32-row tile column sums of the stored dq / dk / dv (packed layout)
+  const float* kbias;  // MASK kernels: the forward's key bias records [B][ROWC]
+  int causal;          // MASK kernels
   unsigned long long* stamps;  // debugging (MMK_ATTN_STAMPS): shader-clock stamps of workgroup 0, 16 per item, first 32 items
 };
 
@@ -468,7 +505,6 @@ __device__ __forceinline__ float* cs_slot(const AttnBwdArgs& a, int b, int hh, i
 // Row constants of the backward, one 2-KiB record per (batch, head):  ws[bh][0][l] = lse[bh][l] * log2(e) (+inf for
 // l >= L, which makes P = 0 on padded rows), ws[bh][1][l] = delta = sum_d dO[b, l, h, d] * O[b, l, h, d] (0 for l >= L).
 // 256 floats per row so that the main kernel fetches a record with two 1-KiB LDS-DMA pieces whatever L is.
-constexpr int ROWC = 256;
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ g,
                                                          const float* __restrict__ lse, float* __restrict__ ws, int B,
                                                          int H, int L) {
@@ -500,6 +536,17 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   }
 }
 
+// P of one (query i, key j) pair in the backward: exp2 of the base-2 logit minus the row's lse2.  MASK: the key bias is added to the
+// scaled score FIRST and the lse2 subtracted from the rounded sum -- a row whose keys are all masked has logits and lse2 of about
+// KB_MASKED, where  sl2 s + (kb - lse2)  would lose the bias altogether and return exp2(sl2 s), possibly huge; this order gives P = 1 on
+// such a row (finite; the row's gradients mean nothing, but they do not poison the batch-summed weight gradients).
+template <bool MASK>
+__device__ __forceinline__ float bwd_prob(float s, float sl2, float kbj, float lse2, bool jvalid, int causal, int j, int i) {
+  if (!MASK) return jvalid ? att_exp2(fmaf(s, sl2, -lse2)) : 0.f;
+  const float p = att_exp2(fmaf(s, sl2, kbj) - lse2);
+  return (jvalid && !(causal && j > i)) ? p : 0.f;
+}
+
 // Persistent workgroups, NT <= NW: wave w owns key tile w in phase 1 and query tile w in phase 2 of every (batch, head)
 // item its workgroup walks.  Four image buffers (Q, dO, K, V) and no idle HBM phase:
 //   barrier A  Q, dO images of item n and its delta / lse2 rows are in LDS; K, V buffers are free
@@ -511,7 +558,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // The lse2 / delta records (delta_i = sum_d dO_id O_id) come from attn_delta_kernel, one streaming pass before this one.
 // Compiler-visible global loads are always issued BEFORE the untracked LDS-DMA pieces of the same window and are
 // consumed only after the next barrier's s_waitcnt vmcnt(0), so no compiler-inserted vmcnt lands inside a phase.
-template <int NT, int NW, bool DROP>
+template <int NT, int NW, bool DROP, bool MASK>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(const AttnBwdArgs a) {
   constexpr int LP = 32 * NT;
   constexpr int IMG = LP * 128;
@@ -521,8 +568,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(cons
   char* Ks = Gs + IMG;
   char* Vs = Ks + IMG;
   constexpr int SROWS = NT <= 7 ? 32 : 16;  // staging slab rows per wave (LDS budget at NT = 8)
-  float* rowc = reinterpret_cast<float*>(Vs + IMG);  // [2 buffers][lse2 | delta][ROWC]
-  char* stage = reinterpret_cast<char*>(rowc + 4 * ROWC) + (threadIdx.x >> 6) * (SROWS * 128);
+  constexpr int REC = MASK ? 3 : 2;                  // row-constant records per buffer
+  float* rowc = reinterpret_cast<float*>(Vs + IMG);  // [2 buffers][lse2 | delta | (MASK) key bias][ROWC]
+  char* stage = reinterpret_cast<char*>(rowc + 2 * REC * ROWC) + (threadIdx.x >> 6) * (SROWS * 128);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -562,7 +610,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(cons
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     if (wave_s < 2)
       lds_dma16(a.delta + ((long)bh * 2 + wave_s) * ROWC, (uint32_t)lo * 16u,
-                lds_addr_of(reinterpret_cast<const char*>(rowc + (buf * 2 + wave_s) * ROWC)));
+                lds_addr_of(reinterpret_cast<const char*>(rowc + (buf * REC + wave_s) * ROWC)));
+    if (MASK && wave_s == 2)
+      lds_dma16(a.kbias + (long)b * ROWC, (uint32_t)lo * 16u, lds_addr_of(reinterpret_cast<const char*>(rowc + (buf * REC + 2) * ROWC)));
   };
   auto issue_kv = [&](int bh) {
     const int b = bh / a.H, hh = bh % a.H;
@@ -580,8 +630,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(cons
   // The s_waitcnt vmcnt(0) for a window's DMA sits at the END of the following MFMA loop, before that phase's output
   // stores: the pieces had the whole phase to land, and the stores stay in flight across the barrier.
   for (int n = 0; item < nitems; item += gridDim.x, ++n) {
-    const float* lse2s = rowc + (n & 1) * 2 * ROWC;
+    const float* lse2s = rowc + (n & 1) * REC * ROWC;
     const float* dls = lse2s + ROWC;
+    const float* kbs = dls + ROWC;   // MASK only
     const long gbase = (long)(item / a.H) * a.g_sb + (long)(item % a.H) * ATT_DH;
     const uint32_t dkey = DROP ? drop_key(a.seed_lo, a.seed_hi, (uint32_t)item) : 0u;
     __syncthreads();  // ---- barrier A
@@ -592,6 +643,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(cons
       // ---------------- phase 1: dK, dV of key tile `wave` (the key on the lane)
       const int j = wave * 32 + r;
       const bool jvalid = j < a.L;
+      const float kbj = MASK ? kbs[j] : 0.f;   // this lane's key
       f32x16 (&dkt)[2] = acc1;
       f32x16 (&dvt)[2] = acc2;
 #pragma unroll
@@ -619,7 +671,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(cons
 #pragma unroll
           for (int e4 = 0; e4 < 4; ++e4) {
             const int e = 4 * g4 + e4;
-            const float p = jvalid ? att_exp2(fmaf(sc[e], sl2, -l2v[e4])) : 0.f;
+            const float p = bwd_prob<MASK>(sc[e], sl2, kbj, l2v[e4], jvalid, a.causal, j, it * 32 + 8 * g4 + 4 * h + e4);
             float keep = 1.f;
             if (DROP) {
               const uint32_t w = drop_word(dkey, it * 32 + 8 * g4 + 4 * h + e4, j >> 1);
@@ -684,8 +736,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(cons
           }
         }
         bf16x8 df[2];
+        if (MASK) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) df[e >> 3][e & 7] = (bf16_t)(att_exp2(fmaf(sc[e], sl2, -l2)) * (dp[e] - dl));
+          for (int e = 0; e < 16; ++e) {
+            const int jk = jt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            df[e >> 3][e & 7] = (bf16_t)(bwd_prob<true>(sc[e], sl2, kbs[jk], l2, true, a.causal, jk, i) * (dp[e] - dl));
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) df[e >> 3][e & 7] = (bf16_t)(att_exp2(fmaf(sc[e], sl2, -l2)) * (dp[e] - dl));
+        }
         if (jt == NT - 1 && a.L < LP) {  // keys beyond L (finite filler rows): dS = 0
 #pragma unroll
           for (int e = 0; e < 16; ++e)
@@ -924,7 +984,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_split_kerne
 // STAGED: the key waves are the only loaders (four 8-row pieces of every image each), K first, then the Q / dO pieces in row
 // order, and a step only waits for the pieces of ITS query tile (counted vmcnt): step 0 starts when K, V, the row constants and
 // the first 32 rows of Q / dO are in, the rest of the 84 KiB lands behind the steps.
-template <int NT, int NW, bool DROP, bool STAGED>
+template <int NT, int NW, bool DROP, bool STAGED, bool MASK>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(const AttnBwdArgs a) {
   static_assert(NT < NW, "needs a spare wave for dQ");
   constexpr int LP = 32 * NT;
@@ -935,8 +995,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
   char* Gs = Qs + IMG;  // dO
   char* Ks = Gs + IMG;
   char* DS = Ks + IMG;                                      // 2 buffers
-  float* rowc = reinterpret_cast<float*>(DS + 2 * DSB);     // [lse2 | delta][ROWC]
-  char* stage = reinterpret_cast<char*>(rowc + 2 * ROWC) + (threadIdx.x >> 6) * STAGE_BYTES;
+  constexpr int REC = MASK ? 3 : 2;
+  float* rowc = reinterpret_cast<float*>(DS + 2 * DSB);     // [lse2 | delta | (MASK) key bias][ROWC]
+  char* stage = reinterpret_cast<char*>(rowc + REC * ROWC) + (threadIdx.x >> 6) * STAGE_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -986,8 +1047,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
         for (int g = 0; g < 4; ++g) img_load_piece(stage, a.v + b * a.v_sb + hh * a.v_sh, a.v_sl, a.L, 4 * wave_s + g, lo, g);
 #pragma unroll
         for (int g = 0; g < 4; ++g) img_load_piece(Ks, a.k + b * a.k_sb + hh * a.k_sh, a.k_sl, a.L, wave_s + NT * g, lo);
-        for (int rc = wave_s; rc < 2; rc += NT)   // the two row-constant records (one loader wave: both)
-          lds_dma16(a.delta + ((long)item * 2 + rc) * ROWC, (uint32_t)lo * 16u, lds_addr_of(reinterpret_cast<const char*>(rowc + rc * ROWC)));
+        for (int rc = wave_s; rc < REC; rc += NT)   // the row-constant records (fewer loader waves than records: several each)
+          lds_dma16(rc < 2 ? a.delta + ((long)item * 2 + rc) * ROWC : a.kbias + (long)b * ROWC, (uint32_t)lo * 16u,
+                    lds_addr_of(reinterpret_cast<const char*>(rowc + rc * ROWC)));
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           img_load_piece(Qs, a.q + b * a.q_sb + hh * a.q_sh, a.q_sl, a.L, wave_s + NT * g, lo);
@@ -1005,6 +1067,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
       if (wave_s < 2)
         lds_dma16(a.delta + ((long)item * 2 + wave_s) * ROWC, (uint32_t)lo * 16u,
                   lds_addr_of(reinterpret_cast<const char*>(rowc + wave_s * ROWC)));
+      if (MASK && wave_s == 2)
+        lds_dma16(a.kbias + (long)b * ROWC, (uint32_t)lo * 16u, lds_addr_of(reinterpret_cast<const char*>(rowc + 2 * ROWC)));
       stamp(1);
       wait_vmem_all();
     }
@@ -1014,6 +1078,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
     f32x16 acc1[2], acc2[2];  // key waves: dKᵀ, dVᵀ;  dQ wave: dQᵀ of one query tile (acc1)
     const int j = wave * 32 + r;  // key waves: this lane's key
     const bool jvalid = j < a.L;
+    const float kbj = (MASK && keyw) ? rowc[2 * ROWC + j] : 0.f;
     if (keyw) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) kf[kk] = lds_row_frag(Ks + wave * 4096 + il.row[kk]);
@@ -1078,7 +1143,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
 #pragma unroll
           for (int e4 = 0; e4 < 4; ++e4) {
             const int e = 4 * g4 + e4;
-            const float p = jvalid ? att_exp2(fmaf(sc[e], sl2, -l2v[e4])) : 0.f;
+            const float p = bwd_prob<MASK>(sc[e], sl2, kbj, l2v[e4], jvalid, a.causal, j, it * 32 + 8 * g4 + 4 * h + e4);
             float keep = 1.f;
             if (DROP) {
               const uint32_t w = drop_word(dkey, it * 32 + 8 * g4 + 4 * h + e4, j >> 1);
@@ -1165,12 +1230,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
   }
 }
 
-template <int NT, int NW, bool DROP, bool STAGED>
+template <int NT, int NW, bool DROP, bool STAGED, bool MASK>
 static int launch_attn_bwd5(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int LP = 32 * NT;
-  constexpr int bytes = 3 * LP * 128 + 2 * LP * 64 + 2 * ROWC * 4 + NW * STAGE_BYTES;
+  constexpr int bytes = 3 * LP * 128 + 2 * LP * 64 + (MASK ? 3 : 2) * ROWC * 4 + NW * STAGE_BYTES;
   static_assert(bytes <= 160 * 1024, "LDS budget");
-  auto kern = attn_bwd5_kernel<NT, NW, DROP, STAGED>;
+  auto kern = attn_bwd5_kernel<NT, NW, DROP, STAGED, MASK>;
   KernelSetup ks;   // LDS opt-in, occupancy and CU count of this kernel on the current device
   if (int rc = kernel_setup(reinterpret_cast<const void*>(kern), 64 * NW, bytes, &ks)) return rc;
   const int cus = ks.cus, wgs_per_cu = ks.wgs_per_cu;
@@ -1186,12 +1251,12 @@ static int launch_attn_bwd5(const AttnBwdArgs& a, hipStream_t st) {
   return 0;
 }
 
-template <int NT, int NW, bool DROP>
+template <int NT, int NW, bool DROP, bool MASK>
 static int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t st) {
   constexpr int LP = 32 * NT;
-  constexpr int bytes = 4 * LP * 128 + 4 * ROWC * 4 + NW * (NT <= 7 ? 32 : 16) * 128;
+  constexpr int bytes = 4 * LP * 128 + 2 * (MASK ? 3 : 2) * ROWC * 4 + NW * (NT <= 7 ? 32 : 16) * 128;
   static_assert(bytes <= 160 * 1024, "LDS budget");
-  auto kern = attn_bwd_kernel<NT, NW, DROP>;
+  auto kern = attn_bwd_kernel<NT, NW, DROP, MASK>;
   KernelSetup ks;   // LDS opt-in, occupancy and CU count of this kernel on the current device
   if (int rc = kernel_setup(reinterpret_cast<const void*>(kern), 64 * NW, bytes, &ks)) return rc;
   const int cus = ks.cus, wgs_per_cu = ks.wgs_per_cu;
@@ -1248,9 +1313,67 @@ namespace {
    (a.v_sh % 8 == 0) && (a.q_sb % 8 == 0) && (a.k_sb % 8 == 0) && (a.v_sb % 8 == 0))
 }  // namespace
 
+// ---- key bias records: one [ROWC] row per sample from a padding mask in any of the forms the callers hold
+namespace mmk {
+template <typename T, bool ADDITIVE>
+__global__ __launch_bounds__(256) void attn_key_bias_kernel(const T* __restrict__ mask, long sb, const int* __restrict__ lengths, int B, int L,
+                                                            float* __restrict__ rec) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * ROWC) return;
+  const int b = (int)(idx / ROWC), l = (int)(idx % ROWC);
+  float v = -INFINITY;
+  if (l < L) {
+    if (lengths) {
+      v = l < lengths[b] ? 0.f : KB_MASKED;
+    } else if (ADDITIVE) {   // an additive mask in natural-log units (0 / finfo.min, or any finite bias); NaN counts as masked
+      const float x = (float)mask[b * sb + l] * 1.4426950408889634f;
+      v = x > KB_MASKED ? x : KB_MASKED;
+    } else {
+      v = mask[b * sb + l] != (T)0 ? 0.f : KB_MASKED;
+    }
+  }
+  rec[idx] = v;
+}
+}  // namespace mmk
+
+extern "C" int mmk_attn_key_bias(const void* mask, int kind, int B, int L, int64_t mask_sb, float* rec, void* stream) {
+  MMK_REQUIRE(mask && rec, "attn_key_bias: null pointer");
+  MMK_REQUIRE(B > 0 && L > 0 && L <= ROWC, "attn_key_bias: need 1 <= L <= 256");
+  MMK_REQUIRE(kind == MMK_KEYMASK_LENGTHS || mask_sb >= L, "attn_key_bias: mask rows overlap");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(((long)B * ROWC + 255) / 256)), block(256);
+  switch (kind) {
+    case MMK_KEYMASK_LENGTHS:
+      hipLaunchKernelGGL((attn_key_bias_kernel<uint8_t, false>), grid, block, 0, st, nullptr, 0l, static_cast<const int*>(mask), B, L, rec);
+      break;
+    case MMK_KEYMASK_U8:
+      hipLaunchKernelGGL((attn_key_bias_kernel<uint8_t, false>), grid, block, 0, st, static_cast<const uint8_t*>(mask), (long)mask_sb, nullptr, B, L, rec);
+      break;
+    case MMK_KEYMASK_I32:
+      hipLaunchKernelGGL((attn_key_bias_kernel<int32_t, false>), grid, block, 0, st, static_cast<const int32_t*>(mask), (long)mask_sb, nullptr, B, L, rec);
+      break;
+    case MMK_KEYMASK_I64:
+      hipLaunchKernelGGL((attn_key_bias_kernel<int64_t, false>), grid, block, 0, st, static_cast<const int64_t*>(mask), (long)mask_sb, nullptr, B, L, rec);
+      break;
+    case MMK_KEYMASK_F32_KEEP:
+      hipLaunchKernelGGL((attn_key_bias_kernel<float, false>), grid, block, 0, st, static_cast<const float*>(mask), (long)mask_sb, nullptr, B, L, rec);
+      break;
+    case MMK_KEYMASK_F32_ADD:
+      hipLaunchKernelGGL((attn_key_bias_kernel<float, true>), grid, block, 0, st, static_cast<const float*>(mask), (long)mask_sb, nullptr, B, L, rec);
+      break;
+    case MMK_KEYMASK_BF16_ADD:
+      hipLaunchKernelGGL((attn_key_bias_kernel<bf16_t, true>), grid, block, 0, st, static_cast<const bf16_t*>(mask), (long)mask_sb, nullptr, B, L, rec);
+      break;
+    default:
+      MMK_REQUIRE(false, "attn_key_bias: unknown mask kind");
+  }
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmk_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int H, int L, int dh,
                             const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, float scale,
-                            float dropout_p, uint64_t seed, void* stream) {
+                            float dropout_p, uint64_t seed, const float* key_bias, int causal, void* stream) {
   MMK_REQUIRE(q && k && v && out && lse && q_strides && k_strides && v_strides, "null pointer");
   MMK_REQUIRE(B > 0 && H > 0 && L > 0, "empty problem");
   MMK_REQUIRE(dh == ATT_DH, "attention kernel supports head_dim 64");
@@ -1265,14 +1388,19 @@ extern "C" int mmk_attn_fwd(const void* q, const void* k, const void* v, void* o
   a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sl = v_strides[2];
   MMK_REQUIRE(MMK_ATTN_STRIDES_OK(a), "q/k/v rows must be 16-byte aligned");
   a.B = B; a.H = H; a.L = L; a.scale = scale;
+  a.kbias = key_bias; a.causal = causal ? 1 : 0;
+  MMK_REQUIRE(!causal || key_bias, "attn_fwd: a causal call needs a key bias record (all-zero for no padding)");
   const bool drop = drop_params(dropout_p, seed, &a.seed_lo, &a.seed_hi, &a.drop_thr, &a.drop_scale);
+  const bool mask = key_bias != nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define MMK_ATTN_FWD_CASE(NT) \
-  case NT: return drop ? launch_attn_fwd<NT, true>(a, st) : launch_attn_fwd<NT, false>(a, st);
+#define MMK_ATTN_FWD_CASE(NT)                                                                                 \
+  case NT:                                                                                                    \
+    if (mask) return drop ? launch_attn_fwd<NT, true, true>(a, st) : launch_attn_fwd<NT, false, true>(a, st); \
+    return drop ? launch_attn_fwd<NT, true, false>(a, st) : launch_attn_fwd<NT, false, false>(a, st);
   switch ((L + 31) / 32) {
     MMK_ATTN_FWD_CASE(1) MMK_ATTN_FWD_CASE(2) MMK_ATTN_FWD_CASE(3) MMK_ATTN_FWD_CASE(4)
     MMK_ATTN_FWD_CASE(5) MMK_ATTN_FWD_CASE(6) MMK_ATTN_FWD_CASE(7)
-    default: return drop ? launch_attn_fwd<8, true>(a, st) : launch_attn_fwd<8, false>(a, st);
+    default: MMK_ATTN_FWD_CASE(8)
   }
 }
 
@@ -1305,7 +1433,7 @@ extern "C" int mmk_attn_bwd_has_colsum(int L) {
 extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
                             float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int L, int dh, const int64_t* q_strides,
                             const int64_t* k_strides, const int64_t* v_strides, const int64_t* grad_strides, float scale,
-                            float dropout_p, uint64_t seed, float* colsum_part, void* stream) {
+                            float dropout_p, uint64_t seed, float* colsum_part, const float* key_bias, int causal, void* stream) {
   MMK_REQUIRE(q && k && v && out && dout && lse && delta_ws && dq && dk && dv && q_strides && k_strides && v_strides &&
                   grad_strides,
               "null pointer");
@@ -1326,7 +1454,10 @@ extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const v
   a.v_sb = v_strides[0]; a.v_sh = v_strides[1]; a.v_sl = v_strides[2];
   MMK_REQUIRE(MMK_ATTN_STRIDES_OK(a), "q/k/v rows must be 16-byte aligned");
   a.B = B; a.H = H; a.L = L; a.scale = scale;
+  a.kbias = key_bias; a.causal = causal ? 1 : 0;
+  MMK_REQUIRE(!causal || key_bias, "attn_bwd: a causal call needs the forward's key bias record");
   const bool drop = drop_params(dropout_p, seed, &a.seed_lo, &a.seed_hi, &a.drop_thr, &a.drop_scale);
+  const bool mask = key_bias != nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   static const bool seven = MMK_DBG_ENV("MMK_ATTN_BWD7") != nullptr;  // force the seven-product kernel (A/B runs)
 #ifdef MMK_DEBUG_SWITCHES
@@ -1334,23 +1465,30 @@ extern "C" int mmk_attn_bwd(const void* q, const void* k, const void* v, const v
 #endif
   static const bool staged = MMK_DBG_ENV("MMK_ATTN_STAGED") ? atoi(MMK_DBG_ENV("MMK_ATTN_STAGED")) != 0 : kAttnStagedDefault;
   MMK_REQUIRE(!colsum_part || mmk_attn_bwd_has_colsum(L), "attn_bwd: column sums are not available for this sequence length");
+#define MMK_ATTN_BWD7(NT, NW)                                                                                          \
+  do {                                                                                                                 \
+    if (mask) return drop ? launch_attn_bwd<NT, NW, true, true>(a, st) : launch_attn_bwd<NT, NW, false, true>(a, st);  \
+    return drop ? launch_attn_bwd<NT, NW, true, false>(a, st) : launch_attn_bwd<NT, NW, false, false>(a, st);          \
+  } while (0)
 #define MMK_ATTN_BWD_CASE(NT, NW) \
-  case NT: return drop ? launch_attn_bwd<NT, NW, true>(a, st) : launch_attn_bwd<NT, NW, false>(a, st);
+  case NT: MMK_ATTN_BWD7(NT, NW);
 #ifdef MMK_DEBUG_SWITCHES
 #define MMK_ATTN_SPLIT_CASE(NT, NW) \
-  if (split && !colsum_part) return drop ? launch_attn_bwd_split<NT, NW, true>(a, st) : launch_attn_bwd_split<NT, NW, false>(a, st);
+  if (split && !colsum_part && !mask) return drop ? launch_attn_bwd_split<NT, NW, true>(a, st) : launch_attn_bwd_split<NT, NW, false>(a, st);
 #else
 #define MMK_ATTN_SPLIT_CASE(NT, NW)
 #endif
-#define MMK_ATTN_BWD5_CASE(NT, NW)                                                                                   \
-  case NT:                                                                                                           \
-    MMK_ATTN_SPLIT_CASE(NT, NW)                                                                                      \
-    if (seven) return drop ? launch_attn_bwd<NT, NW, true>(a, st) : launch_attn_bwd<NT, NW, false>(a, st);           \
-    if (staged) return drop ? launch_attn_bwd5<NT, NW, true, true>(a, st) : launch_attn_bwd5<NT, NW, false, true>(a, st); \
-    return drop ? launch_attn_bwd5<NT, NW, true, false>(a, st) : launch_attn_bwd5<NT, NW, false, false>(a, st);
+  // masked calls always take the staged five-product form (the unstaged one is an A/B switch of the unmasked kernels)
+#define MMK_ATTN_BWD5_CASE(NT, NW)                                                                                                  \
+  case NT:                                                                                                                          \
+    MMK_ATTN_SPLIT_CASE(NT, NW)                                                                                                     \
+    if (seven) MMK_ATTN_BWD7(NT, NW);                                                                                               \
+    if (mask) return drop ? launch_attn_bwd5<NT, NW, true, true, true>(a, st) : launch_attn_bwd5<NT, NW, false, true, true>(a, st); \
+    if (staged) return drop ? launch_attn_bwd5<NT, NW, true, true, false>(a, st) : launch_attn_bwd5<NT, NW, false, true, false>(a, st); \
+    return drop ? launch_attn_bwd5<NT, NW, true, false, false>(a, st) : launch_attn_bwd5<NT, NW, false, false, false>(a, st);
   switch ((L + 31) / 32) {
     MMK_ATTN_BWD5_CASE(1, 4) MMK_ATTN_BWD5_CASE(2, 4) MMK_ATTN_BWD5_CASE(3, 4) MMK_ATTN_BWD_CASE(4, 4)
     MMK_ATTN_BWD5_CASE(5, 8) MMK_ATTN_BWD5_CASE(6, 8) MMK_ATTN_BWD5_CASE(7, 8)
-    default: return drop ? launch_attn_bwd<8, 8, true>(a, st) : launch_attn_bwd<8, 8, false>(a, st);
+    default: MMK_ATTN_BWD7(8, 8);
   }
 }

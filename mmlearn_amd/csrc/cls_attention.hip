@@ -36,6 +36,7 @@ struct ClsAttnArgs {
   float scale;
   uint32_t seed_lo, seed_hi, drop_thr;
   float drop_scale;
+  const float* kbias;  // optional key bias records [B][256] (mmk_attn_key_bias): added to the base-2 logit of key j of sample b
 };
 
 typedef bf16_t ca_bf8 __attribute__((ext_vector_type(8)));
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void cls_attn_fwd_kernel(const ClsAttnArgs a) 
     if (j < a.L) {
       ca_bf8 kr[8];
       ca_load_row(kb + (long)j * a.kv_sl, kr);
-      s[t] = ca_dot(qr, kr) * sc2;
+      s[t] = fmaf(ca_dot(qr, kr), sc2, a.kbias ? a.kbias[(long)b * 256 + j] : 0.f);
     }
     m = fmaxf(m, s[t]);
   }
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(256) void cls_attn_bwd_kernel(const ClsAttnArgs a) 
       ca_bf8 kr[8], vr[8];
       ca_load_row(kb + (long)j * a.kv_sl, kr);
       ca_load_row(vb + (long)j * a.kv_sl, vr);
-      p[t] = __builtin_amdgcn_exp2f(fmaf(ca_dot(qr, kr), sc2, -l2));
+      // (bias first, then the lse: an all-masked row has both at about -1e30, see bwd_prob in attention.hip)
+      p[t] = __builtin_amdgcn_exp2f(fmaf(ca_dot(qr, kr), sc2, a.kbias ? a.kbias[(long)b * 256 + j] : 0.f) - l2);
       keep[t] = ca_keep(a, dkey, j);
       dp[t] = keep[t] * ca_dot(gr, vr);
       del = fmaf(p[t], dp[t], del);
@@ -222,11 +224,11 @@ extern "C" {
 int mmk_cls_attn_supported(int L, int dh) { return dh == CA_DH && L >= 1 && L <= 64 * CA_MAXT; }
 
 int mmk_cls_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse2, int B, int H, int L, int dh, int64_t kv_sb,
-                     int64_t kv_sl, float scale, float dropout_p, uint64_t seed, void* stream) {
+                     int64_t kv_sl, float scale, float dropout_p, uint64_t seed, const float* key_bias, void* stream) {
   MMK_REQUIRE(q && k && v && o && lse2, "cls_attn_fwd: bad arguments");
   ClsAttnArgs a = {};
   a.q = static_cast<const bf16_t*>(q); a.k = static_cast<const bf16_t*>(k); a.v = static_cast<const bf16_t*>(v);
-  a.o = static_cast<bf16_t*>(o); a.lse2 = lse2;
+  a.o = static_cast<bf16_t*>(o); a.lse2 = lse2; a.kbias = key_bias;
   a.B = B; a.H = H; a.L = L; a.kv_sb = kv_sb; a.kv_sl = kv_sl; a.scale = scale;
   if (int rc = cls_attn_check(a, dh)) return rc;
   MMK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "cls_attn: dropout probability must be in [0, 1)");
@@ -243,12 +245,12 @@ int mmk_cls_attn_fwd(const void* q, const void* k, const void* v, void* o, float
 
 int mmk_cls_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const float* lse2, void* dq, void* dk, void* dv, int B,
                      int H, int L, int dh, int64_t kv_sb, int64_t kv_sl, int64_t g_sb, int64_t g_sl, float scale, float dropout_p,
-                     uint64_t seed, void* stream) {
+                     uint64_t seed, const float* key_bias, void* stream) {
   MMK_REQUIRE(q && k && v && dout && lse2 && dq && dk && dv, "cls_attn_bwd: bad arguments");
   ClsAttnArgs a = {};
   a.q = static_cast<const bf16_t*>(q); a.k = static_cast<const bf16_t*>(k); a.v = static_cast<const bf16_t*>(v);
   a.dout = static_cast<const bf16_t*>(dout); a.lse2 = const_cast<float*>(lse2);
-  a.dq = static_cast<bf16_t*>(dq); a.dk = static_cast<bf16_t*>(dk); a.dv = static_cast<bf16_t*>(dv);
+  a.dq = static_cast<bf16_t*>(dq); a.dk = static_cast<bf16_t*>(dk); a.dv = static_cast<bf16_t*>(dv); a.kbias = key_bias;
   a.B = B; a.H = H; a.L = L; a.kv_sb = kv_sb; a.kv_sl = kv_sl; a.g_sb = g_sb; a.g_sl = g_sl; a.scale = scale;
   if (int rc = cls_attn_check(a, dh)) return rc;
   MMK_REQUIRE(g_sl % 8 == 0 && g_sb % 8 == 0, "cls_attn_bwd: gradient rows must be 16-byte aligned");

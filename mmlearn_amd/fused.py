@@ -260,7 +260,7 @@ class _QKVAttentionFn(torch.autograd.Function):
     gradient needs no ``dY.sum(0)`` pass over the [rows, 3E] gradient (0.19 ms per ViT-B/16 layer at B = 1024)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, heads, scale, dropout_p, seed):
+    def forward(ctx, x, w, b, heads, scale, dropout_p, seed, key_bias=None, causal=False):
         B, L, E = x.shape
         x2 = x.reshape(-1, E).to(torch.bfloat16)
         w16, w_bwd, w_twin = _weight_operands(w)
@@ -268,18 +268,19 @@ class _QKVAttentionFn(torch.autograd.Function):
             qkv = x2 @ w16.t() if b is None else torch.addmm(b.detach().to(torch.bfloat16), x2, w16.t())
         qkv = qkv.view(B, L, 3, heads, 64)
         q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
-        out, lse = K.attn_fwd(q, k, v, scale, dropout_p, seed)
-        ctx.save_for_backward(x2, w_bwd, qkv, out, lse)
-        ctx.meta = (x.shape, x.dtype, w.dtype, None if b is None else b.dtype, scale, dropout_p, seed, w_twin)
+        out, lse = K.attn_fwd(q, k, v, scale, dropout_p, seed, key_bias, causal)
+        ctx.save_for_backward(x2, w_bwd, qkv, out, lse, key_bias)
+        ctx.meta = (x.shape, x.dtype, w.dtype, None if b is None else b.dtype, scale, dropout_p, seed, w_twin, causal)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x2, w_bwd, qkv, out, lse = ctx.saved_tensors
-        x_shape, x_dtype, w_dtype, b_dtype, scale, dropout_p, seed, w_twin = ctx.meta
+        x2, w_bwd, qkv, out, lse, key_bias = ctx.saved_tensors
+        x_shape, x_dtype, w_dtype, b_dtype, scale, dropout_p, seed, w_twin, causal = ctx.meta
         q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))
         want_db = b_dtype is not None and ctx.needs_input_grad[2]
-        res = K.attn_bwd(q, k, v, out, lse, dout.contiguous(), scale, dropout_p, seed, packed=True, colsum=want_db)
+        res = K.attn_bwd(q, k, v, out, lse, dout.contiguous(), scale, dropout_p, seed, packed=True, colsum=want_db, key_bias=key_bias,
+                         causal=causal)
         dqkv, db = res if want_db else (res, None)
         dy2 = dqkv.view(x2.shape[0], -1)
         dx = dw = None
@@ -288,14 +289,16 @@ class _QKVAttentionFn(torch.autograd.Function):
                 dx = _dx_gemm(dy2, w_bwd, w_twin).view(x_shape).to(x_dtype)
             if ctx.needs_input_grad[1]:
                 dw = K.wgrad(dy2, x2, w_dtype if w_dtype in (torch.float32, torch.bfloat16) else torch.float32).to(w_dtype)
-        return dx, dw, (None if db is None else db.to(b_dtype)), None, None, None, None
+        return dx, dw, (None if db is None else db.to(b_dtype)), None, None, None, None, None, None
 
 
-def qkv_attention(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], heads: int, scale: float, dropout_p: float):
+def qkv_attention(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], heads: int, scale: float, dropout_p: float,
+                  key_bias: Optional[torch.Tensor] = None, causal: bool = False):
     """``[B, L, E]`` -> ``[B, L, heads, 64]`` through the packed projection ``w [3E, E]`` / ``b [3E]`` and the HIP
     attention kernels; one autograd node where the weight-gradient kernel applies, two (``linear`` +
-    ``attention_qkvpacked``) otherwise.  None when the projection does not come out in bf16."""
-    from .attention import attention_qkvpacked, draw_seed
+    ``attention_qkvpacked``) otherwise.  None when the projection does not come out in bf16.  ``key_bias`` / ``causal``: the
+    key-padding records of ``attention.key_bias_of`` and the causal triangle (``attention.attention``)."""
+    from .attention import _causal_bias, attention_qkvpacked, draw_seed
 
     x16 = getattr(x, "_mmk_bf16", None)   # bf16 twin attached by add_layer_norm(twin=True)
     if x16 is not None and x16.shape == x.shape and _autocast_bf16():
@@ -303,11 +306,12 @@ def qkv_attention(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], h
     B, L, E = x.shape
     if _wgrad_linear_ok(w, x) and L <= 256 and w.shape[0] == 3 * heads * 64 and not os.environ.get("MMK_NO_QKV_NODE"):   # (A/B switch)
         seed = draw_seed() if dropout_p > 0.0 else 0
-        return _QKVAttentionFn.apply(x, w, b, int(heads), float(scale), float(dropout_p), int(seed))
+        return _QKVAttentionFn.apply(x, w, b, int(heads), float(scale), float(dropout_p), int(seed), _causal_bias(key_bias, causal, x, B, L),
+                                     bool(causal))
     qkv = linear(x, w, b)
     if qkv.dtype != torch.bfloat16:
         return None
-    return attention_qkvpacked(qkv.view(B, L, 3, heads, 64), scale, dropout_p)
+    return attention_qkvpacked(qkv.view(B, L, 3, heads, 64), scale, dropout_p, key_bias=key_bias, causal=causal)
 
 
 def _wgrad_linear_ok(weight: torch.Tensor, x: torch.Tensor) -> bool:
@@ -691,7 +695,122 @@ class QuickGELU(nn.Module):
         return _QuickGELUFn.apply(x)
 
 
-def _fused_qkv(self, hidden_states: torch.Tensor, names, scale: float, dropout_p: float):
+class _MaskScope:
+    """What a patched HF text model knows about the ``attention_mask`` of the forward in flight.  HF turns the tokenizer's 2-D mask
+    (``[B, L]`` ones / zeros: mmlearn/modules/encoders/text.py:160-165, clip.py:104-107, 329-346 always forward it) into a materialised
+    ``[B, 1, L, L]`` tensor per call, after a host-synchronising "is it all ones?" test, and hands THAT to every attention module -- from
+    which nobody can tell any more that it masks keys only.  The model-level pre-hook below sees the 2-D mask itself: it builds the key
+    bias records once per forward (``kernels.attn_key_bias``), keeps them here for the model's attention modules, and removes the mask
+    from HF's view, so that no 4-D tensor is built and nothing waits for the device.  An attention module that cannot use the records
+    (head size, sequence length, dtype) rebuilds an additive ``[B, 1, 1, L]`` mask from ``mask2d`` for its stock forward.  A model that
+    re-runs its layers in the backward (gradient checkpointing), when this forward's records are gone, is left alone: HF's own mask
+    reaches the layers in both runs and the stock forward serves it."""
+
+    __slots__ = ("key_bias", "mask2d", "shape", "stripped")
+
+    def __init__(self):
+        self.clear()
+
+    def clear(self):
+        self.key_bias, self.mask2d, self.shape, self.stripped = None, None, None, False
+
+    def additive(self, dtype: torch.dtype) -> torch.Tensor:
+        keep = self.mask2d != 0
+        return torch.zeros(keep.shape, dtype=dtype, device=keep.device).masked_fill_(~keep, torch.finfo(dtype).min)[:, None, None, :]
+
+
+def _mask_argument(model, args, kwargs):
+    """(where, value) of ``attention_mask`` in a call of ``model.forward``."""
+    if "attention_mask" in kwargs:
+        return "kw", kwargs["attention_mask"]
+    names = getattr(model, "_mmk_forward_params", None)
+    if names is None:
+        names = [n for n in inspect.signature(type(model).forward).parameters if n != "self"]
+        object.__setattr__(model, "_mmk_forward_params", names)
+    if "attention_mask" in names and names.index("attention_mask") < len(args):
+        return names.index("attention_mask"), args[names.index("attention_mask")]
+    return None, None
+
+
+def _mask_scope_pre_hook(model, args, kwargs):
+    scope = getattr(model, "_mmk_mask_scope", None)
+    if scope is None:
+        return None
+    scope.clear()
+    where, mask = _mask_argument(model, args, kwargs)
+    cfg = getattr(model, "config", None)
+    if (not isinstance(mask, torch.Tensor) or mask.dim() != 2 or not mask.is_cuda or mask.shape[1] > 256 or mask.is_floating_point()
+            and mask.dtype != torch.float32 or getattr(cfg, "is_decoder", False) or kwargs.get("encoder_hidden_states") is not None
+            or kwargs.get("past_key_values") is not None or os.environ.get("MMK_NO_ATTN_MASK")):
+        return None
+    if model.training and any(getattr(m, "gradient_checkpointing", False) for m in model.modules()):
+        return None   # the layers run again in the backward, after this forward's records are gone: both runs must see HF's own mask
+    from .attention import key_bias_of
+
+    kb = key_bias_of(mask, mask.shape[0], mask.shape[1], additive=False)
+    if kb is None:
+        return None
+    scope.key_bias, scope.mask2d, scope.shape, scope.stripped = kb, mask, tuple(mask.shape), True
+    if where == "kw":
+        return args, dict(kwargs, attention_mask=None)
+    return tuple(None if i == where else a for i, a in enumerate(args)), kwargs
+
+
+def _mask_scope_post_hook(model, args, output):
+    scope = getattr(model, "_mmk_mask_scope", None)
+    if scope is not None:
+        scope.clear()
+    return None
+
+
+_MASK_SCOPE_MODELS = ("BertModel", "CLIPTextTransformer", "CLIPTextModel")   # (CLIPTextModel IS the transformer in transformers 5)
+
+
+def scope_key_masks(module: nn.Module) -> int:
+    """Give every HF ``BertModel`` / CLIP text transformer inside ``module`` a :class:`_MaskScope` shared with its (patched) attention
+    modules and the two hooks that fill and clear it -- the INNERMOST such model where they nest (transformers 4: ``CLIPTextModel`` wraps
+    ``CLIPTextTransformer`` and hands the mask on).  Returns the number of models scoped."""
+    n = 0
+    for m in module.modules():
+        if type(m).__name__ not in _MASK_SCOPE_MODELS or getattr(m, "_mmk_mask_scope", None) is not None:
+            continue
+        if any(c is not m and type(c).__name__ in _MASK_SCOPE_MODELS for c in m.modules()):
+            continue
+        attns = [a for a in m.modules() if type(a).__name__ in _QKV_FORWARDS and hasattr(a, "_mmk_stock_forward")]
+        everyone = [a for a in m.modules() if type(a).__name__ in _QKV_FORWARDS]
+        if not attns or len(attns) != len(everyone):
+            continue   # an attention module that would never look at the scope: the mask stays HF's business
+        scope = _MaskScope()
+        object.__setattr__(m, "_mmk_mask_scope", scope)
+        for a in attns:
+            object.__setattr__(a, "_mmk_mask_scope", scope)
+        m.register_forward_pre_hook(_mask_scope_pre_hook, with_kwargs=True)
+        m.register_forward_hook(_mask_scope_post_hook)
+        n += 1
+    return n
+
+
+def _scoped_key_bias(self, hidden_states, attention_mask):
+    """-> (servable, key bias records or None, scope or None) for a call of a patched attention module."""
+    scope = getattr(self, "_mmk_mask_scope", None)
+    live = scope is not None and scope.key_bias is not None and scope.shape == tuple(hidden_states.shape[:2])
+    if attention_mask is None:
+        return True, (scope.key_bias if (live and scope.stripped) else None), (scope if live else None)
+    B, L = hidden_states.shape[:2]
+    from .attention import key_bias_of
+
+    kb = key_bias_of(attention_mask, B, L) if L <= 256 else None   # provable from shape and strides alone ([B, 1, 1, L], expanded views)
+    return kb is not None, kb, (scope if live else None)
+
+
+def _stock_mask(self, hidden_states, attention_mask, scope):
+    """The mask a stock forward must be given: the caller's, or -- when the model-level hook removed it -- an additive rebuild."""
+    if attention_mask is None and scope is not None and scope.stripped:
+        return scope.additive(hidden_states.dtype if hidden_states.is_floating_point() else torch.float32)
+    return attention_mask
+
+
+def _fused_qkv(self, hidden_states: torch.Tensor, names, scale: float, dropout_p: float, key_bias=None, causal: bool = False):
     """One GEMM for the three projections + the packed attention kernel; None when the call is not servable."""
     from .attention import attention_qkvpacked
 
@@ -705,34 +824,40 @@ def _fused_qkv(self, hidden_states: torch.Tensor, names, scale: float, dropout_p
         return None
     w = torch.cat([q.weight, k.weight, v.weight], 0)
     b = None if q.bias is None else torch.cat([q.bias, k.bias, v.bias], 0)
-    out = qkv_attention(hidden_states, w, b, E // 64, scale, dropout_p)
+    out = qkv_attention(hidden_states, w, b, E // 64, scale, dropout_p, key_bias, causal)
     return None if out is None else out.reshape(B, L, E)
 
 
 def _clip_attention_forward(self, hidden_states, attention_mask=None, **kwargs):
-    """Replaces HF ``CLIPAttention.forward`` (modeling_clip.py): same parameters, same return contract.  The fused kernel
-    is bidirectional: a causal call (HF's CLIP text tower passes no mask for sdpa-style implementations and signals
-    causality only through ``is_causal=True``) takes the stock forward."""
+    """Replaces HF ``CLIPAttention.forward`` (modeling_clip.py): same parameters, same return contract.  Key-padding masks the model
+    -level scope knows (or that are provable from the tensor: :func:`attention.key_mask_view`) run on the masked kernels; the vision
+    tower passes none.  A causal call -- HF's CLIP text tower: ``is_causal=True`` with no mask, or a materialised causal + padding mask
+    -- takes the masked kernels' causal triangle only in the first form (a 4-D mask of unknown content is never guessed at)."""
     causal = bool(kwargs.get("is_causal", False)) or bool(getattr(self, "is_causal", False))
-    if attention_mask is None and not causal and getattr(self, "head_dim", 0) == 64:
-        ctx = _fused_qkv(self, hidden_states, ("q_proj", "k_proj", "v_proj"), self.scale, self.dropout if self.training else 0.0)
+    ok, kb, scope = _scoped_key_bias(self, hidden_states, attention_mask)
+    if causal and attention_mask is not None:
+        ok = False   # causal + a tensor mask: the tensor holds the triangle as well; only the stock forward knows how to read it
+    if ok and getattr(self, "head_dim", 0) == 64:
+        ctx = _fused_qkv(self, hidden_states, ("q_proj", "k_proj", "v_proj"), self.scale, self.dropout if self.training else 0.0, kb, causal)
         if ctx is not None:
             if getattr(self, "_mmk_defer_out_bias", False):   # the enclosing patched layer adds out_proj.bias itself
                 self._mmk_out_bias_deferred = True
                 return linear_nobias(self.out_proj, ctx), None
             return self.out_proj(ctx), None
-    return self._mmk_stock_forward(hidden_states, attention_mask, **kwargs)
+    return self._mmk_stock_forward(hidden_states, _stock_mask(self, hidden_states, attention_mask, scope), **kwargs)
 
 
 def _bert_self_attention_forward(self, hidden_states, attention_mask=None, past_key_values=None, **kwargs):
     """Replaces HF ``BertSelfAttention.forward`` (modeling_bert.py); the output ``dense`` lives in ``BertSelfOutput``.
-    Decoder / causal configurations take the stock forward (the fused kernel is bidirectional)."""
+    Key-padding masks (the tokenizer's, through the model-level scope) run on the masked kernels.  Decoder / causal configurations
+    take the stock forward."""
     causal = bool(kwargs.get("is_causal", False)) or bool(getattr(self, "is_causal", False)) or bool(getattr(self, "is_decoder", False))
-    if attention_mask is None and past_key_values is None and not causal and getattr(self, "attention_head_size", 0) == 64:
-        ctx = _fused_qkv(self, hidden_states, ("query", "key", "value"), self.scaling, self.dropout.p if self.training else 0.0)
+    ok, kb, scope = _scoped_key_bias(self, hidden_states, attention_mask)
+    if ok and past_key_values is None and not causal and getattr(self, "attention_head_size", 0) == 64:
+        ctx = _fused_qkv(self, hidden_states, ("query", "key", "value"), self.scaling, self.dropout.p if self.training else 0.0, kb)
         if ctx is not None:
             return ctx, None
-    return self._mmk_stock_forward(hidden_states, attention_mask, past_key_values, **kwargs)
+    return self._mmk_stock_forward(hidden_states, _stock_mask(self, hidden_states, attention_mask, scope), past_key_values, **kwargs)
 
 
 _QKV_FORWARDS = {"CLIPAttention": _clip_attention_forward, "BertSelfAttention": _bert_self_attention_forward}
@@ -740,8 +865,10 @@ _QKV_FORWARDS = {"CLIPAttention": _clip_attention_forward, "BertSelfAttention": 
 
 def fuse_qkv_attention(module: nn.Module) -> int:
     """Give every HF ``CLIPAttention`` / ``BertSelfAttention`` inside ``module`` the fused-QKV forward (in place; the
-    modules, their parameters and the state_dict stay as they are).  Calls the fused path cannot serve (attention mask,
-    KV cache, head size != 64, L > 256, no bf16 autocast) run the stock forward.  Returns the number of modules patched."""
+    modules, their parameters and the state_dict stay as they are), and every HF text model that owns such modules the key-mask scope
+    (:func:`scope_key_masks`: the tokenizer's ``attention_mask`` then runs on the masked kernels).  Calls the fused path cannot serve
+    (a mask that is not a key-padding mask, KV cache, head size != 64, L > 256, no bf16 autocast) run the stock forward.  Returns the
+    number of modules patched."""
     n = 0
     for m in module.modules():
         fwd = _QKV_FORWARDS.get(type(m).__name__)
@@ -749,6 +876,7 @@ def fuse_qkv_attention(module: nn.Module) -> int:
             m._mmk_stock_forward = m.forward
             m.forward = types.MethodType(fwd, m)
             n += 1
+    scope_key_masks(module)
     return n
 
 
@@ -838,21 +966,21 @@ class _ClsAttnFn(torch.autograd.Function):
     (csrc/cls_attention.hip: one wave per (sample, head), every key / value row read once each way, every gradient row written once)."""
 
     @staticmethod
-    def forward(ctx, q, kv, scale, dropout_p, seed):
-        o, lse2 = K.cls_attn_fwd(q, kv, scale, dropout_p, seed)
-        ctx.save_for_backward(q, kv, lse2)
+    def forward(ctx, q, kv, scale, dropout_p, seed, key_bias=None):
+        o, lse2 = K.cls_attn_fwd(q, kv, scale, dropout_p, seed, key_bias)
+        ctx.save_for_backward(q, kv, lse2, key_bias)
         ctx.cfg = (scale, dropout_p, seed)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, kv, lse2 = ctx.saved_tensors
-        dq, dkv = K.cls_attn_bwd(q, kv, do.contiguous(), lse2, *ctx.cfg)
-        return dq, dkv, None, None, None
+        q, kv, lse2, key_bias = ctx.saved_tensors
+        dq, dkv = K.cls_attn_bwd(q, kv, do.contiguous(), lse2, *ctx.cfg, key_bias=key_bias)
+        return dq, dkv, None, None, None, None
 
 
 def _cls_query_attention(x: torch.Tensor, q_lin: nn.Linear, k_lin: nn.Linear, v_lin: nn.Linear, heads: int, scale: float,
-                         dropout_p: float) -> torch.Tensor:
+                         dropout_p: float, key_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Attention output of query token 0 alone, ``[B, 1, E]``: keys and values of ALL tokens through one packed ``[2E, E]``
     projection (the HIP weight-gradient path of :func:`linear`), the query of token 0 only.  On the GPU in bf16 with 64-wide heads and
     L <= 256 the attention itself is the single-query kernel pair (``_ClsAttnFn``; the library's SDPA takes 1.6 ms for what moves in
@@ -868,18 +996,24 @@ def _cls_query_attention(x: torch.Tensor, q_lin: nn.Linear, k_lin: nn.Linear, v_
         from .attention import draw_seed
 
         seed = draw_seed() if dropout_p > 0.0 else 0
-        return _ClsAttnFn.apply(q.contiguous(), kv, float(scale), float(dropout_p), seed).view(B, 1, E)
+        return _ClsAttnFn.apply(q.contiguous(), kv, float(scale), float(dropout_p), seed, key_bias).view(B, 1, E)
     k, v = kv.unbind(2)
-    a = F.scaled_dot_product_attention(q.unsqueeze(2), k.transpose(1, 2), v.transpose(1, 2), dropout_p=dropout_p, scale=scale)
+    # (key bias records are base-2 logits: back to an additive [B, 1, 1, L] mask in natural-log units for the library call)
+    am = None if key_bias is None else (key_bias[:, :L] * 0.6931471805599453).clamp_(min=torch.finfo(q.dtype).min).to(q.dtype)[:, None, None, :]
+    a = F.scaled_dot_product_attention(q.unsqueeze(2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=am, dropout_p=dropout_p, scale=scale)
     return a.transpose(1, 2).reshape(B, 1, E)
 
 
-def _cls_forward_applies(attn, hidden_states, attention_mask, kwargs, projections=()) -> bool:
+def _cls_forward_applies(attn, hidden_states, attention_mask, kwargs, projections=()):
+    """-> (applies, key bias records or None) for the token-0 form of a last layer."""
     if not all(_plain_linear(p) for p in projections):   # e.g. a LoRA-wrapped q_proj / v_proj: the full layer calls the modules
-        return False
+        return False, None
     causal = bool(kwargs.get("is_causal", False)) or bool(getattr(attn, "is_causal", False)) or bool(getattr(attn, "is_decoder", False))
-    return (attention_mask is None and not causal and hidden_states.dim() == 3 and hidden_states.shape[1] > 1
-            and kwargs.get("past_key_values") is None and not kwargs.get("output_attentions", False))
+    if (causal or hidden_states.dim() != 3 or hidden_states.shape[1] <= 1 or kwargs.get("past_key_values") is not None
+            or kwargs.get("output_attentions", False)):
+        return False, None
+    ok, kb, _ = _scoped_key_bias(attn, hidden_states, attention_mask)   # a key-padding mask is served, any other mask is not
+    return ok, kb
 
 
 def _clip_last_layer_cls_forward(self, hidden_states, attention_mask=None, **kwargs):
@@ -889,12 +1023,13 @@ def _clip_last_layer_cls_forward(self, hidden_states, attention_mask=None, **kwa
     both residual adds -- for token 0 only.  Returns ``[B, 1, E]``: token 0 of what the full layer returns, and the same gradients
     for every parameter (the other tokens' outputs of the last layer reach nothing).  Masked / causal calls run the full layer."""
     attn = self.self_attn
-    if not _cls_forward_applies(attn, hidden_states, attention_mask, kwargs, (attn.q_proj, attn.k_proj, attn.v_proj)):
+    applies, kb = _cls_forward_applies(attn, hidden_states, attention_mask, kwargs, (attn.q_proj, attn.k_proj, attn.v_proj))
+    if not applies:
         return self._mmk_full_forward(hidden_states, attention_mask, **kwargs)
     x = getattr(hidden_states, "_mmk_prenormed", None)
     if x is None:
         x = self.layer_norm1(hidden_states)
-    a = _cls_query_attention(x, attn.q_proj, attn.k_proj, attn.v_proj, attn.num_heads, attn.scale, attn.dropout if self.training else 0.0)
+    a = _cls_query_attention(x, attn.q_proj, attn.k_proj, attn.v_proj, attn.num_heads, attn.scale, attn.dropout if self.training else 0.0, kb)
     h = hidden_states[:, :1] + attn.out_proj(a)
     return h + self.mlp(self.layer_norm2(h))
 
@@ -905,12 +1040,14 @@ def _bert_last_layer_cls_forward(self, hidden_states, attention_mask=None, encod
     values over all tokens, the rest of the layer for position 0.  Returns ``[B, 1, E]``.  Decoder / cross-attention / masked
     calls run the full layer."""
     sa = self.attention.self
-    if (encoder_hidden_states is not None or past_key_values is not None or getattr(self, "is_decoder", False)
-            or not _cls_forward_applies(sa, hidden_states, attention_mask, kwargs, (sa.query, sa.key, sa.value))):
+    applies, kb = False, None
+    if encoder_hidden_states is None and past_key_values is None and not getattr(self, "is_decoder", False):
+        applies, kb = _cls_forward_applies(sa, hidden_states, attention_mask, kwargs, (sa.query, sa.key, sa.value))
+    if not applies:
         return self._mmk_full_forward(hidden_states, attention_mask, encoder_hidden_states, encoder_attention_mask,
                                       past_key_values=past_key_values, **kwargs)
     a = _cls_query_attention(hidden_states, sa.query, sa.key, sa.value, sa.num_attention_heads, sa.scaling,
-                             sa.dropout.p if self.training else 0.0)
+                             sa.dropout.p if self.training else 0.0, kb)
     ao = self.attention.output(a, hidden_states[:, :1])
     return self.output(self.intermediate(ao), ao)
 

@@ -1138,44 +1138,82 @@ def _cls_kv(kv: torch.Tensor):
     return kv[:, :, 0], kv[:, :, 1], B, L, H, L * 2 * H * dh, 2 * H * dh
 
 
-def cls_attn_fwd(q: torch.Tensor, kv: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0):
+_KEYMASK_KINDS = {torch.bool: 1, torch.uint8: 1, torch.int32: 2, torch.int64: 3}   # include/mmlearn_hip.h MMK_KEYMASK_*
+
+
+def attn_key_bias(mask: torch.Tensor, L: Optional[int] = None, additive: bool = False) -> torch.Tensor:
+    """Key-padding mask of a batch -> the f32 ``[B, 256]`` key bias records ``attn_fwd`` / ``attn_bwd`` / ``cls_attn_*`` take
+    (csrc/attention.hip ``mmk_attn_key_bias``: 0 attended, -1e30 masked, -inf beyond L).  ``mask``: ``[B, L]`` with nonzero = attended
+    (bool / uint8 / int32 / int64 / float32; the tokenizer's ``attention_mask``), or with ``additive`` a float32 / bfloat16 additive mask
+    (0 / ``finfo.min``); or, with ``L`` given, int32 ``[B]`` valid lengths (right padding).  Rows may be strided, the last dim not."""
+    require_gpu(mask)
+    if mask.dim() == 1:
+        assert L is not None and mask.dtype == torch.int32 and mask.is_contiguous(), "lengths: contiguous int32 [B] plus L"
+        B, kind, sb = mask.shape[0], 0, 0
+    else:
+        assert mask.dim() == 2 and (L is None or L == mask.shape[1]) and mask.stride(1) == 1 and mask.stride(0) >= mask.shape[1], (mask.shape, mask.stride())
+        B, L = mask.shape
+        sb = mask.stride(0)
+        if additive:
+            kind = {torch.float32: 5, torch.bfloat16: 6}[mask.dtype]
+        else:
+            kind = 4 if mask.dtype == torch.float32 else _KEYMASK_KINDS[mask.dtype]
+    assert 1 <= L <= 256, L
+    rec = torch.empty((B, 256), dtype=torch.float32, device=mask.device)
+    check(_lib.lib().mmk_attn_key_bias(ptr(mask), kind, B, int(L), sb, ptr(rec), stream()))
+    return rec
+
+
+def _key_bias_ok(key_bias, B):
+    assert key_bias is None or (key_bias.shape == (B, 256) and key_bias.dtype == torch.float32 and key_bias.is_contiguous()
+                                and key_bias.is_cuda), "key_bias: the f32 [B, 256] records of attn_key_bias"
+
+
+def cls_attn_fwd(q: torch.Tensor, kv: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0, key_bias: Optional[torch.Tensor] = None):
     """One query per (sample, head): ``q`` bf16 ``[B, H, 64]`` contiguous, ``kv`` bf16 ``[B, L <= 256, 2, H, 64]`` ->
-    (o bf16 ``[B, H, 64]``, lse2 f32 ``[B, H]``).  csrc/cls_attention.hip."""
+    (o bf16 ``[B, H, 64]``, lse2 f32 ``[B, H]``).  csrc/cls_attention.hip.  ``key_bias``: ``attn_key_bias`` records (key padding)."""
     k, v, B, L, H, sb, sl = _cls_kv(kv)
     assert q.shape == (B, H, 64) and q.dtype == torch.bfloat16 and q.is_contiguous()
+    _key_bias_ok(key_bias, B)
     o = torch.empty_like(q)
     lse2 = torch.empty((B, H), dtype=torch.float32, device=q.device)
     check(_lib.lib().mmk_cls_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse2), B, H, L, 64, sb, sl, float(scale), float(dropout_p), int(seed),
-                                      stream()))
+                                      ptr(key_bias), stream()))
     return o, lse2
 
 
-def cls_attn_bwd(q: torch.Tensor, kv: torch.Tensor, dout: torch.Tensor, lse2: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0):
+def cls_attn_bwd(q: torch.Tensor, kv: torch.Tensor, dout: torch.Tensor, lse2: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0,
+                 key_bias: Optional[torch.Tensor] = None):
     """-> (dq bf16 ``[B, H, 64]``, dkv bf16 ``[B, L, 2, H, 64]``: every key / value row written)."""
     k, v, B, L, H, sb, sl = _cls_kv(kv)
     assert dout.shape == q.shape and dout.dtype == torch.bfloat16 and dout.is_contiguous() and lse2.is_contiguous()
+    _key_bias_ok(key_bias, B)
     dq = torch.empty_like(q)
     dkv = torch.empty_like(kv)
     check(_lib.lib().mmk_cls_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(dout), ptr(lse2), ptr(dq), ptr(dkv[:, :, 0]), ptr(dkv[:, :, 1]), B, H, L, 64,
-                                      sb, sl, sb, sl, float(scale), float(dropout_p), int(seed), stream()))
+                                      sb, sl, sb, sl, float(scale), float(dropout_p), int(seed), ptr(key_bias), stream()))
     return dq, dkv
 
 
-def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0):
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0,
+             key_bias: Optional[torch.Tensor] = None, causal: bool = False):
     """q/k/v: [B, H, L, 64] bf16 views (last dim contiguous) -> (out [B, L, H, 64] contiguous, lse f32 [B, H, L]).
-    ``dropout_p`` > 0 drops attention probabilities with the counter-based mask of ``seed`` (see csrc/attention.hip)."""
+    ``dropout_p`` > 0 drops attention probabilities with the counter-based mask of ``seed`` (see csrc/attention.hip).
+    ``key_bias``: the ``attn_key_bias`` records of a key-padding mask; ``causal`` (needs ``key_bias``) masks key j > query i too."""
     require_gpu(q)
     B, H, L, dh = q.shape
+    _key_bias_ok(key_bias, B)
     out = torch.empty((B, L, H, dh), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device)
     qs, ks, vs = _strides3(q), _strides3(k), _strides3(v)
     check(_lib.lib().mmk_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), B, H, L, dh, C.cast(qs, C.c_void_p), C.cast(ks, C.c_void_p),
-                                  C.cast(vs, C.c_void_p), float(scale), float(dropout_p), int(seed), stream()))
+                                  C.cast(vs, C.c_void_p), float(scale), float(dropout_p), int(seed), ptr(key_bias), int(bool(causal)), stream()))
     return out, lse
 
 
 def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, lse: torch.Tensor, dout: torch.Tensor, scale: float,
-             dropout_p: float = 0.0, seed: int = 0, packed: bool = False, colsum: bool = False):
+             dropout_p: float = 0.0, seed: int = 0, packed: bool = False, colsum: bool = False, key_bias: Optional[torch.Tensor] = None,
+             causal: bool = False):
     """Backward of ``attn_fwd``: out / dout are [B, L, H, 64] contiguous.  Returns dq, dk, dv as [B, H, L, 64] VIEWS of
     [B, L, H, 64] buffers (the layout the q/k/v projections' backward consumes without a copy), or with ``packed`` one
     [B, L, 3, H, 64] buffer holding the three (the gradient of a fused QKV projection's output); ``packed`` + ``colsum``
@@ -1183,6 +1221,7 @@ def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
     gradient -- accumulated from per-tile sums the kernel takes while it stores, instead of a pass over the gradient."""
     require_gpu(q)
     B, H, L, dh = q.shape
+    _key_bias_ok(key_bias, B)
     assert out.is_contiguous() and dout.is_contiguous() and out.shape == (B, L, H, dh) == dout.shape
     if packed:
         dqkv = torch.empty((B, L, 3, H, dh), dtype=q.dtype, device=q.device)
@@ -1196,7 +1235,7 @@ def attn_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
     part = torch.empty((B * ((L + 31) // 32), 3 * H * dh), dtype=torch.float32, device=q.device) if in_kernel else None
     check(_lib.lib().mmk_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), B, H, L, dh,
                                   C.cast(qs, C.c_void_p), C.cast(ks, C.c_void_p), C.cast(vs, C.c_void_p), C.cast(gs, C.c_void_p),
-                                  float(scale), float(dropout_p), int(seed), ptr(part), stream()))
+                                  float(scale), float(dropout_p), int(seed), ptr(part), ptr(key_bias), int(bool(causal)), stream()))
     if packed and colsum:
         if not in_kernel:
             return dqkv, dqkv.view(B * L, -1).sum(0, dtype=torch.float32)

@@ -60,9 +60,23 @@ def keep_mask(seed: int, B: int, H: int, L: int, p: float) -> np.ndarray:
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, dropout_p: float = 0.0, seed: int = 0,
-              dtype=torch.float32) -> torch.Tensor:
-    """[B, H, L, dh] operands -> [B, L, H, dh]; differentiable (autograd supplies the backward oracle)."""
+              dtype=torch.float32, key_mask: torch.Tensor | None = None, causal: bool = False) -> torch.Tensor:
+    """[B, H, L, dh] operands -> [B, L, H, dh]; differentiable (autograd supplies the backward oracle).
+
+    ``key_mask``: bool ``[B, L]``, True = the key is attended -- the tokenizer's padding mask the reference's text towers forward
+    (mmlearn/modules/encoders/text.py:160-165, clip.py:104-107, 329-346), i.e. ``attn_mask=key_mask[:, None, None, :]`` of
+    ``F.scaled_dot_product_attention`` / HF's ``[B, 1, 1, L]`` extended mask.  Masked logits are set to ``finfo.min`` of the compute
+    type, not -inf (HF's additive convention): a sample whose keys are ALL masked averages V uniformly instead of producing NaN.
+    ``causal``: key j > query i is masked the same way (HF CLIP's text tower)."""
     s = (q.to(dtype) @ k.to(dtype).transpose(-1, -2)) * scale
+    if key_mask is not None or causal:
+        B, H, L, _ = q.shape
+        allowed = torch.ones(B, 1, L, L, dtype=torch.bool, device=s.device)
+        if key_mask is not None:
+            allowed = allowed & key_mask.to(s.device).bool()[:, None, None, :]
+        if causal:
+            allowed = allowed & torch.ones(L, L, dtype=torch.bool, device=s.device).tril()
+        s = s.masked_fill(~allowed, torch.finfo(dtype).min)
     p = torch.softmax(s, dim=-1)
     if dropout_p > 0:
         B, H, L, _ = q.shape

@@ -261,3 +261,272 @@ def test_cls_only_path_uses_the_single_query_kernel_and_agrees_with_sdpa(monkeyp
         # bf16 noise there, so every tensor is compared on the scale of the real gradients
         scale = r.abs().max().item() if k == 0 else max(r.abs().max().item(), 2e-2 * top)
         assert (r - h).abs().max().item() <= 3e-2 * max(scale, 1e-3), k
+
+
+# ------------------------------------------------------------------------------------------------ key-padding masks / causal
+def _oracle():
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import attention_oracle as AO
+    return AO
+
+
+def _lengths(B, L, g):
+    """Per-sample valid lengths: random in [1, L], with the edge cases pinned -- one key only, the full row, a tile boundary."""
+    n = torch.randint(1, L + 1, (B,), generator=g)
+    n[0] = 1
+    if B > 1:
+        n[1] = L
+    if B > 2:
+        n[2] = min(L, 32)
+    if B > 3:
+        n[3] = min(L, 33)
+    return n
+
+
+@pytest.mark.parametrize("B,H,L,p,causal", [(6, 3, 77, 0.0, False), (5, 2, 197, 0.0, False), (6, 2, 77, 0.1, False), (4, 2, 256, 0.0, False),
+                                             (4, 2, 128, 0.0, False), (4, 1, 40, 0.25, False), (5, 2, 169, 0.1, False), (3, 2, 1, 0.0, False),
+                                             (5, 2, 77, 0.0, True), (4, 2, 197, 0.1, True), (4, 2, 256, 0.0, True), (4, 2, 100, 0.0, True)])
+def test_masked_attention_fwd_bwd_vs_oracle(B, H, L, p, causal):
+    """a key-padding mask (random valid lengths incl. 1 and L; a second case with holes in the middle = left padding /
+    arbitrary 0-1 masks) and the causal triangle inside the HIP kernels: forward, dq, dk, dv against oracle/attention_oracle.py, for the
+    five-product backward (L = 77, 197, 40, 169, 100, 1), the seven-product one (L = 128, 256) and with dropout.  Gradients of masked
+    keys are exactly zero."""
+    AO = _oracle()
+    from mmlearn_amd.attention import attention, key_bias_of
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(1000 * L + 10 * B + int(causal))
+    dh, scale, seed = 64, 0.125, 0x5EED_0000_1234_0000 + L
+    for form in ("lengths", "holes"):
+        if form == "lengths":
+            n = _lengths(B, L, g)
+            keep = torch.arange(L)[None, :] < n[:, None]
+        else:
+            keep = torch.rand(B, L, generator=g) < 0.6
+            keep[:, L // 2] = True                     # at least one key per sample
+            if causal:
+                keep[:, 0] = True                      # ... that every query may look at
+        q0, k0, v0 = ((torch.randn(B, L, H * dh, generator=g) * 1.5).bfloat16() for _ in range(3))
+        qr, kr, vr = (t.float().view(B, L, H, dh).transpose(1, 2).clone().requires_grad_(True) for t in (q0, k0, v0))
+        out_r = AO.attention(qr, kr, vr, scale, p, seed, key_mask=keep, causal=causal)
+        w = torch.randn(B, L, H, dh, generator=g)
+        (out_r * w).sum().backward()
+        qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q0, k0, v0))
+        kb = key_bias_of(keep.to(dev), B, L)
+        assert kb.shape == (B, 256) and (kb[:, :L] == 0).cpu().eq(keep).all() and torch.isinf(kb[:, L:]).all()
+        out = attention(*(t.view(B, L, H, dh).transpose(1, 2) for t in (qd, kd, vd)), scale, p, seed, key_bias=kb, causal=causal)
+        err = (out.float().cpu() - out_r.detach()).abs().max().item()
+        assert err <= 2e-2 * max(1.0, out_r.abs().max().item()), (form, err)
+        (out.float() * w.to(dev)).sum().backward()
+        for got, ref, name in ((qd.grad, qr.grad, "dq"), (kd.grad, kr.grad, "dk"), (vd.grad, vr.grad, "dv")):
+            ref_l = ref.transpose(1, 2).reshape(B, L, H * dh)
+            e = (got.float().cpu() - ref_l).abs().max().item()
+            assert e <= 3e-2 * max(ref_l.abs().max().item(), 1e-3), (form, name, e, ref_l.abs().max().item())
+        dead = ~keep[:, :, None].expand(B, L, H * dh)
+        assert (kd.grad.cpu()[dead] == 0).all() and (vd.grad.cpu()[dead] == 0).all()      # a masked key receives nothing
+
+
+def test_key_bias_records_from_every_mask_form():
+    """mmk_attn_key_bias: lengths, bool / uint8 / int32 / int64 / float keep-masks, float32 / bf16 additive masks, strided rows and the
+    HF 4-D forms attention.key_mask_view can prove; a materialised [B, 1, L, L] tensor is refused."""
+    from mmlearn_amd import kernels as K
+    from mmlearn_amd.attention import key_bias_of, key_mask_view
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    B, L = 7, 77
+    keep = torch.rand(B, L, generator=g) < 0.7
+    n = keep.sum(1).int()
+    right = torch.arange(L)[None, :] < n[:, None]
+    want = torch.full((B, 256), float("-inf"))
+    want[:, :L] = torch.where(keep, 0.0, -1e30)
+    want_r = torch.full((B, 256), float("-inf"))
+    want_r[:, :L] = torch.where(right, 0.0, -1e30)
+    assert torch.equal(K.attn_key_bias(n.to(dev), L=L).cpu(), want_r)
+    for dt in (torch.bool, torch.uint8, torch.int32, torch.int64, torch.float32):
+        assert torch.equal(K.attn_key_bias(keep.to(dt).to(dev)).cpu(), want), dt
+    wide = torch.zeros(B, L + 19, dtype=torch.int64)
+    wide[:, :L] = keep
+    assert torch.equal(K.attn_key_bias(wide.to(dev)[:, :L]).cpu(), want)               # strided rows
+    for dt in (torch.float32, torch.bfloat16):
+        add = torch.zeros(B, L, dtype=dt).masked_fill(~keep, torch.finfo(dt).min)
+        assert torch.equal(K.attn_key_bias(add.to(dev), additive=True).cpu(), want), dt
+        assert torch.equal(key_bias_of(add.to(dev)[:, None, None, :], B, L).cpu(), want)   # HF's extended additive mask
+    soft = torch.randn(B, L, generator=g)                                                 # any finite additive bias: base-2 units
+    got = K.attn_key_bias(soft.to(dev), additive=True).cpu()
+    assert torch.allclose(got[:, :L], soft * 1.4426950408889634, rtol=1e-6)
+    m4 = keep.to(dev)[:, None, None, :]
+    assert torch.equal(key_bias_of(m4, B, L).cpu(), want)
+    assert torch.equal(key_bias_of(m4.expand(B, 1, L, L), B, L).cpu(), want)              # stride-0 query dim: provably a key mask
+    assert torch.equal(key_bias_of(m4.expand(B, 3, L, L), B, L).cpu(), want)
+    assert key_mask_view(m4.expand(B, 1, L, L).contiguous(), B, L) is None                # materialised: could hold anything
+    assert key_bias_of(m4.expand(B, 1, L, L).contiguous(), B, L) is None
+    assert key_mask_view(keep.to(dev)[:, None, :], B, L) is None                          # 3-D masks are per-query masks
+
+
+def test_all_masked_sample_is_finite_and_does_not_poison_the_batch():
+    """A sample with no valid key (an empty caption): HF's additive finfo.min convention averages V uniformly; here the forward does the
+    same and the backward stays finite, so the weight gradients summed over the batch keep the other samples' values."""
+    AO = _oracle()
+    from mmlearn_amd.attention import attention, key_bias_of
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(9)
+    B, H, L, dh = 3, 2, 77, 64
+    keep = torch.ones(B, L, dtype=torch.bool)
+    keep[1] = False
+    keep[2, 40:] = False
+    q0, k0, v0 = ((torch.randn(B, L, H * dh, generator=g)).bfloat16() for _ in range(3))
+    qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q0, k0, v0))
+    out = attention(*(t.view(B, L, H, dh).transpose(1, 2) for t in (qd, kd, vd)), 0.125, key_bias=key_bias_of(keep.to(dev), B, L))
+    ref = AO.attention(*(t.float().view(B, L, H, dh).transpose(1, 2) for t in (q0, k0, v0)), 0.125, key_mask=keep)
+    assert (out.float().cpu() - ref).abs().max().item() <= 2e-2                          # incl. the uniform average of sample 1
+    out.float().square().sum().backward()
+    for t in (qd, kd, vd):
+        assert torch.isfinite(t.grad.float()).all()
+
+
+@pytest.mark.parametrize("B,H,L,p", [(6, 12, 77, 0.0), (5, 3, 77, 0.1), (4, 2, 197, 0.0)])
+def test_single_query_attention_with_a_key_mask(B, H, L, p):
+    """csrc/cls_attention.hip with key bias records: row 0 of the masked oracle, every dk / dv row (masked rows exactly zero)."""
+    AO = _oracle()
+    from mmlearn_amd.attention import key_bias_of
+    from mmlearn_amd.fused import _ClsAttnFn
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(77 * L + B)
+    dh, scale, seed = 64, 0.125, 0x0BAD_5EED_0000_1111 + L
+    n = _lengths(B, L, g)
+    keep = torch.arange(L)[None, :] < n[:, None]
+    q0 = (torch.randn(B, H, dh, generator=g) * 1.5).bfloat16()
+    kv0 = (torch.randn(B, L, 2, H, dh, generator=g) * 1.5).bfloat16()
+    w = torch.randn(B, H, dh, generator=g)
+    qr = torch.zeros(B, H, L, dh)
+    qr[:, :, 0] = q0.float()
+    qr.requires_grad_(True)
+    kr = kv0[:, :, 0].float().transpose(1, 2).clone().requires_grad_(True)
+    vr = kv0[:, :, 1].float().transpose(1, 2).clone().requires_grad_(True)
+    out_r = AO.attention(qr, kr, vr, scale, p, seed, key_mask=keep)[:, 0]
+    (out_r * w).sum().backward()
+    qd, kvd = q0.to(dev).requires_grad_(True), kv0.to(dev).requires_grad_(True)
+    out = _ClsAttnFn.apply(qd, kvd, scale, p, seed, key_bias_of(keep.to(dev), B, L))
+    assert (out.float().cpu() - out_r.detach()).abs().max().item() <= 2e-2 * max(1.0, out_r.abs().max().item())
+    (out.float() * w.to(dev)).sum().backward()
+    dq_ref = qr.grad[:, :, 0]
+    assert (qd.grad.float().cpu() - dq_ref).abs().max().item() <= 3e-2 * max(dq_ref.abs().max().item(), 1e-3)
+    for part, ref, name in ((0, kr.grad, "dk"), (1, vr.grad, "dv")):
+        ref_l = ref.transpose(1, 2)
+        got = kvd.grad[:, :, part].float().cpu()
+        assert (got - ref_l).abs().max().item() <= 3e-2 * max(ref_l.abs().max().item(), 1e-3), name
+        assert (got[~keep] == 0).all(), name
+
+
+def _text_batch(B, L, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(0, 1000, (B, L), generator=g)
+    n = _lengths(B, L, g)
+    n[0] = 5          # (every caption keeps its first tokens)
+    mask = (torch.arange(L)[None, :] < n[:, None]).long()
+    return ids.to(dev), mask.to(dev)
+
+
+def test_bert_with_the_tokenizers_mask_runs_the_masked_kernels_and_matches_stock(monkeypatch):
+    """A padded text batch through a fused BERT: the model-level scope takes the 2-D mask, the attention modules run the MASKED HIP
+    kernels (no stock forward, i.e. no SDPA, is entered), outputs at the valid positions and all parameter gradients match the stock
+    model given the same mask; with gradient checkpointing on, the mask stays HF's and the result is still the stock one."""
+    from transformers import BertConfig, BertModel
+
+    from mmlearn_amd import fused
+    from mmlearn_amd import kernels as K
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=1000,
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    stock = BertModel(cfg, add_pooling_layer=False).to(dev)
+    import copy
+    hip = copy.deepcopy(stock)
+    assert fused.fuse_qkv_attention(hip) == 2 and getattr(hip, "_mmk_mask_scope", None) is not None
+    ids, mask = _text_batch(6, 77, dev, 5)
+    w = torch.randn(6, 77, 128, device=dev) * mask[:, :, None]
+    calls = {"masked": 0, "stock": 0}
+    real_fwd = K.attn_fwd
+
+    def spy(q, k, v, scale, dropout_p=0.0, seed=0, key_bias=None, causal=False):
+        calls["masked"] += key_bias is not None
+        return real_fwd(q, k, v, scale, dropout_p, seed, key_bias, causal)
+
+    monkeypatch.setattr(K, "attn_fwd", spy)
+    for sa in (l.attention.self for l in hip.encoder.layer):
+        orig = sa._mmk_stock_forward
+        sa._mmk_stock_forward = (lambda *a, _o=orig, **k: (calls.__setitem__("stock", calls["stock"] + 1), _o(*a, **k))[1])
+    outs = []
+    for m in (stock, hip):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            h = m(input_ids=ids, attention_mask=mask).last_hidden_state
+        (h.float() * w).sum().backward()
+        outs.append((h.float().detach() * mask[:, :, None], {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    assert calls == {"masked": 2, "stock": 0}, calls
+    assert hip._mmk_mask_scope.key_bias is None                                  # cleared after the forward
+    (e0, g0), (e1, g1) = outs
+    assert (e0 - e1).abs().max() <= 3e-2 * e0.abs().max()
+    gmax = max(v.abs().max().item() for v in g0.values())
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        assert (g0[n] - g1[n]).abs().max() <= 6e-2 * max(g0[n].abs().max().item(), 1e-2 * gmax), n
+    # an all-ones mask and no mask: the unmasked kernels or the masked ones, never the stock forward
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        a = hip(input_ids=ids, attention_mask=torch.ones_like(mask)).last_hidden_state
+        b = hip(input_ids=ids).last_hidden_state
+    assert calls["stock"] == 0 and (a.float() - b.float()).abs().max() <= 2e-2 * b.float().abs().max()
+    # gradient checkpointing: layers re-run in the backward, the mask is left to HF and the stock forward serves it
+    hip.gradient_checkpointing_enable()
+    hip.train()
+    hip.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        h = hip(input_ids=ids, attention_mask=mask).last_hidden_state
+    (h.float() * w).sum().backward()
+    assert (h.float().detach() * mask[:, :, None] - e0).abs().max() <= 3e-2 * e0.abs().max()
+    for n in g0:
+        assert (g0[n] - dict(hip.named_parameters())[n].grad).abs().max() <= 6e-2 * max(g0[n].abs().max().item(), 1e-2 * gmax), n
+
+
+def test_clip_text_tower_causal_plus_padding_matches_stock():
+    """HF CLIP's text tower is causal (clip.py:329-346 forwards the padding mask on top): the fused modules serve ``is_causal`` with the
+    scope's key bias on the masked kernels; text embeddings and parameter gradients match the stock model."""
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+
+    from mmlearn_amd import fused
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1)
+    cfg = CLIPTextConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, vocab_size=1000,
+                         max_position_embeddings=77, projection_dim=64, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    stock = CLIPTextModelWithProjection(cfg).to(dev)
+    import copy
+    hip = copy.deepcopy(stock)
+    assert fused.fuse_qkv_attention(hip) == 2
+    ids, mask = _text_batch(6, 77, dev, 8)
+    ids = ids.clamp(min=3)
+    n = mask.sum(1)
+    ids[torch.arange(6, device=dev), n - 1] = 2           # the EOS token the pooling looks for, at the last valid position
+    ids = ids * mask
+    served = []
+    for sa in (l.self_attn for l in hip.text_model.encoder.layers):
+        orig = sa._mmk_stock_forward
+        sa._mmk_stock_forward = (lambda *a, _o=orig, **k: (served.append("stock"), _o(*a, **k))[1])
+    outs = []
+    for m in (stock, hip):
+        for am in (mask, None):
+            m.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                e = m(input_ids=ids, attention_mask=am).text_embeds
+            e.float().square().sum().backward()
+            outs.append((e.float().detach(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert served == [], served
+    for (e0, g0), (e1, g1) in ((outs[0], outs[2]), (outs[1], outs[3])):
+        assert (e0 - e1).abs().max() <= 3e-2 * e0.abs().max()
+        gmax = max(v.abs().max().item() for v in g0.values())
+        for k in g0:
+            assert (g0[k] - g1[k]).abs().max() <= 6e-2 * max(g0[k].abs().max().item(), 1e-2 * gmax), k

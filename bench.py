@@ -230,7 +230,7 @@ def _timed_steps(step, warmup: int, steps: int) -> float:
     return (time.perf_counter() - t0) / steps
 
 
-def eager_gpu_leg(batch_size: int, rank: int, dev, small: bool, steps: int = 4, warmup: int = 2):
+def eager_gpu_leg(batch_size: int, rank: int, dev, small: bool, steps: int = 8, warmup: int = 2, padded: bool = False):
     """The denominator of the north-star ratio, on the driver's clock: the SAME step as the reference runs it on
     PyTorch-ROCm -- stock HF encoders (SDPA attention, hipBLASLt, ATen elementwise), torch.optim.AdamW, bf16 autocast and
     the reference's loss op sequence (oracle/eager_torch.py = contrastive.py:134-144,327-340) -- same batch, this GPU,
@@ -244,7 +244,7 @@ def eager_gpu_leg(batch_size: int, rank: int, dev, small: bool, steps: int = 4, 
     try:
         task = build_task(EagerContrastiveLoss(), small, fused=False).to(dev)
         opt = task.configure_optimizers()
-        batch = synthetic_batch(batch_size, rank, dev)
+        batch = synthetic_batch(batch_size, rank, dev, padded=padded)
 
         def step():
             opt.zero_grad(set_to_none=True)
@@ -252,16 +252,72 @@ def eager_gpu_leg(batch_size: int, rank: int, dev, small: bool, steps: int = 4, 
                 loss = task.training_step(batch, 0)
             loss.backward()
             opt.step()
+            return loss
 
         sec = _timed_steps(step, warmup, steps)
+        final = float(step().detach().float())
     finally:
         cp.l2_normalize = saved
     peak = torch.cuda.max_memory_allocated() / 2**30
     del task, opt
     torch.cuda.empty_cache()
     return {"ms_per_step": round(sec * 1e3, 2), "pairs_s": round(batch_size / sec, 1), "steps": steps, "warmup": warmup, "per_gpu_batch": batch_size,
-            "peak_hbm_gib": round(peak, 1),
+            "peak_hbm_gib": round(peak, 1), "loss": round(final, 4),
+            "text_mask": "caption lengths ~U[8, 77] (right padding)" if padded else "all ones (SURVEY 8(d))",
             "what": "stock HF CLIP ViT-B/16 + BERT-base, SDPA, hipBLASLt, torch.optim.AdamW, bf16 autocast, reference loss op sequence (eager), 1 GPU, local negatives"}
+
+
+def padded_text_leg(b: int, dev, small: bool, steps: int = 8, warmup: int = 3):
+    """The headline step on a text batch with REAL padding -- caption lengths ~U[8, 77], the mask the tokenizer emits and the
+    reference's text towers forward (mmlearn/modules/encoders/text.py:160-165): every BERT layer then runs the masked HIP attention
+    kernels (csrc/attention.hip MASK variants, the single-query kernel in the last layer), never the library's SDPA; the launches are
+    counted to show it.  NOT part of `value`; the stock step on the same batch is the `padded_text_eager` leg."""
+    from mmlearn_amd import ContrastiveLoss
+    from mmlearn_amd import kernels as K
+
+    task = build_task(ContrastiveLoss(static_shapes=True), small, fused=True).to(dev)
+    opt = task.configure_optimizers()
+    batch = synthetic_batch(b, 0, dev, padded=True)
+    seen = {"attn_fwd_masked": 0, "attn_fwd_unmasked": 0, "cls_attn_masked": 0, "cls_attn_unmasked": 0, "stock_attention_forwards": 0}
+    real_fwd, real_cls = K.attn_fwd, K.cls_attn_fwd
+
+    def fwd(q, k, v, scale, dropout_p=0.0, seed=0, key_bias=None, causal=False):
+        seen["attn_fwd_masked" if key_bias is not None else "attn_fwd_unmasked"] += 1
+        return real_fwd(q, k, v, scale, dropout_p, seed, key_bias, causal)
+
+    def cls(q, kv, scale, dropout_p=0.0, seed=0, key_bias=None):
+        seen["cls_attn_masked" if key_bias is not None else "cls_attn_unmasked"] += 1
+        return real_cls(q, kv, scale, dropout_p, seed, key_bias)
+
+    def counting(orig):
+        def stock(*a, **k):
+            seen["stock_attention_forwards"] += 1
+            return orig(*a, **k)
+        return stock
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = task.training_step(batch, 0)
+        loss.backward()
+        opt.step()
+        return loss
+
+    sec = _timed_steps(step, warmup, steps)
+    K.attn_fwd, K.cls_attn_fwd = fwd, cls
+    for m in task.modules():
+        if hasattr(m, "_mmk_stock_forward") and type(m).__name__ in ("BertSelfAttention", "CLIPAttention"):
+            m._mmk_stock_forward = counting(m._mmk_stock_forward)
+    try:
+        loss = step()
+        torch.cuda.synchronize()
+    finally:
+        K.attn_fwd, K.cls_attn_fwd = real_fwd, real_cls
+    return {"workload": f"the headline step (configs[1], per-GPU batch {b}) on captions of length ~U[8, 77] with the tokenizer's padding mask",
+            "ms_per_step": round(sec * 1e3, 2), "pairs_s": round(b / sec, 1), "steps": steps, "warmup": warmup,
+            "loss": round(float(loss.detach().float()), 4),
+            "attention_launches_in_one_step": seen,
+            "note": "text layers 1-11 = attn_fwd_masked, the token-0 last layer = cls_attn_masked; the image tower has no mask"}
 
 
 class _PooledVision(nn.Module):
@@ -311,7 +367,7 @@ class _PooledAudio(nn.Module):
         return (self.model(input_features=x, is_longer=torch.zeros(x.shape[0], 1, dtype=torch.bool, device=x.device)).pooler_output,)
 
 
-def full_last_layer_leg(b: int, dev, small: bool, steps: int = 6, warmup: int = 3):
+def full_last_layer_leg(b: int, dev, small: bool, steps: int = 8, warmup: int = 3):
     """The headline step with ``accelerate_encoder(..., cls_only=False)`` (NOT part of `value`; round 4's headline).  Both towers are
     pooled at token 0 (mmlearn/modules/encoders/clip.py:463-470; the text tower's ``last_hidden_state[:, 0]``) and say so
     (``mmk_reads_only_token0``), so ``accelerate_encoder``'s default (``cls_only="auto"``) lets the last layer of each compute keys /
@@ -342,7 +398,7 @@ def full_last_layer_leg(b: int, dev, small: bool, steps: int = 6, warmup: int = 
             "loss": round(float(loss.detach().float()), 4)}
 
 
-def three_tower_leg(b: int, dev, small: bool, steps: int = 3, warmup: int = 2, stock: bool = False):
+def three_tower_leg(b: int, dev, small: bool, steps: int = 8, warmup: int = 2, stock: bool = False):
     """BASELINE configs[3] on the driver's clock (bounded, outside the headline region): image + text + audio (HTSAT)
     towers, ONE shared projection head (Linear 768 -> 512), learnable logit scale, three weighted loss pairs -> the
     N-way pairwise similarity path (3 pairs = 6 CE directions in one launch set).  The bioscan_1m recipe shape
@@ -518,7 +574,7 @@ def _three_tower_stock(rgb, text, audio, b: int, dev, small: bool, steps: int, w
             "what": "stock HF CLIP ViT-B/16 + BERT-base + HTSAT (CLAP audio), SDPA, hipBLASLt, torch.optim.AdamW, bf16 autocast, reference loss op sequence (eager), one stream"}
 
 
-def ijepa_leg(b: int, dev, small: bool, steps: int = 4, warmup: int = 3, stock: bool = False):
+def ijepa_leg(b: int, dev, small: bool, steps: int = 8, warmup: int = 3, stock: bool = False):
     """BASELINE configs[4] on the driver's clock (bounded): I-JEPA ViT-L/16 224^2, 4 target blocks, EMA target encoder,
     12 x 384 predictor, bf16, AdamW + EMA update -- the step of tools/bench_ijepa_step.py (mmlearn/tasks/ijepa.py:217-263)."""
     from mmlearn_amd import _lib
@@ -739,6 +795,26 @@ def _leg_eager(args, dev):
     return eager_gpu_leg(args.batch, int(os.environ.get("RANK", "0")), dev, args.small)
 
 
+def _leg_eager_tuned(args, dev):
+    """The stock step once more with the library-GEMM selections file the HIP legs load (mmlearn_amd/tuned): the second denominator --
+    `vs_baseline_tuned_eager` -- so that the ratio does not credit this package with what a TunableOp file gives stock PyTorch too."""
+    tuned_gemms = _enable_tuned_gemms(args)
+    out = eager_gpu_leg(args.batch, int(os.environ.get("RANK", "0")), dev, args.small)
+    out["library_gemm_selection"] = "mmlearn_amd/tuned/gemm_gfx950.csv" if tuned_gemms else "library default"
+    return out
+
+
+def _leg_padded_text(args, dev):
+    tuned_gemms = _enable_tuned_gemms(args)
+    out = padded_text_leg(args.batch, dev, args.small)
+    out["library_gemm_selection"] = "mmlearn_amd/tuned/gemm_gfx950.csv" if tuned_gemms else "library default"
+    return out
+
+
+def _leg_padded_text_eager(args, dev):
+    return eager_gpu_leg(args.batch, 0, dev, args.small, padded=True)
+
+
 def _leg_loss_n8192(args, dev):
     return loss_n8192_leg(dev)
 
@@ -785,9 +861,10 @@ def _leg_ijepa_eager(args, dev):
     return ijepa_leg(16 if args.small else 128, dev, args.small, stock=True)
 
 
-LEGS = {"eager_gpu": _leg_eager, "loss_n8192": _leg_loss_n8192, "loss_shard": _leg_loss_shard, "three_tower": _leg_three_tower, "ijepa_vitl": _leg_ijepa,
+LEGS = {"eager_gpu": _leg_eager, "eager_gpu_tuned": _leg_eager_tuned, "padded_text": _leg_padded_text, "padded_text_eager": _leg_padded_text_eager,
+        "loss_n8192": _leg_loss_n8192, "loss_shard": _leg_loss_shard, "three_tower": _leg_three_tower, "ijepa_vitl": _leg_ijepa,
         "full_last_layer": _leg_full_last_layer, "three_tower_eager": _leg_three_tower_eager, "ijepa_vitl_eager": _leg_ijepa_eager}
-LEG_TIMEOUT_S = {"eager_gpu": 240, "loss_n8192": 120, "loss_shard": 120, "three_tower": 150, "ijepa_vitl": 240, "full_last_layer": 150,
+LEG_TIMEOUT_S = {"eager_gpu": 240, "eager_gpu_tuned": 240, "padded_text": 150, "padded_text_eager": 240, "loss_n8192": 120, "loss_shard": 120, "three_tower": 150, "ijepa_vitl": 240, "full_last_layer": 150,
                  "three_tower_eager": 180, "ijepa_vitl_eager": 240}
 
 
@@ -1032,8 +1109,13 @@ def main():
         eager = run_leg("eager_gpu", args)
     extra = {}
     if rank == 0 and world == 1 and not force_dist and not args.no_extra_legs:
-        for name in ("loss_n8192", "loss_shard", "three_tower", "ijepa_vitl", "full_last_layer"):
+        for name in ("loss_n8192", "loss_shard", "three_tower", "ijepa_vitl", "full_last_layer", "padded_text", "eager_gpu_tuned"):
             extra[name] = run_leg(name, args)
+        if isinstance(extra.get("padded_text"), dict) and "pairs_s" in extra["padded_text"]:
+            base = run_leg("padded_text_eager", args)
+            extra["padded_text"]["eager"] = base
+            if "pairs_s" in base:
+                extra["padded_text"]["vs_baseline"] = round(extra["padded_text"]["pairs_s"] / base["pairs_s"], 3)
         # denominators of the configs[3] / configs[4] legs: the same steps on stock modules, each in a child process of its own
         for name, key in (("three_tower", "samples_s"), ("ijepa_vitl", "images_s")):
             if isinstance(extra.get(name), dict) and "error" not in extra[name]:
@@ -1084,6 +1166,12 @@ def main():
             # value / (N x the stock step's pairs/s on one GPU): the stock step is timed at N = 1 shape (local negatives, no
             # gradient all-reduce), i.e. the baseline is credited with perfect scaling
             "vs_baseline": round(args.batch * world * args.steps / dt / (eager["pairs_s"] * world), 3) if eager and "pairs_s" in eager else None,
+            # the same ratio against the stock step run WITH this package's library-GEMM selections file (the eager_gpu_tuned leg)
+            "vs_baseline_tuned_eager": (round(args.batch * world * args.steps / dt / (extra["eager_gpu_tuned"]["pairs_s"] * world), 3)
+                                        if isinstance(extra.get("eager_gpu_tuned"), dict) and "pairs_s" in extra["eager_gpu_tuned"] else None),
+            # like-for-like with rounds <= 4: the same step with the last layer of both towers computed for ALL tokens
+            "full_last_layer": ({k: extra["full_last_layer"].get(k) for k in ("ms_per_step", "pairs_s", "vs_baseline")}
+                                if isinstance(extra.get("full_last_layer"), dict) and "pairs_s" in extra["full_last_layer"] else None),
             "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: CLIP ViT-B/16 + BERT-base, D=512 projection, bf16 autocast, "

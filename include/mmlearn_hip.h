@@ -409,6 +409,11 @@ int mmk_mlp_gemm_bwd_mul(const void* dY, const void* Wt, const void* G, void* dP
  * (attention output projections: 768 x 768 over M = 201,728).  Split over M, partial tiles in `ws`
  * (mmk_wgrad_plan gives the element count), summed into dw (out_dtype, row stride ldw). */
 int mmk_wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* ws_floats_out);
+/* debugging: segment clocks of the 8-phase weight-gradient kernel (workgroup 0: 8 waves x {MFMA cluster, wait at the closing barrier, load
+ * segment, wait at the opening barrier, loop clocks, loop time in 100 MHz ticks, K-tiles, -}); needs a library built with
+ * -DMMK_WGRAD_STAMPS_BUILD and MMK_WGRAD_STAMPS=1 in the environment (tools/wgrad_stamps.py).  Synchronises the device. */
+int mmk_wgrad_debug_stamps(unsigned long long* out);
+
 /* the split partial tiles only: ws[split][n_pad][k_pad] f32 (n_pad / k_pad = N / K rounded up to 256); the caller sums */
 int mmk_wgrad_partial(const void* dy, const void* x, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx,
                       int32_t* splits_out, int32_t* n_pad_out, int32_t* k_pad_out, void* stream);

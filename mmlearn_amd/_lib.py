@@ -138,6 +138,7 @@ _SIGNATURES = {
     "mmk_win_attn_bwd": [_vp] * 10 + [_i, _i, _i, _i, _i, C.c_float, _i, _i, _i, _i, _vp],
     "mmk_embedding_bwd_sorted": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _i, C.c_int64, _i, _vp],
     "mmk_wgrad_plan": [C.c_int64, _i, _i, _vp, _vp],
+    "mmk_wgrad_debug_stamps": [_vp],
     "mmk_wgrad_partial": [_vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp],
     "mmk_wgrad": [_vp, _vp, _vp, _vp, C.c_int64, _i, _i, C.c_int64, C.c_int64, C.c_int64, _i, _vp],
     "mmk_bias_act_fwd": [_vp, _vp, _vp, C.c_int64, _i, _i, _i, _vp],

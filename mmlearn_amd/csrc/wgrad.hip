@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -31,6 +32,8 @@ constexpr int WG_BM = 64;      // contraction rows per LDS stage
 // a 256 x 256 tile to 14-56 %: the same kernel is instantiated on 128 x 128 tiles -- four waves (2 x 2, still 64 x 64 per wave),
 // 16 KiB stages, 64 KiB of LDS so that TWO workgroups share a CU -- and wg_tile_edge() picks it where it saves padded work.
 constexpr int WG_TILE_NARROW = 128;
+// which kernel serves full 256-tile weights: the 8-phase form (wgrad8_kernel, below) or the two-stage one (A/B: MMK_WGRAD_KERNEL)
+constexpr bool kWgrad8Default = true;
 
 // Output tile edge for an [N, K] weight: 128 when the 128-tiles cover it with at most 0.8 x the padded area of the 256-tiles.
 static inline int wg_tile_edge(int N, int K) {
@@ -51,6 +54,7 @@ struct WgradArgs {
   int M, N, K;
   int splits, tiles_n, tiles_k, rows_per_split;
   int aligned;       // unit map: 1 = every XCD hosts whole splits (T tiles each), 0 = positions of an XCD run through splits and tiles
+  unsigned long long* stamps;   // diagnostic builds (-DMMK_WGRAD_STAMPS_BUILD) only: per wave of workgroup 0, summed segment clocks
 };
 
 // Splits of M and the unit map for T tiles on `per_xcd` workgroup slots per XCD (8 XCDs, one round).  XCD-aligned splits keep all
@@ -73,6 +77,12 @@ __device__ __forceinline__ void wg_dma16(const void* sbase, uint32_t voff, uint3
                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb);
   lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(reinterpret_cast<const void*>(ps)), "s"(lds_addr) : "memory");
+}
+// a pointer the compiler must keep in scalar registers (it is wave-uniform by construction; this makes it provably so)
+__device__ __forceinline__ const char* wg_uniform(const char* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
 }
 __device__ __forceinline__ int wg_opaque(int x) {
   asm volatile("" : "+v"(x));
@@ -471,6 +481,273 @@ __global__ __launch_bounds__(64 * (TE / 64) * (TE / 64), TE == WG_TILE ? 1 : 2) 
       }
 }
 
+// ------------------------------------------------------------------------------------------------ the 8-phase form
+// The schedule of the guide's "256^2 8-phase template" (cdna_hip_programming.md 5: 8 waves as 2 x 4, 128 x 64 of the output per wave,
+// LDS-DMA prefetch that stays in flight across raw s_barriers behind a COUNTED vmcnt, the two waves of every SIMD a barrier apart so
+// that one of them is always inside an MFMA cluster) for THIS product, whose operands both have the contraction along their rows:
+// the fragments come from transposed reads (ds_read_b64_tr_b16) of [64 rows][128 columns] half-tile images instead of ds_read_b128.
+//   * One 64-row step of the contraction ("K-tile") = four half-tiles of 16 KiB: A0 | A1 = columns 0..127 | 128..255 of the dY tile,
+//     B0 | B1 likewise of the x tile; two K-tiles resident (128 KiB).  A wave (wm, wn) owns output rows 64 wm + {0..63} of BOTH A halves
+//     and output columns 32 wn + {0..31} of BOTH B halves, i.e. four 64 x 32 quadrants (qm, qn), so that every half-tile is a contiguous
+//     128-column slab of its operand (whole 128-byte lines per DMA lane group) and is last read in ONE known phase.
+//   * Per K-tile four phases, each  { transposed reads of ONE half-tile | LDS-DMA of ONE half-tile, issued five phases before its
+//     read | s_waitcnt vmcnt(8) -> s_barrier -> 8 x v_mfma_f32_32x32x16_bf16 -> s_barrier }:
+//         phase 1  reads A0 (16)        MFMA (0,0)   stages B1 (t+1)        phase 3  reads A1 (16)        MFMA (1,1)   stages B0 (t+2)
+//         phase 2  reads B1 (8)         MFMA (0,1)   stages A1 (t+1)        phase 4  reads B0 (t+1) (8)   MFMA (1,0)   stages A0 (t+2)
+//     A fragments serve two quadrants from registers, B0 is read one phase early into a second register set (16 + 8 + 16 + 8 reads
+//     instead of 24 + 8 + 16 + 0: no phase's reads outlast the partner wave's MFMA cluster): every LDS byte is read once per wave.
+//   * vmcnt(8) after each phase's issue leaves the four youngest half-tiles (64 KiB per CU) in flight and retires exactly the one the
+//     NEXT phase reads (read one phase after the wait that retires it); a slot is restaged three phases after its last read
+//     (waves 4-7 run one barrier behind waves 0-3, so one phase is not enough).  Never vmcnt(0), never __syncthreads() in the loop.
+// Serves weights whose N and K are multiples of 256; the others keep the two-stage kernel above.
+constexpr int W8_HALF = 64 * 256;          // bytes of one half-tile image: 64 contraction rows x 128 columns bf16
+constexpr int W8_BUF = 4 * W8_HALF;        // one K-tile: A0 | B0 | B1 | A1
+constexpr int W8_A0 = 0, W8_B0 = W8_HALF, W8_B1 = 2 * W8_HALF, W8_A1 = 3 * W8_HALF;
+
+__global__ __launch_bounds__(512, 1) void wgrad8_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 K-tiles][A0 | B0 | B1 | A1]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = a.tiles_n * a.tiles_k;
+  int split, tn, tk;
+  if (a.aligned) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    split = (slot / T) * 8 + xcd;
+    const int tile = slot % T;
+    tn = tile / a.tiles_k;
+    tk = tile % a.tiles_k;
+  } else {   // (the unit map of wgrad_kernel: blocks of all tiles of the short dimension x 4 of the long one per XCD)
+    const int per_xcd = (a.splits * T + 7) >> 3;
+    const int pos = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    split = pos / T;
+    const int q = pos % T;
+    const bool n_short = a.tiles_n <= a.tiles_k;
+    const int ts = n_short ? a.tiles_n : a.tiles_k, tl = n_short ? a.tiles_k : a.tiles_n;
+    const int full = tl / 4, bsz = ts * 4;
+    int s_idx, l_idx;
+    if (q < full * bsz) {
+      const int inner = q % bsz;
+      s_idx = inner / 4;
+      l_idx = (q / bsz) * 4 + inner % 4;
+    } else {
+      const int rem = tl - full * 4, inner = q - full * bsz;
+      s_idx = inner / rem;
+      l_idx = full * 4 + inner % rem;
+    }
+    tn = n_short ? s_idx : l_idx;
+    tk = n_short ? l_idx : s_idx;
+  }
+  if (split >= a.splits) return;
+  const long row0 = (long)split * a.rows_per_split;
+  const int nrows = (int)(min((long)a.M, row0 + a.rows_per_split) - row0);   // contraction rows of this split
+  const int nt = (nrows + WG_BM - 1) / WG_BM;
+
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x16 acc[2][2][2];   // [qm][qn][mt]: rows 128 qm + 64 wm + 32 mt + .., columns 128 qn + 32 wn + ..
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][m][e] = 0.f;
+
+  // transposed-read offsets inside a half-tile image (256-byte rows; chunk position = source chunk ^ ((row & 3) << 2), see wg_fill_te)
+  const int li = lane & 15, q = li >> 2, p = li & 3, g1 = (lane >> 4) & 1, h = lane >> 5;
+  const int tr0 = (8 * h + q) * 256 + ((2 * g1 + (p >> 1)) << 4) + 8 * (p & 1);
+  const int offa0 = tr0 + (((2 * wm) ^ q) << 6), offa1 = tr0 + (((2 * wm + 1) ^ q) << 6), offb = tr0 + ((wn ^ q) << 6);
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  auto tr8 = [&](const char* base) {   // rows +0..3 and +4..7 of one 16-row step
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(base + 1024));
+    s8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, f);
+  };
+
+  // LDS-DMA of one half-tile: 16 pieces of 1 KiB (4 rows x 256 B), two per wave; piece = rows 4 (2 wave + i) .. + 3, lane l -> row + (l >> 4),
+  // chunk position l & 15 <- source chunk (l & 15) ^ (((l >> 4) & 3) << 2).  Rows past the split's end repeat its last row (finite
+  // filler that the A side zeroes); whole K-tiles past the end are still issued (into a slot nobody reads again) so that the vmcnt
+  // arithmetic is the same in every phase.
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smem);
+  const int lrow = lane >> 4, lch = ((lane & 15) ^ ((lrow & 3) << 2)) * 8;
+  // Full K-tiles: the per-lane byte offset (this wave's first piece inside a K-tile + row lrow of the piece + the swizzled source chunk)
+  // never changes; a piece's address is ONE running scalar pointer per operand (K-tile t) plus small scalar constants -- a handful of
+  // scalar adds per piece and no vector arithmetic beside the partner wave's MFMAs.
+  const uint32_t voff_a = (uint32_t)((8 * wave + lrow) * (int)a.ldy + lch) * 2u, voff_b = (uint32_t)((8 * wave + lrow) * (int)a.ldx + lch) * 2u;
+  const char* pa = wg_uniform(reinterpret_cast<const char*>(a.dy + row0 * a.ldy + tn * WG_TILE));   // K-tile t of this unit's dY / x columns
+  const char* pb = wg_uniform(reinterpret_cast<const char*>(a.x + row0 * a.ldx + tk * WG_TILE));
+  const int tile_a = 64 * (int)a.ldy * 2, tile_b = 64 * (int)a.ldx * 2;                   // bytes per K-tile (< 2^31: ld < 2^23)
+  int rows_left = nrows;                                                                  // rows from K-tile t on
+  // dt = K-tiles ahead of t (0 in the prologue, 1 or 2 in the loop)
+  auto stage = [&](bool is_a, int colh, int dt, int slot_off) {
+    const char* p0 = (is_a ? pa + (long)dt * tile_a : pb + (long)dt * tile_b) + colh * 2;
+    const int ld = is_a ? (int)a.ldy : (int)a.ldx;
+    if (rows_left >= 64 * dt + 64) {
+      const uint32_t vo = is_a ? voff_a : voff_b;
+      wg_dma16(p0, vo, smem_addr + slot_off + (2 * wave) * 1024);
+      wg_dma16(p0 + 8 * ld, vo, smem_addr + slot_off + (2 * wave + 1) * 1024);
+    } else {   // the split's last, ragged K-tile and the run-ahead tiles past it: clamp every row to the split's last one
+      const int last = rows_left - 1 - 64 * dt;                 // last valid row relative to the K-tile's first (may be negative)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int pr = 4 * (2 * wave + i);                      // first row of the piece
+        const int srow = min(pr, last);                         // wave-uniform, may be negative (a K-tile wholly past the end): SCALAR part
+        const int drow = min(pr + lrow, last) - srow;           // 0 .. 3: the per-lane offset stays non-negative (it is zero-extended)
+        wg_dma16(p0 + (long)srow * ld * 2, (uint32_t)(drow * ld + lch) * 2u, smem_addr + slot_off + (2 * wave + i) * 1024);
+      }
+    }
+  };
+  bf16x8 af[2][4], b0[2][4], b1[4];   // b0[K-tile parity]: the next K-tile's B0 arrives while this one's is still in use
+  auto zero_tail = [&](int valid) {   // rows >= valid of the last K-tile: zero on the A side (B rows are finite filler)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj)
+        if (16 * ks + 8 * h + jj >= valid) {
+          af[0][ks][jj] = (bf16_t)0.f;
+          af[1][ks][jj] = (bf16_t)0.f;
+        }
+  };
+  auto mfma8 = [&](f32x16 (&c)[2], const bf16x8 (&bb)[4]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      c[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][ks], bb[ks], c[0], 0, 0, 0);
+      c[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][ks], bb[ks], c[1], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // diagnostic build: shader-clock sums of the four segments of a phase (MFMA cluster, wait at the closing barrier, load segment,
+  // wait at the opening barrier), per wave of workgroup 0; read SHARES from it, never the run time (guide 7, In-kernel stamps)
+#ifdef MMK_WGRAD_STAMPS_BUILD
+  unsigned long long st_sum[4] = {0, 0, 0, 0}, st_last = 0, st_first = 0, rt_first = 0;
+#define W8_STAMP(i)                                                                              \
+  {                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    unsigned long long _t;                                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                   \
+    if ((i) >= 0) st_sum[(i) < 0 ? 0 : (i)] += _t - st_last;                                     \
+    st_last = _t;                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  }
+#else
+#define W8_STAMP(i)
+#endif
+#define W8_WAIT_BAR()                                   \
+  __builtin_amdgcn_s_waitcnt(0x0F78); /* vmcnt(8) */    \
+  W8_STAMP(2)                                           \
+  __builtin_amdgcn_s_barrier();                         \
+  W8_STAMP(3)                                           \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+  __builtin_amdgcn_sched_barrier(0)
+#define W8_END_BAR()            \
+  W8_STAMP(0)                   \
+  __builtin_amdgcn_s_barrier(); \
+  W8_STAMP(1)
+  // one K-tile in buffer BUF (compile-time LDS offsets): t = its index
+  auto ktile = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    const char* img = smem + BUF * W8_BUF;
+    const char* nxt = smem + (BUF ^ 1) * W8_BUF;
+    const int valid = rows_left;
+    // ---- phase 1: A0 -> quadrant (0, 0); stage B1 (t + 1)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      af[0][ks] = tr8(img + W8_A0 + ks * 4096 + offa0);
+      af[1][ks] = tr8(img + W8_A0 + ks * 4096 + offa1);
+    }
+    stage(false, 128, 1, (BUF ^ 1) * W8_BUF + W8_B1);
+    W8_WAIT_BAR();
+    if (valid < 64) zero_tail(valid);
+    mfma8(acc[0][0], b0[BUF]);
+    W8_END_BAR();
+    // ---- phase 2: B1 -> quadrant (0, 1); stage A1 (t + 1)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b1[ks] = tr8(img + W8_B1 + ks * 4096 + offb);
+    stage(true, 128, 1, (BUF ^ 1) * W8_BUF + W8_A1);
+    W8_WAIT_BAR();
+    mfma8(acc[0][1], b1);
+    W8_END_BAR();
+    // ---- phase 3: A1 -> quadrant (1, 1); stage B0 (t + 2)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      af[0][ks] = tr8(img + W8_A1 + ks * 4096 + offa0);
+      af[1][ks] = tr8(img + W8_A1 + ks * 4096 + offa1);
+    }
+    stage(false, 0, 2, BUF * W8_BUF + W8_B0);
+    W8_WAIT_BAR();
+    if (valid < 64) zero_tail(valid);
+    mfma8(acc[1][1], b1);
+    W8_END_BAR();
+    // ---- phase 4: B0 of the NEXT K-tile into the other register set; quadrant (1, 0) from registers; stage A0 (t + 2)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b0[BUF ^ 1][ks] = tr8(nxt + W8_B0 + ks * 4096 + offb);
+    stage(true, 0, 2, BUF * W8_BUF + W8_A0);
+    W8_WAIT_BAR();
+    mfma8(acc[1][0], b0[BUF]);
+    W8_END_BAR();
+    pa = wg_uniform(pa + tile_a);
+    pb = wg_uniform(pb + tile_b);
+    rows_left -= 64;
+  };
+  // ---- prologue: the six half-tiles whose reads come first, in the order the phases will keep issuing
+  stage(false, 0, 0, W8_B0);
+  stage(true, 0, 0, W8_A0);
+  stage(false, 128, 0, W8_B1);
+  stage(true, 128, 0, W8_A1);
+  stage(false, 0, 1, W8_BUF + W8_B0);
+  stage(true, 0, 1, W8_BUF + W8_A0);
+  __builtin_amdgcn_s_waitcnt(0x0F78);   // B0, A0 of K-tile 0 (this wave's pieces)
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) b0[0][ks] = tr8(smem + W8_B0 + ks * 4096 + offb);
+  if (wave >= 4) __builtin_amdgcn_s_barrier();   // the second wave of every SIMD runs one barrier behind the first
+#ifdef MMK_WGRAD_STAMPS_BUILD
+  W8_STAMP(-1)
+  st_first = st_last;
+  rt_first = __builtin_amdgcn_s_memrealtime();
+#endif
+  int t = 0;
+#pragma unroll 1
+  for (; t + 1 < nt; t += 2) {
+    ktile(std::integral_constant<int, 0>{});
+    ktile(std::integral_constant<int, 1>{});
+  }
+  if (t < nt) ktile(std::integral_constant<int, 0>{});
+#ifdef MMK_WGRAD_STAMPS_BUILD
+  if (a.stamps != nullptr && blockIdx.x == 0 && lane == 0) {
+    unsigned long long* o = a.stamps + wave * 8;
+    o[0] = st_sum[0]; o[1] = st_sum[1]; o[2] = st_sum[2]; o[3] = st_sum[3];
+    o[4] = st_last - st_first;
+    o[5] = __builtin_amdgcn_s_memrealtime() - rt_first;   // 100 MHz ticks
+    o[6] = (unsigned long long)nt;
+  }
+#endif
+  if (wave < 4) __builtin_amdgcn_s_barrier();    // pairs with the extra barrier of waves 4-7
+  __builtin_amdgcn_s_waitcnt(0x0F70);            // drain the (unused) run-ahead DMAs before the LDS is released
+#undef W8_WAIT_BAR
+#undef W8_END_BAR
+#undef W8_STAMP
+  // ---- partial tile -> workspace: acc[qm][qn][mt][e] = C[n = 128 qm + 64 wm + 32 mt + (e&3) + 8(e>>2) + 4h][k = 128 qn + 32 wn + (lane&31)]
+  const int n_pad = a.tiles_n * WG_TILE, k_pad = a.tiles_k * WG_TILE;
+  float* wsb = a.ws + ((size_t)split * n_pad + (size_t)tn * WG_TILE) * k_pad + (size_t)tk * WG_TILE;
+#pragma unroll
+  for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int n = 128 * qm + 64 * wm + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * h;
+          wsb[(size_t)n * k_pad + 128 * qn + 32 * wn + (lane & 31)] = acc[qm][qn][mt][e];
+        }
+}
+
 }  // namespace mmk
 
 using namespace mmk;
@@ -498,6 +775,28 @@ int mmk_wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* ws_floats_
 static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int N, int K, int64_t ldy, int64_t ldx, WgradArgs* out,
                         hipStream_t st);
 
+// diagnostic builds (-DMMK_WGRAD_STAMPS_BUILD, MMK_WGRAD_STAMPS=1): 8 waves x 8 words that workgroup 0 of the 8-phase kernel fills
+static unsigned long long* wgrad_stamp_buffer() {
+#ifdef MMK_WGRAD_STAMPS_BUILD
+  static unsigned long long* buf = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    if (getenv("MMK_WGRAD_STAMPS") != nullptr && hipMalloc(reinterpret_cast<void**>(&buf), 64 * sizeof(unsigned long long)) != hipSuccess) buf = nullptr;
+  }
+  return buf;
+#else
+  return nullptr;
+#endif
+}
+int mmk_wgrad_debug_stamps(unsigned long long* out) {
+  unsigned long long* buf = wgrad_stamp_buffer();
+  MMK_REQUIRE(buf != nullptr && out != nullptr, "no stamp buffer (needs a library built with -DMMK_WGRAD_STAMPS_BUILD and MMK_WGRAD_STAMPS=1)");
+  MMK_HIP(hipDeviceSynchronize());
+  MMK_HIP(hipMemcpy(out, buf, sizeof(unsigned long long) * 64, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // The split partial tiles only (no reduction): ws[split][n_pad][k_pad] f32 with n_pad / k_pad = N / K rounded up to 256;
 // the caller sums the splits.  Used by the contrastive loss' backward (csrc/clip.hip): dB = G^T A is this kernel's
 // "both operands contracted along their rows" form, so G^T never has to exist.
@@ -520,6 +819,7 @@ static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int
   WgradArgs a;
   a.dy = static_cast<const bf16_t*>(dy); a.x = static_cast<const bf16_t*>(x); a.ws = ws;
   a.ldy = ldy; a.ldx = ldx; a.M = (int)M; a.N = N; a.K = K;
+  a.stamps = wgrad_stamp_buffer();
   const int te = wg_tile_edge(N, K);
   a.tiles_n = cdiv(N, te); a.tiles_k = cdiv(K, te);
   int64_t wsf;
@@ -550,12 +850,20 @@ static int wgrad_launch(const void* dy, const void* x, float* ws, int64_t M, int
 #ifdef MMK_DEBUG_SWITCHES
   if (mfma16 && te == WG_TILE) kern = reinterpret_cast<const void*>(wgrad_kernel16);
 #endif
+  int threads_l = threads;
+  // the 8-phase kernel: full 256-tiles only (N, K multiples of 256) and splits long enough for its two-K-tile prologue to pay
+  bool eight = kWgrad8Default;
+  if (const char* e = MMK_DBG_ENV("MMK_WGRAD_KERNEL")) eight = atoi(e) == 8;   // A/B in debug-switch builds, read per call
+  if (eight && te == WG_TILE && !ragged && a.rows_per_split >= 4 * WG_BM) {
+    kern = reinterpret_cast<const void*>(wgrad8_kernel);
+    threads_l = 512;
+  }
   KernelSetup ks;
-  if (int rc = kernel_setup(kern, threads, bytes, &ks)) return rc;
+  if (int rc = kernel_setup(kern, threads_l, bytes, &ks)) return rc;
   {
     ProfEvents pe(MMK_K_WGRAD);
     void* params[] = {&a};
-    MMK_HIP(hipExtLaunchKernel(kern, dim3(grid), dim3(threads), params, bytes, st, pe.start, pe.stop, 0));
+    MMK_HIP(hipExtLaunchKernel(kern, dim3(grid), dim3(threads_l), params, bytes, st, pe.start, pe.stop, 0));
   }
   MMK_LAUNCH_CHECK();
   *out = a;

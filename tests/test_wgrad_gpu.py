@@ -8,6 +8,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("M,N,K", [(4096, 768, 768), (1000, 256, 512), (77 * 13, 768, 3072), (64, 8, 8), (5000, 2304, 768),
                                    (130, 520, 264),
+                                   # the 8-phase kernel (N, K multiples of 256, >= 4 K-tiles per split): ragged last K-tile of a split,
+                                   # an odd number of K-tiles, run-ahead DMA past the split's end, the shortest split it accepts
+                                   (4096 + 37, 256, 512), (64 * 9 + 1, 768, 256), (64 * 5, 256, 256), (2 * 8191, 512, 768), (12345, 1024, 256),
                                    # the 128 x 128-tile instantiation (narrow layers: HTSAT's 96 / 288 / 384-wide Linears, the I-JEPA
                                    # predictor's 384 / 1152 / 1536): full tiles, ragged tiles, M not a multiple of the 64-row stage,
                                    # more tiles than one XCD has workgroup slots (9 x 12 = 108 > 64)

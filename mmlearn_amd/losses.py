@@ -148,6 +148,9 @@ class _Run:
         self.pairs: list[_Pair] = []
         self.inputs: list[torch.Tensor] = []
         self.input_names: list[str] = []
+        # gradients for EVERY input, whatever its requires_grad says: inside a compiled graph (compiled.py) the operator receives plain
+        # tensors and autograd's bookkeeping lives in the traced graph
+        self.all_grads = False
 
     # ------------------------------------------------------------------ set-up
     def compute_mode(self) -> int:
@@ -422,7 +425,7 @@ class _Run:
             dt = _ACCUM_DTYPE if (a_ or mixed) else t.dtype
             grads[n] = (torch.empty if (covered[n] and not a_) else torch.zeros)(t.shape, dtype=dt, device=dev)
         runs = self.fused   # kept: the kernels' raw sums are only read here, a second backward (retain_graph) repeats the launches
-        want_ds = self.logit_scale.requires_grad
+        want_ds = self.logit_scale.requires_grad or self.all_grads
         # d loss / d scale accumulates into a word the (first) forward launch left at zero; a repeated backward gets a fresh one
         # (the first one's may have become the parameter's .grad)
         head = runs[0][1]
@@ -435,7 +438,7 @@ class _Run:
         for key, t in self.embeddings.items():
             g = grads.get(name_of[key])
             if g is None:
-                out.append(torch.zeros_like(t) if t.requires_grad else None)
+                out.append(torch.zeros_like(t) if (t.requires_grad or self.all_grads) else None)
             else:
                 out.append(g if g.dtype == t.dtype else g.to(t.dtype))
         ds = ds_acc.reshape(self.logit_scale.shape).to(self.logit_scale.dtype) if want_ds else None
@@ -720,10 +723,10 @@ class _Run:
             name = next(n for n, k in key_of.items() if k == key)
             g = grads.get(name)
             if g is None:
-                out.append(torch.zeros_like(t) if t.requires_grad else None)
+                out.append(torch.zeros_like(t) if (t.requires_grad or self.all_grads) else None)
             else:
                 out.append(g if g.dtype == t.dtype else g.to(t.dtype))
-        ds = dscale.reshape(self.logit_scale.shape).to(self.logit_scale.dtype) if self.logit_scale.requires_grad else None
+        ds = dscale.reshape(self.logit_scale.shape).to(self.logit_scale.dtype) if (self.logit_scale.requires_grad or self.all_grads) else None
         return ds, out
 
 
@@ -778,6 +781,9 @@ class ContrastiveLoss(nn.Module):
         self.cache_labels = cache_labels
         self.compute_dtype = compute_dtype
         self.static_shapes = static_shapes
+        from . import compiled
+
+        self._site_id = compiled.register_site(self)   # how a torch.compile'd graph names this module (compiled.py)
         self._pending: dict[str, tuple] = {}
         self.prefetched_gathers_used = 0   # forward() calls that consumed gathers started by prefetch_gather
         self.prefetched_matches_used = 0   # pairings answered by prefetch_match
@@ -981,10 +987,14 @@ class ContrastiveLoss(nn.Module):
         skipped.  With ``static_shapes=True`` across ranks there is no header to agree in and the flag is ignored."""
         if not embeddings:
             raise ValueError("embeddings is empty")
-        for t in embeddings.values():
-            K.require_gpu(t, "embedding")
         if not isinstance(logit_scale, torch.Tensor):
             raise TypeError("logit_scale must be a 0-dim tensor")
+        from . import compiled
+
+        if compiled.is_compiling():   # torch.compile (mmlearn/cli/run.py:139): the whole call is ONE traced operator
+            return compiled.contrastive_loss(self, embeddings, example_ids, logit_scale, modality_loss_pairs, fully_paired)
+        for t in embeddings.values():
+            K.require_gpu(t, "embedding")
         run = _Run(self, embeddings, example_ids, logit_scale, list(modality_loss_pairs), fully_paired)
         self._capture_poison = None
         try:
@@ -996,6 +1006,12 @@ class ContrastiveLoss(nn.Module):
         finally:
             self._pending_match, self._early_ids = [], {}   # answers belong to one batch
             self._capture_poison = None
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        from . import compiled
+
+        self._site_id = compiled.register_site(self)   # a copy / an unpickled module is its own call site
 
     def _forward(self, run: "_Run", embeddings, logit_scale) -> torch.Tensor:
         first = next(iter(embeddings.values()))

@@ -51,6 +51,10 @@ def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     half the bytes.  The copy carries NO gradient, hence a name of its own: ``fused.linear`` and friends pick up
     ``_mmk_bf16`` (``add_layer_norm``'s differentiable twin) and must never see this one; the version stamp lets the loss
     ignore the copy after an in-place edit of ``y``."""
+    from . import compiled
+
+    if compiled.is_compiling():   # torch.compile: one traced operator (compiled.py)
+        return compiled.l2_normalize(x)
     K.require_gpu(x)
     autocast = torch.is_autocast_enabled()
     if autocast and x.dtype != torch.float32:

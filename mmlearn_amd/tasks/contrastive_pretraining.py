@@ -26,6 +26,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from ..compiled import is_compiling
 from ..losses import ContrastiveLoss, LossPairSpec
 from ..modalities import Modalities
 from ..ops import l2_normalize
@@ -299,14 +300,17 @@ class ContrastivePretraining(TrainingTask):
 
     def forward(self, inputs: dict[str, Any]) -> dict[str, torch.Tensor]:
         outputs = {}
-        prefetch = getattr(self.loss_fn, "prefetch_gather", None) if "example_ids" in inputs else None
+        # under torch.compile (mmlearn/cli/run.py:139) the step is traced: the opportunistic overlaps below (gather / matcher ahead of the
+        # loss, one stream per tower) are host-side scheduling that a traced graph cannot express, the loss then does that work itself
+        traced = is_compiling()
+        prefetch = getattr(self.loss_fn, "prefetch_gather", None) if ("example_ids" in inputs and not traced) else None
         mods = [m for m in self._available_modalities if m.name in inputs]
         # opt-in (``task.concurrent_encoders = True``): the encoders are independent until the loss, so every modality
         # after the first gets its own HIP stream; forward AND backward kernels of the towers then overlap (autograd
         # replays each node on the stream its forward ran on), which fills the tails of kernels that do not cover 256 CUs.
-        side = self._encoder_streams(len(mods) - 1) if self.concurrent_encoders and len(mods) > 1 else None
+        side = self._encoder_streams(len(mods) - 1) if (self.concurrent_encoders and len(mods) > 1 and not traced) else None
         main = torch.cuda.current_stream() if side else None
-        early_match = getattr(self.loss_fn, "prefetch_match", None) if "example_ids" in inputs and self.loss_fn is not None else None
+        early_match = getattr(self.loss_fn, "prefetch_match", None) if ("example_ids" in inputs and self.loss_fn is not None and not traced) else None
         if early_match is not None and inputs.get("fully_paired") is not True and self.match_ahead:
             # matcher + status read-back overlap the encoders; on the second tower's stream when there is one
             early_match(inputs["example_ids"], self.modality_loss_pairs, **({"stream": side[0]} if side else {}))

@@ -108,22 +108,24 @@ def test_step_with_the_id_matcher_and_the_repos_own_adamw_is_capturable():
     assert bool(task_g.loss_fn.capture_mismatch) and not (float(loss_g.detach()) == float(loss_g.detach()))
 
 
-@pytest.mark.parametrize("backend", ["eager", "aot_eager"])
-def test_the_task_runs_under_torch_compile_and_trains_to_the_same_parameters(backend):
-    """The reference plumbs ``torch.compile`` at mmlearn/cli/run.py:139 (``torch.compile(task, **compile_kwargs)``).  This package's
-    kernels are reached through ctypes, which TorchDynamo does not trace: it breaks the graph at every HIP op, compiles what lies
-    between them and calls the ops as they are.  With the Triton-free backends (``eager``: Dynamo only; ``aot_eager``: Dynamo + AOT
-    autograd) three compiled training steps leave bit-identical parameters to three eager ones -- switching the reference's compile
-    flag on costs nothing and breaks nothing.  (The default Inductor backend would emit Triton kernels for the traced pieces; that
-    is not this package's path to a launch-free step: HIP-graph capture, above, is.)"""
+@pytest.mark.parametrize("backend,fullgraph,shuffled", [("eager", False, False), ("aot_eager", False, False), ("aot_eager", True, False),
+                                                        ("aot_eager", True, True)])
+def test_the_task_runs_under_torch_compile_and_trains_to_the_same_parameters(backend, fullgraph, shuffled):
+    """The reference plumbs ``torch.compile`` at mmlearn/cli/run.py:139 (``torch.compile(task, **compile_kwargs)``).  The ops on the
+    step's path are ``torch.library`` custom ops with fake implementations (mmlearn_amd/compiled.py): TorchDynamo and AOT autograd
+    trace THROUGH them, so the step compiles with ``fullgraph=True`` -- no graph break at the L2-normalise kernel or anywhere in the
+    loss -- also when the loss has to run the id matcher (``shuffled``).  With the Triton-free backends
+    (``eager``: Dynamo only; ``aot_eager``: Dynamo + AOT autograd) three compiled training steps leave bit-identical parameters to three
+    eager ones.  (The default Inductor backend would emit Triton kernels for the traced pieces; that is not this package's path to a
+    launch-free step: HIP-graph capture, above, is.)"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import graph_step as G
 
     dev = torch.device("cuda", 0)
-    batch = G.make_batch(64, dev)
+    batch = G.make_batch(64, dev, shuffled=shuffled)
     torch._dynamo.reset()
     task_c, opt_c = G.make(dev, 512)
-    compiled = torch.compile(task_c.training_step, backend=backend)
+    compiled = torch.compile(task_c.training_step, backend=backend, fullgraph=fullgraph)
     for _ in range(3):
         opt_c.zero_grad(set_to_none=False)
         with torch.autocast("cuda", dtype=torch.bfloat16):

@@ -700,12 +700,13 @@ def loss_n8192_leg(dev, n: int = 8192, d: int = 512, iters: int = 10):
         wall = (time.perf_counter() - t0) / iters
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
         traffic = pmc.get("n8192", {}).get("hbm_bytes_per_launch")
     except Exception:
         traffic = None
     roof = _loss_roofline(prof, n, n, d, 1, iters, traffic, loss_only=True)
     if roof is not None:
+        roof["traffic_from"] = f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round 6, not of this run)"
         dev_us = sum(v[1] for k, v in prof.items()) / iters * 1e3
         roof["device_us_fwd_bwd"] = round(dev_us, 1)
         roof["wall_us_fwd_bwd"] = round(wall * 1e6, 1)
@@ -713,14 +714,21 @@ def loss_n8192_leg(dev, n: int = 8192, d: int = 512, iters: int = 10):
     return roof
 
 
+PMC_TRAFFIC_FILE = "r06_pmc_traffic.json"                # loss kernels at N = 1024 / 8192 (tools/probes/r6_pmc.sh)
+PMC_TRAFFIC_SHARD_FILES = ("r06_pmc_traffic_shard.json", "r05_pmc_traffic_shard.json")   # C = 8192 from round 6; 2048 / 4096 from round 5
+
+
 def _shard_traffic(cols: int):
-    """HBM-side bytes of one rank's share at this column count from the committed PMC passes (profiles/r05_pmc_traffic_shard.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/bench_loss_shard.py), or None."""
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic_shard.json")))
-        return pmc.get(f"cols{cols}")
-    except Exception:
-        return None
+    """HBM-side bytes of one rank's share at this column count from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE over tools/bench_loss_shard.py: round 6 for C = 8192, round 5 for the smaller widths), or None."""
+    for name in PMC_TRAFFIC_SHARD_FILES:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        if f"cols{cols}" in pmc:
+            return dict(pmc[f"cols{cols}"], traffic_from=f"profiles/{name}")
+    return None
 
 
 def loss_shard_leg(dev, rows: int = 1024, cols: int = 8192, d: int = 512, rank: int = 3, iters: int = 20):
@@ -783,6 +791,7 @@ def loss_shard_leg(dev, rows: int = 1024, cols: int = 8192, d: int = 512, rank: 
         roof["host_enqueue_us_per_rank_share"] = round(sorted(enq)[len(enq) // 2], 1)   # median: Python + ctypes + launches, no device wait
         roof["algorithmic_tflops_per_rank_share"] = round(8.0 * R * C * D / (dev_us * 1e-6) / 1e12, 1)
         roof["hbm_bytes_per_rank_share"] = pmc.get("total_hbm_bytes") if pmc else None
+        roof["traffic_from"] = (pmc.get("traffic_from", "") + " (rocprofv3 --pmc passes, not of this run)") if pmc else None
         roof["operand_bytes_per_rank_share"] = int(2 * (C + R) * D * 2 * 2 + 2 * R * D * 2)
     return roof
 
@@ -1131,7 +1140,7 @@ def main():
         traffic = None  # HBM bytes per launch from rocprofv3 PMC passes of the same kernel and shape (profiles/)
         try:
             if world == 1 and args.batch == 1024:   # (also the 1-rank dry run of the N > 1 path: one rank still runs the one-launch kernel)
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
                 traffic = pmc.get("n1024", {}).get("hbm_bytes_per_launch")
             elif args.batch == 1024:   # N > 1: the rank's sharded shape (R = batch rows x C = batch * world columns)
                 traffic = (_shard_traffic(n_cols) or {}).get("per_kernel")
@@ -1140,6 +1149,8 @@ def main():
         roofline = _loss_roofline(prof, n_rows, n_cols, d, 1, prof_steps, traffic)
         if roofline is not None:
             roofline["events_from"] = "single-stream pass after the timed region" if overlapped else "timed region"
+            roofline["traffic_from"] = (f"profiles/{PMC_TRAFFIC_FILE if world == 1 else PMC_TRAFFIC_SHARD_FILES[0]} (rocprofv3 --pmc FETCH_SIZE / "
+                                        "WRITE_SIZE passes of round 6 over the same kernel and shape, not of this run)") if traffic is not None else None
         # the dominant hand-written kernel of the whole step (SURVEY 8(f1) widening): the weight-gradient GEMM.  Algorithmic
         # FLOPs = 2 M N K summed over the encoder Linears it serves, time from the same HIP-stamped events.
         roofline_widened = None

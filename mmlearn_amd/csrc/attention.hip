@@ -973,6 +973,33 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_split_kerne
 
 #endif  // MMK_DEBUG_SWITCHES
 
+// delta_i = sum_d dO[i][d] O[i][d] of query tile t, by ONE wave: lane (r, h) loads columns 32 h .. + 31 of row 32 t + r of O and dO
+// (four 16-byte pieces each, straight from global memory: dO is on its way into LDS anyway, so these hit the L2), the two halves
+// meet through one cross-lane exchange.  Rows beyond L read row L - 1 and store 0.
+__device__ __forceinline__ void delta_load(const AttnBwdArgs& a, long obase, long osl, int t, int lane, bf16x8 (&o4)[4], bf16x8 (&g4)[4]) {
+  const int row = min(t * 32 + (lane & 31), a.L - 1);
+  const long off = obase + (long)row * osl + 32 * (lane >> 5);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    o4[c] = *reinterpret_cast<const bf16x8*>(a.o + off + 8 * c);
+    g4[c] = *reinterpret_cast<const bf16x8*>(a.dout + off + 8 * c);
+  }
+}
+__device__ __forceinline__ void delta_store(const AttnBwdArgs& a, float* dls, int t, int lane, const bf16x8 (&o4)[4], const bf16x8 (&g4)[4]) {
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      s0 = fmaf((float)o4[c][e], (float)g4[c][e], s0);
+      s1 = fmaf((float)o4[c][e + 1], (float)g4[c][e + 1], s1);
+    }
+  float s = s0 + s1;
+  s += __shfl_xor(s, 32);
+  const int i = t * 32 + (lane & 31);
+  if (lane < 32) dls[i] = i < a.L ? s : 0.f;
+}
+
 // ---- five-product backward for NT < NW (a spare wave exists; L = 197 -> 7 key waves + 1, L = 77 -> 3 + 1)
 // Waves 0..NT-1 each own 32 KEYS for the whole item and sweep the query tiles in lockstep: S = Q Kᵀ and dP = dO Vᵀ
 // with the key on the lane, P and dS = P∘(dP - δ) feed dVᵀ += dOᵀ P and dKᵀ += Qᵀ dS as B operands (as phase 1
@@ -984,9 +1011,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_split_kerne
 // STAGED: the key waves are the only loaders (four 8-row pieces of every image each), K first, then the Q / dO pieces in row
 // order, and a step only waits for the pieces of ITS query tile (counted vmcnt): step 0 starts when K, V, the row constants and
 // the first 32 rows of Q / dO are in, the rest of the 84 KiB lands behind the steps.
+constexpr bool bwd5_makes_rowc(int NT, bool STAGED) { return STAGED && NT <= 3; }   // row constants in the kernel (else attn_delta_kernel)
+
 template <int NT, int NW, bool DROP, bool STAGED, bool MASK>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(const AttnBwdArgs a) {
   static_assert(NT < NW, "needs a spare wave for dQ");
+  constexpr bool INROWC = bwd5_makes_rowc(NT, STAGED);
   constexpr int LP = 32 * NT;
   constexpr int IMG = LP * 128;
   constexpr int DSB = LP * 64;  // one dS image: [LP keys][32 queries] bf16, 8-byte slot index ^= (key>>1)&7
@@ -1010,6 +1040,33 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
   const float* lse2s = rowc;
   const float* dls = rowc + ROWC;
 
+  // ---- the dQ wave makes an item's row constants: lse2 = lse log2(e) (+inf beyond L: P = 0 on padded query rows) and
+  // delta_i = sum_d dO_id O_id of every query tile (one tile's loads in flight while the previous one is summed).  Plain loads: this
+  // wave issues no LDS-DMA, its vmcnt is its own.  It runs AHEAD of the item: for the first item while the key waves' pieces fly,
+  // for every later one right after its last dQ tile of the previous item, beside the key waves' final stores and the next load
+  // phase (the key waves read the row constants for the last time before the step barrier the dQ wave has just left).  This
+  // replaces a streaming pass over O and dO before the kernel (attn_delta_kernel) -- for up to three query tiles (BERT's L = 77:
+  // 11 % off the backward, launch of the streaming pass included).  From five tiles on the dQ wave is the pole of the item (its
+  // 4 NT MFMAs per step against a key wave's 16 + softmax): the same work there cost what the separate pass costs (L = 197: 1038 vs
+  // 1035 us, with four tiles' loads in flight 1042), so those keep attn_delta_kernel and its records.
+  auto make_rowc = [&](int it_) {
+    const int lo = opaque(lane);
+    const long ob = ((long)(it_ / a.H) * a.L * a.H + (it_ % a.H)) * ATT_DH;
+    float* rw = rowc;
+    const float* lrow = a.lse + (long)it_ * a.L;
+    bf16x8 o4[2][4], g4[2][4];
+    delta_load(a, ob, osl, 0, lo, o4[0], g4[0]);
+#pragma unroll
+    for (int k = 0; k < ROWC / 64; ++k) {
+      const int l = lo + 64 * k;
+      rw[l] = l < a.L ? lrow[min(l, a.L - 1)] * 1.4426950408889634f : INFINITY;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t + 1 < NT) delta_load(a, ob, osl, t + 1, lo, o4[(t + 1) & 1], g4[(t + 1) & 1]);
+      delta_store(a, rw + ROWC, t, lo, o4[t & 1], g4[t & 1]);
+    }
+  };
   int n_mine = 0;
   auto stamp = [&](int k) {
 #ifdef MMK_ATTN_STAMPS_BUILD   // debug builds only (make EXTRA=-DMMK_ATTN_STAMPS_BUILD): the checks are not free in this kernel
@@ -1047,9 +1104,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
         for (int g = 0; g < 4; ++g) img_load_piece(stage, a.v + b * a.v_sb + hh * a.v_sh, a.v_sl, a.L, 4 * wave_s + g, lo, g);
 #pragma unroll
         for (int g = 0; g < 4; ++g) img_load_piece(Ks, a.k + b * a.k_sb + hh * a.k_sh, a.k_sl, a.L, wave_s + NT * g, lo);
-        for (int rc = wave_s; rc < REC; rc += NT)   // the row-constant records (fewer loader waves than records: several each)
-          lds_dma16(rc < 2 ? a.delta + ((long)item * 2 + rc) * ROWC : a.kbias + (long)b * ROWC, (uint32_t)lo * 16u,
-                    lds_addr_of(reinterpret_cast<const char*>(rowc + rc * ROWC)));
+        // row constants: the lse2 / delta records of attn_delta_kernel, or (INROWC) made by the dQ wave; the key bias record of a
+        // masked call is one more piece.  All of them are older than the Q / dO pieces, whose counted waits they do not change.
+        if (!INROWC) {
+          for (int rc = wave_s; rc < 2; rc += NT)
+            lds_dma16(a.delta + ((long)item * 2 + rc) * ROWC, (uint32_t)lo * 16u, lds_addr_of(reinterpret_cast<const char*>(rowc + rc * ROWC)));
+        }
+        if (MASK && wave_s == (NT > 2 ? 2 : 0))
+          lds_dma16(a.kbias + (long)b * ROWC, (uint32_t)lo * 16u, lds_addr_of(reinterpret_cast<const char*>(rowc + 2 * ROWC)));
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           img_load_piece(Qs, a.q + b * a.q_sb + hh * a.q_sh, a.q_sl, a.L, wave_s + NT * g, lo);
@@ -1058,6 +1120,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
       }
       stamp(1);
       if (wave_s < NT) wait_vmem_upto(allow(0));
+      if (INROWC && wave_s == NT && n_mine == 0) make_rowc(item);   // (later items: made by the dQ wave at the end of the previous item)
     } else {
       const int lo = opaque(lane);
       img_load(Qs, a.q + b * a.q_sb + hh * a.q_sh, a.q_sl, a.L, LP, wave, NW, lo);
@@ -1210,6 +1273,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd5_kernel(con
       }
       __syncthreads();
     }
+    if (INROWC && item + (int)gridDim.x < nitems) make_rowc(item + (int)gridDim.x);
     } else {
 #pragma unroll 1
       for (int it = 0; it <= NT; ++it) __syncthreads();
@@ -1240,7 +1304,7 @@ static int launch_attn_bwd5(const AttnBwdArgs& a, hipStream_t st) {
   if (int rc = kernel_setup(reinterpret_cast<const void*>(kern), 64 * NW, bytes, &ks)) return rc;
   const int cus = ks.cus, wgs_per_cu = ks.wgs_per_cu;
   const int grid = std::min(a.B * a.H, cus * wgs_per_cu * att_grid_factor());
-  {
+  if (!bwd5_makes_rowc(NT, STAGED)) {   // short sequences make lse2 / delta in the kernel (its dQ wave); the others read this pass's records
     const long chunks = (long)a.B * a.L * a.H * 8;
     const int dgrid = (int)std::min<long>((chunks + 255) / 256, (long)cus * 16);
     hipLaunchKernelGGL(attn_delta_kernel, dim3(dgrid), dim3(256), 0, st, a.o, a.dout, a.lse, a.delta, a.B, a.H, a.L);

@@ -1152,7 +1152,7 @@ def main():
             roofline["traffic_from"] = (f"profiles/{PMC_TRAFFIC_FILE if world == 1 else PMC_TRAFFIC_SHARD_FILES[0]} (rocprofv3 --pmc FETCH_SIZE / "
                                         "WRITE_SIZE passes of round 6 over the same kernel and shape, not of this run)") if traffic is not None else None
         # the dominant hand-written kernel of the whole step (SURVEY 8(f1) widening): the weight-gradient GEMM.  Algorithmic
-        # FLOPs = 2 M N K summed over the encoder Linears it serves, time from the same HIP-stamped events.
+        # FLOPs = 2 M N K summed over the encoder Linears it serves (HISTORY.md 5.5), time from the same HIP-stamped events.
         roofline_widened = None
         if "wgrad" in prof and not args.small and not args.no_fused_encoder_ops:
             m_v, m_t, e = args.batch * 197, args.batch * 77, 768

@@ -16,7 +16,7 @@
 //             kernel in which the key waves hand their dS tile, transposed through LDS, to a dedicated dQ wave.
 //             Dropout (BERT) is a counter-based mask regenerated from (seed, batch * head, query, key) in both passes.
 //   HBM traffic = Q, K, V read once + O written once (forward), Q, K, V, dO, O in + dQ, dK, dV out (backward): both
-//   are HBM-bound by bytes; DESIGN.md 5.2 has the measured distances to that bound.
+//   are HBM-bound by bytes; HISTORY.md 5.2 has the measured distances to that bound.
 #include <hip/hip_ext.h>
 #include <math.h>
 #include <stdlib.h>
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_kernel(cons
 // registers, sweeps the query tiles of the Q / dO images).  PH = 2: dQ (a wave owns 32 queries, Q_i / dO_i fragments in registers,
 // sweeps the key tiles of the K / V images).  The two images of a launch are DOUBLE-BUFFERED (4 x 28 KiB at L = 197): the next
 // item's images, row constants and fragments arrive while the current item is computed; the one barrier per item hands the buffers
-// over.  Selected by MMK_ATTN_SPLIT=1 in debug-switch builds (measured against the five-product kernel: DESIGN.md 5.2).
+// over.  Selected by MMK_ATTN_SPLIT=1 in debug-switch builds (measured against the five-product kernel: HISTORY.md 5.2).
 template <int NT, int NW, bool DROP, int PH>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_split_kernel(const AttnBwdArgs a) {
   constexpr int LP = 32 * NT;

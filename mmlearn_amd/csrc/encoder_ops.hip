@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const G* __restrict__ d
 // ------------------------------------------------------------------ weight cast + transposed twin
 // W [n, k] (the f32 master weight of an nn.Linear, or bf16 / f16) -> W16 [n, k] bf16, the forward's operand (y = x W16^T), and
 // W16T [k, n] bf16 for the backward: dX = dY W is then F.linear(dY, W16T), the operand layout the library's forward kernels
-// are built for (54-87 us faster than dY @ W16 on [201728 x 2304] . [2304 x 768], 60 us on the 3072-wide pair).
+// are built for (54-87 us faster than dY @ W16 on [201728 x 2304] . [2304 x 768], 60 us on the 3072-wide pair; HISTORY.md 5.5).
 // One pass over W replaces the per-step autocast cast; 64 x 64 tiles through LDS.
 constexpr int CT_TILE = 64;
 template <typename T>

@@ -3,7 +3,7 @@
 The reference builds its ``lightning.Trainer`` from ``cfg.trainer`` (mmlearn/cli/run.py:52-61), so a strategy is selected in
 YAML.  Stock ``DDPStrategy`` wraps the whole LightningModule in ONE ``DistributedDataParallel``; with
 ``task.concurrent_encoders`` (one HIP stream per tower) that single instance serialises the towers' backward passes again
-(DESIGN.md 5.9).  This subclass hands the wrapping to the task -- ``ContrastivePretraining.wrap_towers_in_ddp()``: one DDP
+(HISTORY.md 5.9).  This subclass hands the wrapping to the task -- ``ContrastivePretraining.wrap_towers_in_ddp()``: one DDP
 instance per tower, built under that tower's stream, plus an all-reduce hook for the parameters outside the towers -- and
 raises ``GPU_MAX_HW_QUEUES`` before the first HIP call so that the towers' streams and RCCL's do not share a hardware queue.
 

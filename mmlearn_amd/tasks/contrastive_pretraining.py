@@ -103,7 +103,7 @@ class ContrastivePretraining(TrainingTask):
     ) -> None:
         """The last three parameters are additions to the reference signature (defaults = reference behaviour), settable
         from YAML under ``mmlearn_run``: ``concurrent_encoders`` runs every tower after the first on a side HIP stream
-        (DESIGN.md 5.9), ``max_side_streams`` caps the number of such streams, ``match_ahead`` launches the id matcher before
+        (HISTORY.md 5.9), ``max_side_streams`` caps the number of such streams, ``match_ahead`` launches the id matcher before
         the encoders."""
         super().__init__(optimizer=optimizer, lr_scheduler=lr_scheduler, loss_fn=loss,
                          compute_validation_loss=compute_validation_loss, compute_test_loss=compute_test_loss)
@@ -290,7 +290,7 @@ class ContrastivePretraining(TrainingTask):
         """The side stream of tower k >= 1 is entry k - 1.  At most ``max_side_streams`` (default 1) distinct streams are
         created and towers share them round-robin: two compute streams give the overlap (the tails of one tower's kernels
         filled by the other's), more streams multiply the cross-stream waits that the runtime maps onto a handful of
-        hardware queues -- a five-stream experiment stalled in the backward pass, and the three-stream
+        hardware queues -- a five-stream experiment stalled in the backward pass (HISTORY.md 5.9), and the three-stream
         three-tower step was the one benchmark leg that ever hung."""
         have = self.__dict__.setdefault("_side_streams", [])
         cap = max(1, int(self.max_side_streams))

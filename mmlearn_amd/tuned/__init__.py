@@ -16,7 +16,7 @@ Recording more shapes::
 
 and merge the ``GemmTunableOp`` / ``GemmAndBiasTunableOp`` lines.  (Strided-batched entries are left out on purpose: tuning
 the 24 x 64 x 64 batched products of the HTSAT tower's window attention ends in a GPU memory fault inside one of the library's
-candidate kernels)
+candidate kernels, HISTORY.md 5.)
 """
 
 import os

@@ -424,3 +424,90 @@ def test_the_step_traces_with_fullgraph_through_the_custom_ops(monkeypatch):
     torch._dynamo.reset()
     for e, c in zip(*results):
         assert torch.allclose(e, c, rtol=1e-4, atol=1e-6)
+
+
+def test_compiled_loss_meta_round_trip_and_run_registry():
+    """mmlearn_amd/compiled.py host logic: everything of a loss call that is not a tensor travels as one string operand and comes
+    back unchanged; parked runs are redeemed once, and forward passes whose backward never comes are evicted oldest first."""
+    from mmlearn_amd import compiled
+    from mmlearn_amd.tasks import LossPairSpec
+
+    pairs = [LossPairSpec(("rgb", "text")), LossPairSpec(("rgb", "audio"), 0.5), LossPairSpec(("text", "audio"), 1e-3)]
+    for fp in (True, False, None):
+        meta = compiled._encode_meta(["rgb_embedding", "text_embedding", "audio_embedding"], ["rgb", "text", "audio"], pairs, fp)
+        ek, ik, ps, got_fp = compiled._decode_meta(meta)
+        assert ek == ["rgb_embedding", "text_embedding", "audio_embedding"] and ik == ["rgb", "text", "audio"] and got_fp is fp
+        assert [(p.modalities, p.weight) for p in ps] == [(p.modalities, p.weight) for p in pairs]
+    assert compiled._decode_meta(compiled._encode_meta(["a_embedding"], [], [], None))[1:3] == ([], [])
+    compiled._RUNS.clear()
+    toks = [compiled._park(object()) for _ in range(compiled.MAX_PARKED_RUNS + 3)]
+    assert len(compiled._RUNS) == compiled.MAX_PARKED_RUNS and toks[0] not in compiled._RUNS and toks[-1] in compiled._RUNS
+    compiled._RUNS.clear()
+    # every loss module is its own call site, copies included
+    import copy
+    from mmlearn_amd import ContrastiveLoss
+    a = ContrastiveLoss()
+    b = copy.deepcopy(a)
+    assert a._site_id != b._site_id and compiled._SITES[a._site_id] is a and compiled._SITES[b._site_id] is b
+
+
+def test_key_mask_recognition_is_by_shape_and_strides_only():
+    """attention.key_mask_view (the CPU-checkable half of the mask support): what PROVES a key-padding mask is accepted -- [B, L],
+    [B, 1, 1, L], stride-0 expansions over heads / queries -- and a materialised [B, 1, L, L] tensor, a 3-D per-query mask, a wrong
+    batch or length are refused.  (Device tensors only: the test fakes ``is_cuda`` with a subclass, the function never touches data.)"""
+    from mmlearn_amd.attention import key_mask_view
+
+    class Dev(torch.Tensor):
+        is_cuda = property(lambda self: True)
+
+    def dev(t):
+        return t.as_subclass(Dev)
+
+    B, L = 3, 7
+    keep = torch.rand(B, L) > 0.3
+    v, add = key_mask_view(dev(keep), B, L)
+    assert add is False and tuple(v.shape) == (B, L)
+    v, add = key_mask_view(dev(keep[:, None, None, :]), B, L)
+    assert add is False and torch.equal(torch.Tensor(v).bool(), keep)
+    v, add = key_mask_view(dev(keep[:, None, None, :].expand(B, 4, L, L)), B, L)
+    assert torch.equal(torch.Tensor(v).bool(), keep)
+    addm = torch.zeros(B, 1, 1, L).masked_fill(~keep[:, None, None, :], torch.finfo(torch.float32).min)
+    assert key_mask_view(dev(addm), B, L)[1] is True
+    assert key_mask_view(dev(keep[:, None, None, :].expand(B, 1, L, L).contiguous()), B, L) is None   # could hold anything
+    assert key_mask_view(dev(keep[:, None, :]), B, L) is None                                          # 3-D: a per-query mask
+    assert key_mask_view(dev(keep), B + 1, L) is None and key_mask_view(dev(keep), B, L + 1) is None
+    assert key_mask_view(keep, B, L) is None                                                           # host tensors are not served
+    assert key_mask_view(dev(keep.half()[:, None, None, :]), B, L) is None                             # fp16 masks: not a served dtype
+
+
+def test_mask_scope_leaves_hosts_and_checkpointed_models_to_hf():
+    """fused.scope_key_masks on the CPU: the scope is installed on the innermost HF text model only, copies get their own scope, and the
+    pre-hook does nothing for host tensors (so a CPU forward with a padding mask still equals the stock model)."""
+    import copy
+    from transformers import BertConfig, BertModel
+
+    from mmlearn_amd import fused
+
+    torch.manual_seed(0)
+    cfg = BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=1, intermediate_size=128, vocab_size=100,
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    stock = BertModel(cfg, add_pooling_layer=False).eval()
+    wrapped = torch.nn.Sequential()
+    wrapped.add_module("tower", copy.deepcopy(stock))
+    assert fused.fuse_qkv_attention(wrapped) == 2
+    scope = wrapped.tower._mmk_mask_scope
+    assert all(l.attention.self._mmk_mask_scope is scope for l in wrapped.tower.encoder.layer)
+    assert fused.scope_key_masks(wrapped) == 0                      # once
+    twin = copy.deepcopy(wrapped)
+    assert twin.tower._mmk_mask_scope is not scope and twin.tower.encoder.layer[0].attention.self._mmk_mask_scope is twin.tower._mmk_mask_scope
+    ids = torch.randint(0, 100, (3, 9))
+    mask = torch.ones(3, 9, dtype=torch.long)
+    mask[1, 5:] = 0
+    with torch.no_grad():
+        a = stock(input_ids=ids, attention_mask=mask).last_hidden_state
+        b = wrapped.tower(input_ids=ids, attention_mask=mask).last_hidden_state
+    assert torch.allclose(a, b, atol=1e-6) and scope.key_bias is None and scope.stripped is False
+    s = fused._MaskScope()
+    s.mask2d = mask
+    add = s.additive(torch.float32)
+    assert add.shape == (3, 1, 1, 9) and (add[1, 0, 0, 5:] == torch.finfo(torch.float32).min).all() and (add[0] == 0).all()

@@ -1399,6 +1399,19 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
   return 0;
 }
 
+// ---- the one-kernel recompute-G backward of row-sharded directions (csrc/clip_bwd.hip)
+// A direction takes it when it is a SHARD with a tile pass of its own: bf16, k_pad = 512, no alignment term, not one half of a mirrored
+// pair (those share one tile pass and hand G^T over), at least 1024 columns and enough (row block, split) units to fill half the chip.
+template <typename T>
+static bool bwd_fused_eligible(const mmk_clip_dir* dirs, int k, int k_pad, int n_split, int n_dirs) {
+  if (MMK_DBG_ENV("MMK_CLIP_BWD_FUSED") && atoi(MMK_DBG_ENV("MMK_CLIP_BWD_FUSED")) == 0) return false;   // A/B in debug-switch builds
+  const mmk_clip_dir& d = dirs[k];
+  for (int j = 0; j < n_dirs; ++j)   // a mirrored partner reads this direction's G (transposed, csrc/wgrad.hip): G must exist then
+    if (j != k && dirs[j].g_ready && dirs[j].g == d.g) return false;
+  return sizeof(T) == 2 && k_pad == 512 && d.mode == 0 && !d.g_ready && !d.g_transposed && d.gT == nullptr && d.c >= 1024 &&
+         (long)cdiv(d.r, 64) * n_split * n_dirs >= 128;
+}
+
 template <typename T, typename U>
 static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d_user, const float* scale,
                               const float* upstream, float* dscale_out, hipStream_t st) {
@@ -1417,10 +1430,34 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
   db.n_probs = 0;
   const int c_pad_max = round_up(c_max, 128);
   const int k_per_split = round_up(cdiv(c_pad_max, pl.n_split), bk);
+  BwdFusedBatch fz;
+  fz.n_probs = 0;
+  fz.n_split = pl.n_split;
+  fz.cols_per_split = round_up(cdiv(c_pad_max, pl.n_split), 64);
+  fz.row_blocks = 0;
+  fz.dbg = 0;
   for (int k = 0; k < n_dirs; ++k) {
     const mmk_clip_dir& d = dirs[k];
     const int r_pad = round_up(d.r, 128), c_pad = round_up(d.c, 128);
     MMK_REQUIRE(d.ldg >= c_pad && d.ldt >= c_pad, "ldg/ldt must be >= round_up(c, 128)");
+    if (bwd_fused_eligible<T>(dirs, k, k_pad, pl.n_split, n_dirs)) {
+      MMK_REQUIRE(d.lse_col != nullptr || (d.c_col == 0.f && d.s_col == 0.f), "lse_col required when c_col/s_col != 0");
+      BwdFusedProb& q = fz.p[fz.n_probs++];
+      q.x = static_cast<const bf16_t*>(d.x); q.y = static_cast<const bf16_t*>(d.y);
+      q.lse_row = d.lse; q.lse_col = d.lse_col;
+      q.slab = d.slab; q.ds_part = d.ds_part;
+      q.r = d.r; q.c = d.c; q.r_pad = r_pad; q.label_off = d.label_off;
+      q.c_row = d.c_row; q.c_col = d.c_col; q.c_diag = d.c_diag;
+      q.s_row = d.s_row; q.s_col = d.s_col; q.s_diag = d.s_diag;
+      fz.row_blocks = std::max(fz.row_blocks, cdiv(d.r, 64));
+      db.part[db.n_probs] = d.ds_part;
+      db.n[db.n_probs] = cdiv(d.r, 64) * pl.n_split;
+      db.kappa[db.n_probs] = d.ds_kappa;
+      ++db.n_probs;
+      fb.p[k] = FinProb{d.slab, (long)r_pad * k_pad, k_pad, d.r, d.kappa, d.dx, d.dx_rows, d.dx_accumulate, d.src, d.normalize, pl.n_split};
+      max_r = std::max(max_r, d.r);
+      continue;
+    }
     // recompute + G (a direction whose G was written as another direction's G^T has no tile pass of its own)
     Prob p{};
     p.P = static_cast<const char*>(d.y);
@@ -1493,6 +1530,10 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
   xb.n_split = pl.n_split;
   xb.unit_map = (n_x * pl.n_split) % 8 == 0 && !(MMK_DBG_ENV("MMK_GRAD_UNIT_MAP") && atoi(MMK_DBG_ENV("MMK_GRAD_UNIT_MAP")) == 0);
   fb.d = d_user;
+  if (fz.n_probs > 0) {
+    int rc = launch_clip_bwd_fused(fz, scale, st);
+    if (rc) return rc;
+  }
   if (n_tile_probs > 0) {
     int rc = dirs[0].mode == 1 ? launch_gemm<T, EPI_ALIGN_GRAD>(gb, n_tile_probs, pl.bm, pl.bn, max_tiles_g, scale, st)
                                : launch_gemm<T, EPI_GRAD>(gb, n_tile_probs, pl.bm, pl.bn, max_tiles_g, scale, st);

@@ -1,0 +1,304 @@
+// Row-sharded CLIP / InfoNCE backward as ONE kernel that recomputes G: for a direction whose rows are a SHARD of the
+// batch (R owned rows against C >> R gathered columns: what every rank runs at W > 1) the two launches
+//     sim_grad   S = X Y^T again, G = c_row P_row + c_col P_col - c_diag delta -> HBM (R x C bf16)
+//     grad_gemm  dX = G Y (split over C into f32 slabs), reading G back and a TRANSPOSED copy of Y
+// become one.  A workgroup owns 64 owned rows x one column split and walks the split in tiles of 32 columns:
+//     phase S   S^T[32 j x 64 i] = Y_tile X_blk^T, the contraction (D = 512) split over the four waves; the X fragments of a wave's
+//               128-wide k range stay in REGISTERS for the whole kernel (64 VGPRs), the Y tile is an LDS image filled by LDS-DMA
+//     reduce    the four partial tiles meet in LDS; every thread finishes 8 logits: P_row, P_col from the row / column log-sum-exps
+//               (log2 domain), G, the d/dscale term, G rounded to bf16 into a 4-KiB [64 i][32 j] image
+//     phase D   dX[64 i x 512] += G Y_tile: G row fragments x TRANSPOSED reads (ds_read_b64_tr_b16) of the SAME Y image -- no
+//               transposed copy of Y exists, G never leaves the chip; a wave owns 128 of the 512 output columns (8 accumulator tiles)
+// The f32 tile goes to the split's slab; grad_finalize (clip.hip) sums the slabs as before.  One image format serves the row reads of
+// phase S and the transposed reads of phase D: the [rows][64] sub-images of csrc/attention.hip (128-byte rows, chunk ^ img_swz(row)).
+// Per tile and wave 16 + 16 MFMAs (v_mfma_f32_32x32x16_bf16) against the 2 x 8 + recompute of the two-launch form, and HBM sees the
+// operands once per (split, row-block group on one XCD) plus the slabs: no G (2 x 33 MB at R = 1024 x C = 8192), no transposed Y.
+// Eligibility (clip.hip): bf16 compute, k_pad = 512, a direction with a tile pass of its own (not mirrored), no alignment term.
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "clip_internal.h"
+#include "common.h"
+
+namespace mmk {
+
+constexpr int CB_ROWS = 64;        // owned rows per workgroup
+constexpr int CB_JT = 64;          // columns per tile
+constexpr int CB_KP = 512;         // k_pad served
+constexpr int CB_SUB = 32 * 128;               // bytes of one [32 rows][64 k] sub-image
+constexpr int CB_YBUF = 2 * (CB_KP / 64) * CB_SUB;   // one Y tile: 2 (column halves) x 8 (k) sub-images = 64 KiB
+constexpr int CB_GIMG = CB_ROWS * 128;             // G image: [64 i][64 j] bf16 = 8 KiB
+constexpr int CB_LCOL = 256;                       // one tile's column log-sum-exps: 64 floats = one 64-lane x 4-byte LDS-DMA piece
+constexpr int CB_LDS = 2 * CB_YBUF + CB_GIMG + 2 * CB_LCOL;
+
+// (the image helpers of csrc/attention.hip, restated for this translation unit)
+__device__ __forceinline__ int cb_swz(int row) {
+  const int t = row >> 1;
+  return ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1);
+}
+__device__ __forceinline__ void cb_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+  const uint64_t pb = reinterpret_cast<uint64_t>(sbase);
+  const uint64_t ps = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pb >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb);
+  lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(reinterpret_cast<const void*>(ps)), "s"(lds_addr) : "memory");
+}
+
+__device__ __forceinline__ void cb_dma4(const void* sbase, uint32_t voff, uint32_t lds_addr) {   // 64 lanes x 4 bytes
+  const uint64_t pb = reinterpret_cast<uint64_t>(sbase);
+  const uint64_t ps = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pb >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb);
+  lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_addr);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(reinterpret_cast<const void*>(ps)), "s"(lds_addr) : "memory");
+}
+
+__global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch batch, const float* __restrict__ scale_ptr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ybuf = smem;                                               // [2][2 jt][8 k sub-images][32 rows][128 B]
+  char* gimg = smem + 2 * CB_YBUF;                                 // [64 i][128 B], 16-byte chunk ^= i & 7
+  const float* lcol = reinterpret_cast<const float*>(gimg + CB_GIMG);   // [2][64]: lse_col of the tile's 64 columns
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wit = wave & 1, wjt = wave >> 1;   // phase S: this wave's 32 x 32 tile of the 64 x 64 logits
+  // unit map: workgroups are dealt to the XCDs round-robin; all row blocks of a (problem, split) unit read the same 1 MiB of Y, so a
+  // unit lives on ONE XCD (speed only)
+  const int lin = blockIdx.x, xcd = lin & 7, jj_ = lin >> 3;
+  const int unit = xcd + 8 * (jj_ / batch.row_blocks), rb = jj_ % batch.row_blocks;
+  if (unit >= batch.n_probs * batch.n_split) return;
+  const int split = unit % batch.n_split;
+  const BwdFusedProb& p = batch.p[unit / batch.n_split];
+  const int i0 = rb * CB_ROWS;
+  if (i0 >= p.r) return;
+  // (the problem's scalars as values: fields read through the reference become scalar loads wherever they are used -- inside the loop)
+  const int n_cols = p.c;
+  const float c_row = p.c_row, c_col = p.c_col, c_diag = p.c_diag, s_row = p.s_row, s_col = p.s_col, s_diag = p.s_diag;   // rows beyond r are never read by the finalize
+  const int c0 = split * batch.cols_per_split;
+  const int c_pad = (n_cols + 127) & ~127;
+  const int ntile = max(0, (min(c_pad, c0 + batch.cols_per_split) - c0) / CB_JT);
+  const float s2 = *scale_ptr * 1.4426950408889634f;
+  const bool use_col = (c_col != 0.f) || (s_col != 0.f);
+  const int dbg = kDebugSwitches ? batch.dbg : 0;   // timing ablations (debug-switch builds, MMK_CB_DBG; WRONG results): 1 no phase S, 2 no G
+                                                    // arithmetic, 4 no phase D, 8 no Y DMA, 16 no slab stores
+
+  // ---- this wave's X fragments: B operand of phase S, rows i0 + 32 wit + r, k = 16 ks + 8 h .. + 7, the whole contraction
+  bf16x8 xf[32];
+  {
+    const bf16_t* xr = p.x + (long)min(i0 + 32 * wit + r, p.r_pad - 1) * CB_KP + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xr + 16 * ks);
+  }
+  // (consumed here, so that the wait for these loads sits HERE: met first inside the loop it would count the next tile's DMA pieces too)
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) asm volatile("" : "+v"(xf[ks]));
+
+  // ---- per-lane LDS offsets.  Row fragment kk of image row r (k = 16 kk + 8 h ..): r * 128 + (((2 kk + h) ^ swz(r)) << 4).
+  // Transposed fragment in NATURAL k order (element jj <-> image row 16 js + 8 h + jj) of column tile ct: two ds_read_b64_tr_b16,
+  // lane 4 q + pp of a 16-lane group addresses row 8 h + 4 u + q, columns 4 pp .. + 3 of the group's 16 (chunk 4 ct + 2 g1 + (pp >> 1)).
+  int rowoff[4], troff[2][2];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) rowoff[kk] = r * 128 + (((2 * kk + h) ^ cb_swz(r)) << 4);
+  {
+    const int li = lane & 15, q = li >> 2, pp = li & 3, g1 = (lane >> 4) & 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = 8 * h + 4 * u + q;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) troff[u][ct] = row * 128 + (((4 * ct + 2 * g1 + (pp >> 1)) ^ cb_swz(row)) << 4) + 8 * (pp & 1);
+    }
+  }
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  auto tr8 = [&](const char* p0, const char* p1) {
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p0));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p1));
+    s8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, f);
+  };
+
+  // ---- Y tile t -> buffer b: 64 pieces of 1 KiB (8 rows x 128 B of one sub-image), sixteen per wave (k sub-images 2 wave, 2 wave + 1 of
+  // both column halves); the swizzle goes on the SOURCE chunk.  Rows c0 + 64 t .. + 63 exist (the packed operand has c_pad rows).
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smem);
+  auto issue_y = [&](int t, int b) {
+    const bf16_t* base = p.y + (long)(c0 + CB_JT * t) * CB_KP;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int q8 = 0; q8 < 4; ++q8) {
+          const int s = 2 * wave + sub;
+          const int row = 8 * q8 + (lane >> 3);
+          const int ch = (lane & 7) ^ cb_swz(row);
+          cb_dma16(base + (long)(32 * jt) * CB_KP + 64 * s, (uint32_t)(row * CB_KP + ch * 8) * 2u,
+                   smem_addr + b * CB_YBUF + (8 * jt + s) * CB_SUB + q8 * 1024);
+        }
+    // the tile's column log-sum-exps ride along as one more piece (wave 0): a plain load inside the loop would make the compiler wait
+    // for ALL outstanding vector memory operations -- the next tile's pieces included -- at its first use
+    if (use_col && wave == 0)
+      cb_dma4(p.lse_col, (uint32_t)min(c0 + CB_JT * t + lane, p.c - 1) * 4u, smem_addr + 2 * CB_YBUF + CB_GIMG + b * CB_LCOL);
+  };
+
+  f32x16 dacc[2][4];   // [it][kt]: rows i0 + 32 it + .., columns 128 wave + 32 kt + ..
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dacc[it][kt][e] = 0.f;
+  float ds_acc = 0.f;
+  // the G step's constants: a lane finishes the logits of ONE owned row (32 wit + r) against 16 columns of the wave's 32
+  const int ri = 32 * wit + r, iglob = i0 + ri;
+  const bool ivalid = iglob < p.r;
+  const float lr2 = (ivalid ? p.lse_row[iglob] : 0.f) * 1.4426950408889634f;
+  const int lab = p.label_off + iglob;
+  const int lab_lo = p.label_off + i0;          // this block's label columns: lab_lo .. lab_lo + 63
+  const bool rows_full = i0 + CB_ROWS <= p.r;
+  if (!use_col && tid < 2 * (CB_LCOL / 4)) const_cast<float*>(lcol)[tid] = 1e30f;   // exp2(-1e30 log2 e) = 0: P_col vanishes without a select
+
+  if (ntile > 0 && !(dbg & 8)) issue_y(0, 0);
+#pragma unroll 1
+  for (int t = 0; t < ntile; ++t) {
+    const char* yb = ybuf + (t & 1) * CB_YBUF;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t
+    __syncthreads();                                   // tile t complete; phase D of tile t - 1 is over: the other buffer and the G image are free
+    if (t + 1 < ntile && !(dbg & 8)) issue_y(t + 1, (t + 1) & 1);
+    // ---------------- phase S: S^T[32 j (wjt)][32 i (wit)] over the whole contraction, two accumulators (even / odd k steps)
+    f32x16 sacc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[u][e] = 0.f;
+    if (!(dbg & 1)) {   // the Y row fragments run eight k steps ahead of their MFMAs (one wave per SIMD: nobody else hides the LDS latency)
+      const char* ys = yb + 8 * wjt * CB_SUB;
+      bf16x8 yf[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) yf[ks] = *reinterpret_cast<const bf16x8*>(ys + (ks >> 2) * CB_SUB + rowoff[ks & 3]);
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) {
+        sacc[ks & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[ks & 7], xf[ks], sacc[ks & 1], 0, 0, 0);
+        if (ks + 8 < 32) yf[ks & 7] = *reinterpret_cast<const bf16x8*>(ys + ((ks + 8) >> 2) * CB_SUB + rowoff[ks & 3]);
+      }
+      // (the order above, pinned: left alone the scheduler sinks every read to just before its MFMA)
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+      for (int ks = 0; ks < 24; ++ks) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    }
+    // ---------------- G: element e of the tile is logit (row ri, column 32 wjt + (e&3) + 8 (e>>2) + 4 h).  Branch-free (selects
+    // only), and two forms: a tile that holds no label column, no column beyond c and no row beyond r -- all but a few -- skips the
+    // diagonal and validity selects (about 10 VALU operations + 2 exp per element; nothing overlaps them at one wave per SIMD).
+    if (!(dbg & 2)) {
+      const float* lc = lcol + (t & 1) * (CB_LCOL / 4) + 32 * wjt + 4 * h;
+      const int jt0 = c0 + CB_JT * t;
+      auto g_step = [&](auto general) {
+        constexpr bool GEN = decltype(general)::value;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lc + 8 * q4);
+          bf16x4 g4;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = 4 * q4 + u;
+            const float tv = sacc[0][e] + sacc[1][e];
+            const float pr = fast_exp2(fmaf(tv, s2, -lr2));
+            const float pc = fast_exp2(fmaf(tv, s2, l4[u] * -1.4426950408889634f));   // (no column term: the record holds 1e30)
+            float g = fmaf(c_col, pc, c_row * pr), gs = fmaf(s_col, pc, s_row * pr);
+            if (GEN) {
+              const int jglob = jt0 + 32 * wjt + 8 * q4 + 4 * h + u;
+              const bool diag = jglob == lab, valid = ivalid & (jglob < n_cols);
+              g -= diag ? c_diag : 0.f;
+              gs -= diag ? s_diag : 0.f;
+              g = valid ? g : 0.f;
+              gs = valid ? gs : 0.f;
+            }
+            ds_acc = fmaf(gs, tv, ds_acc);
+            g4[u] = (bf16_t)g;
+          }
+          *reinterpret_cast<bf16x4*>(gimg + ri * 128 + (((4 * wjt + q4) ^ (ri & 7)) << 4) + 8 * h) = g4;
+        }
+      };
+      const bool plain = rows_full && jt0 + CB_JT <= n_cols && (jt0 + CB_JT <= lab_lo || jt0 >= lab_lo + CB_ROWS);   // wave-uniform
+      if (plain) g_step(std::false_type{});
+      else g_step(std::true_type{});
+    }
+    __syncthreads();
+    // ---------------- phase D: dX[64 i][128 wave ..] += G[64 i][64 j] Y[64 j][128 wave ..]
+    if (!(dbg & 4)) {
+      // step q = 4 js + 2 sub + ct: 16 columns j (js), output columns 128 wave + 64 sub + 32 ct ..; the G fragments are read up
+      // front, the transposed Y fragments run four steps ahead of their MFMA pairs
+      bf16x8 ga[4][2], yt[4];
+#pragma unroll
+      for (int js = 0; js < 4; ++js)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = 32 * it + r;
+          ga[js][it] = *reinterpret_cast<const bf16x8*>(gimg + row * 128 + (((2 * js + h) ^ (row & 7)) << 4));
+        }
+      auto read_yt = [&](int q) {
+        const int js = q >> 2, sub = (q >> 1) & 1, ct = q & 1;
+        const char* img = yb + (8 * (js >> 1) + 2 * wave + sub) * CB_SUB + (js & 1) * 2048;
+        return tr8(img + troff[0][ct], img + troff[1][ct]);
+      };
+#pragma unroll
+      for (int q = 0; q < 4; ++q) yt[q] = read_yt(q);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int js = q >> 2, kt = q & 3;
+        dacc[0][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[js][0], yt[q & 3], dacc[0][kt], 0, 0, 0);
+        dacc[1][kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[js][1], yt[q & 3], dacc[1][kt], 0, 0, 0);
+        if (q + 4 < 16) yt[q & 3] = read_yt(q + 4);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    }
+  }
+  // ---- the f32 tile -> this split's slab: dacc[it][kt][e] = dX[i0 + 32 it + (e&3) + 8(e>>2) + 4h][128 wave + 32 kt + r]
+  float* sl = p.slab + ((size_t)split * p.r_pad + i0) * CB_KP + 128 * wave + r;
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = 32 * it + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (i0 + row < p.r_pad && !(dbg & 16)) sl[(size_t)row * CB_KP + 32 * kt] = dacc[it][kt][e];
+      }
+  // ---- d/dscale partial of this workgroup
+  __syncthreads();
+  float v = ds_acc;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  float* red = reinterpret_cast<float*>(smem);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (tid == 0) p.ds_part[rb * batch.n_split + split] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// host side: called by clip_backward_impl (clip.hip) for the directions it found eligible
+int launch_clip_bwd_fused(const BwdFusedBatch& b, const float* scale, hipStream_t st) {
+  auto kern = clip_bwd_fused_kernel;
+  KernelSetup ks;
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(kern), 256, CB_LDS, &ks)) return rc;
+  BwdFusedBatch bb = b;
+  bb.dbg = MMK_DBG_ENV("MMK_CB_DBG") ? atoi(MMK_DBG_ENV("MMK_CB_DBG")) : 0;
+  const int units = b.n_probs * b.n_split;
+  const int grid = 8 * cdiv(units, 8) * b.row_blocks;
+  ProfEvents pe(MMK_K_SIM_GRAD);
+  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), CB_LDS, st, pe.start, pe.stop, 0, bb, scale);
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace mmk

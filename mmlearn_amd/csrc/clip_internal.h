@@ -8,6 +8,7 @@ namespace mmk {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MAX_PROBS = 8;
 
@@ -84,5 +85,23 @@ struct DsBatch {
 // one launch: a grid row per direction, plus one (when dscale_out != null) for the d/dscale reduction; U = dx_dtype
 int launch_grad_finalize(const FinBatch& fb, int n_dirs, int max_r, int ld_max, const float* scale, const float* upstream, const DsBatch& db,
                          float* dscale_out, int dx_dtype, hipStream_t st);
+
+// ------------------------------------------------------------------ one-kernel recompute-G backward of row-sharded directions (clip_bwd.hip)
+struct BwdFusedProb {
+  const bf16_t* x;        // packed owned rows   [>= r_pad][512]
+  const bf16_t* y;        // packed columns      [>= c_pad][512]
+  const float* lse_row;   // [r]
+  const float* lse_col;   // [c] or null (c_col = s_col = 0)
+  float* slab;            // [n_split][r_pad][512]
+  float* ds_part;         // [ceil(r / 64) * n_split]
+  int r, c, r_pad, label_off;
+  float c_row, c_col, c_diag, s_row, s_col, s_diag;
+};
+struct BwdFusedBatch {
+  BwdFusedProb p[MAX_PROBS];
+  int n_probs, n_split, cols_per_split, row_blocks;   // cols_per_split: multiple of 64; row_blocks = max over the problems
+  int dbg;                                            // debug-switch builds only (MMK_CB_DBG): timing ablations
+};
+int launch_clip_bwd_fused(const BwdFusedBatch& b, const float* scale, hipStream_t st);
 
 }  // namespace mmk

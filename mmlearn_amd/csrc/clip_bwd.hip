@@ -82,17 +82,6 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
   const int dbg = kDebugSwitches ? batch.dbg : 0;   // timing ablations (debug-switch builds, MMK_CB_DBG; WRONG results): 1 no phase S, 2 no G
                                                     // arithmetic, 4 no phase D, 8 no Y DMA, 16 no slab stores
 
-  // ---- this wave's X fragments: B operand of phase S, rows i0 + 32 wit + r, k = 16 ks + 8 h .. + 7, the whole contraction
-  bf16x8 xf[32];
-  {
-    const bf16_t* xr = p.x + (long)min(i0 + 32 * wit + r, p.r_pad - 1) * CB_KP + 8 * h;
-#pragma unroll
-    for (int ks = 0; ks < 32; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xr + 16 * ks);
-  }
-  // (consumed here, so that the wait for these loads sits HERE: met first inside the loop it would count the next tile's DMA pieces too)
-#pragma unroll
-  for (int ks = 0; ks < 32; ++ks) asm volatile("" : "+v"(xf[ks]));
-
   // ---- per-lane LDS offsets.  Row fragment kk of image row r (k = 16 kk + 8 h ..): r * 128 + (((2 kk + h) ^ swz(r)) << 4).
   // Transposed fragment in NATURAL k order (element jj <-> image row 16 js + 8 h + jj) of column tile ct: two ds_read_b64_tr_b16,
   // lane 4 q + pp of a 16-lane group addresses row 8 h + 4 u + q, columns 4 pp .. + 3 of the group's 16 (chunk 4 ct + 2 g1 + (pp >> 1)).
@@ -122,8 +111,7 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
   // ---- Y tile t -> buffer b: 64 pieces of 1 KiB (8 rows x 128 B of one sub-image), sixteen per wave (k sub-images 2 wave, 2 wave + 1 of
   // both column halves); the swizzle goes on the SOURCE chunk.  Rows c0 + 64 t .. + 63 exist (the packed operand has c_pad rows).
   const uint32_t smem_addr = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smem);
-  auto issue_y = [&](int t, int b) {
-    const bf16_t* base = p.y + (long)(c0 + CB_JT * t) * CB_KP;
+  auto issue_rows = [&](const bf16_t* base, int b) {   // 64 rows x 512 from base -> buffer b
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -136,6 +124,9 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
           cb_dma16(base + (long)(32 * jt) * CB_KP + 64 * s, (uint32_t)(row * CB_KP + ch * 8) * 2u,
                    smem_addr + b * CB_YBUF + (8 * jt + s) * CB_SUB + q8 * 1024);
         }
+  };
+  auto issue_y = [&](int t, int b) {
+    issue_rows(p.y + (long)(c0 + CB_JT * t) * CB_KP, b);
     // the tile's column log-sum-exps ride along as one more piece (wave 0): a plain load inside the loop would make the compiler wait
     // for ALL outstanding vector memory operations -- the next tile's pieces included -- at its first use
     if (use_col && wave == 0)
@@ -149,7 +140,8 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) dacc[it][kt][e] = 0.f;
-  float ds_acc = 0.f;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 ds2 = {0.f, 0.f};
   // the G step's constants: a lane finishes the logits of ONE owned row (32 wit + r) against 16 columns of the wave's 32
   const int ri = 32 * wit + r, iglob = i0 + ri;
   const bool ivalid = iglob < p.r;
@@ -159,7 +151,21 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
   const bool rows_full = i0 + CB_ROWS <= p.r;
   if (!use_col && tid < 2 * (CB_LCOL / 4)) const_cast<float*>(lcol)[tid] = 1e30f;   // exp2(-1e30 log2 e) = 0: P_col vanishes without a select
 
+  // ---- this wave's X fragments: B operand of phase S, rows i0 + 32 wit + r, k = 16 ks + 8 h .. + 7, the whole contraction, in
+  // registers for the whole kernel.  The block is a 64 x 512 tile like any Y tile: it comes through the second buffer as an image
+  // (coalesced 128-byte rows by LDS-DMA; row-strided 32-byte loads straight into registers cost several microseconds here), while
+  // the first Y tile is already on its way into the first.  The packed operand has r_pad >= i0 + 64 rows.
   if (ntile > 0 && !(dbg & 8)) issue_y(0, 0);
+  issue_rows(p.x + (long)i0 * CB_KP, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  bf16x8 xf[32];
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks)
+    xf[ks] = *reinterpret_cast<const bf16x8*>(ybuf + CB_YBUF + (8 * wit + (ks >> 2)) * CB_SUB + rowoff[ks & 3]);
+  // (consumed here: the reads are over before this wave reaches the loop's first barrier, after which the buffer is overwritten)
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) asm volatile("" : "+v"(xf[ks]));
 #pragma unroll 1
   for (int t = 0; t < ntile; ++t) {
     const char* yb = ybuf + (t & 1) * CB_YBUF;
@@ -167,11 +173,9 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
     __syncthreads();                                   // tile t complete; phase D of tile t - 1 is over: the other buffer and the G image are free
     if (t + 1 < ntile && !(dbg & 8)) issue_y(t + 1, (t + 1) & 1);
     // ---------------- phase S: S^T[32 j (wjt)][32 i (wit)] over the whole contraction, two accumulators (even / odd k steps)
-    f32x16 sacc[2];
+    f32x16 sacc;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sacc[u][e] = 0.f;
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
     if (!(dbg & 1)) {   // the Y row fragments run eight k steps ahead of their MFMAs (one wave per SIMD: nobody else hides the LDS latency)
       const char* ys = yb + 8 * wjt * CB_SUB;
       bf16x8 yf[8];
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
       for (int ks = 0; ks < 8; ++ks) yf[ks] = *reinterpret_cast<const bf16x8*>(ys + (ks >> 2) * CB_SUB + rowoff[ks & 3]);
 #pragma unroll
       for (int ks = 0; ks < 32; ++ks) {
-        sacc[ks & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[ks & 7], xf[ks], sacc[ks & 1], 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[ks & 7], xf[ks], sacc, 0, 0, 0);
         if (ks + 8 < 32) yf[ks & 7] = *reinterpret_cast<const bf16x8*>(ys + ((ks + 8) >> 2) * CB_SUB + rowoff[ks & 3]);
       }
       // (the order above, pinned: left alone the scheduler sinks every read to just before its MFMA)
@@ -197,6 +201,8 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
     if (!(dbg & 2)) {
       const float* lc = lcol + (t & 1) * (CB_LCOL / 4) + 32 * wjt + 4 * h;
       const int jt0 = c0 + CB_JT * t;
+      const f32x2 s2v = {s2, s2}, nlr2v = {-lr2, -lr2}, nlog2e = {-1.4426950408889634f, -1.4426950408889634f};
+      const f32x2 c_rowv = {c_row, c_row}, c_colv = {c_col, c_col}, s_rowv = {s_row, s_row}, s_colv = {s_col, s_col};
       auto g_step = [&](auto general) {
         constexpr bool GEN = decltype(general)::value;
 #pragma unroll
@@ -204,22 +210,29 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(lc + 8 * q4);
           bf16x4 g4;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int e = 4 * q4 + u;
-            const float tv = sacc[0][e] + sacc[1][e];
-            const float pr = fast_exp2(fmaf(tv, s2, -lr2));
-            const float pc = fast_exp2(fmaf(tv, s2, l4[u] * -1.4426950408889634f));   // (no column term: the record holds 1e30)
-            float g = fmaf(c_col, pc, c_row * pr), gs = fmaf(s_col, pc, s_row * pr);
+          for (int u2 = 0; u2 < 2; ++u2) {   // two elements at a time: packed f32 multiply-adds (v_pk_fma_f32), half the VALU issue slots
+            const int e = 4 * q4 + 2 * u2;
+            const f32x2 tv = {sacc[e], sacc[e + 1]};
+            const f32x2 nl = {l4[2 * u2], l4[2 * u2 + 1]};
+            const f32x2 ar = __builtin_elementwise_fma(tv, s2v, nlr2v);
+            const f32x2 ac = __builtin_elementwise_fma(nl, nlog2e, tv * s2v);   // (no column term: the record holds 1e30)
+            const f32x2 pr = {fast_exp2(ar[0]), fast_exp2(ar[1])};
+            const f32x2 pc = {fast_exp2(ac[0]), fast_exp2(ac[1])};
+            f32x2 g = __builtin_elementwise_fma(c_colv, pc, c_rowv * pr), gs = __builtin_elementwise_fma(s_colv, pc, s_rowv * pr);
             if (GEN) {
-              const int jglob = jt0 + 32 * wjt + 8 * q4 + 4 * h + u;
-              const bool diag = jglob == lab, valid = ivalid & (jglob < n_cols);
-              g -= diag ? c_diag : 0.f;
-              gs -= diag ? s_diag : 0.f;
-              g = valid ? g : 0.f;
-              gs = valid ? gs : 0.f;
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const int jglob = jt0 + 32 * wjt + 8 * q4 + 4 * h + 2 * u2 + u;
+                const bool diag = jglob == lab, valid = ivalid & (jglob < n_cols);
+                g[u] -= diag ? c_diag : 0.f;
+                gs[u] -= diag ? s_diag : 0.f;
+                g[u] = valid ? g[u] : 0.f;
+                gs[u] = valid ? gs[u] : 0.f;
+              }
             }
-            ds_acc = fmaf(gs, tv, ds_acc);
-            g4[u] = (bf16_t)g;
+            ds2 = __builtin_elementwise_fma(gs, tv, ds2);
+            g4[2 * u2] = (bf16_t)g[0];
+            g4[2 * u2 + 1] = (bf16_t)g[1];
           }
           *reinterpret_cast<bf16x4*>(gimg + ri * 128 + (((4 * wjt + q4) ^ (ri & 7)) << 4) + 8 * h) = g4;
         }
@@ -277,7 +290,7 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
       }
   // ---- d/dscale partial of this workgroup
   __syncthreads();
-  float v = ds_acc;
+  float v = ds2[0] + ds2[1];
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
   float* red = reinterpret_cast<float*>(smem);

@@ -73,6 +73,10 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
   if (i0 >= p.r) return;
   // (the problem's scalars as values: fields read through the reference become scalar loads wherever they are used -- inside the loop)
   const int n_cols = p.c;
+  const bf16_t* y_rows = p.y;
+  const float* lse_col = p.lse_col;
+  asm volatile("" : "+s"(y_rows), "+s"(lse_col));   // (opaque: otherwise re-loaded from the argument block inside the loop, a scalar load
+                                                   // whose wait -- lgkmcnt(0) -- lands between the counted LDS waits of phase S)
   const float c_row = p.c_row, c_col = p.c_col, c_diag = p.c_diag, s_row = p.s_row, s_col = p.s_col, s_diag = p.s_diag;   // rows beyond r are never read by the finalize
   const int c0 = split * batch.cols_per_split;
   const int c_pad = (n_cols + 127) & ~127;
@@ -111,26 +115,27 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
   // ---- Y tile t -> buffer b: 64 pieces of 1 KiB (8 rows x 128 B of one sub-image), sixteen per wave (k sub-images 2 wave, 2 wave + 1 of
   // both column halves); the swizzle goes on the SOURCE chunk.  Rows c0 + 64 t .. + 63 exist (the packed operand has c_pad rows).
   const uint32_t smem_addr = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smem);
+  auto issue_piece = [&](const bf16_t* base, int b, int idx) {   // piece idx (0..15) of this wave's share of 64 rows x 512 from base -> buffer b
+    const int jt = idx >> 3, sub = (idx >> 2) & 1, q8 = idx & 3;
+    const int s = 2 * wave + sub;
+    const int row = 8 * q8 + (lane >> 3);
+    const int ch = (lane & 7) ^ cb_swz(row);
+    cb_dma16(base + (long)(32 * jt) * CB_KP + 64 * s, (uint32_t)(row * CB_KP + ch * 8) * 2u,
+             smem_addr + b * CB_YBUF + (8 * jt + s) * CB_SUB + q8 * 1024);
+  };
   auto issue_rows = [&](const bf16_t* base, int b) {   // 64 rows x 512 from base -> buffer b
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int q8 = 0; q8 < 4; ++q8) {
-          const int s = 2 * wave + sub;
-          const int row = 8 * q8 + (lane >> 3);
-          const int ch = (lane & 7) ^ cb_swz(row);
-          cb_dma16(base + (long)(32 * jt) * CB_KP + 64 * s, (uint32_t)(row * CB_KP + ch * 8) * 2u,
-                   smem_addr + b * CB_YBUF + (8 * jt + s) * CB_SUB + q8 * 1024);
-        }
+    for (int idx = 0; idx < 16; ++idx) issue_piece(base, b, idx);
+  };
+  // the tile's column log-sum-exps ride along as one more piece (wave 0): a plain load inside the loop would make the compiler wait
+  // for ALL outstanding vector memory operations -- the next tile's pieces included -- at its first use
+  auto issue_lcol = [&](int t, int b) {
+    if (use_col && wave == 0)
+      cb_dma4(lse_col, (uint32_t)min(c0 + CB_JT * t + lane, n_cols - 1) * 4u, smem_addr + 2 * CB_YBUF + CB_GIMG + b * CB_LCOL);
   };
   auto issue_y = [&](int t, int b) {
-    issue_rows(p.y + (long)(c0 + CB_JT * t) * CB_KP, b);
-    // the tile's column log-sum-exps ride along as one more piece (wave 0): a plain load inside the loop would make the compiler wait
-    // for ALL outstanding vector memory operations -- the next tile's pieces included -- at its first use
-    if (use_col && wave == 0)
-      cb_dma4(p.lse_col, (uint32_t)min(c0 + CB_JT * t + lane, p.c - 1) * 4u, smem_addr + 2 * CB_YBUF + CB_GIMG + b * CB_LCOL);
+    issue_rows(y_rows + (long)(c0 + CB_JT * t) * CB_KP, b);
+    issue_lcol(t, b);
   };
 
   f32x16 dacc[2][4];   // [it][kt]: rows i0 + 32 it + .., columns 128 wave + 32 kt + ..
@@ -171,29 +176,39 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
     const char* yb = ybuf + (t & 1) * CB_YBUF;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t
     __syncthreads();                                   // tile t complete; phase D of tile t - 1 is over: the other buffer and the G image are free
-    if (t + 1 < ntile && !(dbg & 8)) issue_y(t + 1, (t + 1) & 1);
+    // tile t + 1 goes out piece by piece BETWEEN the MFMAs of phase S (issued in one burst ahead of them the ~100 scalar and DMA
+    // instructions cost this wave ~0.2 us per tile with nothing else to run on its SIMD).  Past the last tile the pieces re-load the
+    // last tile into the free buffer (unused) rather than branch inside the MFMA sequence.
+    const int tn = min(t + 1, ntile - 1), nb = (t + 1) & 1;
+    const bf16_t* ynext = y_rows + (long)(c0 + CB_JT * tn) * CB_KP;
     // ---------------- phase S: S^T[32 j (wjt)][32 i (wit)] over the whole contraction, two accumulators (even / odd k steps)
     f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-    if (!(dbg & 1)) {   // the Y row fragments run eight k steps ahead of their MFMAs (one wave per SIMD: nobody else hides the LDS latency)
-      const char* ys = yb + 8 * wjt * CB_SUB;
+    if (!(dbg & 1)) {
+      // The Y row fragments run eight k steps ahead of their MFMAs (one wave per SIMD: nobody else hides the LDS latency), with the
+      // next tile's DMA pieces between them.  Reads and waits are spelled out: left to the scheduler the reads sink to just before
+      // their MFMA.  LDS operations return in order, so before MFMA ks the reads younger than fragment ks may be outstanding:
+      // min(ks + 8, 32) - (ks + 1) of them.
+      uint32_t ya[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) ya[kk] = smem_addr + (t & 1) * CB_YBUF + 8 * wjt * CB_SUB + rowoff[kk];
       bf16x8 yf[8];
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) yf[ks] = *reinterpret_cast<const bf16x8*>(ys + (ks >> 2) * CB_SUB + rowoff[ks & 3]);
+      for (int ks = 0; ks < 8; ++ks)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yf[ks]) : "v"(ya[ks & 3]), "n"((ks >> 2) * CB_SUB) : "memory");
 #pragma unroll
       for (int ks = 0; ks < 32; ++ks) {
+        if (ks <= 24) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(yf[ks & 7]) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(yf[ks & 7]) : "n"(31 - ks) : "memory");
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[ks & 7], xf[ks], sacc, 0, 0, 0);
-        if (ks + 8 < 32) yf[ks & 7] = *reinterpret_cast<const bf16x8*>(ys + ((ks + 8) >> 2) * CB_SUB + rowoff[ks & 3]);
+        // (the fragment register is re-loaded right behind the MFMA that reads it: the MFMA has taken its operands by then -- issue is
+        // in order and the hardware interlocks a VGPR that a pending MFMA still has to read)
+        if (ks + 8 < 32)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yf[ks & 7]) : "v"(ya[ks & 3]), "n"(((ks + 8) >> 2) * CB_SUB) : "memory");
+        if (ks & 1) issue_piece(ynext, nb, ks >> 1);
       }
-      // (the order above, pinned: left alone the scheduler sinks every read to just before its MFMA)
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-      for (int ks = 0; ks < 24; ++ks) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      issue_lcol(tn, nb);
     }
     // ---------------- G: element e of the tile is logit (row ri, column 32 wjt + (e&3) + 8 (e>>2) + 4 h).  Branch-free (selects
     // only), and two forms: a tile that holds no label column, no column beyond c and no row beyond r -- all but a few -- skips the

@@ -638,6 +638,9 @@ def _loss_roofline(prof: dict, n_rows: int, n_cols: int, d: int, n_pairs: int, s
     fwd = (2.0 if single else 4.0) * n_rows * n_cols * d * n_pairs
     bwd = 4.0 * n_rows * n_cols * d * n_pairs
     algo = {"clip_fwd": fwd, "clip_bwd": bwd, "sim_stats": fwd, "grad_gemm": bwd, "sim_grad": 0.0,
+            # row-sharded directions: ONE launch recomputes the tiles and forms dX (csrc/clip_bwd.hip); it executes twice the
+            # backward's algorithmic 4 R C D (the recompute), counted once
+            "clip_bwd_fused": bwd,
             # one rank, <= 1024 matched rows per pair: ONE launch computes S, its statistics, G and both gradient products
             # (csrc/clip_fused.hip): all 6 N^2 D algorithmic FLOPs of the pair belong to it
             "clip_fused": fwd + bwd}
@@ -749,8 +752,10 @@ def loss_shard_leg(dev, rows: int = 1024, cols: int = 8192, d: int = 512, rank: 
     comp = _lib.COMPUTE_BF16
     kg = 1.0 / (2.0 * C)
 
+    want_t = not K.backward_recomputes_on_chip(R, C, D, comp, 2)   # as mmlearn_amd.losses decides: no transposed copies for the one-kernel backward
+
     def step():
-        (ag, agt), (bg, bgt) = K.pack_rows_many([(A, None, C, False, True), (B, None, C, False, True)], comp)
+        (ag, agt), (bg, bgt) = K.pack_rows_many([(A, None, C, False, want_t), (B, None, C, False, want_t)], comp)
         dirs = []
         for x, y, yt in ((K.slice_packed(ag, p0), bg, bgt), (K.slice_packed(bg, p0), ag, agt)):
             dirs.append(K.Direction(x=x, y=y, y_t=yt, r=R, c=C, label_off=p0, kappa=kg, ds_kappa=kg))

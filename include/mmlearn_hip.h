@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MMK_ABI_VERSION 7
+#define MMK_ABI_VERSION 8
 
 /* element types of user tensors */
 enum { MMK_F32 = 0, MMK_BF16 = 1, MMK_F16 = 2 };
@@ -47,7 +47,7 @@ enum {
   MMK_K_SIM_GRAD, MMK_K_GRAD_GEMM, MMK_K_GRAD_FINALIZE, MMK_K_L2NORM, MMK_K_IJEPA_LOSS_FWD,
   MMK_K_IJEPA_LOSS_BWD, MMK_K_GATHER_ROWS, MMK_K_SCATTER_ROWS, MMK_K_PRED_ASSEMBLE, MMK_K_PRED_ASSEMBLE_BWD,
   MMK_K_EMA, MMK_K_MASK_INDEX, MMK_K_LAYERNORM_FWD, MMK_K_LAYERNORM_BWD, MMK_K_ACT, MMK_K_ATTN_FWD,
-  MMK_K_ATTN_BWD, MMK_K_WGRAD, MMK_K_RECALL, MMK_K_CLIP_FUSED, MMK_K_MLP_GEMM, MMK_K_WIN_ATTN_FWD, MMK_K_WIN_ATTN_BWD, MMK_K_COUNT
+  MMK_K_ATTN_BWD, MMK_K_WGRAD, MMK_K_RECALL, MMK_K_CLIP_FUSED, MMK_K_MLP_GEMM, MMK_K_WIN_ATTN_FWD, MMK_K_WIN_ATTN_BWD, MMK_K_CLIP_BWD_FUSED, MMK_K_COUNT
 };
 int mmk_profile_enable(int on);          /* on=1 start recording (clears), on=0 stop */
 /* resolve recorded events (synchronises on them); fills count[k] and total_ms[k] for k < MMK_K_COUNT */
@@ -91,7 +91,7 @@ int mmk_pack_rows(const void* src, int src_dtype, int n_src, int d, const int32_
 typedef struct {
   const void* x;      /* packed owned rows   [>= r rows, k_pad]            */
   const void* y;      /* packed all columns  [>= c rows, k_pad]            */
-  const void* yT;     /* transpose of y      [k_pad, ldt] (backward only)  */
+  const void* yT;     /* transpose of y      [k_pad, ldt] (backward only; may be NULL for a direction mmk_clip_backward_plan marks fused) */
   int32_t r;          /* owned rows                                         */
   int32_t c;          /* columns                                            */
   int32_t label_off;  /* positive column of row i is label_off + i         */
@@ -102,7 +102,7 @@ typedef struct {
   float* loss_part;   /* fwd out: float[ceil(r/64)] sums of (lse_i - diag_i) over blocks of 64 rows */
   /* backward */
   const float* lse_col; /* float[c]: LSE of the opposite direction for every column */
-  void* g;            /* bwd workspace: [r_pad, ldg] compute type            */
+  void* g;            /* bwd workspace: [r_pad, ldg] compute type (may be NULL for a fused direction) */
   int32_t ldg;        /* >= round_up(c, 128)                                 */
   float c_row, c_col, c_diag;     /* G = c_row*P_row + c_col*P_col - c_diag*[j == label] */
   float s_row, s_col, s_diag;     /* same triple for the d/dscale reduction               */
@@ -191,6 +191,14 @@ int mmk_reduce_sums(const float* const* ptrs, const int32_t* counts, const float
  * dscale_out (float[1], pre-zeroed by the caller); upstream is the device scalar dL/dloss. */
 int mmk_clip_backward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, int compute, const float* scale,
                       const float* upstream, float* dscale_out, void* stream);
+/* Which directions of such a call run as ONE kernel that recomputes its gradient tiles on chip (csrc/clip_bwd.hip: row-sharded
+ * directions, R owned rows against C >> R gathered columns -- what every rank runs at W > 1): fused[k] = 1 means direction k
+ * reads neither `yT` nor `g` (both may be NULL in the call) and leaves `g` unwritten.  Decided from the shapes, the coefficient
+ * mode and the pairing of the descriptors only, so the caller can ask before it builds the transposed operand: no buffer is read,
+ * x, y, yT and the workspaces may be unset.  A mirrored pair is described as in the real call -- the second direction has
+ * g_ready = 1 and the SAME `g` value as the first -- but `g` is only compared here, any distinct non-null tag will do.
+ * No device work. */
+int mmk_clip_backward_plan(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int compute, int32_t* fused);
 
 /* ------------------------------------------------------------------ CLIP loss, one resident-grid launch (small batches)
  * The whole of ContrastiveLoss.forward for up to four LossPairSpecs on ONE rank -- emb[indices] (contrastive.py:290-291),

@@ -22,7 +22,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 F32, BF16, F16 = 0, 1, 2
 COMPUTE_BF16, COMPUTE_F32 = 1, 0
-ABI_VERSION = 7   # include/mmlearn_hip.h MMK_ABI_VERSION this ctypes mirror was written against
+ABI_VERSION = 8   # include/mmlearn_hip.h MMK_ABI_VERSION this ctypes mirror was written against
 
 _DTYPE_TAG = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
@@ -30,7 +30,7 @@ KERNEL_NAMES = [
     "match_ids", "pack_rows", "transpose", "sim_stats", "lse_reduce", "loss_combine", "sim_grad", "grad_gemm",
     "grad_finalize", "l2norm", "ijepa_loss_fwd", "ijepa_loss_bwd", "gather_rows", "scatter_rows", "pred_assemble",
     "pred_assemble_bwd", "ema_update", "mask_to_index", "layernorm_fwd", "layernorm_bwd", "activation", "attn_fwd", "attn_bwd", "wgrad", "recall_ranks", "clip_fused", "mlp_gemm",
-    "win_attn_fwd", "win_attn_bwd",
+    "win_attn_fwd", "win_attn_bwd", "clip_bwd_fused",
 ]
 
 
@@ -100,6 +100,7 @@ _SIGNATURES = {
     "mmk_clip_fused_debug_stamps": [_vp],
     "mmk_match_workspace_ints": [_i, _i],
     "mmk_clip_backward": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "mmk_clip_backward_plan": [_vp, _i, _i, _i, _vp],
     "mmk_l2norm_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mmk_l2norm_fwd_twin": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mmk_l2norm_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -1401,15 +1401,46 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
 
 // ---- the one-kernel recompute-G backward of row-sharded directions (csrc/clip_bwd.hip)
 // A direction takes it when it is a SHARD with a tile pass of its own: bf16, k_pad = 512, no alignment term, not one half of a mirrored
-// pair (those share one tile pass and hand G^T over), at least 1024 columns and enough (row block, split) units to fill half the chip.
-template <typename T>
-static bool bwd_fused_eligible(const mmk_clip_dir* dirs, int k, int k_pad, int n_split, int n_dirs) {
-  if (MMK_DBG_ENV("MMK_CLIP_BWD_FUSED") && atoi(MMK_DBG_ENV("MMK_CLIP_BWD_FUSED")) == 0) return false;   // A/B in debug-switch builds
-  const mmk_clip_dir& d = dirs[k];
-  for (int j = 0; j < n_dirs; ++j)   // a mirrored partner reads this direction's G (transposed, csrc/wgrad.hip): G must exist then
-    if (j != k && dirs[j].g_ready && dirs[j].g == d.g) return false;
-  return sizeof(T) == 2 && k_pad == 512 && d.mode == 0 && !d.g_ready && !d.g_transposed && d.gT == nullptr && d.c >= 1024 &&
-         (long)cdiv(d.r, 64) * n_split * n_dirs >= 128;
+// pair (those share one tile pass and hand G^T over) and at least 1024 columns -- and when the call's directions of that kind, with
+// the column split chosen for them, make at least half a chip of (row block, split) workgroups.  The split is this kernel's own:
+// about 256 workgroups (one per CU: its LDS admits no second), within the slab count the caller sized by mmk_clip_plan at the
+// call's largest shape, at least two 64-column tiles each.  Reads shapes, modes and pairing only (mmk_clip_backward_plan answers
+// before the buffers exist).
+struct BwdFusedPlan {
+  bool fused[MAX_PROBS];
+  int n_split;   // of the fused directions (0: none)
+};
+static BwdFusedPlan bwd_fused_plan(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int compute) {
+  BwdFusedPlan fp{};
+  if (MMK_DBG_ENV("MMK_CLIP_BWD_FUSED") && atoi(MMK_DBG_ENV("MMK_CLIP_BWD_FUSED")) == 0) return fp;   // A/B in debug-switch builds
+  if (compute != MMK_COMPUTE_BF16 || k_pad != 512) return fp;
+  int r_max = 0, c_max = 0, row_blocks = 0, c_pad_min = 1 << 30;
+  for (int k = 0; k < n_dirs; ++k) {
+    r_max = std::max(r_max, dirs[k].r);
+    c_max = std::max(c_max, dirs[k].c);
+  }
+  for (int k = 0; k < n_dirs; ++k) {
+    const mmk_clip_dir& d = dirs[k];
+    bool ok = d.mode == 0 && !d.g_ready && !d.g_transposed && d.gT == nullptr && d.c >= 1024;
+    for (int j = 0; j < n_dirs && ok; ++j)   // a mirrored partner reads this direction's G (transposed, csrc/wgrad.hip): G must exist then
+      if (j != k && dirs[j].g_ready && d.g != nullptr && dirs[j].g == d.g) ok = false;
+    fp.fused[k] = ok;
+    if (ok) {
+      row_blocks += cdiv(d.r, 64);
+      c_pad_min = std::min(c_pad_min, round_up(d.c, 128));
+    }
+  }
+  if (row_blocks == 0) return fp;
+  int32_t cap = 1;
+  mmk_clip_plan(r_max, c_max, k_pad, compute, nullptr, nullptr, &cap);
+  int ns = std::max(1, (256 + row_blocks / 2) / row_blocks);
+  ns = std::min(ns, std::min((int)cap, c_pad_min / 128));
+  if ((long)row_blocks * ns < 128) {   // too little work for this form: the two-launch path tiles finer
+    for (int k = 0; k < n_dirs; ++k) fp.fused[k] = false;
+    return fp;
+  }
+  fp.n_split = ns;
+  return fp;
 }
 
 template <typename T, typename U>
@@ -1430,17 +1461,18 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
   db.n_probs = 0;
   const int c_pad_max = round_up(c_max, 128);
   const int k_per_split = round_up(cdiv(c_pad_max, pl.n_split), bk);
+  const BwdFusedPlan fp = bwd_fused_plan(dirs, n_dirs, k_pad, sizeof(T) == 2 ? MMK_COMPUTE_BF16 : MMK_COMPUTE_F32);
   BwdFusedBatch fz;
   fz.n_probs = 0;
-  fz.n_split = pl.n_split;
-  fz.cols_per_split = round_up(cdiv(c_pad_max, pl.n_split), 64);
+  fz.n_split = std::max(fp.n_split, 1);
+  fz.cols_per_split = round_up(cdiv(c_pad_max, fz.n_split), 64);
   fz.row_blocks = 0;
   fz.dbg = 0;
   for (int k = 0; k < n_dirs; ++k) {
     const mmk_clip_dir& d = dirs[k];
     const int r_pad = round_up(d.r, 128), c_pad = round_up(d.c, 128);
     MMK_REQUIRE(d.ldg >= c_pad && d.ldt >= c_pad, "ldg/ldt must be >= round_up(c, 128)");
-    if (bwd_fused_eligible<T>(dirs, k, k_pad, pl.n_split, n_dirs)) {
+    if (fp.fused[k]) {
       MMK_REQUIRE(d.lse_col != nullptr || (d.c_col == 0.f && d.s_col == 0.f), "lse_col required when c_col/s_col != 0");
       BwdFusedProb& q = fz.p[fz.n_probs++];
       q.x = static_cast<const bf16_t*>(d.x); q.y = static_cast<const bf16_t*>(d.y);
@@ -1451,10 +1483,10 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
       q.s_row = d.s_row; q.s_col = d.s_col; q.s_diag = d.s_diag;
       fz.row_blocks = std::max(fz.row_blocks, cdiv(d.r, 64));
       db.part[db.n_probs] = d.ds_part;
-      db.n[db.n_probs] = cdiv(d.r, 64) * pl.n_split;
+      db.n[db.n_probs] = cdiv(d.r, 64) * fz.n_split;
       db.kappa[db.n_probs] = d.ds_kappa;
       ++db.n_probs;
-      fb.p[k] = FinProb{d.slab, (long)r_pad * k_pad, k_pad, d.r, d.kappa, d.dx, d.dx_rows, d.dx_accumulate, d.src, d.normalize, pl.n_split};
+      fb.p[k] = FinProb{d.slab, (long)r_pad * k_pad, k_pad, d.r, d.kappa, d.dx, d.dx_rows, d.dx_accumulate, d.src, d.normalize, fz.n_split};
       max_r = std::max(max_r, d.r);
       continue;
     }
@@ -1740,9 +1772,14 @@ int mmk_clip_backward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, in
   MMK_REQUIRE(scale && upstream, "null scale/upstream");
   MMK_REQUIRE(d > 0 && d <= k_pad, "bad d");
   const int dt = dirs[0].dx_dtype;
+  const BwdFusedPlan fp = bwd_fused_plan(dirs, n_dirs, k_pad, compute);
   for (int k = 0; k < n_dirs; ++k) {
     const mmk_clip_dir& q = dirs[k];
-    MMK_REQUIRE((q.g_transposed || (q.yT && q.slab)) && (q.lse || q.mode == 1) && q.g && q.ds_part && q.dx, "null backward buffer");
+    if (fp.fused[k])   // one kernel: neither the transposed operand nor G is touched
+      MMK_REQUIRE(q.slab && q.lse && q.ds_part && q.dx, "null backward buffer");
+    else
+      MMK_REQUIRE((q.g_transposed || (q.yT && q.slab)) && (q.lse || q.mode == 1) && q.g && q.ds_part && q.dx,
+                  "null backward buffer (yT and g may only be omitted for the directions mmk_clip_backward_plan marks fused)");
     MMK_REQUIRE(q.dx_dtype == dt, "all directions of one call must share dx_dtype");
     MMK_REQUIRE(!q.dx_accumulate || q.dx_dtype == MMK_F32, "accumulating scatter needs an f32 gradient buffer");
     MMK_REQUIRE(!q.normalize || (q.src && q.src_dtype == q.dx_dtype), "normalize backward needs src of dx dtype");
@@ -1753,6 +1790,14 @@ int mmk_clip_backward(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int d, in
       return clip_backward_impl<bf16_t, U>(dirs, n_dirs, k_pad, d, scale, upstream, dscale_out, st);
     return clip_backward_impl<float, U>(dirs, n_dirs, k_pad, d, scale, upstream, dscale_out, st);
   });
+}
+
+int mmk_clip_backward_plan(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int compute, int32_t* fused) {
+  MMK_REQUIRE(dirs && fused && n_dirs >= 1 && n_dirs <= MAX_PROBS, "bad direction list");
+  MMK_REQUIRE(compute == MMK_COMPUTE_BF16 || compute == MMK_COMPUTE_F32, "bad compute");
+  const BwdFusedPlan fp = bwd_fused_plan(dirs, n_dirs, k_pad, compute);
+  for (int k = 0; k < n_dirs; ++k) fused[k] = fp.fused[k] ? 1 : 0;
+  return 0;
 }
 
 }  // extern "C"

@@ -1,19 +1,25 @@
-// Row-sharded CLIP / InfoNCE backward as ONE kernel that recomputes G: for a direction whose rows are a SHARD of the
-// batch (R owned rows against C >> R gathered columns: what every rank runs at W > 1) the two launches
+// Row-sharded CLIP / InfoNCE backward as ONE kernel that recomputes G: for a direction whose rows are a SHARD of the batch (R owned
+// rows against C >> R gathered columns: what every rank runs at W > 1) the two launches
 //     sim_grad   S = X Y^T again, G = c_row P_row + c_col P_col - c_diag delta -> HBM (R x C bf16)
 //     grad_gemm  dX = G Y (split over C into f32 slabs), reading G back and a TRANSPOSED copy of Y
-// become one.  A workgroup owns 64 owned rows x one column split and walks the split in tiles of 32 columns:
-//     phase S   S^T[32 j x 64 i] = Y_tile X_blk^T, the contraction (D = 512) split over the four waves; the X fragments of a wave's
-//               128-wide k range stay in REGISTERS for the whole kernel (64 VGPRs), the Y tile is an LDS image filled by LDS-DMA
-//     reduce    the four partial tiles meet in LDS; every thread finishes 8 logits: P_row, P_col from the row / column log-sum-exps
-//               (log2 domain), G, the d/dscale term, G rounded to bf16 into a 4-KiB [64 i][32 j] image
+// become one.  A workgroup (4 waves, one per SIMD) owns 64 owned rows x one column split and walks the split in tiles of 64 columns:
+//     phase S   wave (wit, wjt) computes S^T[32 j x 32 i] over the WHOLE contraction (D = 512: 32 MFMAs); its X fragments stay in
+//               REGISTERS for the whole kernel (128 VGPRs), the Y tile is an LDS image filled by LDS-DMA, read as row fragments that
+//               run eight k steps ahead of their MFMAs; the NEXT tile's DMA pieces are issued between the MFMAs
+//     G         each lane finishes 16 logits of one owned row: P_row, P_col from the row / column log-sum-exps (log2 domain), G, the
+//               d/dscale term; G rounded to bf16 into an 8-KiB [64 i][64 j] image.  Packed f32 arithmetic, no branches
 //     phase D   dX[64 i x 512] += G Y_tile: G row fragments x TRANSPOSED reads (ds_read_b64_tr_b16) of the SAME Y image -- no
 //               transposed copy of Y exists, G never leaves the chip; a wave owns 128 of the 512 output columns (8 accumulator tiles)
 // The f32 tile goes to the split's slab; grad_finalize (clip.hip) sums the slabs as before.  One image format serves the row reads of
-// phase S and the transposed reads of phase D: the [rows][64] sub-images of csrc/attention.hip (128-byte rows, chunk ^ img_swz(row)).
-// Per tile and wave 16 + 16 MFMAs (v_mfma_f32_32x32x16_bf16) against the 2 x 8 + recompute of the two-launch form, and HBM sees the
-// operands once per (split, row-block group on one XCD) plus the slabs: no G (2 x 33 MB at R = 1024 x C = 8192), no transposed Y.
-// Eligibility (clip.hip): bf16 compute, k_pad = 512, a direction with a tile pass of its own (not mirrored), no alignment term.
+// phase S and the transposed reads of phase D: the [32 rows][64 k] sub-images of csrc/attention.hip (128-byte rows, chunk ^ swz(row)).
+// Two barriers per 64 columns.  LDS: two 64-KiB Y tiles + the G image = 137 KiB, so ONE workgroup per CU and one wave per SIMD:
+// nothing overlaps a wave's own latencies, which is why the reads, waits and DMA issue are placed by hand.  A third Y tile would let
+// the G arithmetic of tile t run under the MFMAs of tile t + 1; 3 x 64 KiB does not fit (measured split of the 46 us at R = 1024 x
+// C = 8192, two directions: MFMA floor 14 us, G arithmetic ~9 us exposed, prologue + slab stores + launch ~17 us;
+// profiles/r06_loss_shard_fused_bwd.json, which also keeps the first form of this kernel -- 32-column tiles with the contraction
+// split over the waves and an LDS reduction of the partial tiles: 101 us, slower than the two launches' 69 us).
+// HBM sees the operands once per (split, row-block group on one XCD) plus the slabs: no G (2 x 33 MB at R = 1024 x C = 8192), no
+// transposed Y.  Eligibility (clip.hip): bf16 compute, k_pad = 512, a direction with a tile pass of its own whose G nobody else reads.
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -323,7 +329,7 @@ int launch_clip_bwd_fused(const BwdFusedBatch& b, const float* scale, hipStream_
   bb.dbg = MMK_DBG_ENV("MMK_CB_DBG") ? atoi(MMK_DBG_ENV("MMK_CB_DBG")) : 0;
   const int units = b.n_probs * b.n_split;
   const int grid = 8 * cdiv(units, 8) * b.row_blocks;
-  ProfEvents pe(MMK_K_SIM_GRAD);
+  ProfEvents pe(MMK_K_CLIP_BWD_FUSED);
   hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), CB_LDS, st, pe.start, pe.stop, 0, bb, scale);
   MMK_LAUNCH_CHECK();
   return 0;

@@ -146,7 +146,7 @@ const char* mmk_kernel_name(int id) {
       "match_ids", "pack_rows", "transpose", "sim_stats", "lse_reduce", "loss_combine", "sim_grad", "grad_gemm",
       "grad_finalize", "l2norm", "ijepa_loss_fwd", "ijepa_loss_bwd", "gather_rows", "scatter_rows", "pred_assemble",
       "pred_assemble_bwd", "ema_update", "mask_to_index", "layernorm_fwd", "layernorm_bwd", "activation", "attn_fwd",
-      "attn_bwd", "wgrad", "recall_ranks", "clip_fused", "mlp_gemm", "win_attn_fwd", "win_attn_bwd"};
+      "attn_bwd", "wgrad", "recall_ranks", "clip_fused", "mlp_gemm", "win_attn_fwd", "win_attn_bwd", "clip_bwd_fused"};
   if (id < 0 || id >= MMK_K_COUNT) return "?";
   return names[id];
 }

@@ -381,10 +381,39 @@ def reduce_sums(parts: Sequence[torch.Tensor], weights: Sequence[float], separat
     return out
 
 
+def _backward_plan(shapes: Sequence[tuple], k_pad: int, compute: int) -> list:
+    """``[(r, c, mode, mirror_of), ...]`` (``mirror_of``: index of the direction whose gradient tiles this one reuses, or None) ->
+    per direction, whether ``mmk_clip_backward`` runs it as ONE kernel that recomputes its tiles on chip (csrc/clip_bwd.hip): such a
+    direction needs neither the transposed operand nor the G workspace.  A host-side query, no buffers involved."""
+    arr = (ClipDir * len(shapes))()
+    for k, (r, c, mode, mirror_of) in enumerate(shapes):
+        e = arr[k]
+        e.r, e.c, e.mode = r, c, mode
+        if mirror_of is not None:   # described as in the real call: same g, g_ready on the second; only compared, never read
+            e.g_ready = 1
+            e.g = arr[mirror_of].g = C.c_void_p(mirror_of + 1)
+    flags = (C.c_int32 * len(shapes))()
+    check(_lib.lib().mmk_clip_backward_plan(C.cast(arr, C.c_void_p), len(shapes), k_pad, compute, C.cast(flags, C.c_void_p)))
+    return [bool(f) for f in flags]
+
+
+def backward_recomputes_on_chip(r: int, c: int, d: int, compute: int, n_dirs: int = 2) -> bool:
+    """Would ``n_dirs`` unpaired cross-entropy directions of r owned rows x c columns each take the one-kernel backward?  What
+    ``losses`` asks before it packs the gathered operands: such directions need no transposed copy (``clip_backward`` makes one
+    on demand if the answer turns out different for the directions it is finally given)."""
+    return all(_backward_plan([(r, c, 0, None)] * n_dirs, round_up(d, 64), compute))
+
+
+def transposed_operand(y: torch.Tensor, c: int, compute: int) -> torch.Tensor:
+    """[k_pad, c_pad] transpose of a packed operand that was packed without one."""
+    return pack_rows(y, None, c, False, compute, True)[1]
+
+
 def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.Tensor, upstream: torch.Tensor,
                   dscale: Optional[torch.Tensor]) -> None:
     """dX for every direction (scattered into dir.dx) and dscale += d loss / d scale.  Mirrored directions share one
-    gradient-tile pass: it stores G for the first and G^T, which is the second one's G."""
+    gradient-tile pass: it stores G for the first and G^T, which is the second one's G.  Row-sharded directions run as one kernel
+    each that keeps G on chip (``_backward_plan``): no G workspace, ``y_t`` may be None."""
     dev = scale.device
     assert upstream.dtype == torch.float32 and upstream.is_cuda
     cdt = compute_torch_dtype(compute)
@@ -403,6 +432,8 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.
         keep = []
         gbuf = {}
         in_chunk = {id(x) for x in chunk}
+        pos = {id(x): k for k, x in enumerate(chunk)}
+        on_chip = _backward_plan([(x.r, x.c, x.mode, pos.get(id(mirror_src.get(id(x))))) for x in chunk], k_pad, compute)
         for k, dr in enumerate(chunk):
             r_pad, c_pad = round_up(dr.r, 128), round_up(dr.c, 128)
             _, n_grad_blocks, _ = _plan(dr.r, dr.c, k_pad, compute)
@@ -411,14 +442,18 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.
             tn = ready and gbuf[id(src)][1] is None     # the mirror source kept G only: this direction reads it transposed
             if tn:
                 g = gbuf[id(src)][0]
+            elif on_chip[k]:
+                g = None
             else:
                 g = gbuf[id(src)][1] if ready else torch.empty((r_pad, c_pad), dtype=cdt, device=dev)
+            if dr.y_t is None and not on_chip[k]:   # packed on the expectation of the one-kernel backward, which this call does not take
+                dr.y_t = transposed_operand(dr.y, dr.c, compute)
             slab = torch.empty((1 if tn else n_split, 1 if tn else r_pad, k_pad), dtype=torch.float32, device=dev)
             ds_part = torch.empty(n_grad_blocks, dtype=torch.float32, device=dev)
             keep += [g, slab, ds_part]
             e = arr[k]
             e.x, e.y, e.yT, e.r, e.c, e.label_off = ptr(dr.x), ptr(dr.y), ptr(dr.y_t), dr.r, dr.c, dr.label_off
-            e.ldt = dr.y_t.shape[1]
+            e.ldt = dr.y_t.shape[1] if dr.y_t is not None else c_pad
             e.lse, e.lse_col, e.g, e.ldg = ptr(dr.lse), ptr(dr.lse_col), ptr(g), c_pad
             e.c_row, e.c_col, e.c_diag = dr.c_row, dr.c_col, dr.c_diag
             e.s_row, e.s_col, e.s_diag = dr.s_row, dr.s_col, dr.s_diag

@@ -294,12 +294,25 @@ class _Run:
             return loss
 
         # ---- operand packing per pair
+        n_dirs = min(2 * len(self.pairs), K.MAX_DIRS_PER_CALL)
         for p in self.pairs:
             ma, mb, mg = p.ma, p.mb, p.mg
             va, vb = views[ma], views[mb]
+            # The transposed copies feed the dX = G Y GEMM of the two-launch backward.  At W > 1 every direction is a row shard
+            # (this rank's rows against all gathered columns), which at CLIP widths runs as one kernel that reads Y^T out of the
+            # row-major tile it already holds (csrc/clip_bwd.hip): no copy then.  Decided on this rank's row counts (side a's
+            # transpose serves the direction whose rows are side b's, and the other way round; a side without rows here has no
+            # direction); should the directions come out different in the end, clip_backward makes the copy it needs.
+            def wants_t(own_rows_other_side: int) -> bool:
+                if not self.needs_grad:
+                    return False
+                if W == 1:
+                    return True
+                return own_rows_other_side > 0 and not K.backward_recomputes_on_chip(own_rows_other_side, mg.n, va.src.shape[1], self.compute, n_dirs)
+
             (p.a_g, p.a_gt), (p.b_g, p.b_gt) = K.pack_rows_many(
-                [(va.src, _compose(va.rows, mg.idx_a), mg.n, o.l2_normalize, self.needs_grad),
-                 (vb.src, _compose(vb.rows, mg.idx_b), mg.n, o.l2_normalize, self.needs_grad)], self.compute)
+                [(va.src, _compose(va.rows, mg.idx_a), mg.n, o.l2_normalize, wants_t(vb.counts[rank])),
+                 (vb.src, _compose(vb.rows, mg.idx_b), mg.n, o.l2_normalize, wants_t(va.counts[rank]))], self.compute)
             if local_mode:
                 has_local = va.local is not None and vb.local is not None
                 if not has_local:
@@ -528,8 +541,8 @@ class _Run:
                     p.col_perm[role] = perm
                     other_view, other_idx = (vb, mg.idx_b) if role == "a" else (va, mg.idx_a)
                     x, _ = K.pack_rows(view.src, _compose(view.rows, idx[sel_t].contiguous()), r, o.l2_normalize, self.compute, False)
-                    y, yt = K.pack_rows(other_view.src, _compose(other_view.rows, other_idx[perm].contiguous()), R, o.l2_normalize,
-                                        self.compute, self.needs_grad)
+                    y, yt = K.pack_rows(other_view.src, _compose(other_view.rows, other_idx[perm].contiguous()), R, o.l2_normalize, self.compute,
+                                        self.needs_grad and not K.backward_recomputes_on_chip(r, R, view.src.shape[1], self.compute, 2))
                     label_off = 0
                     dx_rows = (idx[sel_t] - lo).to(torch.int32).contiguous()
                 dr = K.Direction(x=x, y=y, y_t=yt, r=r, c=R, label_off=label_off,

@@ -16,7 +16,8 @@ from mmlearn_amd.kernels import Direction, Match  # dataclasses only  # noqa: F4
 from oracle import clip_oracle as co
 
 MAX_DIRS_PER_CALL = 8
-CALLS = {"pack_rows": 0, "clip_forward": 0, "clip_backward": 0, "match_ids": 0}
+CALLS = {"pack_rows": 0, "clip_forward": 0, "clip_backward": 0, "match_ids": 0, "transposes": 0}
+ON_CHIP_BACKWARD = False   # what backward_recomputes_on_chip answers: the tests flip it to walk both of the host's packing branches
 
 
 def require_gpu(t, what="tensor"):
@@ -52,11 +53,17 @@ def pack_rows(src, idx, r, normalize, compute, want_transpose):
     r_pad, k_pad = round_up(max(r, 1), 128), round_up(d, 64)
     dst = torch.zeros(r_pad, k_pad, dtype=torch.float64)
     dst[:r, :d] = rows
+    CALLS["transposes"] += int(bool(want_transpose))
     return dst, (dst.T.contiguous() if want_transpose else None)
 
 
 def pack_rows_many(reqs, compute):
     return [pack_rows(*q[:4], compute, q[4]) for q in reqs]
+
+
+def backward_recomputes_on_chip(r, c, d, compute, n_dirs=2):
+    """contract of kernels.backward_recomputes_on_chip: True = the directions need no transposed operand (y_t may be None)"""
+    return ON_CHIP_BACKWARD
 
 
 def clip_forward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.Tensor, loss_weights=None) -> None:
@@ -115,7 +122,10 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale, upstre
     up = upstream.double().item()
     for dr in dirs:
         x, y = dr.x[: dr.r], dr.y[: dr.c]
-        assert torch.equal(dr.y_t[:, : dr.c], y.T), "yT must be the transpose of y"
+        if dr.y_t is not None:   # (None: packed for the one-kernel backward, include/mmlearn_hip.h mmk_clip_backward_plan)
+            assert torch.equal(dr.y_t[:, : dr.c], y.T), "yT must be the transpose of y"
+        else:
+            assert ON_CHIP_BACKWARD and dr.mode == 0
         t = x @ y.T
         v = s * t
         if dr.mode == 1:

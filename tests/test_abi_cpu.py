@@ -49,7 +49,7 @@ def test_shipped_library_reads_no_experiment_switches(built):
 
 def test_library_loads_without_gpu(built):
     lib = built.lib()
-    assert lib.mmk_abi_version() == 7
+    assert lib.mmk_abi_version() == 8
     assert lib.mmk_kernel_name(3) == b"sim_stats"
     for k, name in enumerate(built.KERNEL_NAMES):
         assert lib.mmk_kernel_name(k).decode() == name

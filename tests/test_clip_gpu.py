@@ -393,3 +393,110 @@ def test_bf16_rows_with_a_repeated_id_in_one_modality_only(l2, loss_path):
     res = _run_hip({"rgb": a, "text": b}, ids, 1 / 0.07, pairs, dtype="bfloat16", l2_normalize=l2)
     ref = co.contrastive_loss({"rgb": a, "text": b}, ids, 1 / 0.07, pairs, l2norm=l2)
     _check(res, ref["loss"], ref["grads"], ref["dscale"], TOL["bfloat16"], (l2, loss_path))
+
+
+# ------------------------------------------------------------------ row-sharded directions: the one-kernel backward (csrc/clip_bwd.hip)
+def _shard_reference(x, y, r, c, p0, scale, lse, lse_col, coef, kappa, ds_kappa):
+    """float64 restatement of mmk_clip_backward for one direction from the PACKED (rounded) operands: G = c_row P_row + c_col P_col
+    - c_diag [j = label], dX = kappa * scale * G Y, d/dscale = ds_kappa * sum (s_row P_row + s_col P_col - s_diag [j = label]) * T
+    (include/mmlearn_hip.h, mmk_clip_dir)."""
+    X, Y = x[:r].double(), y[:c].double()
+    T = X @ Y.T
+    V = scale * T
+    pr = torch.exp(V - lse[:r].double()[:, None])
+    pc = torch.exp(V - lse_col[:c].double()[None, :]) if lse_col is not None else torch.zeros_like(V)
+    eye = torch.zeros_like(V)
+    eye[torch.arange(r), p0 + torch.arange(r)] = 1.0
+    c_row, c_col, c_diag, s_row, s_col, s_diag = coef
+    G = c_row * pr + c_col * pc - c_diag * eye
+    GS = s_row * pr + s_col * pc - s_diag * eye
+    return kappa * scale * (G @ Y), ds_kappa * float((GS * T).sum())
+
+
+@pytest.mark.parametrize("r,c,p0,d,col_term", [(1024, 8192, 3072, 512, True), (1024, 2048, 1024, 512, False), (1000, 3000, 517, 500, True),
+                                               (640, 1100, 0, 512, True), (2048, 4096, 2048, 450, False)])
+def test_sharded_backward_one_kernel_vs_float64(r, c, p0, d, col_term):
+    """A rank's row shards (r owned rows against c gathered columns, label(i) = p0 + i) run their backward as ONE kernel that
+    recomputes the similarity tiles and keeps G on chip.  Against a float64 product of the same packed operands: ragged row
+    blocks and column tiles (r, c off the 64 / 128 grids, d < k_pad), label columns in the middle of a tile, with and without the
+    column-softmax term (gather_with_grad), both directions of the pair in one launch, and no transposed operand handed in."""
+    from mmlearn_amd import _lib, kernels as K
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(r + c)
+    A = torch.nn.functional.normalize(torch.randn(c, d, generator=g), dim=-1).to(dev).bfloat16()
+    B = torch.nn.functional.normalize(0.6 * A.float().cpu() + torch.nn.functional.normalize(torch.randn(c, d, generator=g), dim=-1), dim=-1).to(dev).bfloat16()
+    comp = _lib.COMPUTE_BF16
+    assert K.backward_recomputes_on_chip(r, c, d, comp, 2)
+    scale = torch.tensor([1 / 0.07], device=dev)
+    upstream = torch.ones((), device=dev)
+    (ag, _), (bg, _) = K.pack_rows_many([(A, None, c, False, False), (B, None, c, False, False)], comp)
+    kap = 1.0 / (2.0 * r)
+    coef = (1.0, 1.0, 2.0, 1.0, 0.0, 1.0) if col_term else (1.0, 0.0, 1.0, 1.0, 0.0, 1.0)
+    dirs = []
+    for x, y in ((K.slice_packed(ag, p0), bg), (K.slice_packed(bg, p0), ag)):
+        dr = K.Direction(x=x, y=y, y_t=None, r=r, c=c, label_off=p0, kappa=kap, ds_kappa=kap)
+        dr.c_row, dr.c_col, dr.c_diag, dr.s_row, dr.s_col, dr.s_diag = coef
+        dirs.append(dr)
+    K.clip_forward(dirs, d, comp, scale)
+    # column log-sum-exps: what the all-reduce delivers -- here the exact ones of the full [c, c] problem's other direction
+    full = (float(scale) * (ag[:c].double() @ bg[:c].double().T))
+    lse_cols = (torch.logsumexp(full, dim=0).float(), torch.logsumexp(full, dim=1).float())   # direction 0: columns = rows of B
+    for dr, lc in zip(dirs, lse_cols):
+        dr.lse_col = lc.contiguous() if col_term else None
+        dr.dx = torch.zeros((r, d), dtype=torch.bfloat16, device=dev)
+    ds = torch.zeros(1, device=dev)
+    _lib.profile_read()
+    _lib.profile_enable(True)
+    K.clip_backward(dirs, d, comp, scale, upstream, ds)
+    torch.cuda.synchronize()
+    prof = _lib.profile_read()
+    _lib.profile_enable(False)
+    assert prof["clip_bwd_fused"][0] == 1 and prof.get("grad_gemm", (0, 0))[0] == 0 and prof.get("sim_grad", (0, 0))[0] == 0, prof
+    ds_ref = 0.0
+    for dr in dirs:
+        ref, dsr = _shard_reference(dr.x, dr.y, r, c, p0, float(scale), dr.lse, dr.lse_col, coef, kap, kap)
+        ds_ref += dsr
+        got = dr.dx.double()
+        err = (got - ref[:, :d]).abs().max().item()
+        assert err <= 1e-2 * ref.abs().max().item(), (err, ref.abs().max().item())
+        assert (got - ref[:, :d]).abs().mean().item() <= 2e-3 * ref.abs().max().item()
+    assert abs(float(ds) - ds_ref) <= 1e-2 * max(1e-3, abs(ds_ref)), (float(ds), ds_ref)
+
+
+def test_backward_plan_and_the_transposed_operand_made_on_demand():
+    """mmk_clip_backward_plan: which directions keep G on chip (bf16, k_pad 512, unpaired, >= 1024 columns, enough row blocks).  A
+    direction that is NOT such a one but arrives without its transposed operand gets it made by clip_backward: same bits as with
+    the operand packed up front."""
+    from mmlearn_amd import _lib, kernels as K
+
+    bf, f32 = _lib.COMPUTE_BF16, _lib.COMPUTE_F32
+    assert K._backward_plan([(1024, 8192, 0, None)] * 2, 512, bf) == [True, True]
+    assert K._backward_plan([(1024, 8192, 0, None)] * 2, 512, f32) == [False, False]          # f32 arithmetic
+    assert K._backward_plan([(1024, 8192, 0, None)] * 2, 256, bf) == [False, False]           # another width
+    assert K._backward_plan([(1024, 512, 0, None)] * 2, 512, bf) == [False, False]            # few columns
+    assert K._backward_plan([(64, 8192, 0, None)] * 2, 512, bf) == [False, False]             # one row block: not half a chip of work
+    assert K._backward_plan([(2048, 2048, 0, None), (2048, 2048, 0, 0)], 512, bf) == [False, False]   # mirrored pair: one tile pass, G handed over
+    assert not K.backward_recomputes_on_chip(1024, 8192, 200, bf, 2) and K.backward_recomputes_on_chip(1024, 8192, 500, bf, 2)
+
+    dev = _dev()
+    r, c, d, p0 = 256, 768, 96, 256
+    g = torch.Generator().manual_seed(5)
+    A = torch.nn.functional.normalize(torch.randn(c, d, generator=g), dim=-1).to(dev)
+    B = torch.nn.functional.normalize(torch.randn(c, d, generator=g), dim=-1).to(dev)
+    scale, upstream = torch.tensor([1 / 0.07], device=dev), torch.ones((), device=dev)
+    outs = []
+    for with_t in (True, False):
+        (ag, agt), (bg, bgt) = K.pack_rows_many([(A, None, c, False, with_t), (B, None, c, False, with_t)], f32)
+        dirs = [K.Direction(x=K.slice_packed(ag, p0), y=bg, y_t=bgt, r=r, c=c, label_off=p0, kappa=0.5 / r, ds_kappa=0.5 / r),
+                K.Direction(x=K.slice_packed(bg, p0), y=ag, y_t=agt, r=r, c=c, label_off=p0, kappa=0.5 / r, ds_kappa=0.5 / r)]
+        K.clip_forward(dirs, d, f32, scale)
+        for dr in dirs:
+            dr.c_row, dr.c_col, dr.c_diag, dr.s_row, dr.s_col, dr.s_diag = 1.0, 0.0, 1.0, 1.0, 0.0, 1.0   # local loss: no column term
+            dr.dx = torch.zeros((r, d), dtype=torch.float32, device=dev)
+        ds = torch.zeros(1, device=dev)
+        K.clip_backward(dirs, d, f32, scale, upstream, ds)
+        assert all(dr.y_t is not None for dr in dirs)
+        outs.append((dirs[0].dx.clone(), dirs[1].dx.clone(), ds.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)

@@ -56,9 +56,12 @@ def _worker(rank, world, port, case_names, q, done):
                 s.grad = None
                 fn = L.ContrastiveLoss(local_loss=bool(c["local_loss"]), gather_with_grad=bool(c["gather_with_grad"]),
                                        static_shapes=static is True)
+                # this variant also takes the "backward keeps G on chip" packing branch: no transposed operand may be asked for
+                fake_kernels.ON_CHIP_BACKWARD = static == "paired"
                 if static == "paired":   # wire-format hint: identity pairing only when EVERY rank's batch is paired
-                    before = fake_kernels.CALLS["match_ids"]
+                    before, before_t = fake_kernels.CALLS["match_ids"], fake_kernels.CALLS["transposes"]
                     loss = fn(embs, ids, s, specs, fully_paired=hint)
+                    assert fake_kernels.CALLS["transposes"] == before_t or "alignment" in name, "transposed operands packed for the one-kernel backward"
                     if all(flags):
                         assert fake_kernels.CALLS["match_ids"] == before, "paired batch must not run the matcher"
                     else:

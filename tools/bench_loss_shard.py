@@ -34,8 +34,10 @@ def main():
     comp = _lib.COMPUTE_BF16
     kg = 1.0 / (2.0 * C)
 
+    want_t = not K.backward_recomputes_on_chip(R, C, D, comp, 2)   # as mmlearn_amd.losses decides: no transposed copies for the one-kernel backward
+
     def step():
-        (ag, agt), (bg, bgt) = K.pack_rows_many([(A, None, C, False, True), (B, None, C, False, True)], comp)
+        (ag, agt), (bg, bgt) = K.pack_rows_many([(A, None, C, False, want_t), (B, None, C, False, want_t)], comp)
         dirs = []
         for x, y, yt in ((K.slice_packed(ag, p0), bg, bgt), (K.slice_packed(bg, p0), ag, agt)):
             dirs.append(K.Direction(x=x, y=y, y_t=yt, r=R, c=C, label_off=p0, kappa=kg, ds_kappa=kg))

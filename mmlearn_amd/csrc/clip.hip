@@ -1404,7 +1404,7 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
 // pair (those share one tile pass and hand G^T over) and at least 1024 columns -- and when the call's directions of that kind, with
 // the column split chosen for them, make at least half a chip of (row block, split) workgroups.  The split is this kernel's own:
 // about 256 workgroups (one per CU: its LDS admits no second), within the slab count the caller sized by mmk_clip_plan at the
-// call's largest shape, at least two 64-column tiles each.  Reads shapes, modes and pairing only (mmk_clip_backward_plan answers
+// call's largest shape, at least two 64-column tiles each, whole rounds of the chip preferred.  Reads shapes, modes and pairing only (mmk_clip_backward_plan answers
 // before the buffers exist).
 struct BwdFusedPlan {
   bool fused[MAX_PROBS];
@@ -1433,8 +1433,18 @@ static BwdFusedPlan bwd_fused_plan(const mmk_clip_dir* dirs, int n_dirs, int k_p
   if (row_blocks == 0) return fp;
   int32_t cap = 1;
   mmk_clip_plan(r_max, c_max, k_pad, compute, nullptr, nullptr, &cap);
-  int ns = std::max(1, (256 + row_blocks / 2) / row_blocks);
-  ns = std::min(ns, std::min((int)cap, c_pad_min / 128));
+  // the split that minimises (rounds of 256 workgroups) x (per-workgroup fixed cost + its tiles); the fixed cost -- prologue, slab
+  // stores -- is about eight tile times (measured: ~17 us against ~2 us per 64-column tile)
+  const int ns_max = std::max(1, std::min((int)cap, c_pad_min / 128));
+  int ns = 1;
+  long best = -1;
+  for (int s = 1; s <= ns_max; ++s) {
+    const long cost = (long)cdiv(row_blocks * s, 256) * (8 + cdiv(c_pad_min / 64, s));
+    if (best < 0 || cost < best) {
+      best = cost;
+      ns = s;
+    }
+  }
   if ((long)row_blocks * ns < 128) {   // too little work for this form: the two-launch path tiles finer
     for (int k = 0; k < n_dirs; ++k) fp.fused[k] = false;
     return fp;
@@ -1468,6 +1478,8 @@ static int clip_backward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, i
   fz.cols_per_split = round_up(cdiv(c_pad_max, fz.n_split), 64);
   fz.row_blocks = 0;
   fz.dbg = 0;
+  fz.groups = 1;
+  fz.rows_per_group = 0;
   for (int k = 0; k < n_dirs; ++k) {
     const mmk_clip_dir& d = dirs[k];
     const int r_pad = round_up(d.r, 128), c_pad = round_up(d.c, 128);

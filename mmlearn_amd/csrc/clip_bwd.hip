@@ -70,9 +70,11 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
   const int wit = wave & 1, wjt = wave >> 1;   // phase S: this wave's 32 x 32 tile of the 64 x 64 logits
   // unit map: workgroups are dealt to the XCDs round-robin; all row blocks of a (problem, split) unit read the same 1 MiB of Y, so a
   // unit lives on ONE XCD (speed only)
+  // (with fewer than 8 units the row blocks of a unit are dealt to `groups` XCDs, so that all eight are busy)
   const int lin = blockIdx.x, xcd = lin & 7, jj_ = lin >> 3;
-  const int unit = xcd + 8 * (jj_ / batch.row_blocks), rb = jj_ % batch.row_blocks;
-  if (unit >= batch.n_probs * batch.n_split) return;
+  const int vunit = xcd + 8 * (jj_ / batch.rows_per_group);
+  const int unit = vunit / batch.groups, rb = (vunit % batch.groups) * batch.rows_per_group + jj_ % batch.rows_per_group;
+  if (unit >= batch.n_probs * batch.n_split || rb >= batch.row_blocks) return;
   const int split = unit % batch.n_split;
   const BwdFusedProb& p = batch.p[unit / batch.n_split];
   const int i0 = rb * CB_ROWS;
@@ -328,7 +330,9 @@ int launch_clip_bwd_fused(const BwdFusedBatch& b, const float* scale, hipStream_
   BwdFusedBatch bb = b;
   bb.dbg = MMK_DBG_ENV("MMK_CB_DBG") ? atoi(MMK_DBG_ENV("MMK_CB_DBG")) : 0;
   const int units = b.n_probs * b.n_split;
-  const int grid = 8 * cdiv(units, 8) * b.row_blocks;
+  bb.groups = units < 8 ? cdiv(8, units) : 1;
+  bb.rows_per_group = cdiv(b.row_blocks, bb.groups);
+  const int grid = 8 * cdiv(units * bb.groups, 8) * bb.rows_per_group;
   ProfEvents pe(MMK_K_CLIP_BWD_FUSED);
   hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), CB_LDS, st, pe.start, pe.stop, 0, bb, scale);
   MMK_LAUNCH_CHECK();

@@ -100,6 +100,7 @@ struct BwdFusedProb {
 struct BwdFusedBatch {
   BwdFusedProb p[MAX_PROBS];
   int n_probs, n_split, cols_per_split, row_blocks;   // cols_per_split: multiple of 64; row_blocks = max over the problems
+  int groups, rows_per_group;                         // set by the launcher: the unit map (clip_bwd.hip)
   int dbg;                                            // debug-switch builds only (MMK_CB_DBG): timing ablations
 };
 int launch_clip_bwd_fused(const BwdFusedBatch& b, const float* scale, hipStream_t st);

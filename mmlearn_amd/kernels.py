@@ -27,6 +27,11 @@ MAX_DIRS_PER_CALL = 8
 BOUNDED_SOFTMAX = True    # False: never hand the row norms to the tile kernels -> per-row / per-column maxima everywhere
 PAIR_MIRRORS = True       # False: the two directions of a pair on one rank as two tile passes (round-1 behaviour)
 TN_MIN_ROWS = 2048        # from this many rows a mirrored pair stores G once; the mirror's dX uses the transposed-read kernel
+ONE_KERNEL_PAIRS = True   # backward of a mirrored pair of >= TN_MIN_ROWS rows on one rank: when each direction alone would run as one
+                          # kernel that keeps G on chip (csrc/clip_bwd.hip), the pair is NOT tied (no shared tile pass, no G, no transposed
+                          # operands).  Measured (tools/probes/pair_backward_ab.py, device us fwd + bwd, untied / tied): 2048 rows 80 / 109,
+                          # 3072 129 / 153, 4096 154 / 181, 8192 414 / 447; below 2048 rows the tied form has no third launch and wins
+                          # (1280: 74 / 68, 1536: 81 / 78).  A/B switch
 
 _SEAMS = ("BOUNDED_SOFTMAX", "PAIR_MIRRORS", "TN_MIN_ROWS", "FUSED_LOSS")
 _seam_lock = threading.RLock()
@@ -404,6 +409,11 @@ def backward_recomputes_on_chip(r: int, c: int, d: int, compute: int, n_dirs: in
     return all(_backward_plan([(r, c, 0, None)] * n_dirs, round_up(d, 64), compute))
 
 
+def pair_runs_untied(n: int, d: int, compute: int, n_dirs: int = 2) -> bool:
+    """A mirrored pair of n x n directions on one rank: will ``clip_backward`` run its halves as two one-kernel directions?"""
+    return bool(ONE_KERNEL_PAIRS) and n >= _tn_min_rows() and backward_recomputes_on_chip(n, n, d, compute, n_dirs)
+
+
 def transposed_operand(y: torch.Tensor, c: int, compute: int) -> torch.Tensor:
     """[k_pad, c_pad] transpose of a packed operand that was packed without one."""
     return pack_rows(y, None, c, False, compute, True)[1]
@@ -421,6 +431,13 @@ def clip_backward(dirs: Sequence[Direction], d: int, compute: int, scale: torch.
     for a, b in _pair_up(dirs, backward=True):
         if b is not None:
             mirror_src[id(b)] = a
+    if mirror_src and ONE_KERNEL_PAIRS:
+        for i0 in range(0, len(dirs), MAX_DIRS_PER_CALL):
+            chunk = dirs[i0:i0 + MAX_DIRS_PER_CALL]
+            alone = _backward_plan([(x.r, x.c, x.mode, None) for x in chunk], chunk[0].x.shape[1], compute)
+            for k, x in enumerate(chunk):   # (the two halves of a pair have the same shape: flagged together or not at all)
+                if alone[k] and x.r >= _tn_min_rows() and id(x) in mirror_src:
+                    del mirror_src[id(x)]
     for i0 in range(0, len(dirs), MAX_DIRS_PER_CALL):
         chunk = dirs[i0:i0 + MAX_DIRS_PER_CALL]
         if any(id(x) in mirror_src for x in chunk[:1]):   # a pair must not straddle two calls

@@ -306,8 +306,8 @@ class _Run:
             def wants_t(own_rows_other_side: int) -> bool:
                 if not self.needs_grad:
                     return False
-                if W == 1:
-                    return True
+                if W == 1:   # one rank: the pair's two directions, each over all mg.n rows and columns
+                    return not K.pair_runs_untied(mg.n, va.src.shape[1], self.compute, n_dirs)
                 return own_rows_other_side > 0 and not K.backward_recomputes_on_chip(own_rows_other_side, mg.n, va.src.shape[1], self.compute, n_dirs)
 
             (p.a_g, p.a_gt), (p.b_g, p.b_gt) = K.pack_rows_many(

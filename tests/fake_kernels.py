@@ -17,6 +17,7 @@ from oracle import clip_oracle as co
 
 MAX_DIRS_PER_CALL = 8
 CALLS = {"pack_rows": 0, "clip_forward": 0, "clip_backward": 0, "match_ids": 0, "transposes": 0}
+ONE_KERNEL_PAIRS = True
 ON_CHIP_BACKWARD = False   # what backward_recomputes_on_chip answers: the tests flip it to walk both of the host's packing branches
 
 
@@ -59,6 +60,10 @@ def pack_rows(src, idx, r, normalize, compute, want_transpose):
 
 def pack_rows_many(reqs, compute):
     return [pack_rows(*q[:4], compute, q[4]) for q in reqs]
+
+
+def pair_runs_untied(n, d, compute, n_dirs=2):
+    return False
 
 
 def backward_recomputes_on_chip(r, c, d, compute, n_dirs=2):

@@ -249,6 +249,7 @@ def test_transposed_read_gradient_equals_stored_transpose(n, d, monkeypatch):
     b = torch.nn.functional.normalize(0.5 * a.float() + torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1), dim=-1).bfloat16()
     ids = torch.stack([torch.zeros(n, dtype=torch.long), torch.arange(n)], 1).to(dev)
     out = {}
+    monkeypatch.setattr(K, "ONE_KERNEL_PAIRS", False)   # (at k_pad = 512 the pair would otherwise run untied, on the one-kernel backward)
     for mode, rows in (("tn", 1024), ("gt", 1000000000)):
         monkeypatch.setattr(K, "TN_MIN_ROWS", rows)
         ea, eb = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
@@ -500,3 +501,36 @@ def test_backward_plan_and_the_transposed_operand_made_on_demand():
         outs.append((dirs[0].dx.clone(), dirs[1].dx.clone(), ds.clone()))
     for x, y in zip(*outs):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("n,d", [(2048, 512), (3000, 480)])
+def test_untied_pair_backward_equals_tied(n, d, monkeypatch):
+    """From 2048 rows a mirrored pair on one rank runs its backward as two one-kernel directions (no shared tile pass, no G in HBM,
+    no transposed operands); the tied form (one tile pass -> G, gradient GEMM + transposed-read kernel) must give the same loss --
+    the forward is the same launches -- and gradients equal up to the rounding of G and the order of the f32 sums."""
+    from mmlearn_amd import ContrastiveLoss, LossPairSpec, _lib
+    from mmlearn_amd import kernels as K
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(n)
+    a = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1).bfloat16()
+    b = torch.nn.functional.normalize(0.5 * a.float() + torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1), dim=-1).bfloat16()
+    ids = torch.stack([torch.zeros(n, dtype=torch.long), torch.arange(n)], 1).to(dev)
+    out = {}
+    for mode in ("untied", "tied"):
+        monkeypatch.setattr(K, "ONE_KERNEL_PAIRS", mode == "untied")
+        ea, eb = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        s = torch.tensor(1 / 0.07, device=dev, requires_grad=True)
+        _lib.profile_read()
+        _lib.profile_enable(True)
+        loss = ContrastiveLoss()({"rgb_embedding": ea, "text_embedding": eb}, {"rgb": ids, "text": ids}, s, [LossPairSpec(("rgb", "text"))])
+        loss.float().backward()
+        torch.cuda.synchronize()
+        prof = _lib.profile_read()
+        _lib.profile_enable(False)
+        assert ("clip_bwd_fused" in prof) == (mode == "untied") and ("sim_grad" in prof) == (mode == "tied"), prof
+        out[mode] = (float(loss.detach().float()), ea.grad.float().cpu(), eb.grad.float().cpu(), float(s.grad))
+    assert out["untied"][0] == out["tied"][0]
+    assert abs(out["untied"][3] - out["tied"][3]) <= 1e-3 * max(1e-3, abs(out["tied"][3]))
+    for x, y in ((out["untied"][1], out["tied"][1]), (out["untied"][2], out["tied"][2])):
+        assert (x - y).abs().max() <= 1e-2 * y.abs().max() and (x - y).abs().mean() <= 1e-4 * y.abs().max()

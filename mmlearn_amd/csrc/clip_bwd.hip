@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
                                                    // whose wait -- lgkmcnt(0) -- lands between the counted LDS waits of phase S)
   const float c_row = p.c_row, c_col = p.c_col, c_diag = p.c_diag, s_row = p.s_row, s_col = p.s_col, s_diag = p.s_diag;   // rows beyond r are never read by the finalize
   const int c0 = split * batch.cols_per_split;
-  const int c_pad = (n_cols + 127) & ~127;
-  const int ntile = max(0, (min(c_pad, c0 + batch.cols_per_split) - c0) / CB_JT);
+  // tiles that begin inside the c columns (a tile of padding only contributes nothing); the last one may be ragged
+  const int ntile = max(0, (min(n_cols, c0 + batch.cols_per_split) - c0 + CB_JT - 1) / CB_JT);
   const float s2 = *scale_ptr * 1.4426950408889634f;
   const bool use_col = (c_col != 0.f) || (s_col != 0.f);
   const int dbg = kDebugSwitches ? batch.dbg : 0;   // timing ablations (debug-switch builds, MMK_CB_DBG; WRONG results): 1 no phase S, 2 no G
@@ -121,19 +121,21 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
   };
 
   // ---- Y tile t -> buffer b: 64 pieces of 1 KiB (8 rows x 128 B of one sub-image), sixteen per wave (k sub-images 2 wave, 2 wave + 1 of
-  // both column halves); the swizzle goes on the SOURCE chunk.  Rows c0 + 64 t .. + 63 exist (the packed operand has c_pad rows).
+  // both column halves); the swizzle goes on the SOURCE chunk.  Only rows the descriptor promises are read (x: r rows, y: c rows --
+  // include/mmlearn_hip.h; a shard is often a SLICE of the gathered operand that ends with it): a row past the last one reads the
+  // last one again (`avail` = last valid row - first row of the tile, >= 0), and the G arithmetic zeroes what comes of it.
   const uint32_t smem_addr = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smem);
-  auto issue_piece = [&](const bf16_t* base, int b, int idx) {   // piece idx (0..15) of this wave's share of 64 rows x 512 from base -> buffer b
+  auto issue_piece = [&](const bf16_t* base, int avail, int b, int idx) {   // piece idx (0..15) of this wave's share of 64 rows x 512 from base -> buffer b
     const int jt = idx >> 3, sub = (idx >> 2) & 1, q8 = idx & 3;
     const int s = 2 * wave + sub;
     const int row = 8 * q8 + (lane >> 3);
     const int ch = (lane & 7) ^ cb_swz(row);
-    cb_dma16(base + (long)(32 * jt) * CB_KP + 64 * s, (uint32_t)(row * CB_KP + ch * 8) * 2u,
+    cb_dma16(base + 64 * s, (uint32_t)(min(32 * jt + row, avail) * CB_KP + ch * 8) * 2u,
              smem_addr + b * CB_YBUF + (8 * jt + s) * CB_SUB + q8 * 1024);
   };
-  auto issue_rows = [&](const bf16_t* base, int b) {   // 64 rows x 512 from base -> buffer b
+  auto issue_rows = [&](const bf16_t* base, int avail, int b) {   // 64 rows x 512 from base -> buffer b
 #pragma unroll
-    for (int idx = 0; idx < 16; ++idx) issue_piece(base, b, idx);
+    for (int idx = 0; idx < 16; ++idx) issue_piece(base, avail, b, idx);
   };
   // the tile's column log-sum-exps ride along as one more piece (wave 0): a plain load inside the loop would make the compiler wait
   // for ALL outstanding vector memory operations -- the next tile's pieces included -- at its first use
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
       cb_dma4(lse_col, (uint32_t)min(c0 + CB_JT * t + lane, n_cols - 1) * 4u, smem_addr + 2 * CB_YBUF + CB_GIMG + b * CB_LCOL);
   };
   auto issue_y = [&](int t, int b) {
-    issue_rows(y_rows + (long)(c0 + CB_JT * t) * CB_KP, b);
+    issue_rows(y_rows + (long)(c0 + CB_JT * t) * CB_KP, n_cols - 1 - (c0 + CB_JT * t), b);
     issue_lcol(t, b);
   };
 
@@ -167,9 +169,9 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
   // ---- this wave's X fragments: B operand of phase S, rows i0 + 32 wit + r, k = 16 ks + 8 h .. + 7, the whole contraction, in
   // registers for the whole kernel.  The block is a 64 x 512 tile like any Y tile: it comes through the second buffer as an image
   // (coalesced 128-byte rows by LDS-DMA; row-strided 32-byte loads straight into registers cost several microseconds here), while
-  // the first Y tile is already on its way into the first.  The packed operand has r_pad >= i0 + 64 rows.
+  // the first Y tile is already on its way into the first.
   if (ntile > 0 && !(dbg & 8)) issue_y(0, 0);
-  issue_rows(p.x + (long)i0 * CB_KP, 1);
+  issue_rows(p.x + (long)i0 * CB_KP, p.r - 1 - i0, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   bf16x8 xf[32];
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
     // last tile into the free buffer (unused) rather than branch inside the MFMA sequence.
     const int tn = min(t + 1, ntile - 1), nb = (t + 1) & 1;
     const bf16_t* ynext = y_rows + (long)(c0 + CB_JT * tn) * CB_KP;
+    const int avail_next = n_cols - 1 - (c0 + CB_JT * tn);
     // ---------------- phase S: S^T[32 j (wjt)][32 i (wit)] over the whole contraction, two accumulators (even / odd k steps)
     f32x16 sacc;
 #pragma unroll
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
         // in order and the hardware interlocks a VGPR that a pending MFMA still has to read)
         if (ks + 8 < 32)
           asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yf[ks & 7]) : "v"(ya[ks & 3]), "n"(((ks + 8) >> 2) * CB_SUB) : "memory");
-        if (ks & 1) issue_piece(ynext, nb, ks >> 1);
+        if (ks & 1) issue_piece(ynext, avail_next, nb, ks >> 1);
       }
       issue_lcol(tn, nb);
     }

@@ -415,12 +415,14 @@ def _shard_reference(x, y, r, c, p0, scale, lse, lse_col, coef, kappa, ds_kappa)
 
 
 @pytest.mark.parametrize("r,c,p0,d,col_term", [(1024, 8192, 3072, 512, True), (1024, 2048, 1024, 512, False), (1000, 3000, 517, 500, True),
-                                               (640, 1100, 0, 512, True), (2048, 4096, 2048, 450, False)])
+                                               (640, 1100, 0, 512, True), (2048, 4096, 2048, 450, False), (1000, 3072, 2072, 512, True)])
 def test_sharded_backward_one_kernel_vs_float64(r, c, p0, d, col_term):
     """A rank's row shards (r owned rows against c gathered columns, label(i) = p0 + i) run their backward as ONE kernel that
     recomputes the similarity tiles and keeps G on chip.  Against a float64 product of the same packed operands: ragged row
     blocks and column tiles (r, c off the 64 / 128 grids, d < k_pad), label columns in the middle of a tile, with and without the
-    column-softmax term (gather_with_grad), both directions of the pair in one launch, and no transposed operand handed in."""
+    column-softmax term (gather_with_grad), both directions of the pair in one launch, and no transposed operand handed in.  The
+    last case is the LAST rank's shard: its rows are a slice that ends with the gathered operand, so the 64-row blocks must not
+    read past it."""
     from mmlearn_amd import _lib, kernels as K
 
     dev = _dev()

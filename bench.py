@@ -704,7 +704,7 @@ def loss_n8192_leg(dev, n: int = 8192, d: int = 512, iters: int = 10):
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
-        traffic = pmc.get("n8192", {}).get("hbm_bytes_per_launch")
+        traffic = pmc.get("n8192", {}).get("per_kernel") or pmc.get("n8192", {}).get("hbm_bytes_per_launch")
     except Exception:
         traffic = None
     roof = _loss_roofline(prof, n, n, d, 1, iters, traffic, loss_only=True)

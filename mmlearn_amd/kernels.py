@@ -387,6 +387,11 @@ def reduce_sums(parts: Sequence[torch.Tensor], weights: Sequence[float], separat
 
 
 def _backward_plan(shapes: Sequence[tuple], k_pad: int, compute: int) -> list:
+    return list(_backward_plan_cached(tuple(shapes), k_pad, compute))
+
+
+@functools.lru_cache(maxsize=256)
+def _backward_plan_cached(shapes: tuple, k_pad: int, compute: int) -> tuple:
     """``[(r, c, mode, mirror_of), ...]`` (``mirror_of``: index of the direction whose gradient tiles this one reuses, or None) ->
     per direction, whether ``mmk_clip_backward`` runs it as ONE kernel that recomputes its tiles on chip (csrc/clip_bwd.hip): such a
     direction needs neither the transposed operand nor the G workspace.  A host-side query, no buffers involved."""
@@ -399,7 +404,7 @@ def _backward_plan(shapes: Sequence[tuple], k_pad: int, compute: int) -> list:
             e.g = arr[mirror_of].g = C.c_void_p(mirror_of + 1)
     flags = (C.c_int32 * len(shapes))()
     check(_lib.lib().mmk_clip_backward_plan(C.cast(arr, C.c_void_p), len(shapes), k_pad, compute, C.cast(flags, C.c_void_p)))
-    return [bool(f) for f in flags]
+    return tuple(bool(f) for f in flags)
 
 
 def backward_recomputes_on_chip(r: int, c: int, d: int, compute: int, n_dirs: int = 2) -> bool:

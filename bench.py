@@ -678,9 +678,9 @@ def loss_n8192_leg(dev, n: int = 8192, d: int = 512, iters: int = 10):
     s = torch.tensor(1 / 0.07, device=dev, requires_grad=True)
     fn, pairs = ContrastiveLoss(), [LossPairSpec(("rgb", "text"))]
 
-    def step():
+    def step(paired=None):
         a.grad = b.grad = s.grad = None
-        loss = fn({"rgb_embedding": a, "text_embedding": b}, {"rgb": ids, "text": ids}, s, pairs)
+        loss = fn({"rgb_embedding": a, "text_embedding": b}, {"rgb": ids, "text": ids}, s, pairs, fully_paired=paired)
         loss.float().backward()
 
     for _ in range(3):
@@ -701,6 +701,17 @@ def loss_n8192_leg(dev, n: int = 8192, d: int = 512, iters: int = 10):
             step()
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / iters
+        # the same with the collator's `fully_paired` hint (mmlearn_amd.wire): no matcher launch and, above all, no host read of its
+        # result in the middle of the path -- in a training step that read is taken ahead of the encoders (prefetch_match); here,
+        # with nothing in front of the loss, it leaves the device idle while the host enqueues the rest
+        for _ in range(3):
+            step(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            step(True)
+        torch.cuda.synchronize()
+        wall_paired = (time.perf_counter() - t0) / iters
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
@@ -713,6 +724,7 @@ def loss_n8192_leg(dev, n: int = 8192, d: int = 512, iters: int = 10):
         dev_us = sum(v[1] for k, v in prof.items()) / iters * 1e3
         roof["device_us_fwd_bwd"] = round(dev_us, 1)
         roof["wall_us_fwd_bwd"] = round(wall * 1e6, 1)
+        roof["wall_us_fwd_bwd_paired_hint"] = round(wall_paired * 1e6, 1)
         roof["algorithmic_tflops_fwd_bwd"] = round(6.0 * n * n * d / (dev_us * 1e-6) / 1e12, 1)
     return roof
 

@@ -13,12 +13,15 @@
 // The f32 tile goes to the split's slab; grad_finalize (clip.hip) sums the slabs as before.  One image format serves the row reads of
 // phase S and the transposed reads of phase D: the [32 rows][64 k] sub-images of csrc/attention.hip (128-byte rows, chunk ^ swz(row)).
 // Two barriers per 64 columns.  LDS: two 64-KiB Y tiles + the G image = 137 KiB, so ONE workgroup per CU and one wave per SIMD:
-// nothing overlaps a wave's own latencies, which is why the reads, waits and DMA issue are placed by hand.  What bounds it is the LDS
-// itself: ~300 KiB go through it per 64 columns and CU (32 row fragments per wave for the logits, 32 transposed + 8 G fragments for
-// dX, the tile's 64 KiB of DMA writes); rocprofv3: SQ_LDS_IDX_ACTIVE ~80 % of the kernel, MFMA pipe 33 % busy.  A variant that ran
-// the G arithmetic of tile t under the dX MFMAs of tile t - 1 (operands in registers, one barrier per tile) measured the same 47 us
-// and was dropped (profiles/r06_loss_shard_fused_bwd.json, which also keeps the first form of this kernel -- 32-column tiles with
-// the contraction split over the waves and an LDS reduction of the partial tiles: 101 us, slower than the two launches' 69 us).
+// nothing overlaps a wave's own latencies, which is why the reads, waits and DMA issue are placed by hand.  No single unit bounds
+// it (rocprofv3 --pmc, R = 1024 x C = 8192: MFMA pipe busy 33 % of the kernel, LDS array 20 % -- 82 LDS instructions per wave and
+// tile, 15 % of their cycles bank conflicts --, ~4,500 VALU instructions per wave ~25 %, waits 29 % of the wave cycles): what is
+// left is the serial order of a tile's phases on each SIMD.  A variant that ran the G arithmetic of tile t between the dX MFMAs of
+// tile t - 1 (their operands read into registers at the top of the tile, one barrier per tile, MFMAs as inline instructions with
+// fixed register files) measured the same 47 us and was dropped: it trades the exposed arithmetic for 40 exposed LDS reads at the
+// top of every tile and a four-deep read ring in phase S (registers).  profiles/r06_loss_shard_fused_bwd.json keeps that and the
+// first form of this kernel (32-column tiles with the contraction split over the waves and an LDS reduction of the partial tiles:
+// 101 us, slower than the two launches' 69 us).
 // HBM sees the operands once per (split, row-block group on one XCD) plus the slabs: no G (2 x 33 MB at R = 1024 x C = 8192), no
 // transposed Y.  Eligibility (clip.hip): bf16 compute, k_pad = 512, a direction with a tile pass of its own whose G nobody else reads.
 #include <hip/hip_ext.h>

@@ -17,8 +17,8 @@ Each has a fake implementation (shapes and dtypes only), so Dynamo + AOT autogra
 with Python state (which pairs matched, the packed operands, workspaces): the forward op parks its run in a small registry and
 returns a token tensor that the backward op redeems; a run whose backward never comes (evaluation) is evicted by the next ones.
 
-The towers' fused blocks (``mmlearn_amd.fused``) are not wrapped: a compiled task with accelerated HF towers still breaks the graph
-at their kernels (and stays correct) -- the launch-free form of those steps is HIP-graph capture (``mmlearn_amd.graph``).
+An encoder patched by ``mmlearn_amd.fused.accelerate_encoder`` is ONE operator (``mmlearn_amd::tower_fwd`` / ``tower_bwd``, below): its
+kernels are not traced one by one -- the launch-free form of those steps is HIP-graph capture (``mmlearn_amd.graph``).
 """
 
 from __future__ import annotations
@@ -196,3 +196,244 @@ def contrastive_loss(module, embeddings: dict, example_ids: dict, logit_scale: T
     if first.dtype != torch.float32 and not torch.is_autocast_enabled():
         loss = loss.to(first.dtype)
     return loss
+
+
+# ------------------------------------------------------------------------------------------------ accelerated towers
+# An encoder that ``mmlearn_amd.fused.accelerate_encoder`` has patched runs dozens of autograd Functions over ctypes kernels.  Under
+# ``torch.compile`` the task hands such a tower to the tracer as ONE operator: the forward op runs the tower's own (eager) forward with
+# autograd on and parks the output's graph, the backward op differentiates that graph for the parameters (and for inputs that asked for
+# it).  The parameters are operands of the forward op, so their gradients arrive through the compiled graph like any other.  Nothing
+# inside the tower is traced or changed -- which is the point: the kernels are the fast path already, and ``fullgraph=True`` holds.
+_TOWERS: "weakref.WeakValueDictionary[int, Any]" = weakref.WeakValueDictionary()
+_tower_counter = itertools.count(1)
+_TOWER_RUNS: "OrderedDict[int, Any]" = OrderedDict()
+
+
+def mark_tower(module) -> None:
+    """Called by ``accelerate_encoder``: this module's forward reaches HIP kernels the tracer cannot see into.  Call it again on a
+    (deep) COPY of such a module: the copy carries its original's key."""
+    tid = module.__dict__.get("_mmk_tower_id")
+    if tid is None or _TOWERS.get(tid) is not module:
+        tid = next(_tower_counter)
+        module.__dict__["_mmk_tower_id"] = tid
+        module.__dict__.pop("_mmk_out_meta", None)
+        _TOWERS[tid] = module
+
+
+def is_opaque_tower(module) -> bool:
+    """(plain attribute reads only: the tracer evaluates this while tracing)"""
+    return getattr(module, "_mmk_tower_id", None) is not None
+
+
+def _flatten_inputs(inputs: dict, prefix: str = ""):
+    """(key paths of the tensor leaves, the tensors, the other leaves as a JSON-able dict) of a (nested) batch dict."""
+    keys, tensors, consts = [], [], {}
+    for k, v in inputs.items():
+        path = f"{prefix}{k}"
+        if isinstance(v, Tensor):
+            keys.append(path)
+            tensors.append(v)
+        elif isinstance(v, dict):
+            kk, tt, cc = _flatten_inputs(v, path + "/")
+            keys += kk
+            tensors += tt
+            consts.update(cc)
+        elif v is None or isinstance(v, (bool, int, float, str)):
+            consts[path] = v
+        # anything else (python objects a tower does not read) stays outside the operator
+    return keys, tensors, consts
+
+
+def _rebuild_inputs(keys: Sequence[str], tensors: Sequence[Tensor], consts: dict) -> dict:
+    out: dict = {}
+    for path, v in itertools.chain(zip(keys, tensors), consts.items()):
+        d = out
+        parts = path.split("/")
+        for part in parts[:-1]:
+            d = d.setdefault(part, {})
+        d[parts[-1]] = v
+    return out
+
+
+def _encode_tower_meta(keys: Sequence[str], consts: dict, grad_inputs: Sequence[int]) -> str:
+    """The non-tensor part of a tower call as one string operand (built with plain string operations: the tracer runs this)."""
+    cs = []
+    for path, v in consts.items():
+        if v is None:
+            cs.append(path + "=n:")
+        elif isinstance(v, bool):
+            cs.append(path + "=b:" + ("1" if v else "0"))
+        elif isinstance(v, int):
+            cs.append(path + "=i:" + str(v))
+        elif isinstance(v, float):
+            cs.append(path + "=f:" + repr(v))
+        else:
+            cs.append(path + "=s:" + v)
+    return "|".join(keys) + "\x1f" + "|".join(cs) + "\x1f" + ",".join(str(i) for i in grad_inputs)
+
+
+def _decode_tower_meta(meta: str):
+    ks, cs, gi = meta.split("\x1f")
+    consts = {}
+    for item in filter(None, cs.split("|")):
+        path, tv = item.split("=", 1)
+        t, v = tv.split(":", 1)
+        consts[path] = None if t == "n" else (v == "1") if t == "b" else int(v) if t == "i" else float(v) if t == "f" else v
+    return {"keys": [k for k in ks.split("|") if k], "consts": consts, "grad_inputs": [int(i) for i in gi.split(",") if i]}
+
+
+class _autograd_inside_an_operator:
+    """An operator's implementation runs BELOW the autograd dispatch keys (they are excluded for the thread): nothing it calls is
+    recorded, whatever the grad mode.  The tower operator's forward needs its encoder's own autograd graph -- this puts the keys back
+    for the duration (and restores the exclusions after)."""
+
+    _KEYS = tuple(getattr(torch._C.DispatchKey, n) for n in ("AutogradCPU", "AutogradCUDA", "AutogradOther", "ADInplaceOrView", "AutogradFunctionality")
+                  if hasattr(torch._C.DispatchKey, n))
+
+    def __enter__(self):
+        self._prev = [torch._C._dispatch_tls_is_dispatch_key_excluded(k) for k in self._KEYS]
+        for k in self._KEYS:
+            torch._C._dispatch_tls_set_dispatch_key_excluded(k, False)
+
+    def __exit__(self, *exc):
+        for k, was in zip(self._KEYS, self._prev):
+            torch._C._dispatch_tls_set_dispatch_key_excluded(k, was)
+
+
+def _tower_call(module, keys, tensors, consts, bf16_autocast: bool, cache: bool = True):
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bool(bf16_autocast), cache_enabled=cache):
+        return module(_rebuild_inputs(keys, tensors, consts))[0]
+
+
+@torch.library.custom_op("mmlearn_amd::tower_fwd", mutates_args=())
+def _tower_fwd(tensors: List[Tensor], params: List[Tensor], tower: int, meta: str, needs_grad: bool, bf16_autocast: bool) -> Tuple[Tensor, Tensor]:
+    module = _TOWERS.get(tower)
+    if module is None:
+        raise RuntimeError("mmlearn_amd::tower_fwd: the encoder of this compiled graph no longer exists")
+    first = next(iter(module.parameters()), None)
+    if first is not None and (not params or params[0].data_ptr() != first.data_ptr()):
+        raise RuntimeError("mmlearn_amd::tower_fwd: the registered encoder is not the one whose parameters were passed -- a copy of an "
+                           "accelerated encoder must be registered again: mmlearn_amd.compiled.mark_tower(copy)")
+    m = _decode_tower_meta(meta)
+    leaves, ins = [], []
+    for i, t in enumerate(tensors):
+        if needs_grad and i in m["grad_inputs"]:
+            t = t.detach().requires_grad_(True)
+            leaves.append(t)
+        ins.append(t)
+    if needs_grad:
+        with _autograd_inside_an_operator(), torch.enable_grad():
+            for i, t in enumerate(ins):
+                if i in m["grad_inputs"]:
+                    t.requires_grad_(True)   # (the flag set above, below the autograd keys, does not make a leaf)
+            out = _tower_call(module, m["keys"], ins, m["consts"], bf16_autocast)
+    else:
+        with torch.no_grad():
+            out = _tower_call(module, m["keys"], ins, m["consts"], bf16_autocast)
+    tok = 0
+    if needs_grad and out.requires_grad:
+        tok = next(_run_counter)
+        _TOWER_RUNS[tok] = (out, leaves, [p for p in module.parameters() if p.requires_grad])
+        while len(_TOWER_RUNS) > MAX_PARKED_RUNS:
+            _TOWER_RUNS.popitem(last=False)
+    return out.detach(), torch.tensor([tok], dtype=torch.int64)
+
+
+@_tower_fwd.register_fake
+def _(tensors, params, tower, meta, needs_grad, bf16_autocast):
+    from torch._subclasses.fake_tensor import unset_fake_temporarily
+
+    module = _TOWERS.get(tower)
+    if module is None:
+        raise RuntimeError("mmlearn_amd::tower_fwd: unknown encoder")
+    sig = (tuple((tuple(t.shape), t.dtype) for t in tensors), bool(bf16_autocast))
+    cache = module.__dict__.setdefault("_mmk_out_meta", {})
+    if sig not in cache:
+        # the output's shape and dtype: learnt once per input signature from ONE real forward on zeros (evaluation mode, no
+        # autograd, so no random numbers are drawn and nothing is kept), outside the tracer's fake-tensor mode
+        m = _decode_tower_meta(meta)
+        with unset_fake_temporarily(), torch.no_grad():
+            real = [torch.zeros(tuple(t.shape), dtype=t.dtype, device=t.device) for t in tensors]
+            was_training = module.training
+            module.eval()
+            try:
+                # (no autocast weight cache: a bf16 copy cached here, made without autograd, would be what the REAL forward of the
+                # same enclosing autocast region picks up -- and the weight's gradient would be lost)
+                out = _tower_call(module, m["keys"], real, m["consts"], bf16_autocast, cache=False)
+            finally:
+                module.train(was_training)
+            cache[sig] = (tuple(out.shape), out.dtype, out.device)
+    shape, dt, dev = cache[sig]
+    return torch.empty(shape, dtype=dt, device=dev), torch.empty((1,), dtype=torch.int64, device="cpu")
+
+
+@torch.library.custom_op("mmlearn_amd::tower_bwd", mutates_args=())
+def _tower_bwd(token: Tensor, grad_out: Tensor, grad_inputs: List[Tensor], grad_params: List[Tensor]) -> Tuple[List[Tensor], List[Tensor]]:
+    """grad_inputs / grad_params: the operands that receive a gradient (only their shapes are used: the outputs look like them)."""
+    run = _TOWER_RUNS.pop(int(token[0]), None)
+    if run is None:
+        raise RuntimeError("mmlearn_amd::tower_bwd: no parked forward run for this token (backward called twice, or more than "
+                           f"{MAX_PARKED_RUNS} forward passes without a backward in between)")
+    out, leaves, ps = run
+    with _autograd_inside_an_operator():
+        grads = torch.autograd.grad([out], leaves + ps, [grad_out.to(out.dtype)], allow_unused=True)
+    # an operator's outputs may alias neither its inputs nor each other: gradients that are views (the q / k / v slices of one packed
+    # weight gradient, an expanded bias gradient) or that share a buffer with the incoming gradient are copied out
+    seen = {grad_out.untyped_storage().data_ptr()}
+
+    def own(g, like):
+        if g is None:
+            return torch.zeros_like(like)
+        key = g.untyped_storage().data_ptr()
+        if g._base is not None or key in seen or not g.is_contiguous():
+            g = g.clone(memory_format=torch.contiguous_format)
+            key = g.untyped_storage().data_ptr()
+        seen.add(key)
+        return g
+
+    gl = [own(g, t) for g, t in zip(grads[:len(leaves)], leaves)]
+    gp = [own(g, p) for g, p in zip(grads[len(leaves):], ps)]
+    return gl, gp
+
+
+@_tower_bwd.register_fake
+def _(token, grad_out, grad_inputs, grad_params):
+    return [torch.empty_like(t) for t in grad_inputs], [torch.empty_like(p) for p in grad_params]
+
+
+def _tower_setup(ctx, inputs, output):
+    tensors, params, _tower, meta, _needs_grad, _bf16 = inputs
+    gi = _decode_tower_meta(meta)["grad_inputs"]
+    ctx.grad_inputs = gi
+    ctx.grad_params = [i for i, p in enumerate(params) if p.requires_grad]
+    ctx.n_tensors, ctx.n_params = len(tensors), len(params)
+    ctx.save_for_backward(output[1], *[tensors[i] for i in gi], *[params[i] for i in ctx.grad_params])
+
+
+def _tower_backward(ctx, gout, _gtoken):
+    token, *rest = ctx.saved_tensors
+    gi_t, gp_t = rest[:len(ctx.grad_inputs)], rest[len(ctx.grad_inputs):]
+    gl, gp = _tower_bwd(token, gout, list(gi_t), list(gp_t))
+    g_tensors = [None] * ctx.n_tensors
+    for i, g in zip(ctx.grad_inputs, gl):
+        g_tensors[i] = g
+    g_params = [None] * ctx.n_params
+    for i, g in zip(ctx.grad_params, gp):
+        g_params[i] = g
+    return g_tensors, g_params, None, None, None, None
+
+
+_tower_fwd.register_autograd(_tower_backward, setup_context=_tower_setup)
+
+
+def tower_forward(module, inputs: dict) -> Tensor:
+    """The traced form of ``module(inputs)[0]`` for an accelerated encoder: one operator in the graph."""
+    keys, tensors, consts = _flatten_inputs(inputs)
+    params = list(module.parameters())
+    grad_on = torch.is_grad_enabled()
+    grad_inputs = [i for i, t in enumerate(tensors) if grad_on and t.is_floating_point() and t.requires_grad]
+    needs_grad = grad_on and (bool(grad_inputs) or any(p.requires_grad for p in params))
+    meta = _encode_tower_meta(keys, consts, grad_inputs)
+    bf16_autocast = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+    out, _token = _tower_fwd(tensors, params, module._mmk_tower_id, meta, needs_grad, bf16_autocast)
+    return out

@@ -1377,4 +1377,8 @@ def accelerate_encoder(module: nn.Module, low_precision_ln: Iterable[str] = (), 
         swapped["cls_only"] = why if (proven or cls_only is True) else f"off: {why}"
         if proven or cls_only is True:     # last: it wraps whatever forward the last layer has by now (fused or stock)
             swapped["cls_only_last_layer"] = cls_only_last_layer(module)
+    if any(isinstance(v, int) and not isinstance(v, bool) and v > 0 for v in swapped.values()):
+        from .compiled import mark_tower
+
+        mark_tower(module)   # under torch.compile the task hands this encoder to the tracer as one operator (mmlearn_amd/compiled.py)
     return swapped

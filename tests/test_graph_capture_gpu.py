@@ -304,3 +304,52 @@ def test_captured_ijepa_step_with_stock_blocks_and_torch_adamw():
     for (n, pe), (_, pg) in zip(task_e.named_parameters(), task_g.named_parameters()):
         assert (pe.detach() - pg.detach()).abs().max().item() <= 1e-4 * scale, n
     assert task_e.target_encoder.num_updates == task_g.target_encoder.num_updates == 6
+
+
+def test_accelerated_hf_towers_compile_with_fullgraph_as_one_operator_each():
+    """An encoder patched by ``accelerate_encoder`` (fused QKV attention, residual add + LayerNorm, MLP GEMM epilogues ... dozens of
+    autograd Functions over ctypes kernels) is ONE operator to the tracer (``mmlearn_amd::tower_fwd`` / ``tower_bwd``): the step of the
+    small ViT + BERT task -- both towers accelerated, the text tower with the tokenizer's padding mask -- compiles with
+    ``fullgraph=True`` on ``aot_eager`` and three compiled training steps leave the parameters three eager steps leave
+    (the reference plumbs whole-task compilation, mmlearn/cli/run.py:139)."""
+    import bench
+    from mmlearn_amd import ContrastiveLoss
+    from mmlearn_amd.compiled import is_opaque_tower
+
+    dev = torch.device("cuda", 0)
+    batch = bench.synthetic_batch(16, 0, dev, padded=True)
+    torch._dynamo.reset()
+
+    def make():
+        task = bench.build_task(ContrastiveLoss(), small=True, fused=True).to(dev)
+        task.concurrent_encoders = False
+        for m in task.modules():   # BERT's dropout draws random numbers: off, so that the two runs can be compared bit for bit
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        for m in task.modules():
+            cfg = getattr(m, "config", None)
+            if cfg is not None and hasattr(cfg, "attention_probs_dropout_prob"):
+                cfg.attention_probs_dropout_prob = 0.0
+        return task, task.configure_optimizers()
+
+    task_c, opt_c = make()
+    assert all(is_opaque_tower(m) for m in task_c.encoders.values())
+    step_c = torch.compile(task_c.training_step, backend="aot_eager", fullgraph=True)
+    for _ in range(3):
+        opt_c.zero_grad(set_to_none=False)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss_c = step_c(batch, 0)
+        loss_c.backward()
+        opt_c.step()
+    task_e, opt_e = make()
+    for _ in range(3):
+        opt_e.zero_grad(set_to_none=False)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss_e = task_e.training_step(batch, 0)
+        loss_e.backward()
+        opt_e.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss_c.detach()).all() and float(loss_c.detach()) == float(loss_e.detach())
+    for (n, pc), pe in zip(task_c.named_parameters(), task_e.parameters()):
+        assert torch.equal(pc.detach(), pe.detach()), n
+    torch._dynamo.reset()

@@ -511,3 +511,35 @@ def test_mask_scope_leaves_hosts_and_checkpointed_models_to_hf():
     s.mask2d = mask
     add = s.additive(torch.float32)
     assert add.shape == (3, 1, 1, 9) and (add[1, 0, 0, 5:] == torch.finfo(torch.float32).min).all() and (add[0] == 0).all()
+
+
+def test_tower_operator_host_side_round_trips_a_batch_and_keys_towers_per_module_object():
+    """mmlearn_amd.compiled hands an accelerated encoder to torch.compile as ONE operator.  Host side: the (nested) batch dict is split
+    into tensor operands + one string operand and rebuilt inside the operator; the registry key lives on the module object, and a
+    deep copy -- which carries its original's key -- gets its own on ``mark_tower`` (the task's ``__deepcopy__`` does that)."""
+    import copy
+
+    from mmlearn_amd import compiled as C
+
+    batch = {"rgb": torch.zeros(2, 3), "attention_mask": torch.ones(2, 5, dtype=torch.long), "fully_paired": True, "note": "a b", "k": None, "n": 7,
+             "scale": 0.25, "example_ids": {"rgb": torch.arange(4).view(2, 2), "text": torch.arange(4).view(2, 2)}, "obj": object()}
+    keys, tensors, consts = C._flatten_inputs(batch)
+    assert keys == ["rgb", "attention_mask", "example_ids/rgb", "example_ids/text"] and len(tensors) == 4
+    assert consts == {"fully_paired": True, "note": "a b", "k": None, "n": 7, "scale": 0.25}          # the python object stays outside
+    meta = C._encode_tower_meta(keys, consts, [0])
+    m = C._decode_tower_meta(meta)
+    assert m == {"keys": keys, "consts": consts, "grad_inputs": [0]}
+    back = C._rebuild_inputs(m["keys"], tensors, m["consts"])
+    assert set(back) == set(batch) - {"obj"} and back["example_ids"]["text"] is batch["example_ids"]["text"] and back["fully_paired"] is True
+    assert C._decode_tower_meta(C._encode_tower_meta([], {}, [])) == {"keys": [], "consts": {}, "grad_inputs": []}
+
+    enc = torch.nn.Linear(3, 2)
+    assert not C.is_opaque_tower(enc)
+    C.mark_tower(enc)
+    tid = enc._mmk_tower_id
+    C.mark_tower(enc)
+    assert C.is_opaque_tower(enc) and enc._mmk_tower_id == tid and C._TOWERS[tid] is enc
+    twin = copy.deepcopy(enc)
+    assert twin._mmk_tower_id == tid and C._TOWERS[tid] is enc      # the copy carries the key of the original ...
+    C.mark_tower(twin)
+    assert twin._mmk_tower_id != tid and C._TOWERS[twin._mmk_tower_id] is twin and C._TOWERS[tid] is enc   # ... until it is registered itself

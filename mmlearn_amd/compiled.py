@@ -10,6 +10,8 @@ ops).  Here every kernel entry of the step is ONE opaque operator to the tracer:
 ``mmlearn_amd::contrastive_loss_fwd``   the whole of ``ContrastiveLoss.forward`` (modules/losses/contrastive.py:59-160): gather,
                                         matching, similarity statistics, CE in both directions -- host logic included
 ``mmlearn_amd::contrastive_loss_bwd``   its gradients w.r.t. every embedding and the logit scale
+``mmlearn_amd::tower_fwd/bwd``          an encoder patched by ``accelerate_encoder`` (tasks/contrastive_pretraining.py:400-431 ``encode``):
+                                        its whole forward, and the gradients of its parameters
 =====================================  ==================================================================================
 
 Each has a fake implementation (shapes and dtypes only), so Dynamo + AOT autograd trace THROUGH them: the small task compiles with

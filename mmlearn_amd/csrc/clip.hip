@@ -1306,6 +1306,47 @@ static int launch_gemm(const ProbBatch& b, int n_probs, int bm, int bn, int max_
   return launch_tile<T, 64, 64, EPI>(b, grid, scale, st);
 }
 
+// ---- forward statistics of row-sharded directions as ONE streaming launch (csrc/clip_bwd.hip, clip_fwd_shard_kernel)
+// A direction takes it when it is a row shard with no mirrored partner (W > 1: column statistics come through the all-reduce): bf16,
+// k_pad = 512, cross-entropy mode, >= 1024 columns, and the call's directions of that kind make half a chip of workgroups.  The
+// column split minimises (rounds of 256 workgroups) x (fixed cost of ~4 tile times + tiles); one partial per (split, row) lands in
+// the direction's `part` rows 0 .. n_split - 1 (the caller sized it for ceil(c / 64) column tiles).
+struct FwdShardPlan {
+  bool shard[MAX_PROBS];
+  int n_split;
+};
+static FwdShardPlan fwd_shard_plan(const mmk_clip_dir* dirs, int n_dirs, int k_pad, int compute) {
+  FwdShardPlan fp{};
+  if (MMK_DBG_ENV("MMK_CLIP_FWD_SHARD") && atoi(MMK_DBG_ENV("MMK_CLIP_FWD_SHARD")) == 0) return fp;   // A/B in debug-switch builds
+  if (compute != MMK_COMPUTE_BF16 || k_pad != 512) return fp;
+  int row_blocks = 0, c_min = 1 << 30;
+  for (int k = 0; k < n_dirs; ++k) {
+    const mmk_clip_dir& d = dirs[k];
+    fp.shard[k] = d.mode == 0 && d.mirror_part == nullptr && d.c >= 1024;
+    if (fp.shard[k]) {
+      row_blocks += cdiv(d.r, 64);
+      c_min = std::min(c_min, d.c);
+    }
+  }
+  if (row_blocks == 0) return fp;
+  const int ns_max = std::max(1, std::min(16, cdiv(c_min, 64) / 2));
+  int ns = 1;
+  long best = -1;
+  for (int s = 1; s <= ns_max; ++s) {
+    const long cost = (long)cdiv(row_blocks * s, 256) * (4 + cdiv(cdiv(c_min, 64), s));
+    if (best < 0 || cost < best) {
+      best = cost;
+      ns = s;
+    }
+  }
+  if ((long)row_blocks * ns < 128) {
+    for (int k = 0; k < n_dirs; ++k) fp.shard[k] = false;
+    return fp;
+  }
+  fp.n_split = ns;
+  return fp;
+}
+
 template <typename T>
 static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, const float* scale, const float* loss_w, float* loss_out,
                              int32_t* tickets, int n_tickets, hipStream_t st) {
@@ -1329,11 +1370,30 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
   b.unit_map = 0;
   MergeBatch mb;
   AlignReduceBatch ab;
-  int max_tiles = 0, n_red = 0, r_red_max = 0;
+  int max_tiles = 0, n_red = 0, r_red_max = 0, n_tile_dirs = 0;
   const bool align = dirs[0].mode == 1;
+  const FwdShardPlan sp = fwd_shard_plan(dirs, n_dirs, k_pad, sizeof(T) == 2 ? MMK_COMPUTE_BF16 : MMK_COMPUTE_F32);
+  FwdShardBatch fs;
+  fs.n_probs = 0;
+  fs.n_split = std::max(sp.n_split, 1);
+  fs.cols_per_split = round_up(cdiv(round_up(c_max, 64), fs.n_split), 64);
+  fs.row_blocks = 0;
+  fs.groups = 1;
+  fs.rows_per_group = 0;
   for (int k = 0; k < n_dirs; ++k) {
     const mmk_clip_dir& d = dirs[k];
-    Prob& p = b.p[k];
+    if (sp.shard[k]) {
+      FwdShardProb& q = fs.p[fs.n_probs++];
+      q.x = static_cast<const bf16_t*>(d.x); q.y = static_cast<const bf16_t*>(d.y);
+      q.part = reinterpret_cast<float2*>(d.part); q.diag = d.diag;
+      q.r = d.r; q.c = d.c; q.part_ld = d.r; q.label_off = d.label_off;
+      fs.row_blocks = std::max(fs.row_blocks, cdiv(d.r, 64));
+      mb.p[n_red] = MergeProb{q.part, q.part_ld, fs.n_split, d.r, d.diag, d.lse, d.loss_part, loss_w ? loss_w[n_red] : 0.f};
+      ++n_red;
+      r_red_max = std::max(r_red_max, d.r);
+      continue;
+    }
+    Prob& p = b.p[n_tile_dirs];
     p = Prob{};
     p.P = static_cast<const char*>(d.y);
     p.Q = static_cast<const char*>(d.x);
@@ -1353,7 +1413,8 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
       p.pn = d.y_norm;
     }
     max_tiles = std::max(max_tiles, p.tiles_m * p.tiles_n);
-    ab.p[k] = AlignReduceProb{p.part, p.part_ld, p.tiles_m, d.r, d.c, d.label_off, d.hmax, d.loss_part};
+    ab.p[n_tile_dirs] = AlignReduceProb{p.part, p.part_ld, p.tiles_m, d.r, d.c, d.label_off, d.hmax, d.loss_part};
+    ++n_tile_dirs;
     if (!align) {
       mb.p[n_red] = MergeProb{p.part, p.part_ld, p.tiles_m, d.r, d.diag, d.lse, d.loss_part, loss_w ? loss_w[n_red] : 0.f};
       ++n_red;
@@ -1369,11 +1430,14 @@ static int clip_forward_impl(const mmk_clip_dir* dirs, int n_dirs, int k_pad, co
     }
   }
   b.n_split = 1;
-  b.n_probs = n_dirs;
+  b.n_probs = n_tile_dirs;
   b.dbg = MMK_DBG_ENV("MMK_SIM_DBG") ? atoi(MMK_DBG_ENV("MMK_SIM_DBG")) : 0;
-  {
-    int rc = align ? launch_gemm<T, EPI_ALIGN_STATS>(b, n_dirs, pl.bm, pl.bn, max_tiles, scale, st)
-                   : launch_gemm<T, EPI_STATS>(b, n_dirs, pl.bm, pl.bn, max_tiles, scale, st);
+  if (fs.n_probs > 0) {
+    if (int rc = launch_clip_fwd_shard(fs, scale, st)) return rc;
+  }
+  if (n_tile_dirs > 0) {
+    int rc = align ? launch_gemm<T, EPI_ALIGN_STATS>(b, n_tile_dirs, pl.bm, pl.bn, max_tiles, scale, st)
+                   : launch_gemm<T, EPI_STATS>(b, n_tile_dirs, pl.bm, pl.bn, max_tiles, scale, st);
     if (rc) return rc;
   }
   {

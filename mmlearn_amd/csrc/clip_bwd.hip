@@ -329,6 +329,166 @@ __global__ __launch_bounds__(256) void clip_bwd_fused_kernel(const BwdFusedBatch
   if (tid == 0) p.ds_part[rb * batch.n_split + split] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Forward statistics of the same directions (row shards): per owned row the log-sum-exp partial over one column split and the
+// positive logit.  The general tile kernel (clip.hip, gemm_nt_kernel with the statistics epilogue) runs such a shape as 1,024
+// independent 128 x 128 tiles, each with its own prologue and epilogue around eight K steps: 28 us for 17 GFLOP at R = 1024 x
+// C = 8192.  Here a workgroup owns 64 rows x one column split as in the backward: the X fragments stay in registers, the Y tiles
+// stream through the two LDS buffers, and a lane keeps the running (maximum, sum) of ONE row over all the tiles of its split -- the
+// online form of the reduction, in the log2 domain, with the row's 16 logits of a tile in its own registers (S^T layout: no
+// cross-lane step until the very end).  Column statistics are not made: at W > 1 they come from the other direction's rows through
+// the all-reduce.  One partial per (split, row); lse_merge_kernel (clip.hip) merges them as it merges the tile partials.
+constexpr int CF_LDS = 2 * CB_YBUF + 1024;   // two Y tiles + the cross-wave exchange of the final partials
+
+__global__ __launch_bounds__(256) void clip_fwd_shard_kernel(const FwdShardBatch batch, const float* __restrict__ scale_ptr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ybuf = smem;
+  float2* xch = reinterpret_cast<float2*>(smem + 2 * CB_YBUF);   // [2 wit][32 rows]: wave (wit, 1) hands its partial to wave (wit, 0)
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wit = wave & 1, wjt = wave >> 1;
+  const int lin = blockIdx.x, xcd = lin & 7, jj_ = lin >> 3;
+  const int vunit = xcd + 8 * (jj_ / batch.rows_per_group);
+  const int unit = vunit / batch.groups, rb = (vunit % batch.groups) * batch.rows_per_group + jj_ % batch.rows_per_group;
+  if (unit >= batch.n_probs * batch.n_split || rb >= batch.row_blocks) return;
+  const int split = unit % batch.n_split;
+  const FwdShardProb& p = batch.p[unit / batch.n_split];
+  const int i0 = rb * CB_ROWS;
+  if (i0 >= p.r) return;
+  const int n_cols = p.c;
+  const bf16_t* y_rows = p.y;
+  asm volatile("" : "+s"(y_rows));
+  const int c0 = split * batch.cols_per_split;
+  const int ntile = max(0, (min(n_cols, c0 + batch.cols_per_split) - c0 + CB_JT - 1) / CB_JT);
+  const float sc = *scale_ptr, s2 = sc * 1.4426950408889634f;
+
+  int rowoff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) rowoff[kk] = r * 128 + (((2 * kk + h) ^ cb_swz(r)) << 4);
+  const uint32_t smem_addr = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) char*)smem);
+  auto issue_piece = [&](const bf16_t* base, int avail, int b, int idx) {   // as in the backward: 16 pieces per wave and tile, rows clamped
+    const int jt = idx >> 3, sub = (idx >> 2) & 1, q8 = idx & 3;
+    const int s = 2 * wave + sub;
+    const int row = 8 * q8 + (lane >> 3);
+    const int ch = (lane & 7) ^ cb_swz(row);
+    cb_dma16(base + 64 * s, (uint32_t)(min(32 * jt + row, avail) * CB_KP + ch * 8) * 2u,
+             smem_addr + b * CB_YBUF + (8 * jt + s) * CB_SUB + q8 * 1024);
+  };
+  auto issue_rows = [&](const bf16_t* base, int avail, int b) {
+#pragma unroll
+    for (int idx = 0; idx < 16; ++idx) issue_piece(base, avail, b, idx);
+  };
+  const int ri = 32 * wit + r, iglob = i0 + ri;
+  const int lab = p.label_off + iglob;
+  const int lab_lo = p.label_off + i0;
+
+  if (ntile > 0) issue_rows(y_rows + (long)c0 * CB_KP, n_cols - 1 - c0, 0);
+  issue_rows(p.x + (long)i0 * CB_KP, p.r - 1 - i0, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  bf16x8 xf[32];
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks)
+    xf[ks] = *reinterpret_cast<const bf16x8*>(ybuf + CB_YBUF + (8 * wit + (ks >> 2)) * CB_SUB + rowoff[ks & 3]);
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) asm volatile("" : "+v"(xf[ks]));
+
+  float m_run = -INFINITY, l_run = 0.f;   // this lane's row: running maximum (log2 domain) and sum of 2^(u - m_run) over its 16 columns per tile
+  // (A variant that carried the statistics of tile t between the MFMAs of tile t + 1 measured the same 24 us: with one wave per SIMD
+  // the tile time follows the wave's instruction count, not what overlaps what.)
+#pragma unroll 1
+  for (int t = 0; t < ntile; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t
+    __syncthreads();                                   // tile t complete; every wave has finished reading tile t - 1: its buffer is free
+    const int tn = min(t + 1, ntile - 1), nb = (t + 1) & 1;
+    const bf16_t* ynext = y_rows + (long)(c0 + CB_JT * tn) * CB_KP;
+    const int avail_next = n_cols - 1 - (c0 + CB_JT * tn);
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+    {
+      uint32_t ya[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) ya[kk] = smem_addr + (t & 1) * CB_YBUF + 8 * wjt * CB_SUB + rowoff[kk];
+      bf16x8 yf[8];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yf[ks]) : "v"(ya[ks & 3]), "n"((ks >> 2) * CB_SUB) : "memory");
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) {
+        if (ks <= 24) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(yf[ks & 7]) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(yf[ks & 7]) : "n"(31 - ks) : "memory");
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[ks & 7], xf[ks], sacc, 0, 0, 0);
+        if (ks + 8 < 32)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yf[ks & 7]) : "v"(ya[ks & 3]), "n"(((ks + 8) >> 2) * CB_SUB) : "memory");
+        if (ks & 1) issue_piece(ynext, avail_next, nb, ks >> 1);
+      }
+    }
+    // ---- element e: logit of row ri against column jt0 + 32 wjt + (e&3) + 8 (e>>2) + 4 h
+    const int jt0 = c0 + CB_JT * t;
+    const int jb = jt0 + 32 * wjt + 4 * h;
+    float u[16];
+    const bool edge = jt0 + CB_JT > n_cols;                                            // wave-uniform: the ragged last tile
+    const bool has_lab = !(jt0 + CB_JT <= lab_lo || jt0 >= lab_lo + CB_ROWS);          // wave-uniform: a label column in this tile
+#pragma unroll
+    for (int e = 0; e < 16; ++e) u[e] = sacc[e] * s2;
+    if (edge) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) u[e] = (jb + (e & 3) + 8 * (e >> 2) < n_cols) ? u[e] : -INFINITY;
+    }
+    if (has_lab) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        if (jb + (e & 3) + 8 * (e >> 2) == lab && iglob < p.r) p.diag[iglob] = sc * sacc[e];
+    }
+    float mt = u[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mt = fmaxf(mt, u[e]);
+    const float mn = fmaxf(m_run, mt);
+    if (mn > -INFINITY) {   // (a lane whose 16 columns of the ragged tile are all beyond c, with nothing before: nothing to add)
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sum += fast_exp2(u[e] - mn);
+      l_run = fmaf(l_run, fast_exp2(m_run - mn), sum);
+      m_run = mn;
+    }
+  }
+  // ---- the row's partial over this split: the two column halves of the lane pair (h), then the two column-half waves (wjt)
+  {
+    const float mo = __shfl_xor(m_run, 32), lo = __shfl_xor(l_run, 32);
+    const float mn = fmaxf(m_run, mo);
+    if (mn > -INFINITY) {
+      l_run = l_run * fast_exp2(m_run - mn) + lo * fast_exp2(mo - mn);
+      m_run = mn;
+    }
+  }
+  __syncthreads();
+  if (wjt == 1 && h == 0) xch[32 * wit + r] = make_float2(m_run, l_run);
+  __syncthreads();
+  if (wjt == 0 && h == 0 && iglob < p.r) {
+    const float2 o = xch[32 * wit + r];
+    const float mn = fmaxf(m_run, o.x);
+    float l = 0.f;
+    if (mn > -INFINITY) l = l_run * fast_exp2(m_run - mn) + o.y * fast_exp2(o.x - mn);
+    p.part[(size_t)split * p.part_ld + iglob] = make_float2(mn, l);
+  }
+}
+
+int launch_clip_fwd_shard(const FwdShardBatch& b, const float* scale, hipStream_t st) {
+  auto kern = clip_fwd_shard_kernel;
+  KernelSetup ks;
+  if (int rc = kernel_setup(reinterpret_cast<const void*>(kern), 256, CF_LDS, &ks)) return rc;
+  FwdShardBatch bb = b;
+  const int units = b.n_probs * b.n_split;
+  bb.groups = units < 8 ? cdiv(8, units) : 1;
+  bb.rows_per_group = cdiv(b.row_blocks, bb.groups);
+  const int grid = 8 * cdiv(units * bb.groups, 8) * bb.rows_per_group;
+  ProfEvents pe(MMK_K_SIM_STATS);
+  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), CF_LDS, st, pe.start, pe.stop, 0, bb, scale);
+  MMK_LAUNCH_CHECK();
+  return 0;
+}
+
 // host side: called by clip_backward_impl (clip.hip) for the directions it found eligible
 int launch_clip_bwd_fused(const BwdFusedBatch& b, const float* scale, hipStream_t st) {
   auto kern = clip_bwd_fused_kernel;

@@ -105,4 +105,19 @@ struct BwdFusedBatch {
 };
 int launch_clip_bwd_fused(const BwdFusedBatch& b, const float* scale, hipStream_t st);
 
+// ------------------------------------------------------------------ forward statistics of row-sharded directions (clip_bwd.hip)
+struct FwdShardProb {
+  const bf16_t* x;        // packed owned rows   [>= r][512]
+  const bf16_t* y;        // packed columns      [>= c][512]
+  float2* part;           // [n_split][part_ld]: per (column split, owned row) the partial (ref2, sum of 2^(u - ref2)), log2 domain
+  float* diag;            // [r]: the positive logit s * <x_i, y_label(i)>
+  int r, c, part_ld, label_off;
+};
+struct FwdShardBatch {
+  FwdShardProb p[MAX_PROBS];
+  int n_probs, n_split, cols_per_split, row_blocks;   // as BwdFusedBatch
+  int groups, rows_per_group;
+};
+int launch_clip_fwd_shard(const FwdShardBatch& b, const float* scale, hipStream_t st);
+
 }  // namespace mmk

@@ -441,7 +441,21 @@ def test_sharded_backward_one_kernel_vs_float64(r, c, p0, d, col_term):
         dr = K.Direction(x=x, y=y, y_t=None, r=r, c=c, label_off=p0, kappa=kap, ds_kappa=kap)
         dr.c_row, dr.c_col, dr.c_diag, dr.s_row, dr.s_col, dr.s_diag = coef
         dirs.append(dr)
+    _lib.profile_read()
+    _lib.profile_enable(True)
     K.clip_forward(dirs, d, comp, scale)
+    torch.cuda.synchronize()
+    prof_f = _lib.profile_read()
+    _lib.profile_enable(False)
+    # the forward of such directions is ONE streaming launch too (clip_fwd_shard_kernel: a lane keeps the running log-sum-exp of one
+    # row over its column split): row LSEs and positive logits against float64
+    assert prof_f["sim_stats"][0] == 1, prof_f
+    for dr in dirs:
+        V = float(scale) * (dr.x[:r].double() @ dr.y[:c].double().T)
+        lse_ref = torch.logsumexp(V, dim=1)
+        assert (dr.lse[:r].double() - lse_ref).abs().max().item() <= 2e-5 * max(1.0, lse_ref.abs().max().item())
+        diag_ref = V[torch.arange(r), p0 + torch.arange(r)]
+        assert (dr.diag[:r].double() - diag_ref).abs().max().item() <= 1e-5 * max(1.0, diag_ref.abs().max().item())
     # column log-sum-exps: what the all-reduce delivers -- here the exact ones of the full [c, c] problem's other direction
     full = (float(scale) * (ag[:c].double() @ bg[:c].double().T))
     lse_cols = (torch.logsumexp(full, dim=0).float(), torch.logsumexp(full, dim=1).float())   # direction 0: columns = rows of B

@@ -1,3 +1,4 @@
+// (This file also holds the forward statistics of the same directions as one streaming launch: clip_fwd_shard_kernel, below.)
 // Row-sharded CLIP / InfoNCE backward as ONE kernel that recomputes G: for a direction whose rows are a SHARD of the batch (R owned
 // rows against C >> R gathered columns: what every rank runs at W > 1) the two launches
 //     sim_grad   S = X Y^T again, G = c_row P_row + c_col P_col - c_diag delta -> HBM (R x C bf16)

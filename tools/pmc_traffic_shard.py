@@ -8,7 +8,7 @@ Per column count: bytes per launch of every kernel of the share, their sum (one 
 dominant counted MFMA kernel (sim_stats) -- what bench.py's `roofline.traffic` / `roofline_shard` quote."""
 import collections, csv, json, sys
 
-NAMES = {"clip_bwd_fused": "clip_bwd_fused", "Li0ELi1E": "sim_stats", "Li1ELi1E": "sim_grad", "Li2ELi1E": "grad_gemm", "lse_merge": "lse_merge", "pack_tr": "pack_rows",
+NAMES = {"clip_bwd_fused": "clip_bwd_fused", "clip_fwd_shard": "sim_stats", "Li0ELi1E": "sim_stats", "Li1ELi1E": "sim_grad", "Li2ELi1E": "grad_gemm", "lse_merge": "lse_merge", "pack_tr": "pack_rows",
          "grad_finalize": "grad_finalize", "wgrad_kernel": "wgrad", "wgrad_reduce": "wgrad_reduce"}
 
 

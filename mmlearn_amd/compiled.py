@@ -259,29 +259,29 @@ def _rebuild_inputs(keys: Sequence[str], tensors: Sequence[Tensor], consts: dict
 
 def _encode_tower_meta(keys: Sequence[str], consts: dict, grad_inputs: Sequence[int]) -> str:
     """The non-tensor part of a tower call as one string operand (built with plain string operations: the tracer runs this)."""
+    # separators are control characters (unit / record / group separator): keys and string values are free to hold '|', '=', ':'
     cs = []
     for path, v in consts.items():
         if v is None:
-            cs.append(path + "=n:")
+            cs.append(path + "\x1dn\x1d")
         elif isinstance(v, bool):
-            cs.append(path + "=b:" + ("1" if v else "0"))
+            cs.append(path + "\x1db\x1d" + ("1" if v else "0"))
         elif isinstance(v, int):
-            cs.append(path + "=i:" + str(v))
+            cs.append(path + "\x1di\x1d" + str(v))
         elif isinstance(v, float):
-            cs.append(path + "=f:" + repr(v))
+            cs.append(path + "\x1df\x1d" + repr(v))
         else:
-            cs.append(path + "=s:" + v)
-    return "|".join(keys) + "\x1f" + "|".join(cs) + "\x1f" + ",".join(str(i) for i in grad_inputs)
+            cs.append(path + "\x1ds\x1d" + v)
+    return "\x1e".join(keys) + "\x1f" + "\x1e".join(cs) + "\x1f" + ",".join(str(i) for i in grad_inputs)
 
 
 def _decode_tower_meta(meta: str):
     ks, cs, gi = meta.split("\x1f")
     consts = {}
-    for item in filter(None, cs.split("|")):
-        path, tv = item.split("=", 1)
-        t, v = tv.split(":", 1)
+    for item in filter(None, cs.split("\x1e")):
+        path, t, v = item.split("\x1d", 2)
         consts[path] = None if t == "n" else (v == "1") if t == "b" else int(v) if t == "i" else float(v) if t == "f" else v
-    return {"keys": [k for k in ks.split("|") if k], "consts": consts, "grad_inputs": [int(i) for i in gi.split(",") if i]}
+    return {"keys": [k for k in ks.split("\x1e") if k], "consts": consts, "grad_inputs": [int(i) for i in gi.split(",") if i]}
 
 
 class _autograd_inside_an_operator:
@@ -356,14 +356,15 @@ def _(tensors, params, tower, meta, needs_grad, bf16_autocast):
         m = _decode_tower_meta(meta)
         with unset_fake_temporarily(), torch.no_grad():
             real = [torch.zeros(tuple(t.shape), dtype=t.dtype, device=t.device) for t in tensors]
-            was_training = module.training
+            modes = [(mod, mod.training) for mod in module.modules()]   # (restored one by one: a tower may keep parts of itself in eval mode)
             module.eval()
             try:
                 # (no autocast weight cache: a bf16 copy cached here, made without autograd, would be what the REAL forward of the
                 # same enclosing autocast region picks up -- and the weight's gradient would be lost)
                 out = _tower_call(module, m["keys"], real, m["consts"], bf16_autocast, cache=False)
             finally:
-                module.train(was_training)
+                for mod, was in modes:
+                    mod.training = was
             cache[sig] = (tuple(out.shape), out.dtype, out.device)
     shape, dt, dev = cache[sig]
     return torch.empty(shape, dtype=dt, device=dev), torch.empty((1,), dtype=torch.int64, device="cpu")

@@ -521,11 +521,11 @@ def test_tower_operator_host_side_round_trips_a_batch_and_keys_towers_per_module
 
     from mmlearn_amd import compiled as C
 
-    batch = {"rgb": torch.zeros(2, 3), "attention_mask": torch.ones(2, 5, dtype=torch.long), "fully_paired": True, "note": "a b", "k": None, "n": 7,
+    batch = {"rgb": torch.zeros(2, 3), "attention_mask": torch.ones(2, 5, dtype=torch.long), "fully_paired": True, "note": "a|b=c:d", "k": None, "n": 7,
              "scale": 0.25, "example_ids": {"rgb": torch.arange(4).view(2, 2), "text": torch.arange(4).view(2, 2)}, "obj": object()}
     keys, tensors, consts = C._flatten_inputs(batch)
     assert keys == ["rgb", "attention_mask", "example_ids/rgb", "example_ids/text"] and len(tensors) == 4
-    assert consts == {"fully_paired": True, "note": "a b", "k": None, "n": 7, "scale": 0.25}          # the python object stays outside
+    assert consts == {"fully_paired": True, "note": "a|b=c:d", "k": None, "n": 7, "scale": 0.25}          # the python object stays outside
     meta = C._encode_tower_meta(keys, consts, [0])
     m = C._decode_tower_meta(meta)
     assert m == {"keys": keys, "consts": consts, "grad_inputs": [0]}
